@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(REPO, 'context-transformer_amd')
+for p in (REPO, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden():
+    cache = {}
+
+    def load(name):
+        if name not in cache:
+            cache[name] = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+        return cache[name]
+    return load
+
+
+def sampled(t, g, name):
+    """Compare tensor `t` against the strided sample stored by tools/gen_goldens.py."""
+    a = np.asarray(t.detach().cpu().numpy() if hasattr(t, 'detach') else t, dtype=np.float32).ravel()
+    stride = int(g[name + '__stride'])
+    assert list(g[name + '__shape']) == list(t.shape), (name, g[name + '__shape'], t.shape)
+    return a[::stride], g[name + '__vals'], float(a.astype(np.float64).sum()), float(g[name + '__sum'])
+
+
+def rel_err(a, b):
+    """max|a-b| / max|b| -- the normalised error of SURVEY 7 (elementwise rel error is
+    meaningless next to post-ReLU zeros)."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    d = np.abs(b).max()
+    return float(np.abs(a - b).max() / (d if d > 0 else 1.0))

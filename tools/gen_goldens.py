@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+    cd /root/repo && PYTHONDONTWRITEBYTECODE=1 python tools/gen_goldens.py
+
+Imports Ze-Yang/Context-Transformer from /root/reference (read-only; nothing is copied),
+fills its modules with the build's name-seeded synthetic weights (ctdet.synth) through
+``load_state_dict`` (the key set is the frozen contract), runs the hot-path functions on
+seeded inputs and stores inputs-by-seed + (sampled) outputs.  The fixtures are data only.
+They pin oracle/ (tests/test_oracle_golden.py); /root/reference does not exist on the GPU box.
+"""
+import hashlib
+import importlib.util
+import os
+import subprocess
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = '/root/reference'
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REPO, 'context-transformer_amd'))
+from ctdet import synth  # noqa: E402  (product-side synthetic data; no oracle import here)
+
+for k in [k for k in sys.modules if k.split('.')[0] in ('models', 'layers', 'utils', 'data')]:
+    del sys.modules[k]
+sys.path.insert(0, REF)
+from models.RFB_Net_vgg import build_net            # noqa: E402
+from layers.functions import Detect, PriorBox        # noqa: E402
+from layers.modules.multibox_loss_combined import MultiBoxLoss_combined  # noqa: E402
+from utils import box_utils as rbu                   # noqa: E402
+from utils.nms.py_cpu_nms import py_cpu_nms          # noqa: E402
+
+spec = importlib.util.spec_from_file_location('refcfg', os.path.join(REF, 'data/config.py'))
+refcfg = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(refcfg)
+
+OUT = os.path.join(REPO, 'tests', 'golden')
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+MAX_SAMPLES = 4096
+
+
+def sample(t):
+    """-> dict(stride, vals, sum, asum, shape) of a tensor (strided flat subsample)."""
+    a = t.detach().cpu().numpy().astype(np.float32).ravel()
+    stride = max(1, a.size // MAX_SAMPLES)
+    if stride > 1 and stride % 2 == 0:
+        stride += 1                      # odd stride walks over all channel/position residues
+    return dict(stride=np.int64(stride), vals=a[::stride].copy(),
+                sum=np.float64(a.astype(np.float64).sum()),
+                asum=np.float64(np.abs(a.astype(np.float64)).sum()),
+                shape=np.array(t.shape, dtype=np.int64))
+
+
+def put(store, name, t):
+    for k, v in sample(t).items():
+        store['%s__%s' % (name, k)] = v
+
+
+def save(fname, store):
+    path = os.path.join(OUT, fname)
+    np.savez_compressed(path, **store)
+    print('%-28s %8.1f KB  %d arrays' % (fname, os.path.getsize(path) / 1024, len(store)))
+
+
+# ---------------------------------------------------------------------------
+def gen_box_ops():
+    st = {}
+    for name in ['VOC_300', 'VOC_512', 'COCO_300', 'COCO_512', 'VOC_SSD_300', 'COCO_SSD_300', 'COCO_mobile_300']:
+        p = PriorBox(getattr(refcfg, name)).forward()
+        a = p.numpy()
+        st['prior_%s__shape' % name] = np.array(a.shape)
+        st['prior_%s__sum' % name] = np.float64(a.astype(np.float64).sum())
+        st['prior_%s__sha' % name] = np.frombuffer(hashlib.sha256(a.tobytes()).digest(), dtype=np.uint8)
+        st['prior_%s__rows' % name] = a[::97].copy()
+    priors = PriorBox(refcfg.VOC_300).forward()
+    g = torch.Generator().manual_seed(7)
+    P = priors.shape[0]
+    loc = torch.randn(P, 4, generator=g)
+    st['decode_out'] = rbu.decode(loc, priors, [0.1, 0.2]).numpy()[::7].copy()
+    st['point_form_out'] = rbu.point_form(priors).numpy()[::7].copy()
+    # ground truth boxes: G=6 incl. two GTs sharing a best prior (force-match collision) and an exact prior box
+    truths = torch.tensor([[0.10, 0.12, 0.45, 0.60], [0.30, 0.30, 0.80, 0.90], [0.05, 0.55, 0.25, 0.95],
+                           [0.52, 0.08, 0.97, 0.44], [0.521, 0.081, 0.969, 0.441], [0.0, 0.0, 0.03, 0.03]])
+    labels = torch.tensor([[3., 1.], [7., 0.6], [1., 1.], [12., 0.4], [5., 1.], [20., 1.]])
+    st['match_truths'] = truths.numpy()
+    st['match_labels'] = labels.numpy()
+    ov = rbu.jaccard(truths, rbu.point_form(priors))
+    st['jaccard_out'] = ov.numpy()[:, ::5].copy()
+    st['jaccard_rowmax'] = ov.max(1)[0].numpy()
+    st['jaccard_argmax0'] = ov.max(0)[1].numpy().astype(np.int64)
+    matched = truths[ov.max(0)[1]]
+    st['encode_out'] = rbu.encode(matched, priors, [0.1, 0.2]).numpy()[::7].copy()
+    for thr in (0.5, 0.35):
+        loc_t = torch.zeros(1, P, 4); conf_t = torch.zeros(1, P, 2); obj_t = torch.zeros(1, P, dtype=torch.bool)
+        ovl = torch.zeros(1, P)
+        rbu.match(thr, truths, priors, [0.1, 0.2], labels, loc_t, conf_t, obj_t, 0, overlap=ovl)
+        tag = 'match%02d' % int(thr * 100)
+        st[tag + '_loc'] = loc_t[0].numpy()[::7].copy()
+        st[tag + '_conf'] = conf_t[0].numpy()
+        st[tag + '_obj'] = obj_t[0].numpy()
+        st[tag + '_overlap'] = ovl[0].numpy()[::7].copy()
+    # Detect on random softmaxed heads, B=2, T=20
+    g = torch.Generator().manual_seed(11)
+    locb = torch.randn(2, P, 4, generator=g)
+    conf = torch.softmax(torch.randn(2, P, 20, generator=g) * 2, -1)
+    obj = torch.softmax(torch.randn(2, P, 2, generator=g), -1)
+    boxes, scores = Detect(21, 0, refcfg.VOC_300).forward((locb, conf, obj), priors)
+    put(st, 'detect_boxes', boxes); put(st, 'detect_scores', scores)
+    # box_utils.nms (torch greedy, no +1, top_k) on decoded boxes / tie-free scores
+    sc = torch.rand(P, generator=g)
+    for (ovt, topk) in ((0.5, 200), (0.3, 400)):
+        keep, count = rbu.nms(boxes[0], sc, ovt, topk)
+        st['bunms_%02d_%d_keep' % (int(ovt * 100), topk)] = keep[:count].numpy().astype(np.int64)
+    # known-answer anchors quoted in SURVEY 8c
+    st['ka_decode'] = rbu.decode(torch.tensor([[1, -2, .5, -.5], [0, 0, 0, 0.]]),
+                                 torch.tensor([[.5, .5, .2, .4], [.1, .9, .3, .3]]), [0.1, 0.2]).numpy()
+    st['ka_jaccard'] = rbu.jaccard(torch.tensor([[0, 0, .5, .5]]),
+                                   torch.tensor([[.25, .25, .75, .75], [0, 0, .5, .5], [.6, .6, .9, .9]])).numpy()
+    st['ka_encode'] = rbu.encode(torch.tensor([[.3, .3, .7, .8]]), torch.tensor([[.5, .5, .2, .4]]), [0.1, 0.2]).numpy()
+    save('box_ops.npz', st)
+
+
+# ---------------------------------------------------------------------------
+def build_patched_cpu_nms():
+    """cpu_nms.pyx does not cythonize against numpy 2.x; apply the 3-token API patch to a
+    COPY in a temp dir (np.int_t->np.intp_t, np.int->np.intp, np.float->float), build it
+    there and import it.  Only its OUTPUTS are stored.  Returns module or None."""
+    try:
+        tmp = tempfile.mkdtemp(prefix='ctref_nms_')
+        src = open(os.path.join(REF, 'utils/nms/cpu_nms.pyx')).read()
+        src = src.replace('np.int_t', 'np.intp_t').replace('dtype=np.int)', 'dtype=np.intp)')
+        src = src.replace('np.float thresh', 'float thresh')
+        open(os.path.join(tmp, 'ref_cpu_nms.pyx'), 'w').write(src)
+        open(os.path.join(tmp, 'setup.py'), 'w').write(
+            "from setuptools import setup, Extension\nfrom Cython.Build import cythonize\nimport numpy\n"
+            "setup(ext_modules=cythonize([Extension('ref_cpu_nms',['ref_cpu_nms.pyx'],"
+            "include_dirs=[numpy.get_include()])], language_level=2))\n")
+        subprocess.check_call([sys.executable, 'setup.py', 'build_ext', '--inplace'], cwd=tmp,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        sys.path.insert(0, tmp)
+        import ref_cpu_nms
+        return ref_cpu_nms
+    except Exception as e:  # pragma: no cover
+        print('patched cpu_nms build failed:', e)
+        return None
+
+
+def gen_nms():
+    st = {}
+    ref_ge = build_patched_cpu_nms()
+    st['have_ge'] = np.int64(ref_ge is not None)
+    cases = []
+    rng = np.random.RandomState(2024)
+    for n in (1, 2, 5, 63, 64, 65, 128, 200, 400, 1000, 2500):
+        cases.append(synth.clustered_dets(n, rng=rng))
+    # integer-grid boxes: many IoUs hit simple fractions exactly (stresses > vs >=)
+    for n in (64, 300):
+        xy = rng.randint(0, 40, (n, 2)).astype(np.float32) * 5
+        wh = rng.randint(1, 8, (n, 2)).astype(np.float32) * 5 - 1
+        sc = rng.permutation(np.linspace(0.02, 0.98, n)).astype(np.float32)
+        cases.append(np.concatenate([xy, xy + wh, sc[:, None]], 1).astype(np.float32))
+    st['ncases'] = np.int64(len(cases))
+    for ci, d in enumerate(cases):
+        st['c%d_dets' % ci] = d
+        for thr in (0.45, 0.3, 0.5, 0.7):
+            tag = 'c%d_t%02d' % (ci, int(round(thr * 100)))
+            st[tag + '_gt'] = np.asarray(py_cpu_nms(d, thr), dtype=np.int64)
+            if ref_ge is not None:
+                st[tag + '_ge'] = np.asarray(ref_ge.cpu_nms(d, thr), dtype=np.int64)
+    # known answers
+    ka = np.array([[10, 10, 60, 60, .9], [12, 12, 62, 62, .8], [100, 100, 150, 150, .7], [10, 10, 60, 110, .6]], np.float32)
+    st['ka_dets'] = ka
+    st['ka_gt'] = np.asarray(py_cpu_nms(ka, 0.45), dtype=np.int64)
+    eq = np.array([[0, 0, 9, 9, .9], [0, 0, 9, 19, .8]], np.float32)     # IoU exactly 0.5
+    st['eq_dets'] = eq
+    st['eq_gt'] = np.asarray(py_cpu_nms(eq, 0.5), dtype=np.int64)
+    if ref_ge is not None:
+        st['eq_ge'] = np.asarray(ref_ge.cpu_nms(eq, 0.5), dtype=np.int64)
+        # soft-NMS (in place) for the three methods
+        for m in (0, 1, 2):
+            b = cases[6].copy()
+            keep = ref_ge.cpu_soft_nms(b, 0.5, 0.3, 0.001, m)
+            st['soft_m%d_boxes' % m] = b
+            st['soft_m%d_n' % m] = np.int64(len(keep))
+    save('nms.npz', st)
+
+
+# ---------------------------------------------------------------------------
+def make_net(size, C, phase, setting='transfer', method='ours'):
+    args = types.SimpleNamespace(method=method, phase=phase, setting=setting)
+    net = build_net(args, size, C)
+    sd = synth.fill_state_dict(net.state_dict())
+    missing = net.load_state_dict(sd, strict=True)
+    net.device = 'cpu'
+    return net
+
+
+def hook_sources(net, store, tag):
+    hs = []
+    grab = {'base22': net.base[22], 'norm': net.Norm, 'conv7': net.base[34]}
+    for k, m in enumerate(net.extras):
+        grab['extra%d' % k] = m
+    for name, m in grab.items():
+        hs.append(m.register_forward_hook(lambda mod, i, o, name=name: put(store, '%s_%s' % (tag, name), o)))
+    return hs
+
+
+def gen_model():
+    with torch.no_grad():
+        # phase 1, 300, C=20, eval, B=2 -- plus intermediates
+        st = {}
+        net = make_net(300, 20, 1).eval()
+        st['keys'] = np.array(list(net.state_dict().keys()))
+        st['nparams'] = np.int64(sum(p.numel() for p in net.parameters()))
+        x = synth.images(2, 300, 'randn', 1234)
+        hs = hook_sources(net, st, 'p1')
+        loc, conf, obj = net(x)
+        for h in hs:
+            h.remove()
+        put(st, 'p1_loc', loc); put(st, 'p1_conf', conf); put(st, 'p1_obj', obj)
+        raw = net(x, init=True)
+        put(st, 'p1_init_conf', raw)
+        # image-like input
+        x2 = synth.images(1, 300, 'u8', 1234)
+        loc, conf, obj = net(x2)
+        put(st, 'p1u8_loc', loc); put(st, 'p1u8_conf', conf); put(st, 'p1u8_obj', obj)
+        # Detect + test.py pipeline on the model outputs (B=2), image scale (500,375)
+        priors = PriorBox(refcfg.VOC_300).forward()
+        loc, conf, obj = net(x)
+        boxes, scores = Detect(21, 0, refcfg.VOC_300).forward((loc, conf, obj), priors)
+        put(st, 'p1_boxes', boxes); put(st, 'p1_scores', scores)
+        st['p1_ncand'] = np.array([[int((scores[i, :, j] > 0.01).sum()) for j in range(21)] for i in range(2)])
+        net.train()
+        loc, conf, obj = net(x)
+        put(st, 'p1tr_loc', loc); put(st, 'p1tr_conf', conf); put(st, 'p1tr_obj', obj)
+        save('rfb300_phase1.npz', st)
+
+        # phase 2 transfer (C=60 -> T=20) and incre (C=15 -> 15+5)
+        for setting, C in (('transfer', 60), ('incre', 15)):
+            st = {}
+            net = make_net(300, C, 2, setting).eval()
+            st['keys'] = np.array(list(net.state_dict().keys()))
+            st['nparams'] = np.int64(sum(p.numel() for p in net.parameters()))
+            x = synth.images(2, 300, 'randn', 1234)
+            loc, conf, obj = net(x)
+            put(st, 'loc', loc); put(st, 'conf', conf); put(st, 'obj', obj)
+            raw = net(x, init=True)
+            put(st, 'init_conf', raw)
+            net.train()
+            loc, conf, obj = net(x)
+            put(st, 'tr_loc', loc); put(st, 'tr_conf', conf); put(st, 'tr_obj', obj)
+            save('rfb300_phase2_%s.npz' % setting, st)
+
+        # 512 phase 1 (C=20), B=1
+        st = {}
+        net = make_net(512, 20, 1).eval()
+        st['keys'] = np.array(list(net.state_dict().keys()))
+        st['nparams'] = np.int64(sum(p.numel() for p in net.parameters()))
+        x = synth.images(1, 512, 'randn', 1234)
+        hs = hook_sources(net, st, 'p1')
+        loc, conf, obj = net(x)
+        for h in hs:
+            h.remove()
+        put(st, 'p1_loc', loc); put(st, 'p1_conf', conf); put(st, 'p1_obj', obj)
+        save('rfb512_phase1.npz', st)
+
+
+# ---------------------------------------------------------------------------
+def gen_loss():
+    st = {}
+    priors = PriorBox(refcfg.VOC_300).forward()
+    for tag, (C, phase, setting, ncls) in {'p1': (20, 1, 'transfer', 21), 'p2': (60, 2, 'transfer', 21)}.items():
+        net = make_net(300, C, phase, setting).train()
+        x = synth.images(2, 300, 'randn', 1234)
+        tg = synth.targets(2, ncls, 99)
+        tg[1][0, 5] = 0.37      # one mixup weight != 1
+        crit = MultiBoxLoss_combined(ncls, 0.5, True, 0, True, 3, 0.5, False)
+        out = net(x)
+        out = tuple(o.detach().requires_grad_(True) for o in out)
+        ld = crit(out, priors, tg)
+        total = sum(ld.values())
+        total.backward()
+        for k, v in ld.items():
+            st['%s_%s' % (tag, k)] = np.float64(v.item())
+        for name, o in zip(('loc', 'conf', 'obj'), out):
+            put(st, '%s_in_%s' % (tag, name), o)
+            put(st, '%s_grad_%s' % (tag, name), o.grad)
+        for i, t in enumerate(tg):
+            st['%s_target%d' % (tag, i)] = t.numpy()
+    save('loss.npz', st)
+
+
+# ---------------------------------------------------------------------------
+def gen_pipeline():
+    """test.py:130-161 with py_cpu_nms as the NMS (same '>' rule as gpu_nms), on
+    trained-like synthetic heads so candidate counts are realistic and tie-free."""
+    st = {}
+    priors = PriorBox(refcfg.VOC_300).forward()
+    P = priors.shape[0]
+    g = torch.Generator().manual_seed(31)
+    B, T = 2, 20
+    loc = torch.randn(B, P, 4, generator=g) * 0.5
+    conf = torch.softmax(torch.randn(B, P, T, generator=g) * 3.0, -1)
+    obj = torch.softmax(torch.randn(B, P, 2, generator=g) * 2.0 + torch.tensor([2.5, 0.0]), -1)
+    boxes, scores = Detect(T + 1, 0, refcfg.VOC_300).forward((loc, conf, obj), priors)
+    scale = torch.Tensor([500, 375, 500, 375])
+    for i in range(B):
+        b = (boxes[i] * scale).cpu().numpy()
+        s = scores[i].cpu().numpy()
+        allb = [None] * (T + 1)
+        for j in range(1, T + 1):
+            inds = np.where(s[:, j] > 0.01)[0]
+            if len(inds) == 0:
+                allb[j] = np.empty([0, 5], dtype=np.float32)
+                continue
+            c_dets = np.hstack((b[inds], s[inds, j][:, np.newaxis])).astype(np.float32, copy=False)
+            keep = py_cpu_nms(c_dets, 0.45)
+            allb[j] = c_dets[keep, :]
+            st['img%d_cls%d_ncand' % (i, j)] = np.int64(len(inds))
+        image_scores = np.hstack([allb[j][:, -1] for j in range(1, T + 1)])
+        if len(image_scores) > 200:
+            th = np.sort(image_scores)[-200]
+            for j in range(1, T + 1):
+                k = np.where(allb[j][:, -1] >= th)[0]
+                allb[j] = allb[j][k, :]
+        for j in range(1, T + 1):
+            st['img%d_cls%d' % (i, j)] = allb[j]
+    st['seed'] = np.int64(31)
+    save('pipeline.npz', st)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1:] or ['box', 'nms', 'model', 'loss', 'pipeline']
+    if 'box' in which:
+        gen_box_ops()
+    if 'nms' in which:
+        gen_nms()
+    if 'model' in which:
+        gen_model()
+    if 'loss' in which:
+        gen_loss()
+    if 'pipeline' in which:
+        gen_pipeline()
