@@ -1,0 +1,303 @@
+// libctdet: the Context-Transformer block (models/RFB_Net_vgg.py:253-271) as two kernels.
+//
+//   ctx_project_kernel   theta/phi/g (and fc_base) = Linear(x) + x, written straight into the
+//                        operand layouts the attention kernel wants (zero padded d -> 64):
+//                          Qs [B][P_pad][2][32]   Qs[.][p][h][s] = theta[p][2s+h]
+//                          Kt [B][64][M_pad]      phi transposed (d-major, keys contiguous)
+//                          Vs [B][M_pad][64]      g rows
+//   ctx_attn_kernel      flash-style fused  softmax(theta phi^T) g  on the fp32 MFMA path
+//                        (v_mfma_f32_32x32x2_f32), the [P,M] affinity matrix (86 MB/image in
+//                        the reference) never exists.  One wave = 32 queries, workgroup = 128.
+//                        Per 32-key tile:
+//                          S^T = K Q^T   A = Kt tile from LDS (keys contiguous), B = Q registers
+//                                        -> lane (q = l&31, h = l>>5) holds 16 keys of query q,
+//                                        so the softmax max / sum are in-lane + one lane^32 swap
+//                          O^T += V^T P^T  B operand = the S^T accumulator registers as they
+//                                        are (key pairing is free to choose), A = V tile rows
+//                        Epilogue in registers: (conf + O/l * Wz) -> L2 normalise -> cosine
+//                        classifier OBJ_Target * scale, written to out[B,P,(d)+T].
+#include "ct_common.h"
+#include <algorithm>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int DP = 64;      // padded feature dim
+constexpr int QW = 32;      // queries per wave
+constexpr int QB = 128;     // queries per workgroup
+constexpr int KT = 32;      // keys per tile
+
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// mode 0: Qs, 1: Kt, 2: Vs, 3: plain rows into `out` (row stride ostride)
+__global__ __launch_bounds__(256) void ctx_project_kernel(const float* __restrict__ x, int rows_valid,
+                                                          int rows_pad, int d,
+                                                          const float* __restrict__ W,
+                                                          const float* __restrict__ bias, int mode,
+                                                          float* __restrict__ out, int ostride)
+{
+    __shared__ float Wt[DP * DP];      // Wt[i][o]
+    __shared__ float Xs[64 * DP];      // 64 rows
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < DP * DP; e += 256) {
+        const int i = e / DP, o = e % DP;
+        Wt[e] = (i < d && o < d) ? W[o * d + i] : 0.f;
+    }
+    for (int e = tid; e < 64 * DP; e += 256) {
+        const int r = e / DP, i = e % DP;
+        const int row = r0 + r;
+        Xs[e] = (row < rows_valid && i < d) ? x[((size_t)b * rows_valid + row) * d + i] : 0.f;
+    }
+    __syncthreads();
+    const int o = tid & 63, rg = tid >> 6;
+    const float bo = (o < d) ? bias[o] : 0.f;
+    for (int r = rg; r < 64; r += 4) {
+        const int row = r0 + r;
+        if (row >= rows_pad) break;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < DP; ++i) acc += Xs[r * DP + i] * Wt[i * DP + o];
+        float y = (row < rows_valid && o < d) ? acc + bo + Xs[r * DP + o] : 0.f;
+        if (mode == 0)
+            out[((size_t)b * rows_pad + row) * DP + (o & 1) * 32 + (o >> 1)] = y;
+        else if (mode == 1)
+            out[((size_t)b * DP + o) * rows_pad + row] = y;
+        else if (mode == 2)
+            out[((size_t)b * rows_pad + row) * DP + o] = y;
+        else if (row < rows_valid && o < d)
+            out[((size_t)b * rows_valid + row) * ostride + o] = y;
+    }
+}
+
+struct AttnArgs {
+    const float* Qs;
+    const float* Kt;
+    const float* Vs;
+    const float* conf;
+    const float* wz;
+    const float* obj_w;
+    float* out;
+    int P, P_pad, M, M_pad, d, T, ostride, ooff;
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float ks[2][DP * KT];   // [d][key]
+    __shared__ __attribute__((aligned(16))) float vs[2][KT * DP];   // [key][d]
+    __shared__ float objw[32 * DP];
+    __shared__ float wzs[DP];
+
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = blockIdx.x * QB + wave * QW + l31;       // < P_pad by construction
+
+    for (int e = tid; e < 32 * DP; e += 256) {
+        const int t = e / DP, dd = e % DP;
+        objw[e] = (t < a.T && dd < a.d) ? a.obj_w[t * a.d + dd] : 0.f;
+    }
+    if (tid < DP) wzs[tid] = tid < a.d ? a.wz[tid] : 0.f;
+
+    // Q fragment: B operand of step s is Qs[q][h][s]
+    float qreg[32];
+    {
+        const float4* qp = reinterpret_cast<const float4*>(a.Qs + ((size_t)b * a.P_pad + q) * DP + h * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 v = qp[i];
+            qreg[4 * i + 0] = v.x; qreg[4 * i + 1] = v.y; qreg[4 * i + 2] = v.z; qreg[4 * i + 3] = v.w;
+        }
+    }
+
+    const float* Ktb = a.Kt + (size_t)b * DP * a.M_pad;
+    const float* Vsb = a.Vs + (size_t)b * a.M_pad * DP;
+    const int nt = a.M_pad / KT;
+
+    float4 kreg[2], vreg[2];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;                   // 512 float4 per tile
+            const int row = f >> 3, c4 = f & 7;
+            kreg[i] = *reinterpret_cast<const float4*>(Ktb + (size_t)row * a.M_pad + t * KT + c4 * 4);
+            vreg[i] = *reinterpret_cast<const float4*>(Vsb + (size_t)t * KT * DP + f * 4);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            *reinterpret_cast<float4*>(&ks[buf][f * 4]) = kreg[i];   // row*32 + c4*4 == f*4
+            *reinterpret_cast<float4*>(&vs[buf][f * 4]) = vreg[i];
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < nt;
+        if (more) load_tile(t + 1);
+
+        // ---- S^T = K Q^T ----
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        const float* kb = &ks[buf][h * KT + l31];
+#pragma unroll
+        for (int st = 0; st < 32; ++st)
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[(2 * st) * KT], qreg[st], s, 0, 0, 0);
+
+        // ---- online softmax over this tile's 32 keys (16 in-lane + partner lane^32) ----
+        if (t == nt - 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (t * KT + acc_row(r, h) >= a.M) s[r] = -INFINITY;
+        }
+        float mloc = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = expf(m_run - m_new);
+        float lsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = expf(s[r] - m_new);
+            lsum += s[r];
+        }
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+
+        // ---- O^T += V^T P^T ----
+        const float* vb = &vs[buf][l31];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+            const int key = acc_row(st, h);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[key * DP], s[st], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[key * DP + 32], s[st], o1, 0, 0, 0);
+        }
+
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: residual, L2 normalise, cosine classifier ----
+    if (q >= a.P) return;
+    const float inv_l = 1.f / l_run;
+    const float* crow = a.conf + ((size_t)b * a.P + q) * a.d;
+    float x[32];
+    float n2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d0 = acc_row(r, h), d1 = 32 + d0;
+        const float c0 = d0 < a.d ? crow[d0] : 0.f;
+        const float c1 = d1 < a.d ? crow[d1] : 0.f;
+        x[r] = c0 + o0[r] * inv_l * wzs[d0];
+        x[16 + r] = c1 + o1[r] * inv_l * wzs[d1];
+        n2 += x[r] * x[r] + x[16 + r] * x[16 + r];
+    }
+    n2 += __shfl_xor(n2, 32);
+    const float nrm = sqrtf(n2);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) x[r] = x[r] / nrm;
+    float* orow = a.out + ((size_t)b * a.P + q) * a.ostride + a.ooff;
+    for (int t = 0; t < a.T; ++t) {
+        float acc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d0 = acc_row(r, h);
+            acc += x[r] * objw[t * DP + d0] + x[16 + r] * objw[t * DP + 32 + d0];
+        }
+        acc += __shfl_xor(acc, 32);
+        if (h == 0) orow[t] = acc * a.scale;
+    }
+}
+
+struct Ws {
+    float *Qs, *Kt, *Vs;
+    int P_pad, M_pad;
+    size_t total;
+};
+
+Ws carve(char* base, int batch, int P, int M)
+{
+    Ws w{};
+    w.P_pad = (P + QB - 1) / QB * QB;
+    w.M_pad = (M + KT - 1) / KT * KT;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? base + off : nullptr;
+        off += ctdet::align_up(bytes, 256);
+        return (float*)p;
+    };
+    w.Qs = take((size_t)batch * w.P_pad * DP * 4);
+    w.Kt = take((size_t)batch * DP * w.M_pad * 4);
+    w.Vs = take((size_t)batch * w.M_pad * DP * 4);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t ct_ctx_attention_workspace_bytes(int batch, int num_priors, int num_ctx, int)
+{
+    return carve(nullptr, batch, num_priors, num_ctx).total;
+}
+
+extern "C" int ct_ctx_attention_fwd(const float* conf, const float* pool, int batch, int num_priors,
+                                    int num_ctx, const ct_ctx_params* prm, float* out, void* workspace,
+                                    size_t workspace_bytes, ct_stream_t stream)
+{
+    CT_REQUIRE(conf && pool && prm && out && workspace, "ct_ctx_attention_fwd: null pointer");
+    CT_REQUIRE(batch > 0 && num_priors > 0 && num_ctx > 0, "ct_ctx_attention_fwd: bad sizes");
+    CT_REQUIRE(prm->d >= 1 && prm->d <= DP && prm->t >= 1 && prm->t <= 32,
+               "ct_ctx_attention_fwd: d=%d (<=64) t=%d (<=32)", prm->d, prm->t);
+    CT_REQUIRE(prm->theta_w && prm->theta_b && prm->phi_w && prm->phi_b && prm->g_w && prm->g_b &&
+                   prm->wz && prm->obj_w, "ct_ctx_attention_fwd: null parameter");
+    const size_t need = ct_ctx_attention_workspace_bytes(batch, num_priors, num_ctx, prm->d);
+    if (workspace_bytes < need)
+        return ctdet::fail(CT_ERR_WORKSPACE, "ct_ctx_attention_fwd: workspace %zu < %zu", workspace_bytes, need);
+    Ws w = carve((char*)workspace, batch, num_priors, num_ctx);
+    hipStream_t st = ctdet::as_stream(stream);
+    const int d = prm->d;
+    const int ostride = (prm->fc_w ? d : 0) + prm->t;
+    const dim3 blk(256);
+    hipLaunchKernelGGL(ctx_project_kernel, dim3(w.P_pad / 64, batch), blk, 0, st, conf, num_priors,
+                       w.P_pad, d, prm->theta_w, prm->theta_b, 0, w.Qs, 0);
+    CT_LAUNCH_CHECK("ctx_project_kernel(theta)");
+    hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
+                       w.M_pad, d, prm->phi_w, prm->phi_b, 1, w.Kt, 0);
+    CT_LAUNCH_CHECK("ctx_project_kernel(phi)");
+    hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
+                       w.M_pad, d, prm->g_w, prm->g_b, 2, w.Vs, 0);
+    CT_LAUNCH_CHECK("ctx_project_kernel(g)");
+    if (prm->fc_w) {
+        CT_REQUIRE(prm->fc_b, "ct_ctx_attention_fwd: fc_b missing");
+        hipLaunchKernelGGL(ctx_project_kernel, dim3((num_priors + 63) / 64, batch), blk, 0, st, conf,
+                           num_priors, num_priors, d, prm->fc_w, prm->fc_b, 3, out, ostride);
+        CT_LAUNCH_CHECK("ctx_project_kernel(fc_base)");
+    }
+    AttnArgs a{};
+    a.Qs = w.Qs; a.Kt = w.Kt; a.Vs = w.Vs;
+    a.conf = conf; a.wz = prm->wz; a.obj_w = prm->obj_w; a.out = out;
+    a.P = num_priors; a.P_pad = w.P_pad; a.M = num_ctx; a.M_pad = w.M_pad;
+    a.d = d; a.T = prm->t; a.ostride = ostride; a.ooff = prm->fc_w ? d : 0;
+    a.scale = prm->scale;
+    hipLaunchKernelGGL(ctx_attn_kernel, dim3(w.P_pad / QB, batch), blk, 0, st, a);
+    CT_LAUNCH_CHECK("ctx_attn_kernel");
+    return CT_OK;
+}

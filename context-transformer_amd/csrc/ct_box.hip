@@ -1,0 +1,336 @@
+// libctdet: prior-box decode / encode, Detect score fusion, last-dim softmax, pairwise IoU and
+// batched prior<->ground-truth matching.  All HBM-bound elementwise / small-reduction kernels.
+//
+// This translation unit is compiled with -ffp-contract=off: every fp32 expression keeps the
+// reference's rounding sequence (no FMA contraction), so integer results derived from these
+// values (arg-max indices, match labels) are reproducible against the CPU path.
+#include "ct_common.h"
+#include <algorithm>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+inline int grid_for(long total, int block = 256)
+{
+    return (int)std::min<long>((total + block - 1) / block, 256 * 16);
+}
+
+// utils/box_utils.py:184-202.  x2y2 is formed from the already rounded x1y1 (:200-201).
+__device__ __forceinline__ float4 decode_one(const float4 l, const float4 p, float v0, float v1)
+{
+    const float cx = p.x + l.x * v0 * p.z;
+    const float cy = p.y + l.y * v0 * p.w;
+    const float w = p.z * expf(l.z * v1);
+    const float h = p.w * expf(l.w * v1);
+    float4 o;
+    o.x = cx - w / 2.f;
+    o.y = cy - h / 2.f;
+    o.z = w + o.x;
+    o.w = h + o.y;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void decode_kernel(const float4* __restrict__ loc,
+                                                     const float4* __restrict__ priors, int batch,
+                                                     int P, float v0, float v1,
+                                                     const float* __restrict__ scale4, int per_image,
+                                                     float4* __restrict__ boxes)
+{
+    const long total = (long)batch * P;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(idx % P);
+        float4 o = decode_one(loc[idx], priors[p], v0, v1);
+        if (scale4) {
+            const float* s = scale4 + (per_image ? 4 * (idx / P) : 0);
+            o.x *= s[0]; o.y *= s[1]; o.z *= s[2]; o.w *= s[3];
+        }
+        boxes[idx] = o;
+    }
+}
+
+// utils/box_utils.py:135-156
+__global__ __launch_bounds__(256) void encode_kernel(const float4* __restrict__ matched,
+                                                     const float4* __restrict__ priors, int P,
+                                                     float v0, float v1, float4* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float4 m = matched[i], p = priors[i];
+    float4 o;
+    o.x = ((m.x + m.z) / 2.f - p.x) / (v0 * p.z);
+    o.y = ((m.y + m.w) / 2.f - p.y) / (v0 * p.w);
+    o.z = logf((m.z - m.x) / p.z) / v1;
+    o.w = logf((m.w - m.y) / p.w) / v1;
+    out[i] = o;
+}
+
+// layers/functions/detection.py:44-53 (+ models/RFB_Net_vgg.py:282-284 when SOFTMAX)
+template <bool SOFTMAX>
+__global__ __launch_bounds__(256) void detect_kernel(const float4* __restrict__ loc,
+                                                     const float* __restrict__ conf,
+                                                     const float2* __restrict__ obj,
+                                                     const float4* __restrict__ priors, int batch,
+                                                     int P, int C, float v0, float v1,
+                                                     float4* __restrict__ boxes, float* __restrict__ scores)
+{
+    const long total = (long)batch * P;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(idx % P);
+        boxes[idx] = decode_one(loc[idx], priors[p], v0, v1);
+        float2 o = obj[idx];
+        const float* c = conf + idx * C;
+        float* s = scores + idx * (C + 1);
+        if (SOFTMAX) {
+            const float om = fmaxf(o.x, o.y);
+            const float e0 = expf(o.x - om), e1 = expf(o.y - om);
+            const float os = e0 + e1;
+            o.x = e0 / os;
+            o.y = e1 / os;
+            float m = -INFINITY;
+            for (int k = 0; k < C; ++k) m = fmaxf(m, c[k]);
+            float sum = 0.f;
+            for (int k = 0; k < C; ++k) sum += expf(c[k] - m);
+            s[0] = o.x;
+            for (int k = 0; k < C; ++k) s[1 + k] = o.y * (expf(c[k] - m) / sum);
+        } else {
+            s[0] = o.x;
+            for (int k = 0; k < C; ++k) s[1 + k] = o.y * c[k];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ in,
+                                                           float* __restrict__ out, long rows, int cols)
+{
+    for (long r = blockIdx.x * (long)blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+        const float* x = in + r * cols;
+        float* y = out + r * cols;
+        float m = -INFINITY;
+        for (int k = 0; k < cols; ++k) m = fmaxf(m, x[k]);
+        float sum = 0.f;
+        for (int k = 0; k < cols; ++k) sum += expf(x[k] - m);
+        for (int k = 0; k < cols; ++k) y[k] = expf(x[k] - m) / sum;
+    }
+}
+
+// utils/box_utils.py:29-68: inter / (area_a + area_b - inter), no +1
+__device__ __forceinline__ float iou_plain(const float4 a, const float4 b)
+{
+    const float w = fmaxf(fminf(a.z, b.z) - fmaxf(a.x, b.x), 0.f);
+    const float h = fmaxf(fminf(a.w, b.w) - fmaxf(a.y, b.y), 0.f);
+    const float inter = w * h;
+    const float area_a = (a.z - a.x) * (a.w - a.y);
+    const float area_b = (b.z - b.x) * (b.w - b.y);
+    return inter / (area_a + area_b - inter);
+}
+
+// utils/box_utils.py:5-14
+__device__ __forceinline__ float4 point_form(const float4 p)
+{
+    return make_float4(p.x - p.z / 2.f, p.y - p.w / 2.f, p.x + p.z / 2.f, p.y + p.w / 2.f);
+}
+
+__global__ __launch_bounds__(256) void jaccard_kernel(const float4* __restrict__ a, int na,
+                                                      const float4* __restrict__ b, int nb,
+                                                      int b_center, float* __restrict__ out)
+{
+    const long total = (long)na * nb;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % nb), i = (int)(idx / nb);
+        const float4 bb = b_center ? point_form(b[j]) : b[j];
+        out[idx] = iou_plain(a[i], bb);
+    }
+}
+
+// ---- match (utils/box_utils.py:83-132), two passes -----------------------------------
+constexpr int kMaxGT = 256;
+
+// pass 1: one thread per (image, prior): best GT per prior; per-GT best prior through a
+// packed 64-bit atomicMax (iou bits << 32 | ~prior) so ties resolve to the LOWEST prior index,
+// as torch.max(dim) does on CPU.
+__global__ __launch_bounds__(256) void match_pass1(const float* __restrict__ truths,
+                                                   const int* __restrict__ gt_off,
+                                                   const float4* __restrict__ priors, int P,
+                                                   float* __restrict__ best_ov, int* __restrict__ best_idx,
+                                                   unsigned long long* __restrict__ gt_best, int max_gt)
+{
+    __shared__ float4 gtb[kMaxGT];
+    __shared__ unsigned long long gbest[kMaxGT];
+    const int b = blockIdx.y;
+    const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        const float* t = truths + (size_t)(g0 + g) * 6;
+        gtb[g] = make_float4(t[0], t[1], t[2], t[3]);
+        gbest[g] = 0ull;
+    }
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < P) {
+        const float4 pf = point_form(priors[p]);
+        float bo = -INFINITY;
+        int bi = 0;
+        for (int g = 0; g < G; ++g) {
+            const float ov = iou_plain(gtb[g], pf);
+            if (ov > bo) { bo = ov; bi = g; }          // first maximal GT wins
+            const unsigned long long key =
+                ((unsigned long long)__float_as_uint(ov) << 32) | (unsigned)(~(unsigned)p);
+            atomicMax(&gbest[g], key);
+        }
+        best_ov[(size_t)b * P + p] = bo;
+        best_idx[(size_t)b * P + p] = bi;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x; g < G; g += blockDim.x)
+        atomicMax(&gt_best[(size_t)b * max_gt + g], gbest[g]);
+}
+
+// pass 2: force-match (later GT wins), labels, encode, outputs
+__global__ __launch_bounds__(256) void match_pass2(const float* __restrict__ truths,
+                                                   const int* __restrict__ gt_off,
+                                                   const float4* __restrict__ priors, int P,
+                                                   const float* __restrict__ best_ov,
+                                                   const int* __restrict__ best_idx,
+                                                   const unsigned long long* __restrict__ gt_best,
+                                                   int max_gt, float threshold, float v0, float v1,
+                                                   float4* __restrict__ loc_t, float2* __restrict__ conf_t,
+                                                   uint8_t* __restrict__ obj_t, float* __restrict__ overlap)
+{
+    __shared__ int bprior[kMaxGT];
+    const int b = blockIdx.y;
+    const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
+    for (int g = threadIdx.x; g < G; g += blockDim.x)
+        bprior[g] = (int)(~(unsigned)(gt_best[(size_t)b * max_gt + g] & 0xFFFFFFFFull));
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const size_t o = (size_t)b * P + p;
+    float ov = best_ov[o];
+    int gi = best_idx[o];
+    if (overlap) overlap[o] = ov;
+    for (int g = 0; g < G; ++g)
+        if (bprior[g] == p) { ov = 2.f; gi = g; }
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    float label = 0.f, weight = 1.f;
+    if (G > 0) {
+        const float* t = truths + (size_t)(g0 + gi) * 6;
+        label = t[4];
+        weight = t[5];
+        if (ov < threshold) { label = 0.f; weight = 1.f; }
+        const float4 pr = priors[p];
+        out.x = ((t[0] + t[2]) / 2.f - pr.x) / (v0 * pr.z);
+        out.y = ((t[1] + t[3]) / 2.f - pr.y) / (v0 * pr.w);
+        out.z = logf((t[2] - t[0]) / pr.z) / v1;
+        out.w = logf((t[3] - t[1]) / pr.w) / v1;
+    }
+    loc_t[o] = out;
+    conf_t[o] = make_float2(label, weight);
+    obj_t[o] = label != 0.f ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" int ct_decode(const float* loc, const float* priors, int batch, int num_priors, float var0,
+                         float var1, const float* scale4, int scale_per_image, float* boxes,
+                         ct_stream_t stream)
+{
+    CT_REQUIRE(loc && priors && boxes && batch > 0 && num_priors > 0, "ct_decode: bad arguments");
+    hipLaunchKernelGGL(decode_kernel, dim3(grid_for((long)batch * num_priors)), dim3(256), 0,
+                       ctdet::as_stream(stream), (const float4*)loc, (const float4*)priors, batch,
+                       num_priors, var0, var1, scale4, scale_per_image, (float4*)boxes);
+    CT_LAUNCH_CHECK("decode_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_encode(const float* matched, const float* priors, int num_priors, float var0,
+                         float var1, float* out, ct_stream_t stream)
+{
+    CT_REQUIRE(matched && priors && out && num_priors > 0, "ct_encode: bad arguments");
+    hipLaunchKernelGGL(encode_kernel, dim3((num_priors + 255) / 256), dim3(256), 0,
+                       ctdet::as_stream(stream), (const float4*)matched, (const float4*)priors,
+                       num_priors, var0, var1, (float4*)out);
+    CT_LAUNCH_CHECK("encode_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_detect_fused(const float* loc, const float* conf, const float* obj,
+                               const float* priors, int batch, int num_priors, int num_fg, float var0,
+                               float var1, int apply_softmax, float* boxes, float* scores,
+                               ct_stream_t stream)
+{
+    CT_REQUIRE(loc && conf && obj && priors && boxes && scores, "ct_detect_fused: null tensor");
+    CT_REQUIRE(batch > 0 && num_priors > 0 && num_fg > 0, "ct_detect_fused: bad shape");
+    const dim3 grid(grid_for((long)batch * num_priors)), block(256);
+    hipStream_t st = ctdet::as_stream(stream);
+    if (apply_softmax)
+        hipLaunchKernelGGL(detect_kernel<true>, grid, block, 0, st, (const float4*)loc, conf,
+                           (const float2*)obj, (const float4*)priors, batch, num_priors, num_fg, var0,
+                           var1, (float4*)boxes, scores);
+    else
+        hipLaunchKernelGGL(detect_kernel<false>, grid, block, 0, st, (const float4*)loc, conf,
+                           (const float2*)obj, (const float4*)priors, batch, num_priors, num_fg, var0,
+                           var1, (float4*)boxes, scores);
+    CT_LAUNCH_CHECK("detect_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_softmax_lastdim(const float* in, float* out, long rows, int cols, ct_stream_t stream)
+{
+    CT_REQUIRE(in && out && rows > 0 && cols > 0, "ct_softmax_lastdim: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for(rows)), dim3(256), 0,
+                       ctdet::as_stream(stream), in, out, rows, cols);
+    CT_LAUNCH_CHECK("softmax_rows_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_jaccard(const float* a, int na, const float* b, int nb, int b_center_form,
+                          float* out, ct_stream_t stream)
+{
+    CT_REQUIRE(a && b && out && na > 0 && nb > 0, "ct_jaccard: bad arguments");
+    hipLaunchKernelGGL(jaccard_kernel, dim3(grid_for((long)na * nb)), dim3(256), 0,
+                       ctdet::as_stream(stream), (const float4*)a, na, (const float4*)b, nb,
+                       b_center_form, out);
+    CT_LAUNCH_CHECK("jaccard_kernel");
+    return CT_OK;
+}
+
+extern "C" size_t ct_match_workspace_bytes(int batch, int num_priors, int max_gt)
+{
+    const size_t bp = (size_t)batch * num_priors;
+    return ctdet::align_up(bp * 4, 256) + ctdet::align_up(bp * 4, 256) +
+           ctdet::align_up((size_t)batch * std::max(max_gt, 1) * 8, 256);
+}
+
+extern "C" int ct_match_batched(const float* truths, const int* gt_off, int batch, int max_gt,
+                                const float* priors, int num_priors, float threshold, float var0,
+                                float var1, float* loc_t, float* conf_t, uint8_t* obj_t, float* overlap,
+                                void* workspace, size_t workspace_bytes, ct_stream_t stream)
+{
+    CT_REQUIRE(truths && gt_off && priors && loc_t && conf_t && obj_t && workspace, "ct_match_batched: null");
+    CT_REQUIRE(batch > 0 && num_priors > 0, "ct_match_batched: bad shape");
+    CT_REQUIRE(max_gt >= 1 && max_gt <= kMaxGT, "ct_match_batched: max_gt=%d (1..%d)", max_gt, kMaxGT);
+    if (workspace_bytes < ct_match_workspace_bytes(batch, num_priors, max_gt))
+        return ctdet::fail(CT_ERR_WORKSPACE, "ct_match_batched: workspace %zu < %zu", workspace_bytes,
+                           ct_match_workspace_bytes(batch, num_priors, max_gt));
+    const size_t bp = (size_t)batch * num_priors;
+    char* ws = (char*)workspace;
+    float* best_ov = (float*)ws;
+    ws += ctdet::align_up(bp * 4, 256);
+    int* best_idx = (int*)ws;
+    ws += ctdet::align_up(bp * 4, 256);
+    unsigned long long* gt_best = (unsigned long long*)ws;
+    hipStream_t st = ctdet::as_stream(stream);
+    CT_HIP(hipMemsetAsync(gt_best, 0, (size_t)batch * max_gt * 8, st));
+    const dim3 grid((num_priors + 255) / 256, batch), block(256);
+    hipLaunchKernelGGL(match_pass1, grid, block, 0, st, truths, gt_off, (const float4*)priors,
+                       num_priors, best_ov, best_idx, gt_best, max_gt);
+    CT_LAUNCH_CHECK("match_pass1");
+    hipLaunchKernelGGL(match_pass2, grid, block, 0, st, truths, gt_off, (const float4*)priors,
+                       num_priors, best_ov, best_idx, gt_best, max_gt, threshold, var0, var1,
+                       (float4*)loc_t, (float2*)conf_t, obj_t, overlap);
+    CT_LAUNCH_CHECK("match_pass2");
+    return CT_OK;
+}

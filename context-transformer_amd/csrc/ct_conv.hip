@@ -1,0 +1,492 @@
+// libctdet: fused implicit-GEMM convolution for the RFBNet-VGG stack on gfx950.
+//
+// GEMM view:  C[M = cout][N = batch*oh*ow] = W[M][K = cin*kh*kw] * im2col(X)[K][N]
+// computed with v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
+//
+// Data flow per workgroup (256 threads = 4 wave64, one per SIMD):
+//   * A tile (weights, pre-packed k-major [k_pad][m_pad] so a tile row is contiguous in cout)
+//     -> buffer_load_dwordx4 -> registers -> LDS As[buf][BK][BM]
+//   * B tile (im2col gather from the NCHW activation): every thread owns ONE output pixel
+//     for the whole kernel, so (n, oh, ow), the input base offset and the 3x3/1x3/... tap
+//     validity mask are computed once; every k row of a k-step is wave-uniform, so channel
+//     and tap offsets live in SGPRs and each gathered element costs one v_add + one
+//     v_cndmask + one buffer_load_dword whose out-of-range offset returns 0 (zero padding
+//     and ragged edges come from the buffer bounds check, no branches)
+//     -> registers -> LDS Bs[buf][BK][BN] (pixel-contiguous: coalesced HBM reads, conflict
+//     free ds_write_b32 / ds_read_b32)
+//   * LDS double buffer, ONE barrier per k-step; global loads of step s+1 are issued before
+//     the MFMAs of step s and written to the other buffer after them
+//   * epilogue in registers: *scale[co] + shift[co] (bias or folded eval-BatchNorm),
+//     optional (*res_scale + residual), ReLU, then either an NCHW store into a channel
+//     slice of a wider buffer (concat fusion) or a channels-last scatter into the flattened
+//     loc/conf/obj head buffers (permute+view+cat fusion).
+//
+// k ordering: k = ci*KH*KW + tap (the natural [cout][cin][kh][kw] order); a k-step covers
+// CPB whole input channels so the row -> (channel, tap) split is a compile-time constant.
+#include "ct_common.h"
+#include <algorithm>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kInvalidOff = 0x7FFFFFF0;          // >= num_records of every descriptor -> loads 0
+constexpr long long kMaxBufBytes = 0x7FFFFF00LL;  // descriptors stay below 2 GiB
+
+struct ConvArgs {
+    const float* in;
+    const float* wpk;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    const float* lo;
+    float* out;
+    unsigned in_bytes, w_bytes;
+    int Cin, H, W, in_ctot, in_coff;
+    int M, M_pad, nsteps;
+    int stride, pad_h, pad_w, dil;
+    int OW, OHW, Npix;
+    int out_ctot, out_coff, res_ctot, res_coff;
+    float res_scale;
+    int relu;
+    int nseg;
+    ct_out_segment seg[3];
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+template <int KH, int KW, int CPB, int BM, int BN, int WAVES_M>
+__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
+{
+    constexpr int KHW = KH * KW;
+    constexpr int BK = CPB * KHW;
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int RPP = 256 / BN;             // B rows gathered per pass of the workgroup
+    constexpr int NB = BK / RPP;              // gathered elements per thread per k-step
+    constexpr int A_F4 = BK * BM / 4;         // float4s in one A tile
+    constexpr int NA = (A_F4 + 255) / 256;
+    static_assert(BK % 2 == 0 && BK % RPP == 0, "k-step must be even and divide into passes");
+    static_assert(TM >= 1 && TN >= 1 && BN >= 64, "wave tile");
+
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * BM + 2 * BK * BN];
+    float* const As = smem;                   // [2][BK][BM]
+    float* const Bs = smem + 2 * BK * BM;     // [2][BK][BN]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int l31 = lane & 31;
+    const int hsel = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave % WAVES_M) * WM;
+    const int wn0 = (wave / WAVES_M) * WN;
+
+    // XCD-aware tile order: workgroup b runs on XCD b%8; give every XCD a contiguous chunk of
+    // the (cout-tile fastest) tile sequence so the workgroups sharing an im2col tile share an L2.
+    int wg;
+    {
+        const int nwg = a.tiles_m * a.tiles_n;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, local = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int m0 = (wg % a.tiles_m) * BM;
+    const int n0 = (wg / a.tiles_m) * BN;
+
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpk, a.w_bytes);
+
+    // ---- per-thread im2col constants (this thread's pixel never changes) ----
+    const int bp = tid % BN;
+    const int rowgrp = __builtin_amdgcn_readfirstlane(tid / BN);
+    const int HW = a.H * a.W;
+    int pix_base;
+    unsigned tapmask = 0;
+    {
+        const int P = n0 + bp;
+        const bool pvalid = P < a.Npix;
+        const int Pc = pvalid ? P : 0;
+        const int n = Pc / a.OHW;
+        const int s = Pc - n * a.OHW;
+        const int oh = s / a.OW, ow = s - oh * a.OW;
+        const int ih0 = oh * a.stride - a.pad_h, iw0 = ow * a.stride - a.pad_w;
+        pix_base = ((n * a.in_ctot + a.in_coff) * a.H + ih0) * a.W + iw0;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < KW; ++kw) {
+                const int ih = ih0 + kh * a.dil, iw = iw0 + kw * a.dil;
+                const bool ok = pvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                tapmask |= (ok ? 1u : 0u) << (kh * KW + kw);
+            }
+    }
+
+    // ---- A tile constants ----
+    int a_voff[NA];       // byte offset inside one k-step slab, or kInvalidOff
+    int a_lds[NA];        // float index inside As[buf], or -1
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int f = tid + 256 * j;
+        const int arow = f / (BM / 4), ac4 = f % (BM / 4);
+        const int col = m0 + ac4 * 4;
+        const bool ok = (f < A_F4) && (col < a.M_pad);
+        a_voff[j] = ok ? (arow * a.M_pad + col) * 4 : kInvalidOff;
+        a_lds[j] = (f < A_F4) ? arow * BM + ac4 * 4 : -1;
+    }
+    const int a_step_bytes = BK * a.M_pad * 4;
+
+    i32x4 areg[NA];
+    float breg[NB];
+
+    auto load_tile = [&](int step) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int v = a_voff[j] == kInvalidOff ? kInvalidOff : a_voff[j] + step * a_step_bytes;
+            areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, v, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int r = rowgrp + RPP * i;                 // wave-uniform
+            const int c = r / KHW, tap = r - c * KHW;
+            const int kh = tap / KW, kw = tap - kh * KW;
+            const int ci = step * CPB + c;
+            const int koff = ci * HW + kh * a.dil * a.W + kw * a.dil;
+            const unsigned bit = (ci < a.Cin) ? (1u << tap) : 0u;
+            const int off = (int)((unsigned)(pix_base + koff) * 4u);
+            const int v = (tapmask & bit) ? off : kInvalidOff;
+            breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, v, 0, 0));
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* Ab = As + buf * (BK * BM);
+        float* Bb = Bs + buf * (BK * BN);
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            if (a_lds[j] >= 0) *reinterpret_cast<i32x4*>(Ab + a_lds[j]) = areg[j];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) Bb[(rowgrp + RPP * i) * BN + bp] = breg[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int step = 0; step < a.nsteps; ++step) {
+        const int buf = step & 1;
+        const bool more = step + 1 < a.nsteps;
+        if (more) load_tile(step + 1);
+        const float* Ab = As + buf * (BK * BM) + hsel * BM + wm0 + l31;
+        const float* Bb = Bs + buf * (BK * BN) + hsel * BN + wn0 + l31;
+#pragma unroll
+        for (int kp = 0; kp < BK / 2; ++kp) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = Ab[(2 * kp) * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = Bb[(2 * kp) * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int P = n0 + wn0 + j * 32 + l31;
+        if (P >= a.Npix) continue;
+        const int n = P / a.OHW;
+        const int s = P - n * a.OHW;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                if (co >= a.M) continue;
+                float v = acc[i][j][r] * a.scale[co] + a.shift[co];
+                if (a.res)
+                    v = v * a.res_scale +
+                        a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
+                if (a.lo) v = fmaxf(v, a.lo[co]);
+                else if (a.relu) v = fmaxf(v, 0.f);
+                if (a.nseg == 0) {
+                    a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
+                            a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                         (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+struct PackArgs {
+    const float* w[6];
+    int mbeg[7];
+    int nparts, K, K_pad, M_pad;
+    float* out;
+};
+
+__global__ void pack_weights_kernel(const PackArgs p)
+{
+    const long total = (long)p.K_pad * p.M_pad;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx / p.M_pad), m = (int)(idx - (long)k * p.M_pad);
+        float v = 0.f;
+        if (k < p.K) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (i < p.nparts && m >= p.mbeg[i] && m < p.mbeg[i + 1])
+                    v = p.w[i][(size_t)(m - p.mbeg[i]) * p.K + k];
+        }
+        p.out[idx] = v;
+    }
+}
+
+__global__ void fold_epilogue_kernel(const float* gamma, const float* beta, const float* mean,
+                                     const float* var, float eps, const float* bias, int n,
+                                     float* scale, float* shift)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (gamma) {
+        const float sc = gamma[i] / sqrtf(var[i] + eps);
+        scale[i] = sc;
+        shift[i] = beta[i] - mean[i] * sc;
+    } else {
+        scale[i] = 1.f;
+        shift[i] = bias ? bias[i] : 0.f;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+struct TileCfg {
+    int bm, bn;
+    const char* name;
+};
+const TileCfg kCfgs[] = {
+    {128, 128, "128x128"}, {64, 128, "64x128"}, {128, 64, "128x64"}, {64, 64, "64x64"}, {32, 128, "32x128"},
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+// channels per k-step for (geometry, BN)
+constexpr int cpb_for(int kh, int kw, int bn)
+{
+    return (kh == 3 && kw == 3) ? (bn == 128 ? 2 : 4)
+         : (kh == 1 && kw == 1) ? 16
+         : (kh * kw == 3)       ? (bn == 128 ? 6 : 4)
+         : (kh == 4 && kw == 4) ? 1
+                                : 0;
+}
+
+template <int KH, int KW>
+hipError_t launch_geo(int cfg, const ConvArgs& a, hipStream_t st)
+{
+    const dim3 grid(a.tiles_m * a.tiles_n), block(256);
+    switch (cfg) {
+#define CT_CASE(idx, BM, BN, WMV)                                                            \
+    case idx:                                                                                \
+        hipLaunchKernelGGL((conv_igemm_f32<KH, KW, cpb_for(KH, KW, BN), BM, BN, WMV>), grid, \
+                           block, 0, st, a);                                                 \
+        break;
+        CT_CASE(0, 128, 128, 2)
+        CT_CASE(1, 64, 128, 2)
+        CT_CASE(2, 128, 64, 2)
+        CT_CASE(3, 64, 64, 2)
+        CT_CASE(4, 32, 128, 1)
+#undef CT_CASE
+        default:
+            return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+int pick_config(int M, long N)
+{
+    // Heuristic default (the Python engine can autotune and pass an explicit config).
+    const int pad64 = (M + 63) / 64 * 64, pad128 = (M + 127) / 128 * 128;
+    const int bm = M <= 32 ? 32 : (pad64 < pad128 ? 64 : 128);
+    if (bm == 32) return 4;
+    const long tm = (M + bm - 1) / bm;
+    const long blocks128 = tm * ((N + 127) / 128);
+    const bool small = blocks128 < 2 * 256;
+    if (bm == 128) return small ? 2 : 0;
+    return small ? 3 : 1;
+}
+
+}  // namespace
+
+extern "C" int ct_conv_kpad(int cin, int kh, int kw)
+{
+    // k_pad must be a multiple of BK for every BN variant: lcm of the CPB choices.
+    const int c128 = cpb_for(kh, kw, 128), c64 = cpb_for(kh, kw, 64);
+    if (c128 == 0) return -1;
+    const int cpb = (c128 % c64 == 0) ? c128 : (c64 % c128 == 0 ? c64 : c128 * c64);
+    return (cin + cpb - 1) / cpb * cpb * kh * kw;
+}
+
+extern "C" int ct_conv_mpad(int cout) { return (cout + 31) / 32 * 32; }
+
+extern "C" int ct_conv_num_configs(void) { return kNumCfgs; }
+
+extern "C" const char* ct_conv_config_name(int i)
+{
+    return (i >= 0 && i < kNumCfgs) ? kCfgs[i].name : "?";
+}
+
+extern "C" int ct_conv_pack_weights(const float* const* w, const int* cout, int nparts, int cin,
+                                    int kh, int kw, float* wpacked, int m_pad, int k_pad,
+                                    ct_stream_t stream)
+{
+    CT_REQUIRE(nparts >= 1 && nparts <= 6, "ct_conv_pack_weights: nparts=%d (1..6)", nparts);
+    PackArgs p{};
+    int mtot = 0;
+    for (int i = 0; i < nparts; ++i) {
+        p.w[i] = w[i];
+        p.mbeg[i] = mtot;
+        mtot += cout[i];
+    }
+    p.mbeg[nparts] = mtot;
+    for (int i = nparts + 1; i < 7; ++i) p.mbeg[i] = mtot;
+    CT_REQUIRE(mtot <= m_pad, "ct_conv_pack_weights: sum(cout)=%d > m_pad=%d", mtot, m_pad);
+    CT_REQUIRE(k_pad >= cin * kh * kw, "ct_conv_pack_weights: k_pad=%d < K=%d", k_pad, cin * kh * kw);
+    p.nparts = nparts;
+    p.K = cin * kh * kw;
+    p.K_pad = k_pad;
+    p.M_pad = m_pad;
+    p.out = wpacked;
+    const long total = (long)k_pad * m_pad;
+    const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, ctdet::as_stream(stream), p);
+    CT_LAUNCH_CHECK("pack_weights_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_conv_fold_epilogue(const float* gamma, const float* beta, const float* mean,
+                                     const float* var, float eps, const float* bias, int n,
+                                     int offset, float* scale, float* shift, ct_stream_t stream)
+{
+    CT_REQUIRE(n > 0 && offset >= 0, "ct_conv_fold_epilogue: n=%d offset=%d", n, offset);
+    CT_REQUIRE(!gamma || (beta && mean && var), "ct_conv_fold_epilogue: BN needs beta/mean/var");
+    hipLaunchKernelGGL(fold_epilogue_kernel, dim3((n + 255) / 256), dim3(256), 0,
+                       ctdet::as_stream(stream), gamma, beta, mean, var, eps, bias, n,
+                       scale + offset, shift + offset);
+    CT_LAUNCH_CHECK("fold_epilogue_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_conv2d_fwd(const ct_conv_desc* d, ct_stream_t stream)
+{
+    CT_REQUIRE(d != nullptr, "ct_conv2d_fwd: null descriptor");
+    CT_REQUIRE(d->in && d->wpacked && d->scale && d->shift, "ct_conv2d_fwd: null tensor");
+    CT_REQUIRE(d->batch > 0 && d->cin > 0 && d->cout > 0 && d->h > 0 && d->w > 0,
+               "ct_conv2d_fwd: bad shape");
+    CT_REQUIRE(d->stride >= 1 && d->dil >= 1, "ct_conv2d_fwd: stride/dilation");
+    const int eoh = (d->h + 2 * d->pad_h - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+    const int eow = (d->w + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    CT_REQUIRE(eoh == d->oh && eow == d->ow, "ct_conv2d_fwd: oh/ow %dx%d != expected %dx%d", d->oh,
+               d->ow, eoh, eow);
+    CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "ct_conv2d_fwd: input slice");
+    CT_REQUIRE(d->m_pad >= d->cout && d->m_pad % 4 == 0, "ct_conv2d_fwd: m_pad");
+    const int kpad = ct_conv_kpad(d->cin, d->kh, d->kw);
+    if (kpad < 0)
+        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_fwd: %dx%d filters not built", d->kh, d->kw);
+    CT_REQUIRE(d->k_pad == kpad, "ct_conv2d_fwd: k_pad=%d, expected %d", d->k_pad, kpad);
+    CT_REQUIRE(d->nseg >= 0 && d->nseg <= 3, "ct_conv2d_fwd: nseg");
+    if (d->nseg == 0) {
+        CT_REQUIRE(d->out && d->out_coff >= 0 && d->out_coff + d->cout <= d->out_ctot,
+                   "ct_conv2d_fwd: output slice");
+        CT_REQUIRE(!d->res || (d->res_coff >= 0 && d->res_coff + d->cout <= d->res_ctot),
+                   "ct_conv2d_fwd: residual slice");
+    } else {
+        CT_REQUIRE(!d->res, "ct_conv2d_fwd: residual with segmented output");
+        for (int g = 0; g < d->nseg; ++g) CT_REQUIRE(d->seg[g].ptr, "ct_conv2d_fwd: null segment");
+    }
+    CT_REQUIRE((long long)d->k_pad * d->m_pad * 4 < kMaxBufBytes, "ct_conv2d_fwd: weights too large");
+
+    const long long img_in_bytes = (long long)d->in_ctot * d->h * d->w * 4;
+    CT_REQUIRE(img_in_bytes < kMaxBufBytes, "ct_conv2d_fwd: one image exceeds 2 GiB");
+    const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / img_in_bytes);
+
+    int cfg = d->config > 0 ? d->config - 1 : pick_config(d->cout, (long)d->batch * d->oh * d->ow);
+    CT_REQUIRE(cfg >= 0 && cfg < kNumCfgs, "ct_conv2d_fwd: config %d", d->config);
+    const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
+    const int cpb = cpb_for(d->kh, d->kw, bn);
+
+    for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
+        const int nb = std::min(max_chunk, d->batch - b0);
+        ConvArgs a{};
+        a.in = d->in + (size_t)b0 * d->in_ctot * d->h * d->w;
+        a.wpk = d->wpacked;
+        a.scale = d->scale;
+        a.shift = d->shift;
+        a.lo = d->lo;
+        a.OW = d->ow;
+        a.OHW = d->oh * d->ow;
+        a.res = d->res ? d->res + (size_t)b0 * d->res_ctot * a.OHW : nullptr;
+        a.out = d->nseg == 0 ? d->out + (size_t)b0 * d->out_ctot * a.OHW : nullptr;
+        a.in_bytes = (unsigned)(img_in_bytes * nb);
+        a.w_bytes = (unsigned)((long long)d->k_pad * d->m_pad * 4);
+        a.Cin = d->cin;
+        a.H = d->h;
+        a.W = d->w;
+        a.in_ctot = d->in_ctot;
+        a.in_coff = d->in_coff;
+        a.M = d->cout;
+        a.M_pad = d->m_pad;
+        a.nsteps = (d->cin + cpb - 1) / cpb;
+        a.stride = d->stride;
+        a.pad_h = d->pad_h;
+        a.pad_w = d->pad_w;
+        a.dil = d->dil;
+        a.Npix = nb * a.OHW;
+        a.out_ctot = d->out_ctot;
+        a.out_coff = d->out_coff;
+        a.res_ctot = d->res_ctot;
+        a.res_coff = d->res_coff;
+        a.res_scale = d->res_scale;
+        a.relu = d->relu;
+        a.nseg = d->nseg;
+        for (int g = 0; g < d->nseg; ++g) {
+            a.seg[g] = d->seg[g];
+            a.seg[g].ptr += (size_t)b0 * d->seg[g].img_stride;
+        }
+        a.tiles_m = (d->cout + bm - 1) / bm;
+        a.tiles_n = (a.Npix + bn - 1) / bn;
+        hipError_t e;
+        hipStream_t st = ctdet::as_stream(stream);
+        if (d->kh == 3 && d->kw == 3) e = launch_geo<3, 3>(cfg, a, st);
+        else if (d->kh == 1 && d->kw == 1) e = launch_geo<1, 1>(cfg, a, st);
+        else if (d->kh == 1 && d->kw == 3) e = launch_geo<1, 3>(cfg, a, st);
+        else if (d->kh == 3 && d->kw == 1) e = launch_geo<3, 1>(cfg, a, st);
+        else if (d->kh == 4 && d->kw == 4) e = launch_geo<4, 4>(cfg, a, st);
+        else return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_fwd: %dx%d filters not built", d->kh, d->kw);
+        if (e != hipSuccess)
+            return ctdet::fail(CT_ERR_HIP, "conv_igemm_f32 launch failed: %s", hipGetErrorString(e));
+    }
+    return CT_OK;
+}

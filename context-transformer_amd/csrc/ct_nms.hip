@@ -1,0 +1,274 @@
+// libctdet: greedy NMS with the reference's +1 pixel convention, bit-exact keep lists.
+//
+// Reference: utils/nms/nms_kernel.cu:24-144 builds an N x N/64 bit matrix of "IoU > thresh"
+// on the device, copies it to the host and reduces it sequentially there.  Only rows of boxes
+// that end up KEPT are ever used by that reduction, so this kernel never computes the others:
+//
+//   one workgroup (4 wave64) per segment = one (image, class) problem, boxes sorted by score;
+//   the kept boxes live in an LDS list (x1,y1,x2,y2 + area, broadcast ds_reads);
+//   candidates are taken 256 at a time, one per lane:
+//     phase A  every lane tests its candidate against the kept list so far (uniform loop,
+//              ~N*K/2 IoUs in total instead of N^2/2);
+//     phase B  the four 64-candidate sub-chunks are resolved in order by their own wave with
+//              a ballot loop (lowest surviving lane = next kept box, broadcast by readlane,
+//              later lanes test against it), the other waves then test against the few boxes
+//              that sub-chunk appended.
+//   The result is the greedy keep list of the reference for ANY evaluation order, because
+//   IoU(i, j) uses the reference's exact fp32 expression:
+//       w = max(min(ax2,bx2) - max(ax1,bx1) + 1, 0); inter = w*h;
+//       ovr = inter / (Sa + Sb - inter)           (IEEE division, no FMA contraction)
+//   The division is only executed when a guarded reciprocal estimate is within 1e-5 of the
+//   threshold (a few ulp), which never changes the decision.
+//
+// Compiled with -ffp-contract=off.
+#include "ct_common.h"
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int kKeptLds = 2048;   // kept boxes held in LDS; further ones are re-read from HBM/L2
+constexpr int kThreads = 256;
+
+struct Thr {
+    float t, lo, hi;
+};
+
+__host__ inline Thr make_thr(float t)
+{
+    Thr r;
+    r.t = t;
+    if (t > 1e-30f && t < 1e30f) {
+        r.lo = t * (1.f - 1e-5f);
+        r.hi = t * (1.f + 1e-5f);
+    } else {             // degenerate thresholds: always take the exact path
+        r.lo = -INFINITY;
+        r.hi = INFINITY;
+    }
+    return r;
+}
+
+// true if the reference would suppress b given kept box a.  (a = higher score.)
+// PLAIN: no +1 and union = (Sb - inter) + Sa, the expression of utils/box_utils.py:288-299.
+template <bool GE, bool PLAIN>
+__device__ __forceinline__ bool overlaps(const float ax1, const float ay1, const float ax2,
+                                         const float ay2, const float sa, const float bx1,
+                                         const float by1, const float bx2, const float by2,
+                                         const float sb, const Thr th)
+{
+    const float left = fmaxf(ax1, bx1), right = fminf(ax2, bx2);
+    const float top = fmaxf(ay1, by1), bottom = fminf(ay2, by2);
+    const float w = PLAIN ? fmaxf(right - left, 0.f) : fmaxf(right - left + 1.f, 0.f);
+    const float h = PLAIN ? fmaxf(bottom - top, 0.f) : fmaxf(bottom - top + 1.f, 0.f);
+    const float inter = w * h;
+    const float uni = PLAIN ? (sb - inter) + sa : sa + sb - inter;
+    const float q = inter * __builtin_amdgcn_rcpf(uni);
+    if (q > th.hi) return true;
+    if (q < th.lo) return false;
+    const float ovr = inter / uni;                 // exact IEEE quotient, rare
+    return GE ? (ovr >= th.t) : (ovr > th.t);
+}
+
+// value of lane `i` (wave-uniform i) in every lane
+__device__ __forceinline__ float bcast(float v, int i)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+}
+
+template <bool GE, bool PLAIN>
+__global__ __launch_bounds__(kThreads) void nms_segments_kernel(const float* __restrict__ dets,
+                                                                const int* __restrict__ seg_off,
+                                                                const int* __restrict__ seg_len,
+                                                                const int seg_stride,
+                                                                const Thr th, int* __restrict__ keep,
+                                                                int* __restrict__ keep_count)
+{
+    __shared__ float4 kbox[kKeptLds];
+    __shared__ float karea[kKeptLds];
+    __shared__ int s_kept[kThreads / 64];   // one slot per sub-chunk (no reuse within 3 barriers)
+
+    const int seg = blockIdx.x;
+    // segments are either CSR (seg_off) or fixed-stride slots with a length array
+    const int base = seg_len ? seg * seg_stride : seg_off[seg];
+    const int n = seg_len ? seg_len[seg] : seg_off[seg + 1] - base;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* d = dets + (size_t)base * 5;
+    int* kp = keep + base;
+
+    // fetch kept box i (uniform i)
+    auto kept_box = [&](int i, float4& b, float& s) {
+        if (i < kKeptLds) {
+            b = kbox[i];
+            s = karea[i];
+        } else {
+            const float* r = d + (size_t)kp[i] * 5;
+            b = make_float4(r[0], r[1], r[2], r[3]);
+            s = PLAIN ? (b.z - b.x) * (b.w - b.y) : (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+        }
+    };
+
+    int kept = 0;   // uniform across the workgroup at chunk boundaries
+    for (int c0 = 0; c0 < n; c0 += kThreads) {
+        const int j = c0 + tid;
+        const bool valid = j < n;
+        float x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+        if (valid) {
+            const float* r = d + (size_t)j * 5;
+            x1 = r[0]; y1 = r[1]; x2 = r[2]; y2 = r[3];
+        }
+        const float sj = PLAIN ? (x2 - x1) * (y2 - y1) : (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
+        bool alive = valid;
+
+        // ---- phase A: against everything kept before this chunk ----
+        for (int i = 0; i < kept; ++i) {
+            if ((i & 15) == 0 && !__any(alive)) break;
+            float4 b; float s;
+            kept_box(i, b, s);
+            if (overlaps<GE, PLAIN>(b.x, b.y, b.z, b.w, s, x1, y1, x2, y2, sj, th)) alive = false;
+        }
+
+        // ---- phase B: resolve the four 64-candidate sub-chunks in order ----
+        int kstart = kept;
+#pragma unroll 1
+        for (int w = 0; w < kThreads / 64; ++w) {
+            if (c0 + w * 64 >= n) break;                    // uniform
+            if (wave == w) {
+                int k = kstart;
+                unsigned long long m = __ballot(alive);
+                while (m) {
+                    const int i = __builtin_ctzll(m);       // highest-scoring survivor
+                    const float bx1 = bcast(x1, i), by1 = bcast(y1, i);
+                    const float bx2 = bcast(x2, i), by2 = bcast(y2, i);
+                    const float bs = bcast(sj, i);
+                    if (lane == i) {
+                        if (k < kKeptLds) {
+                            kbox[k] = make_float4(x1, y1, x2, y2);
+                            karea[k] = sj;
+                        }
+                        kp[k] = j;
+                    }
+                    ++k;
+                    if (lane > i && alive &&
+                        overlaps<GE, PLAIN>(bx1, by1, bx2, by2, bs, x1, y1, x2, y2, sj, th))
+                        alive = false;
+                    m = __ballot(alive) & ~((2ull << i) - 1ull);
+                }
+                if (lane == 0) s_kept[w] = k;
+            }
+            __syncthreads();
+            const int know = s_kept[w];
+            if (wave > w) {
+                for (int i = kstart; i < know; ++i) {
+                    float4 b; float s;
+                    kept_box(i, b, s);
+                    if (overlaps<GE, PLAIN>(b.x, b.y, b.z, b.w, s, x1, y1, x2, y2, sj, th)) alive = false;
+                }
+            }
+            kstart = know;
+        }
+        kept = kstart;
+    }
+    if (tid == 0) keep_count[seg] = kept;
+}
+
+int launch_nms(const float* dets, const int* seg_off, const int* seg_len, int seg_stride, int nseg,
+               float thresh, int ge, int* keep, int* keep_count, hipStream_t st)
+{
+    const Thr th = make_thr(thresh);
+    const dim3 grid(nseg), block(kThreads);
+#define CT_NMS_LAUNCH(GE, PL)                                                                  \
+    hipLaunchKernelGGL((nms_segments_kernel<GE, PL>), grid, block, 0, st, dets, seg_off, seg_len, \
+                       seg_stride, th, keep, keep_count)
+    switch (ge & 3) {            // bit0: >=, bit1: plain IoU
+        case 0: CT_NMS_LAUNCH(false, false); break;
+        case 1: CT_NMS_LAUNCH(true, false); break;
+        case 2: CT_NMS_LAUNCH(false, true); break;
+        default: CT_NMS_LAUNCH(true, true); break;
+    }
+#undef CT_NMS_LAUNCH
+    CT_LAUNCH_CHECK("nms_segments_kernel");
+    return CT_OK;
+}
+
+}  // namespace
+
+namespace ctdet {
+// fixed-stride segments (slot s = rows [s*stride, s*stride + seg_len[s])); used by ct_post.hip
+int nms_launch_strided(const float* dets, const int* seg_len, int seg_stride, int nseg, float thresh,
+                       int ge, int* keep, int* keep_count, hipStream_t st)
+{
+    return launch_nms(dets, nullptr, seg_len, seg_stride, nseg, thresh, ge, keep, keep_count, st);
+}
+}  // namespace ctdet
+
+extern "C" size_t ct_nms_batched_workspace_bytes(int, int) { return 256; }
+
+extern "C" int ct_nms_batched_dev(const float* dets, const int* seg_off, int num_segments,
+                                  int max_seg_len, float thresh, int ge, int* keep, int* keep_count,
+                                  void*, size_t, ct_stream_t stream)
+{
+    CT_REQUIRE(dets && seg_off && keep && keep_count, "ct_nms_batched_dev: null pointer");
+    CT_REQUIRE(num_segments > 0 && max_seg_len >= 0, "ct_nms_batched_dev: bad sizes");
+    return launch_nms(dets, seg_off, nullptr, 0, num_segments, thresh, ge, keep, keep_count,
+                      ctdet::as_stream(stream));
+}
+
+extern "C" int ct_nms_sorted_host_mode(int* keep_out, int* num_out, const float* boxes_host,
+                                       int boxes_num, int boxes_dim, float thresh, int ge, int device_id)
+{
+    CT_REQUIRE(keep_out && num_out && (boxes_host || boxes_num == 0), "ct_nms_sorted_host: null pointer");
+    CT_REQUIRE(boxes_num >= 0 && boxes_dim >= 4, "ct_nms_sorted_host: boxes_num=%d boxes_dim=%d", boxes_num, boxes_dim);
+    *num_out = 0;
+    if (boxes_num == 0) return CT_OK;
+    int prev = -1;
+    CT_HIP(hipGetDevice(&prev));
+    if (prev != device_id) CT_HIP(hipSetDevice(device_id));
+    // rows -> [x1,y1,x2,y2,score] (score column is unused by the kernel)
+    std::vector<float> packed((size_t)boxes_num * 5);
+    for (int i = 0; i < boxes_num; ++i) {
+        const float* r = boxes_host + (size_t)i * boxes_dim;
+        float* o = &packed[(size_t)i * 5];
+        o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+        o[4] = boxes_dim > 4 ? r[4] : 0.f;
+    }
+    const size_t det_bytes = ctdet::align_up(packed.size() * 4, 256);
+    const size_t keep_bytes = ctdet::align_up((size_t)boxes_num * 4, 256);
+    char* dev = nullptr;
+    int rc = CT_OK;
+    hipError_t e = hipMalloc((void**)&dev, det_bytes + keep_bytes + 256);
+    if (e != hipSuccess) {
+        rc = ctdet::fail(CT_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
+    } else {
+        float* d_dets = (float*)dev;
+        int* d_keep = (int*)(dev + det_bytes);
+        int* d_meta = (int*)(dev + det_bytes + keep_bytes);   // [0..1] seg_off, [2] count
+        const int meta[3] = {0, boxes_num, 0};
+        e = hipMemcpy(d_dets, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            rc = launch_nms(d_dets, d_meta, nullptr, 0, 1, thresh, ge, d_keep, d_meta + 2, nullptr);
+            if (rc == CT_OK) {
+                int cnt = 0;
+                e = hipMemcpy(&cnt, d_meta + 2, 4, hipMemcpyDeviceToHost);
+                if (e == hipSuccess && cnt > 0)
+                    e = hipMemcpy(keep_out, d_keep, (size_t)cnt * 4, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) *num_out = cnt;
+            }
+        }
+        if (e != hipSuccess) rc = ctdet::fail(CT_ERR_HIP, "ct_nms_sorted_host: %s", hipGetErrorString(e));
+        (void)hipFree(dev);
+    }
+    if (prev != device_id) (void)hipSetDevice(prev);
+    return rc;
+}
+
+extern "C" int ct_nms_sorted_host(int* keep_out, int* num_out, const float* boxes_host, int boxes_num,
+                                  int boxes_dim, float nms_overlap_thresh, int device_id)
+{
+    return ct_nms_sorted_host_mode(keep_out, num_out, boxes_host, boxes_num, boxes_dim,
+                                   nms_overlap_thresh, 0, device_id);
+}

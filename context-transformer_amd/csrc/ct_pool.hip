@@ -1,0 +1,80 @@
+// libctdet: max-pooling kernels (HBM-bound, one output element per thread, coalesced along w
+// for NCHW planes and along channels for the channels-last head buffers).
+#include "ct_common.h"
+#include <algorithm>
+
+namespace {
+
+__global__ __launch_bounds__(256) void maxpool2d_nchw(const float* __restrict__ in,
+                                                      float* __restrict__ out, long planes, int H,
+                                                      int W, int OH, int OW, int k, int stride, int pad)
+{
+    const long total = planes * OH * OW;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int ow = (int)(idx % OW);
+        const long t = idx / OW;
+        const int oh = (int)(t % OH);
+        const long pl = t / OH;
+        const int h0 = oh * stride - pad, w0 = ow * stride - pad;
+        const int h1 = min(h0 + k, H), w1 = min(w0 + k, W);
+        const float* p = in + pl * (long)H * W;
+        float m = -INFINITY;
+        for (int h = max(h0, 0); h < h1; ++h)
+            for (int w = max(w0, 0); w < w1; ++w) m = fmaxf(m, p[(long)h * W + w]);
+        out[idx] = m;
+    }
+}
+
+// channels-last: in [n][h*w][ch] -> out [n][oh*ow][ch], kernel = stride = k, ceil_mode
+__global__ __launch_bounds__(256) void ctx_pool_nhwc(const float* __restrict__ in, long long in_img,
+                                                     float* __restrict__ out, long long out_img,
+                                                     int batch, int H, int W, int OH, int OW, int ch, int k)
+{
+    const long total = (long)batch * OH * OW * ch;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % ch);
+        long t = idx / ch;
+        const int ow = (int)(t % OW);
+        t /= OW;
+        const int oh = (int)(t % OH);
+        const int n = (int)(t / OH);
+        const int h1 = min(oh * k + k, H), w1 = min(ow * k + k, W);
+        const float* p = in + (long long)n * in_img;
+        float m = -INFINITY;
+        for (int h = oh * k; h < h1; ++h)
+            for (int w = ow * k; w < w1; ++w) m = fmaxf(m, p[((long)h * W + w) * ch + c]);
+        out[(long long)n * out_img + ((long)oh * OW + ow) * ch + c] = m;
+    }
+}
+
+inline int grid_for(long total) { return (int)std::min<long>((total + 255) / 256, 256 * 16); }
+
+}  // namespace
+
+extern "C" int ct_maxpool2d_fwd(const float* in, float* out, long planes, int h, int w, int oh, int ow,
+                                int k, int stride, int pad, ct_stream_t stream)
+{
+    CT_REQUIRE(in && out && planes > 0 && h > 0 && w > 0 && oh > 0 && ow > 0, "ct_maxpool2d_fwd: bad shape");
+    CT_REQUIRE(k >= 1 && stride >= 1 && pad >= 0 && pad < k, "ct_maxpool2d_fwd: k=%d stride=%d pad=%d", k, stride, pad);
+    CT_REQUIRE((oh - 1) * stride - pad < h && (ow - 1) * stride - pad < w,
+               "ct_maxpool2d_fwd: last window starts outside the input");
+    hipLaunchKernelGGL(maxpool2d_nchw, dim3(grid_for(planes * oh * ow)), dim3(256), 0,
+                       ctdet::as_stream(stream), in, out, planes, h, w, oh, ow, k, stride, pad);
+    CT_LAUNCH_CHECK("maxpool2d_nchw");
+    return CT_OK;
+}
+
+extern "C" int ct_ctx_pool_fwd(const float* in, long long in_img_stride, float* out,
+                               long long out_img_stride, int batch, int h, int w, int ch, int k,
+                               ct_stream_t stream)
+{
+    CT_REQUIRE(in && out && batch > 0 && h > 0 && w > 0 && ch > 0 && k >= 1, "ct_ctx_pool_fwd: bad shape");
+    const int oh = (h + k - 1) / k, ow = (w + k - 1) / k;
+    hipLaunchKernelGGL(ctx_pool_nhwc, dim3(grid_for((long)batch * oh * ow * ch)), dim3(256), 0,
+                       ctdet::as_stream(stream), in, in_img_stride, out, out_img_stride, batch, h, w,
+                       oh, ow, ch, k);
+    CT_LAUNCH_CHECK("ctx_pool_nhwc");
+    return CT_OK;
+}

@@ -1,0 +1,316 @@
+// libctdet: batched form of the reference's per-image / per-class post-processing loop
+// (test.py:136-161): score threshold -> descending-score order -> NMS -> per-image top-k.
+//
+//   select_sort_kernel  one workgroup per (image, class): collects priors with score > thresh
+//                       as 64-bit keys (~score_bits << 32 | prior_index), sorts them ascending
+//                       (= descending score, lower index first on ties -- the build's defined
+//                       tie order) with a bitonic network that runs in LDS for strides < 4096
+//                       and through L2 for the few larger strides, then writes the sorted
+//                       [x1,y1,x2,y2,score] rows.
+//   nms_segments_kernel (ct_nms.hip) on the fixed-stride segments.
+//   topk_kernel         one workgroup per image: if more than max_per_image boxes survive,
+//                       8-bit radix select of the k-th largest score; because every segment is
+//                       in descending order the survivors `score >= thresh_k` are a prefix.
+//   gather_kernel       copies the surviving rows to the caller's [B,T,cap,5] buffer.
+// Nothing synchronises with the host; counts / overflow flag stay on the device.
+#include "ct_common.h"
+#include <algorithm>
+
+#pragma clang fp contract(off)
+
+namespace ctdet {
+int nms_launch_strided(const float* dets, const int* seg_len, int seg_stride, int nseg, float thresh,
+                       int ge, int* keep, int* keep_count, hipStream_t st);
+}
+
+namespace {
+
+typedef unsigned long long u64;
+constexpr int kSortThreads = 512;
+constexpr int kLdsKeys = 4096;       // 32 KiB of keys per workgroup
+
+__device__ __forceinline__ void cmpswap(u64& a, u64& b, bool asc)
+{
+    if ((a > b) == asc) {
+        const u64 t = a;
+        a = b;
+        b = t;
+    }
+}
+
+// all sub-stages j = jstart .. 1 of bitonic stage k on one LDS chunk whose first key has
+// global index gbase
+__device__ void lds_substages(u64* sk, int nloc, int k, int jstart, int gbase)
+{
+    for (int j = jstart; j > 0; j >>= 1) {
+        for (int t = threadIdx.x; t < nloc / 2; t += kSortThreads) {
+            const int i = 2 * t - (t & (j - 1));
+            const bool asc = ((gbase + i) & k) == 0;
+            u64 a = sk[i], b = sk[i + j];
+            cmpswap(a, b, asc);
+            sk[i] = a;
+            sk[i + j] = b;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
+    const float* __restrict__ boxes, const float* __restrict__ scores, int P, int T, float thresh,
+    int npow2_cap, u64* __restrict__ keys_ws, float* __restrict__ dets_sorted,
+    int* __restrict__ sorted_idx, int* __restrict__ seg_count)
+{
+    __shared__ u64 sk[kLdsKeys];
+    __shared__ int s_cnt;
+    const int seg = blockIdx.x;
+    const int b = seg / T, cls = 1 + seg % T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    u64* keys = keys_ws + (size_t)seg * npow2_cap;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+
+    // ---- select (wave-aggregated append; order is irrelevant, the keys are unique) ----
+    const float* sc = scores + (size_t)b * P * (T + 1) + cls;
+    for (int p0 = 0; p0 < P; p0 += kSortThreads) {
+        const int p = p0 + tid;
+        float v = 0.f;
+        bool pass = false;
+        if (p < P) {
+            v = sc[(size_t)p * (T + 1)];
+            pass = v > thresh;
+        }
+        const u64 m = __ballot(pass);
+        int basepos = 0;
+        if (lane == 0 && m) basepos = atomicAdd(&s_cnt, __popcll(m));
+        basepos = __shfl(basepos, 0);
+        if (pass) {
+            const int pos = basepos + __popcll(m & ((1ull << lane) - 1ull));
+            keys[pos] = ((u64)(~__float_as_uint(v)) << 32) | (unsigned)p;
+        }
+    }
+    __syncthreads();
+    const int n = s_cnt;
+    if (tid == 0) seg_count[seg] = n;
+    if (n == 0) return;
+    int N = 1;
+    while (N < n) N <<= 1;
+    for (int i = n + tid; i < N; i += kSortThreads) keys[i] = ~0ull;
+    __syncthreads();
+
+    // ---- bitonic sort of keys[0..N) ----
+    if (N <= kLdsKeys) {
+        for (int i = tid; i < N; i += kSortThreads) sk[i] = keys[i];
+        __syncthreads();
+        for (int k = 2; k <= N; k <<= 1) lds_substages(sk, N, k, k >> 1, 0);
+        for (int i = tid; i < N; i += kSortThreads) keys[i] = sk[i];
+    } else {
+        for (int c = 0; c < N; c += kLdsKeys) {            // sort every chunk
+            for (int i = tid; i < kLdsKeys; i += kSortThreads) sk[i] = keys[c + i];
+            __syncthreads();
+            for (int k = 2; k <= kLdsKeys; k <<= 1) lds_substages(sk, kLdsKeys, k, k >> 1, c);
+            for (int i = tid; i < kLdsKeys; i += kSortThreads) keys[c + i] = sk[i];
+            __syncthreads();
+        }
+        for (int k = 2 * kLdsKeys; k <= N; k <<= 1) {
+            for (int j = k >> 1; j >= kLdsKeys; j >>= 1) {  // long strides through L2
+                for (int t = tid; t < N / 2; t += kSortThreads) {
+                    const int i = 2 * t - (t & (j - 1));
+                    u64 a = keys[i], bb = keys[i + j];
+                    cmpswap(a, bb, (i & k) == 0);
+                    keys[i] = a;
+                    keys[i + j] = bb;
+                }
+                __syncthreads();
+            }
+            for (int c = 0; c < N; c += kLdsKeys) {
+                for (int i = tid; i < kLdsKeys; i += kSortThreads) sk[i] = keys[c + i];
+                __syncthreads();
+                lds_substages(sk, kLdsKeys, k, kLdsKeys >> 1, c);
+                for (int i = tid; i < kLdsKeys; i += kSortThreads) keys[c + i] = sk[i];
+                __syncthreads();
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- sorted rows ----
+    const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)b * P;
+    float* out = dets_sorted + (size_t)seg * P * 5;
+    int* oi = sorted_idx + (size_t)seg * P;
+    for (int i = tid; i < n; i += kSortThreads) {
+        const u64 key = keys[i];
+        const int p = (int)(key & 0xFFFFFFFFull);
+        const float v = __uint_as_float(~(unsigned)(key >> 32));
+        const float4 q = bx[p];
+        float* r = out + (size_t)i * 5;
+        r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w; r[4] = v;
+        oi[i] = p;
+    }
+}
+
+// per image: the `>= k-th largest score` rule of test.py:155-161
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dets_sorted,
+                                                   const int* __restrict__ keep,
+                                                   const int* __restrict__ keep_count, int P, int T,
+                                                   int max_per_image, int out_cap,
+                                                   int* __restrict__ out_count, int* __restrict__ overflow)
+{
+    __shared__ int hist[256];
+    __shared__ int s_total, s_digit, s_krem;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int t = 0;
+        for (int c = 0; c < T; ++c) t += keep_count[b * T + c];
+        s_total = t;
+    }
+    __syncthreads();
+    const int total = s_total;
+    unsigned thr_bits = 0;    // every positive score passes
+    if (max_per_image > 0 && total > max_per_image) {
+        unsigned prefix = 0, pmask = 0;
+        int krem = max_per_image;
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            hist[tid] = 0;
+            __syncthreads();
+            for (int c = 0; c < T; ++c) {
+                const int seg = b * T + c, kc = keep_count[seg];
+                const float* d = dets_sorted + (size_t)seg * P * 5;
+                const int* kp = keep + (size_t)seg * P;
+                for (int i = tid; i < kc; i += 256) {
+                    const unsigned u = __float_as_uint(d[(size_t)kp[i] * 5 + 4]);
+                    if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int cum = 0, x = 255;
+                for (; x > 0; --x) {
+                    if (cum + hist[x] >= krem) break;
+                    cum += hist[x];
+                }
+                s_digit = x;
+                s_krem = krem - cum;
+            }
+            __syncthreads();
+            prefix |= (unsigned)s_digit << shift;
+            pmask |= 255u << shift;
+            krem = s_krem;
+            __syncthreads();
+        }
+        thr_bits = prefix;
+    }
+    // survivors of every class are a prefix of its descending kept list
+    for (int c = tid; c < T; c += 256) {
+        const int seg = b * T + c, kc = keep_count[seg];
+        const float* d = dets_sorted + (size_t)seg * P * 5;
+        const int* kp = keep + (size_t)seg * P;
+        int lo = 0, hi = kc;               // first index with score < thr
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (__float_as_uint(d[(size_t)kp[mid] * 5 + 4]) >= thr_bits) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo > out_cap) {
+            atomicExch(overflow, 1);
+            lo = out_cap;
+        }
+        out_count[seg] = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_kernel(const float* __restrict__ dets_sorted,
+                                                     const int* __restrict__ sorted_idx,
+                                                     const int* __restrict__ keep,
+                                                     const int* __restrict__ out_count, int P,
+                                                     int out_cap, float* __restrict__ out_dets,
+                                                     int* __restrict__ out_index)
+{
+    const int seg = blockIdx.x;
+    const int n = out_count[seg];
+    const float* d = dets_sorted + (size_t)seg * P * 5;
+    const int* kp = keep + (size_t)seg * P;
+    for (int e = threadIdx.x; e < n * 5; e += blockDim.x) {
+        const int i = e / 5, c = e - i * 5;
+        out_dets[((size_t)seg * out_cap + i) * 5 + c] = d[(size_t)kp[i] * 5 + c];
+    }
+    if (out_index)
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            out_index[(size_t)seg * out_cap + i] = sorted_idx[(size_t)seg * P + kp[i]];
+}
+
+int next_pow2(int n)
+{
+    int v = 1;
+    while (v < n) v <<= 1;
+    return v;
+}
+
+struct PostWs {
+    u64* keys;
+    float* dets_sorted;
+    int* sorted_idx;
+    int* keep;
+    int* seg_count;
+    int* keep_count;
+    size_t total;
+};
+
+PostWs carve(char* base, int batch, int P, int T)
+{
+    const size_t S = (size_t)batch * T;
+    const int np2 = std::max(next_pow2(P), 2);
+    PostWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        char* p = base ? base + off : nullptr;
+        off += ctdet::align_up(bytes, 256);
+        return p;
+    };
+    w.keys = (u64*)take(S * np2 * 8);
+    w.dets_sorted = (float*)take(S * P * 5 * 4);
+    w.sorted_idx = (int*)take(S * P * 4);
+    w.keep = (int*)take(S * P * 4);
+    w.seg_count = (int*)take(S * 4);
+    w.keep_count = (int*)take(S * 4);
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t ct_postprocess_workspace_bytes(int batch, int num_priors, int num_fg)
+{
+    return carve(nullptr, batch, num_priors, num_fg).total;
+}
+
+extern "C" int ct_postprocess_batched(const float* boxes, const float* scores, int batch, int num_priors,
+                                      int num_fg, float conf_thresh, float nms_thresh, int ge,
+                                      int max_per_image, int out_cap, float* out_dets, int* out_count,
+                                      int* out_index, int* overflow, void* workspace,
+                                      size_t workspace_bytes, ct_stream_t stream)
+{
+    CT_REQUIRE(boxes && scores && out_dets && out_count && overflow && workspace, "ct_postprocess_batched: null pointer");
+    CT_REQUIRE(batch > 0 && num_priors > 0 && num_fg > 0 && out_cap > 0, "ct_postprocess_batched: bad sizes");
+    CT_REQUIRE(conf_thresh >= 0.f, "ct_postprocess_batched: conf_thresh must be >= 0 (scores are compared as unsigned bit patterns)");
+    const size_t need = ct_postprocess_workspace_bytes(batch, num_priors, num_fg);
+    if (workspace_bytes < need)
+        return ctdet::fail(CT_ERR_WORKSPACE, "ct_postprocess_batched: workspace %zu < %zu", workspace_bytes, need);
+    PostWs w = carve((char*)workspace, batch, num_priors, num_fg);
+    const int S = batch * num_fg;
+    const int np2 = std::max(next_pow2(num_priors), 2);
+    hipStream_t st = ctdet::as_stream(stream);
+    CT_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
+    hipLaunchKernelGGL(select_sort_kernel, dim3(S), dim3(kSortThreads), 0, st, boxes, scores, num_priors,
+                       num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count);
+    CT_LAUNCH_CHECK("select_sort_kernel");
+    int rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_count, num_priors, S, nms_thresh, ge, w.keep,
+                                       w.keep_count, st);
+    if (rc != CT_OK) return rc;
+    hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(256), 0, st, w.dets_sorted, w.keep, w.keep_count,
+                       num_priors, num_fg, max_per_image, out_cap, out_count, overflow);
+    CT_LAUNCH_CHECK("topk_kernel");
+    hipLaunchKernelGGL(gather_kernel, dim3(S), dim3(256), 0, st, w.dets_sorted, w.sorted_idx, w.keep,
+                       out_count, num_priors, out_cap, out_dets, out_index);
+    CT_LAUNCH_CHECK("gather_kernel");
+    return CT_OK;
+}

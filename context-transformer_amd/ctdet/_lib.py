@@ -1,0 +1,120 @@
+"""ctypes binding of libctdet.so (include/ctdet.h).
+
+The HIP library is the product: if it is missing or fails to load, importing the ops
+FAILS LOUDLY -- there is no PyTorch / CPU fallback for the device path.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libctdet.so')
+
+CT_OK = 0
+
+
+class CtdetError(RuntimeError):
+    pass
+
+
+class OutSegment(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('co_begin', C.c_int), ('co_end', C.c_int),
+                ('pix_stride', C.c_int), ('img_stride', C.c_longlong), ('base', C.c_longlong)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ('in_', C.c_void_p),
+        ('batch', C.c_int), ('cin', C.c_int), ('h', C.c_int), ('w', C.c_int),
+        ('in_ctot', C.c_int), ('in_coff', C.c_int),
+        ('wpacked', C.c_void_p), ('scale', C.c_void_p), ('shift', C.c_void_p),
+        ('cout', C.c_int), ('m_pad', C.c_int), ('k_pad', C.c_int),
+        ('kh', C.c_int), ('kw', C.c_int), ('stride', C.c_int),
+        ('pad_h', C.c_int), ('pad_w', C.c_int), ('dil', C.c_int),
+        ('oh', C.c_int), ('ow', C.c_int),
+        ('out', C.c_void_p), ('out_ctot', C.c_int), ('out_coff', C.c_int),
+        ('res', C.c_void_p), ('res_ctot', C.c_int), ('res_coff', C.c_int),
+        ('res_scale', C.c_float), ('relu', C.c_int), ('lo', C.c_void_p),
+        ('nseg', C.c_int), ('seg', OutSegment * 3),
+        ('config', C.c_int),
+    ]
+
+
+class CtxParams(C.Structure):
+    _fields_ = [('theta_w', C.c_void_p), ('theta_b', C.c_void_p), ('phi_w', C.c_void_p),
+                ('phi_b', C.c_void_p), ('g_w', C.c_void_p), ('g_b', C.c_void_p),
+                ('wz', C.c_void_p), ('obj_w', C.c_void_p), ('fc_w', C.c_void_p), ('fc_b', C.c_void_p),
+                ('scale', C.c_float), ('d', C.c_int), ('t', C.c_int)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+_Z = C.c_size_t
+_L = C.c_long
+_LL = C.c_longlong
+
+# name -> (restype, argtypes); every symbol include/ctdet.h declares
+SIGNATURES = {
+    'ct_abi_version': (_I, []),
+    'ct_last_error_string': (C.c_char_p, []),
+    'ct_device_info': (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
+    'ct_nms_sorted_host': (_I, [_P, _P, _P, _I, _I, _F, _I]),
+    'ct_nms_sorted_host_mode': (_I, [_P, _P, _P, _I, _I, _F, _I, _I]),
+    'ct_nms_batched_workspace_bytes': (_Z, [_I, _I]),
+    'ct_nms_batched_dev': (_I, [_P, _P, _I, _I, _F, _I, _P, _P, _P, _Z, _P]),
+    'ct_cpu_nms': (_I, [_P, _I, _F, _I, _P, _P]),
+    'ct_cpu_soft_nms': (_I, [_P, _I, _F, _F, _F, C.c_uint, _P]),
+    'ct_decode': (_I, [_P, _P, _I, _I, _F, _F, _P, _I, _P, _P]),
+    'ct_encode': (_I, [_P, _P, _I, _F, _F, _P, _P]),
+    'ct_detect_fused': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P]),
+    'ct_softmax_lastdim': (_I, [_P, _P, _L, _I, _P]),
+    'ct_jaccard': (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    'ct_match_workspace_bytes': (_Z, [_I, _I, _I]),
+    'ct_match_batched': (_I, [_P, _P, _I, _I, _P, _I, _F, _F, _F, _P, _P, _P, _P, _P, _Z, _P]),
+    'ct_postprocess_workspace_bytes': (_Z, [_I, _I, _I]),
+    'ct_postprocess_batched': (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _I, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    'ct_conv_kpad': (_I, [_I, _I, _I]),
+    'ct_conv_mpad': (_I, [_I]),
+    'ct_conv_num_configs': (_I, []),
+    'ct_conv_config_name': (C.c_char_p, [_I]),
+    'ct_conv_pack_weights': (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
+    'ct_conv_fold_epilogue': (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _P, _P, _P]),
+    'ct_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P]),
+    'ct_maxpool2d_fwd': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'ct_ctx_pool_fwd': (_I, [_P, _LL, _P, _LL, _I, _I, _I, _I, _I, _P]),
+    'ct_ctx_attention_workspace_bytes': (_Z, [_I, _I, _I, _I]),
+    'ct_ctx_attention_fwd': (_I, [_P, _P, _I, _I, _I, C.POINTER(CtxParams), _P, _P, _Z, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises CtdetError when it cannot)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CtdetError(
+                'libctdet.so not found at %s -- build it with `python context-transformer_amd/build.py` '
+                '(the HIP library is the product; there is no fallback path)' % LIB_PATH)
+        try:
+            handle = C.CDLL(LIB_PATH)
+        except OSError as e:
+            raise CtdetError('cannot load %s: %s' % (LIB_PATH, e))
+        for name, (res, args) in SIGNATURES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError:
+                raise CtdetError('%s does not export %s (stale build?)' % (LIB_PATH, name))
+            fn.restype = res
+            fn.argtypes = args
+        if handle.ct_abi_version() != 1:
+            raise CtdetError('libctdet ABI version %d, expected 1' % handle.ct_abi_version())
+        _lib = handle
+    return _lib
+
+
+def check(status, what=''):
+    if status != CT_OK:
+        msg = lib().ct_last_error_string().decode(errors='replace')
+        raise CtdetError('%s failed (status %d): %s' % (what or 'libctdet call', status, msg))

@@ -1,0 +1,532 @@
+"""Inference engine: turns an RFBNet module tree into a flat list of fused HIP launches.
+
+The plan is built once per (network, batch size): every launch owns pre-packed weights,
+folded epilogue vectors and pre-allocated activation buffers, so a forward pass is a
+straight sequence of `ct_conv2d_fwd` / `ct_maxpool2d_fwd` / ... calls on the current HIP
+stream with no allocation and no host synchronisation (and can be captured in a hipGraph).
+
+Fusions relative to the reference's op-by-op PyTorch execution (models/RFB_Net_vgg.py):
+  * Conv2d + bias/BatchNorm(eval) + ReLU                      -> one launch (:7-22, :332-336)
+  * the parallel 1x1 "reduce" convs of an RFB block + shortcut -> one launch, per-channel ReLU
+    mask (:33-50, :75-97)
+  * torch.cat of the branches                                  -> branch convs write channel
+    slices of one buffer (:58, :106)
+  * ConvLinear + `out*scale + short` + ReLU                    -> one launch (:59-62, :107-110)
+  * loc/conf/obj head convs + permute + view + cat             -> one launch per source writing
+    the flattened [B,P*4] / [B,P*C] / [B,P*2] buffers directly (:238-248)
+  * the conf head is evaluated once (the reference runs it twice in phase 2, :240/:243).
+
+The `backend` indirection exists so tests can replay a plan with a torch-CPU emulation of the
+launch descriptors (tests/emu_backend.py) and check the wiring without a GPU; the product
+ships exactly one backend, the HIP one, and `RFBNet.forward` refuses non-HIP devices.
+"""
+import ctypes as C
+import math
+import os
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+CTX_POOL = {300: [3, 2, 2, 2, 1, 1],           # models/RFB_Net_vgg.py:235-236
+            512: [3, 2, 2, 2, 2, 1, 1]}        # build-defined: the reference crashes at 512 (:243)
+
+
+def conv_out(n, k, s, p, d):
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def pool_out(n, k, s, p, ceil_mode):
+    num = n + 2 * p - k
+    o = (-(-num // s) if ceil_mode else num // s) + 1
+    if ceil_mode and (o - 1) * s >= n + p:
+        o -= 1
+    return o
+
+
+@dataclass
+class ConvPart:
+    """One torch conv folded into a fused launch: weight [cout,cin,kh,kw] + its epilogue source."""
+    weight: torch.nn.Parameter
+    bias: Optional[torch.nn.Parameter] = None
+    bn: Optional[torch.nn.Module] = None
+    relu: bool = False
+
+    @property
+    def cout(self):
+        return self.weight.shape[0]
+
+
+@dataclass
+class Segment:
+    dst: str            # flat buffer name [B, img_stride]
+    co_begin: int
+    co_end: int
+    pix_stride: int
+    base: int
+
+
+@dataclass
+class ConvStep:
+    name: str
+    parts: List[ConvPart]
+    cin: int
+    kh: int
+    kw: int
+    stride: int
+    ph: int
+    pw: int
+    dil: int
+    src: str
+    src_coff: int
+    h: int
+    w: int
+    dst: Optional[str] = None
+    dst_coff: int = 0
+    res: Optional[str] = None
+    res_coff: int = 0
+    res_scale: float = 1.0
+    segs: Optional[List[Segment]] = None
+    kind: str = 'conv'
+    rt: dict = field(default_factory=dict)      # backend-private runtime state
+
+    @property
+    def cout(self):
+        return sum(p.cout for p in self.parts)
+
+    @property
+    def oh(self):
+        return conv_out(self.h, self.kh, self.stride, self.ph, self.dil)
+
+    @property
+    def ow(self):
+        return conv_out(self.w, self.kw, self.stride, self.pw, self.dil)
+
+    def flops(self, batch):
+        return 2.0 * batch * self.cout * self.oh * self.ow * self.cin * self.kh * self.kw
+
+
+@dataclass
+class PoolStep:
+    name: str
+    src: str
+    dst: str
+    ch: int
+    h: int
+    w: int
+    k: int
+    stride: int
+    pad: int
+    ceil_mode: bool
+    kind: str = 'pool'
+
+    @property
+    def oh(self):
+        return pool_out(self.h, self.k, self.stride, self.pad, self.ceil_mode)
+
+    @property
+    def ow(self):
+        return pool_out(self.w, self.k, self.stride, self.pad, self.ceil_mode)
+
+
+@dataclass
+class CtxPoolStep:
+    name: str
+    src: str            # flat conf buffer
+    src_base: int
+    dst: str            # flat pooled buffer
+    dst_base: int
+    h: int
+    w: int
+    ch: int
+    k: int
+    kind: str = 'ctxpool'
+
+
+class Plan:
+    """Flat launch list + buffer table for one (network, batch)."""
+
+    def __init__(self, net, batch):
+        self.net = net
+        self.batch = batch
+        self.size = net.size
+        self.C = net.num_classes
+        self.ctx = (net.method == 'ours' and net.phase == 2)
+        self.steps = []
+        self.buf_shapes = {}          # name -> shape tuple (without batch for 4D: (C,H,W); flat: (n,))
+        self._build()
+
+    # -- buffer helpers
+    def _buf4(self, name, c, h, w):
+        self.buf_shapes[name] = (c, h, w)
+        return name
+
+    def _flat(self, name, n):
+        self.buf_shapes[name] = (n,)
+        return name
+
+    def _conv(self, name, parts, src, src_c, h, w, k, stride=1, pad=0, dil=1, src_coff=0, cin=None,
+              dst=None, dst_c=None, dst_coff=0, res=None, res_coff=0, res_scale=1.0):
+        kh, kw = (k, k) if isinstance(k, int) else k
+        ph, pw = (pad, pad) if isinstance(pad, int) else pad
+        st = ConvStep(name, parts, cin if cin is not None else src_c, kh, kw, stride, ph, pw, dil,
+                      src, src_coff, h, w, dst, dst_coff, res, res_coff, res_scale)
+        if dst is not None and dst not in self.buf_shapes:
+            self._buf4(dst, dst_c if dst_c is not None else st.cout, st.oh, st.ow)
+        self.steps.append(st)
+        return st
+
+    @staticmethod
+    def _bc(m, relu=None):
+        """ConvPart of a BasicConv module (conv without bias + BN [+ ReLU])."""
+        return ConvPart(m.conv.weight, None, m.bn, m.relu if relu is None else relu)
+
+    # -- network walk (models/RFB_Net_vgg.py:219-248)
+    def _build(self):
+        net, S = self.net, self.size
+        self._buf4('x', 3, S, S)
+        cur, c, h, w = 'x', 3, S, S
+        sources = []
+        k = 0
+        nbase = len(net.base)
+        while k < nbase:
+            m = net.base[k]
+            if isinstance(m, torch.nn.Conv2d):
+                relu = k + 1 < nbase and isinstance(net.base[k + 1], torch.nn.ReLU)
+                st = self._conv('base.%d' % k, [ConvPart(m.weight, m.bias, None, relu)], cur, c, h, w,
+                                m.kernel_size, m.stride[0], m.padding, m.dilation[0], dst='a_base%d' % k)
+                cur, c, h, w = st.dst, st.cout, st.oh, st.ow
+                k += 2 if relu else 1
+                if k == 23:
+                    sources.append(self._rfb_a('Norm', net.Norm, cur, c, h, w))
+            elif isinstance(m, torch.nn.MaxPool2d):
+                ps = PoolStep('base.%d' % k, cur, 'a_base%d' % k, c, h, w, m.kernel_size, m.stride, m.padding,
+                              m.ceil_mode)
+                self._buf4(ps.dst, c, ps.oh, ps.ow)
+                self.steps.append(ps)
+                cur, h, w = ps.dst, ps.oh, ps.ow
+                k += 1
+            else:
+                raise TypeError('unexpected module in base: %r' % m)
+        indicator = net.indicator
+        for i, m in enumerate(net.extras):
+            name = 'extras.%d' % i
+            if hasattr(m, 'branch0'):
+                cur, c, h, w = self._rfb(name, m, cur, c, h, w)
+            else:
+                st = self._conv(name, [self._bc(m)], cur, c, h, w, m.conv.kernel_size, m.conv.stride[0],
+                                m.conv.padding, m.conv.dilation[0], dst='a_' + name)
+                cur, c, h, w = st.dst, st.cout, st.oh, st.ow
+            if i < indicator or i % 2 == 0:
+                sources.append((cur, c, h, w))
+        # heads
+        mbox = [l.out_channels // 4 for l in net.loc]
+        assert len(mbox) == len(sources)
+        C = self.C
+        self.P = sum(hh * ww * mb for (_, _, hh, ww), mb in zip(sources, mbox))
+        self._flat('loc', self.P * 4)
+        self._flat('conf', self.P * C)
+        self._flat('obj', self.P * 2)
+        self.src_info = []
+        pbase = 0
+        for i, ((sname, sc, sh, sw), mb) in enumerate(zip(sources, mbox)):
+            parts = [ConvPart(net.loc[i].weight, net.loc[i].bias), ConvPart(net.conf[i].weight, net.conf[i].bias),
+                     ConvPart(net.obj[i].weight, net.obj[i].bias)]
+            st = self._conv('head.%d' % i, parts, sname, sc, sh, sw, 3, 1, 1, 1)
+            st.segs = [Segment('loc', 0, mb * 4, mb * 4, pbase * 4),
+                       Segment('conf', mb * 4, mb * 4 + mb * C, mb * C, pbase * C),
+                       Segment('obj', mb * (4 + C), mb * (6 + C), mb * 2, pbase * 2)]
+            self.src_info.append((sh, sw, mb, pbase))
+            pbase += sh * sw * mb
+        if self.ctx:
+            kk = CTX_POOL[S]
+            assert len(kk) == len(sources)
+            self.M = sum(-(-sh // kv) * -(-sw // kv) * mb for (sh, sw, mb, _), kv in zip(self.src_info, kk))
+            self._flat('pool', self.M * C)
+            mbase = 0
+            for i, ((sh, sw, mb, pb), kv) in enumerate(zip(self.src_info, kk)):
+                self.steps.append(CtxPoolStep('ctxpool.%d' % i, 'conf', pb * C, 'pool', mbase * C, sh, sw, mb * C, kv))
+                mbase += -(-sh // kv) * -(-sw // kv) * mb
+
+    def _rfb_a(self, name, m, src, c, h, w):
+        """BasicRFB_a (models/RFB_Net_vgg.py:68-112)."""
+        b0, b1, b2, b3 = m.branch0, m.branch1, m.branch2, m.branch3
+        i0, i1, i2, i3 = b0[0].out_channels, b1[0].out_channels, b2[0].out_channels, b3[0].out_channels
+        co = m.shortcut.out_channels
+        t0 = name + '.t0'
+        self._conv(name + '.reduce', [self._bc(b0[0]), self._bc(b1[0]), self._bc(b2[0]), self._bc(b3[0]),
+                                      self._bc(m.shortcut)], src, c, h, w, 1, dst=t0)
+        cat = name + '.cat'
+        ccat = b0[1].out_channels + b1[2].out_channels + b2[2].out_channels + b3[3].out_channels
+        self._buf4(cat, ccat, h, w)
+        off = 0
+        self._conv(name + '.b0.1', [self._bc(b0[1])], t0, i0, h, w, 3, 1, 1, 1, src_coff=0, dst=cat, dst_coff=off)
+        off += b0[1].out_channels
+        self._conv(name + '.b1.1', [self._bc(b1[1])], t0, i1, h, w, (3, 1), 1, (1, 0), 1, src_coff=i0, dst=name + '.t1')
+        self._conv(name + '.b1.2', [self._bc(b1[2])], name + '.t1', b1[1].out_channels, h, w, 3, 1, 3, 3, dst=cat, dst_coff=off)
+        off += b1[2].out_channels
+        self._conv(name + '.b2.1', [self._bc(b2[1])], t0, i2, h, w, (1, 3), 1, (0, 1), 1, src_coff=i0 + i1, dst=name + '.t2')
+        self._conv(name + '.b2.2', [self._bc(b2[2])], name + '.t2', b2[1].out_channels, h, w, 3, 1, 3, 3, dst=cat, dst_coff=off)
+        off += b2[2].out_channels
+        self._conv(name + '.b3.1', [self._bc(b3[1])], t0, i3, h, w, (1, 3), 1, (0, 1), 1, src_coff=i0 + i1 + i2, dst=name + '.t3a')
+        self._conv(name + '.b3.2', [self._bc(b3[2])], name + '.t3a', b3[1].out_channels, h, w, (3, 1), 1, (1, 0), 1, dst=name + '.t3b')
+        self._conv(name + '.b3.3', [self._bc(b3[3])], name + '.t3b', b3[2].out_channels, h, w, 3, 1, 5, 5, dst=cat, dst_coff=off)
+        out = name + '.out'
+        # out = relu(ConvLinear(cat)*scale + shortcut(x))   (:107-110)
+        self._conv(name + '.linear', [self._bc(m.ConvLinear, relu=True)], cat, ccat, h, w, 1, dst=out,
+                   res=t0, res_coff=i0 + i1 + i2 + i3, res_scale=float(m.scale))
+        return out, co, h, w
+
+    def _rfb(self, name, m, src, c, h, w):
+        """BasicRFB (models/RFB_Net_vgg.py:26-64)."""
+        b0, b1, b2 = m.branch0, m.branch1, m.branch2
+        s = b0[0].conv.stride[0]
+        c0, c1, c2 = b0[0].out_channels, b1[0].out_channels, b2[0].out_channels
+        co = m.shortcut.out_channels
+        v0, v1, v2 = b0[1].conv.dilation[0], b1[2].conv.dilation[0], b2[3].conv.dilation[0]
+        if s == 1:
+            t0 = name + '.t0'
+            self._conv(name + '.reduce', [self._bc(b0[0]), self._bc(b1[0]), self._bc(b2[0]), self._bc(m.shortcut)],
+                       src, c, h, w, 1, dst=t0)
+            b0src, b0off, b12src, b1off, b2off = t0, 0, t0, c0, c0 + c1
+            shsrc, shoff = t0, c0 + c1 + c2
+            ho, wo = h, w
+        else:
+            ta, tb = name + '.ta', name + '.tb'
+            self._conv(name + '.reduce1', [self._bc(b1[0]), self._bc(b2[0])], src, c, h, w, 1, dst=ta)
+            st = self._conv(name + '.reduce2', [self._bc(b0[0]), self._bc(m.shortcut)], src, c, h, w, 1, s, dst=tb)
+            b0src, b0off, b12src, b1off, b2off = tb, 0, ta, 0, c1
+            shsrc, shoff = tb, c0
+            ho, wo = st.oh, st.ow
+        cat = name + '.cat'
+        ccat = b0[1].out_channels + b1[2].out_channels + b2[3].out_channels
+        self._buf4(cat, ccat, ho, wo)
+        off = 0
+        self._conv(name + '.b0.1', [self._bc(b0[1])], b0src, c0, ho, wo, 3, 1, v0, v0, src_coff=b0off, dst=cat, dst_coff=off)
+        off += b0[1].out_channels
+        self._conv(name + '.b1.1', [self._bc(b1[1])], b12src, c1, h, w, 3, s, 1, 1, src_coff=b1off, dst=name + '.t1')
+        self._conv(name + '.b1.2', [self._bc(b1[2])], name + '.t1', b1[1].out_channels, ho, wo, 3, 1, v1, v1, dst=cat, dst_coff=off)
+        off += b1[2].out_channels
+        self._conv(name + '.b2.1', [self._bc(b2[1])], b12src, c2, h, w, 3, 1, 1, 1, src_coff=b2off, dst=name + '.t2a')
+        self._conv(name + '.b2.2', [self._bc(b2[2])], name + '.t2a', b2[1].out_channels, h, w, 3, s, 1, 1, dst=name + '.t2b')
+        self._conv(name + '.b2.3', [self._bc(b2[3])], name + '.t2b', b2[2].out_channels, ho, wo, 3, 1, v2, v2, dst=cat, dst_coff=off)
+        out = name + '.out'
+        self._conv(name + '.linear', [self._bc(m.ConvLinear, relu=True)], cat, ccat, ho, wo, 1, dst=out,
+                   res=shsrc, res_coff=shoff, res_scale=float(m.scale))
+        return out, co, ho, wo
+
+    def conv_flops(self):
+        return sum(s.flops(self.batch) for s in self.steps if s.kind == 'conv')
+
+
+# ======================================================================================
+class HipBackend:
+    """Executes plan steps through libctdet (the only backend the product ships)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.CtdetError('HipBackend needs a HIP device, got %s' % device)
+        self.lib = _lib.lib()
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def alloc(self, shape, dtype=torch.float32):
+        return torch.empty(shape, device=self.device, dtype=dtype)
+
+    # ---- conv
+    def prepare_conv(self, st, bufs, batch):
+        lib = self.lib
+        kpad = lib.ct_conv_kpad(st.cin, st.kh, st.kw)
+        if kpad < 0:
+            raise _lib.CtdetError('%s: %dx%d filters are not built' % (st.name, st.kh, st.kw))
+        mpad = lib.ct_conv_mpad(st.cout)
+        rt = st.rt
+        rt['wpk'] = self.alloc((kpad, mpad))
+        rt['scale'] = self.alloc((mpad,))
+        rt['shift'] = self.alloc((mpad,))
+        relus = [p.relu for p in st.parts]
+        rt['lo'] = None
+        if any(relus) and not all(relus):
+            lo = torch.empty(mpad, device=self.device)
+            off = 0
+            for p in st.parts:
+                lo[off:off + p.cout] = 0.0 if p.relu else -float('inf')
+                off += p.cout
+            lo[off:] = 0.0
+            rt['lo'] = lo
+        rt['kpad'], rt['mpad'] = kpad, mpad
+        self.pack_conv(st)
+        d = _lib.ConvDesc()
+        src = bufs[st.src]
+        d.in_ = src.data_ptr()
+        d.batch, d.cin, d.h, d.w = batch, st.cin, st.h, st.w
+        d.in_ctot, d.in_coff = src.shape[1], st.src_coff
+        d.wpacked, d.scale, d.shift = rt['wpk'].data_ptr(), rt['scale'].data_ptr(), rt['shift'].data_ptr()
+        d.cout, d.m_pad, d.k_pad = st.cout, mpad, kpad
+        d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil = st.kh, st.kw, st.stride, st.ph, st.pw, st.dil
+        d.oh, d.ow = st.oh, st.ow
+        if st.segs:
+            d.nseg = len(st.segs)
+            for g, sg in enumerate(st.segs):
+                t = bufs[sg.dst]
+                d.seg[g].ptr = t.data_ptr()
+                d.seg[g].co_begin, d.seg[g].co_end = sg.co_begin, sg.co_end
+                d.seg[g].pix_stride = sg.pix_stride
+                d.seg[g].img_stride = t.shape[1]
+                d.seg[g].base = sg.base
+        else:
+            dst = bufs[st.dst]
+            assert dst.shape[2] == st.oh and dst.shape[3] == st.ow, (st.name, dst.shape, st.oh, st.ow)
+            d.out, d.out_ctot, d.out_coff = dst.data_ptr(), dst.shape[1], st.dst_coff
+        if st.res is not None:
+            r = bufs[st.res]
+            d.res, d.res_ctot, d.res_coff, d.res_scale = r.data_ptr(), r.shape[1], st.res_coff, st.res_scale
+        d.relu = int(all(relus))
+        d.lo = rt['lo'].data_ptr() if rt['lo'] is not None else None
+        d.config = rt.get('config', 0)
+        rt['desc'] = d
+
+    def pack_conv(self, st):
+        """(Re)pack weights and fold the epilogue from the CURRENT parameter values."""
+        rt, lib = st.rt, self.lib
+        n = len(st.parts)
+        ws = [p.weight.detach() for p in st.parts]
+        for wt in ws:
+            if not (wt.is_cuda and wt.is_contiguous() and wt.dtype == torch.float32):
+                raise _lib.CtdetError('%s: parameters must be contiguous fp32 on the HIP device' % st.name)
+        ptrs = (C.c_void_p * n)(*[wt.data_ptr() for wt in ws])
+        couts = (C.c_int * n)(*[p.cout for p in st.parts])
+        _lib.check(lib.ct_conv_pack_weights(ptrs, couts, n, st.cin, st.kh, st.kw, rt['wpk'].data_ptr(),
+                                            rt['mpad'], rt['kpad'], self._stream()), 'ct_conv_pack_weights')
+        rt['scale'].fill_(1.0)
+        rt['shift'].zero_()
+        off = 0
+        for p in st.parts:
+            if p.bn is not None:
+                bn = p.bn
+                args = (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                        bn.running_var.data_ptr(), float(bn.eps), None)
+            else:
+                args = (None, None, None, None, 0.0, p.bias.data_ptr() if p.bias is not None else None)
+            _lib.check(lib.ct_conv_fold_epilogue(*args, p.cout, off, rt['scale'].data_ptr(),
+                                                 rt['shift'].data_ptr(), self._stream()), 'ct_conv_fold_epilogue')
+            off += p.cout
+        rt['versions'] = self.param_versions(st)
+
+    @staticmethod
+    def param_versions(st):
+        v = []
+        for p in st.parts:
+            v.append((p.weight.data_ptr(), p.weight._version))
+            if p.bias is not None:
+                v.append((p.bias.data_ptr(), p.bias._version))
+            if p.bn is not None:
+                for t in (p.bn.weight, p.bn.bias, p.bn.running_mean, p.bn.running_var):
+                    v.append((t.data_ptr(), t._version))
+        return v
+
+    def run_conv(self, st):
+        _lib.check(self.lib.ct_conv2d_fwd(C.byref(st.rt['desc']), self._stream()), st.name)
+
+    def run_pool(self, st, bufs, batch):
+        _lib.check(self.lib.ct_maxpool2d_fwd(bufs[st.src].data_ptr(), bufs[st.dst].data_ptr(), batch * st.ch,
+                                             st.h, st.w, st.oh, st.ow, st.k, st.stride, st.pad, self._stream()),
+                   st.name)
+
+    def run_ctxpool(self, st, bufs, batch):
+        src, dst = bufs[st.src], bufs[st.dst]
+        _lib.check(self.lib.ct_ctx_pool_fwd(src.data_ptr() + 4 * st.src_base, src.shape[1],
+                                            dst.data_ptr() + 4 * st.dst_base, dst.shape[1], batch, st.h, st.w,
+                                            st.ch, st.k, self._stream()), st.name)
+
+    # ---- autotune: time every tile config of a conv step on its real buffers
+    def tune_conv(self, st, iters=3):
+        ncfg = self.lib.ct_conv_num_configs()
+        best, best_t = 0, float('inf')
+        times = []
+        for cfg in range(ncfg):
+            st.rt['desc'].config = cfg + 1
+            try:
+                self.run_conv(st)
+            except _lib.CtdetError:
+                times.append(float('inf'))
+                continue
+            torch.cuda.synchronize(self.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                self.run_conv(st)
+            e1.record()
+            torch.cuda.synchronize(self.device)
+            t = e0.elapsed_time(e1) / iters
+            times.append(t)
+            if t < best_t:
+                best, best_t = cfg, t
+        st.rt['desc'].config = best + 1
+        st.rt['config'] = best + 1
+        st.rt['tune_ms'] = times
+        return best, times
+
+
+class Runtime:
+    """A Plan bound to a backend: buffers, packed weights, and the forward entry points."""
+
+    def __init__(self, net, batch, backend, tune=None):
+        self.plan = Plan(net, batch)
+        self.backend = backend
+        self.batch = batch
+        self.net = net
+        bufs = {}
+        for name, shp in self.plan.buf_shapes.items():
+            bufs[name] = backend.alloc((batch,) + tuple(shp))
+        self.bufs = bufs
+        for st in self.plan.steps:
+            if st.kind == 'conv':
+                backend.prepare_conv(st, bufs, batch)
+        if tune is None:
+            tune = os.environ.get('CTDET_TUNE', '1') != '0'
+        self.tuned = False
+        if tune and hasattr(backend, 'tune_conv'):
+            self.autotune()
+
+    def autotune(self):
+        self.bufs['x'].normal_()
+        for st in self.plan.steps:            # run once so every buffer holds realistic data
+            self._run_step(st)
+        for st in self.plan.steps:
+            if st.kind == 'conv':
+                self.backend.tune_conv(st)
+        self.tuned = True
+
+    def refresh_weights(self):
+        """Re-pack any fused conv whose parameters changed since the last pack."""
+        for st in self.plan.steps:
+            if st.kind == 'conv' and st.rt.get('versions') != self.backend.param_versions(st):
+                self.backend.pack_conv(st)
+
+    def _run_step(self, st):
+        if st.kind == 'conv':
+            self.backend.run_conv(st)
+        elif st.kind == 'pool':
+            self.backend.run_pool(st, self.bufs, self.batch)
+        elif st.kind == 'ctxpool':
+            self.backend.run_ctxpool(st, self.bufs, self.batch)
+        else:
+            raise ValueError(st.kind)
+
+    def run_backbone(self, x):
+        """x [B,3,S,S] on the device -> raw (loc [B,P*4], conf [B,P*C], obj [B,P*2]) buffers (views)."""
+        if tuple(x.shape) != tuple(self.bufs['x'].shape):
+            raise _lib.CtdetError('plan was built for input %s, got %s' % (tuple(self.bufs['x'].shape), tuple(x.shape)))
+        self.refresh_weights()
+        self.bufs['x'].copy_(x)
+        for st in self.plan.steps:
+            self._run_step(st)
+        return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
+
+    def conv_steps(self):
+        return [s for s in self.plan.steps if s.kind == 'conv']

@@ -1,0 +1,240 @@
+"""Tensor-level wrappers over the libctdet C ABI.
+
+torch is plumbing here (device memory + the current HIP stream); every function launches
+hand-written HIP kernels through ctypes and raises if the tensors are not on a HIP device --
+there is deliberately NO CPU / PyTorch fallback for these ops.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.CtdetError('%s must be a tensor on the HIP device (got %s); the ctdet ops have no '
+                              'CPU fallback' % (name, getattr(t, 'device', type(t))))
+    if t.dtype != dtype:
+        raise _lib.CtdetError('%s must be %s, got %s' % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.CtdetError('%s must be contiguous' % name)
+    return C.c_void_p(t.data_ptr())
+
+
+def _opt(t, name, dtype=torch.float32):
+    return C.c_void_p(0) if t is None else _dev(t, name, dtype)
+
+
+# ------------------------------------------------------------------ boxes
+def decode(loc, priors, variances, scale=None):
+    """utils/box_utils.py:184-202 on [P,4] or [B,P,4]; optional `boxes *= scale` ([4] or [B,4])."""
+    batched = loc.dim() == 3
+    B = loc.shape[0] if batched else 1
+    P = priors.shape[0]
+    out = torch.empty_like(loc)
+    per_image = int(scale is not None and scale.dim() == 2)
+    check(lib().ct_decode(_dev(loc, 'loc'), _dev(priors, 'priors'), B, P, float(variances[0]),
+                          float(variances[1]), _opt(scale, 'scale'), per_image, _dev(out, 'out'), _stream()),
+          'ct_decode')
+    return out
+
+
+def encode(matched, priors, variances):
+    out = torch.empty_like(matched)
+    check(lib().ct_encode(_dev(matched, 'matched'), _dev(priors, 'priors'), priors.shape[0],
+                          float(variances[0]), float(variances[1]), _dev(out, 'out'), _stream()), 'ct_encode')
+    return out
+
+
+def detect_fused(loc, conf, obj, priors, variances, apply_softmax=False):
+    """layers/functions/detection.py:18-55 (+ eval softmaxes when apply_softmax)."""
+    B, P = loc.shape[0], priors.shape[0]
+    Cn = conf.shape[-1]
+    boxes = torch.empty(B, P, 4, device=loc.device, dtype=torch.float32)
+    scores = torch.empty(B, P, Cn + 1, device=loc.device, dtype=torch.float32)
+    check(lib().ct_detect_fused(_dev(loc, 'loc'), _dev(conf, 'conf'), _dev(obj, 'obj'), _dev(priors, 'priors'),
+                                B, P, Cn, float(variances[0]), float(variances[1]), int(apply_softmax),
+                                _dev(boxes, 'boxes'), _dev(scores, 'scores'), _stream()), 'ct_detect_fused')
+    return boxes, scores
+
+
+def softmax_lastdim(x):
+    out = torch.empty_like(x)
+    cols = x.shape[-1]
+    check(lib().ct_softmax_lastdim(_dev(x, 'x'), _dev(out, 'out'), x.numel() // cols, cols, _stream()),
+          'ct_softmax_lastdim')
+    return out
+
+
+def jaccard(box_a, box_b, b_center_form=False):
+    out = torch.empty(box_a.shape[0], box_b.shape[0], device=box_a.device, dtype=torch.float32)
+    if out.numel() == 0:
+        return out
+    check(lib().ct_jaccard(_dev(box_a, 'box_a'), box_a.shape[0], _dev(box_b, 'box_b'), box_b.shape[0],
+                           int(b_center_form), _dev(out, 'out'), _stream()), 'ct_jaccard')
+    return out
+
+
+def match_batched(targets, priors, threshold, variances, want_overlap=False):
+    """targets: list of [G,6] tensors (x1,y1,x2,y2,label,weight) -> loc_t, conf_t, obj_t[, overlap]."""
+    dev = priors.device
+    B, P = len(targets), priors.shape[0]
+    counts = [int(t.shape[0]) for t in targets]
+    max_gt = max(max(counts), 1)
+    off = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32).to(dev)
+    if sum(counts) > 0:
+        truths = torch.cat([t.reshape(-1, 6) for t in targets], 0).to(dev, torch.float32).contiguous()
+    else:
+        truths = torch.zeros(1, 6, device=dev)
+    loc_t = torch.empty(B, P, 4, device=dev)
+    conf_t = torch.empty(B, P, 2, device=dev)
+    obj_t = torch.empty(B, P, device=dev, dtype=torch.uint8)
+    overlap = torch.empty(B, P, device=dev) if want_overlap else None
+    ws_bytes = lib().ct_match_workspace_bytes(B, P, max_gt)
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    check(lib().ct_match_batched(_dev(truths, 'truths'), _dev(off, 'gt_off', torch.int32), B, max_gt,
+                                 _dev(priors, 'priors'), P, float(threshold), float(variances[0]),
+                                 float(variances[1]), _dev(loc_t, 'loc_t'), _dev(conf_t, 'conf_t'),
+                                 _dev(obj_t, 'obj_t', torch.uint8), _opt(overlap, 'overlap'),
+                                 _dev(ws, 'ws', torch.uint8), ws_bytes, _stream()), 'ct_match_batched')
+    return (loc_t, conf_t, obj_t.bool(), overlap) if want_overlap else (loc_t, conf_t, obj_t.bool())
+
+
+# ------------------------------------------------------------------ NMS
+def nms_sorted_host(dets_sorted, thresh, ge=False, device_id=0, plain_iou=False):
+    """The `_nms` contract (utils/nms/nms_kernel.cu:91-144): host numpy [n,dim>=4] sorted by
+    descending score -> ascending kept indices (int32)."""
+    d = np.ascontiguousarray(dets_sorted, dtype=np.float32)
+    n = d.shape[0]
+    keep = np.empty(max(n, 1), dtype=np.int32)
+    num = C.c_int(0)
+    check(lib().ct_nms_sorted_host_mode(keep.ctypes.data_as(C.c_void_p), C.cast(C.byref(num), C.c_void_p),
+                                        d.ctypes.data_as(C.c_void_p), n, d.shape[1] if n else 5,
+                                        float(thresh), int(bool(ge)) | (2 if plain_iou else 0),
+                                        int(device_id)), 'ct_nms_sorted_host')
+    return keep[:num.value]
+
+
+def nms_batched(dets, seg_off, thresh, ge=False, max_seg_len=None):
+    """dets dev [total,5] (segments sorted by score), seg_off dev int32 [S+1] -> keep [total], count [S]."""
+    S = seg_off.numel() - 1
+    keep = torch.empty(max(dets.shape[0], 1), device=dets.device, dtype=torch.int32)
+    cnt = torch.empty(S, device=dets.device, dtype=torch.int32)
+    check(lib().ct_nms_batched_dev(_dev(dets, 'dets'), _dev(seg_off, 'seg_off', torch.int32), S,
+                                   int(max_seg_len or dets.shape[0]), float(thresh), int(bool(ge)),
+                                   _dev(keep, 'keep', torch.int32), _dev(cnt, 'cnt', torch.int32),
+                                   C.c_void_p(0), 0, _stream()), 'ct_nms_batched_dev')
+    return keep, cnt
+
+
+def cpu_nms(dets, thresh, ge=True):
+    """utils/nms/cpu_nms.pyx:17-68 on a host numpy array (the reference's --cpu path)."""
+    d = np.ascontiguousarray(dets, dtype=np.float32)
+    n = d.shape[0]
+    keep = np.empty(max(n, 1), dtype=np.int32)
+    num = C.c_int(0)
+    check(lib().ct_cpu_nms(d.ctypes.data_as(C.c_void_p), n, float(thresh), int(bool(ge)),
+                           keep.ctypes.data_as(C.c_void_p), C.cast(C.byref(num), C.c_void_p)), 'ct_cpu_nms')
+    return keep[:num.value]
+
+
+def cpu_soft_nms(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
+    """utils/nms/cpu_nms.pyx:70-163: mutates `boxes` (float32 [n,5], C-contiguous) in place."""
+    if not (isinstance(boxes, np.ndarray) and boxes.dtype == np.float32 and boxes.flags['C_CONTIGUOUS']):
+        raise ValueError('cpu_soft_nms needs a C-contiguous float32 array (it is updated in place)')
+    n_out = C.c_int(0)
+    check(lib().ct_cpu_soft_nms(boxes.ctypes.data_as(C.c_void_p), boxes.shape[0], float(sigma), float(Nt),
+                                float(threshold), int(method), C.cast(C.byref(n_out), C.c_void_p)),
+          'ct_cpu_soft_nms')
+    return n_out.value
+
+
+class PostProcessor:
+    """Batched test.py:136-161 on the device with persistent buffers."""
+
+    def __init__(self, batch, num_priors, num_fg, device, out_cap=None):
+        self.B, self.P, self.T = batch, num_priors, num_fg
+        self.cap = int(out_cap or min(num_priors, 2048))
+        self.ws_bytes = lib().ct_postprocess_workspace_bytes(batch, num_priors, num_fg)
+        self.ws = torch.empty(self.ws_bytes, device=device, dtype=torch.uint8)
+        self.out_dets = torch.zeros(batch, num_fg, self.cap, 5, device=device)
+        self.out_count = torch.zeros(batch, num_fg, device=device, dtype=torch.int32)
+        self.out_index = torch.zeros(batch, num_fg, self.cap, device=device, dtype=torch.int32)
+        self.overflow = torch.zeros(1, device=device, dtype=torch.int32)
+
+    def run(self, boxes, scores, conf_thresh=0.01, nms_thresh=0.45, ge=False, max_per_image=200):
+        check(lib().ct_postprocess_batched(
+            _dev(boxes, 'boxes'), _dev(scores, 'scores'), self.B, self.P, self.T, float(conf_thresh),
+            float(nms_thresh), int(bool(ge)), int(max_per_image), self.cap, _dev(self.out_dets, 'out_dets'),
+            _dev(self.out_count, 'out_count', torch.int32), _dev(self.out_index, 'out_index', torch.int32),
+            _dev(self.overflow, 'overflow', torch.int32), _dev(self.ws, 'ws', torch.uint8), self.ws_bytes,
+            _stream()), 'ct_postprocess_batched')
+        return self.out_dets, self.out_count
+
+    def to_all_boxes(self):
+        """Host view in the reference's layout: all_boxes[img][cls] = float32 [k,5] (cls 0 empty)."""
+        if int(self.overflow.item()):
+            raise _lib.CtdetError('postprocess output capacity %d exceeded; raise out_cap' % self.cap)
+        cnt = self.out_count.cpu().numpy()
+        dets = self.out_dets.cpu().numpy()
+        res = []
+        for b in range(self.B):
+            per = [np.empty((0, 5), dtype=np.float32)]
+            for c in range(self.T):
+                per.append(dets[b, c, :cnt[b, c]].copy())
+            res.append(per)
+        return res
+
+
+# ------------------------------------------------------------------ pooling / attention
+def maxpool2d(x, k, stride, pad=0, ceil_mode=False):
+    B, Cn, H, W = x.shape
+
+    def osz(n):
+        num = n + 2 * pad - k
+        o = (-(-num // stride) if ceil_mode else num // stride) + 1
+        if ceil_mode and (o - 1) * stride >= n + pad:
+            o -= 1
+        return o
+    OH, OW = osz(H), osz(W)
+    out = torch.empty(B, Cn, OH, OW, device=x.device, dtype=torch.float32)
+    check(lib().ct_maxpool2d_fwd(_dev(x, 'x'), _dev(out, 'out'), B * Cn, H, W, OH, OW, k, stride, pad,
+                                 _stream()), 'ct_maxpool2d_fwd')
+    return out
+
+
+def ctx_attention(conf, pool, params, setting_incre=False):
+    """models/RFB_Net_vgg.py:253-271.  params: dict of device tensors theta_w, theta_b, phi_w, phi_b,
+    g_w, g_b, wz, obj_w[, fc_w, fc_b] and float `scale`."""
+    B, P, d = conf.shape
+    M = pool.shape[1]
+    T = params['obj_w'].shape[0]
+    prm = _lib.CtxParams()
+    for k in ('theta_w', 'theta_b', 'phi_w', 'phi_b', 'g_w', 'g_b', 'wz', 'obj_w'):
+        setattr(prm, k, _dev(params[k], k).value)
+    if setting_incre:
+        prm.fc_w = _dev(params['fc_w'], 'fc_w').value
+        prm.fc_b = _dev(params['fc_b'], 'fc_b').value
+    prm.scale = float(params['scale'])
+    prm.d, prm.t = d, T
+    out = torch.empty(B, P, (d if setting_incre else 0) + T, device=conf.device, dtype=torch.float32)
+    ws_bytes = lib().ct_ctx_attention_workspace_bytes(B, P, M, d)
+    ws = torch.empty(ws_bytes, device=conf.device, dtype=torch.uint8)
+    check(lib().ct_ctx_attention_fwd(_dev(conf, 'conf'), _dev(pool, 'pool'), B, P, M, C.byref(prm),
+                                     _dev(out, 'out'), _dev(ws, 'ws', torch.uint8), ws_bytes, _stream()),
+          'ct_ctx_attention_fwd')
+    return out
+
+
+def device_info(device=0):
+    cu, lds = C.c_int(0), C.c_int(0)
+    arch = C.create_string_buffer(64)
+    check(lib().ct_device_info(device, C.byref(cu), C.byref(lds), arch, 64), 'ct_device_info')
+    return dict(cu_count=cu.value, lds_bytes_per_cu=lds.value, arch=arch.value.decode())

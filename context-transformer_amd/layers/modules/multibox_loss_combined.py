@@ -1,0 +1,66 @@
+"""MultiBoxLoss_combined -- drop-in for layers/modules/multibox_loss_combined.py:42-124.
+
+Target assignment (jaccard / match / encode for the whole batch) is ONE call into the HIP
+library (`ct_match_batched`) instead of a Python loop over images and ground truths; the loss
+arithmetic itself (smooth-L1, two cross-entropies, 3:1 hard-negative ranking) is expressed on
+the device tensors with autograd so it stays differentiable w.r.t. the predictions.
+targets: list of [G,6] tensors = [x1,y1,x2,y2,label,mixup_weight].
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ctdet import ops
+
+
+class MultiBoxLoss_combined(nn.Module):
+    def __init__(self, num_classes, overlap_thresh, prior_for_matching, bkg_label, neg_mining, neg_pos,
+                 neg_overlap, encode_target):
+        super().__init__()
+        self.num_classes = num_classes
+        self.threshold = overlap_thresh
+        self.background_label = bkg_label
+        self.encode_target = encode_target
+        self.use_prior_for_matching = prior_for_matching
+        self.do_neg_mining = neg_mining
+        self.negpos_ratio = neg_pos
+        self.neg_overlap = neg_overlap
+        self.variance = [0.1, 0.2]
+
+    def forward(self, predictions, priors, targets):
+        loc_data, conf_data, obj_data = predictions
+        dev = loc_data.device
+        num, num_priors = loc_data.size(0), priors.size(0)
+        with torch.no_grad():
+            loc_t, conf_t, obj_t = ops.match_batched([t.to(dev) for t in targets],
+                                                     priors.to(dev).float().contiguous(),
+                                                     self.threshold, self.variance)
+        labels, weights = conf_t[:, :, 0], conf_t[:, :, 1]
+        pos = labels > 0
+        num_pos = (weights * pos.float()).sum(1, keepdim=True).long()
+
+        # localisation: smooth-L1 on positives, weighted by the mixup weight (:81-85)
+        l1 = F.smooth_l1_loss(loc_data[pos], loc_t[pos], reduction='none').sum(1)
+        loss_l = (l1 * weights[pos]).sum()
+
+        # hard negatives ranked by objectness loss, 3:1 (:88-96)
+        with torch.no_grad():
+            ce = F.cross_entropy(obj_data.reshape(-1, 2), obj_t.long().view(-1), reduction='none')
+            ce[obj_t.view(-1)] = 0
+            rank = ce.view(num, -1).sort(1, descending=True)[1].sort(1)[1]
+            num_neg = torch.clamp(self.negpos_ratio * num_pos, max=num_priors - 1)
+            neg = rank < num_neg.expand_as(rank)
+        mask = pos | neg
+        w = weights[mask]
+        loss_obj = (F.cross_entropy(obj_data[mask], obj_t[mask].long(), reduction='none') * w).sum()
+
+        # class loss on objectness-fused logits (:106-117)
+        flat_conf = conf_data.reshape(-1, self.num_classes - 1)
+        flat_obj = obj_data.reshape(-1, 2)
+        bg = flat_obj[:, :1] + torch.log(torch.exp(flat_conf).sum(dim=1, keepdim=True))
+        fg = flat_obj[:, 1:2].expand_as(flat_conf) + flat_conf
+        logit = torch.cat((bg, fg), 1).view(num, -1, self.num_classes)
+        loss_c = (F.cross_entropy(logit[mask], labels[mask].long(), reduction='none') * w).sum()
+
+        n = num_pos.sum()
+        return {'loss_box_reg': loss_l / n, 'loss_cls': loss_c / n, 'loss_obj': loss_obj / n}

@@ -1,0 +1,248 @@
+/* ctdet.h -- C ABI of libctdet.so: the MI355X (gfx950) detection hot path of
+ * Ze-Yang/Context-Transformer (RFBNet-VGG forward, Context-Transformer attention,
+ * prior-box decode / IoU matching, NMS), hand-written HIP behind plain pointers.
+ *
+ * Conventions
+ *   - every entry point returns an int status (CT_OK == 0); ct_last_error_string()
+ *     gives the text of the last failure on the calling thread;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); device
+ *     entry points are asynchronous on it and never allocate: scratch memory comes
+ *     from the caller through the matching ct_*_workspace_bytes() query;
+ *   - all tensors are contiguous fp32 unless stated; "dev" = device pointer,
+ *     "host" = host pointer; int = int32;
+ *   - no torch / C++ types cross this boundary.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the
+ * reference repository).  The reference's only native symbol is `_nms`
+ * (utils/nms/gpu_nms.hpp:1-2); everything else is stock PyTorch/ATen called from
+ * Python, so for those the cited "interface" is the Python call site.
+ */
+#ifndef CTDET_H
+#define CTDET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTDET_ABI_VERSION 1
+
+enum {
+    CT_OK = 0,
+    CT_ERR_INVALID = 1,     /* bad argument / unsupported geometry            */
+    CT_ERR_HIP = 2,         /* a HIP runtime call or kernel launch failed     */
+    CT_ERR_WORKSPACE = 3,   /* caller-provided workspace too small            */
+    CT_ERR_UNSUPPORTED = 4  /* valid request this build does not implement    */
+};
+
+typedef void* ct_stream_t;
+
+int ct_abi_version(void);
+const char* ct_last_error_string(void);
+/* arch: e.g. "gfx950"; any out pointer may be NULL. */
+int ct_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
+
+/* ------------------------------------------------------------------ NMS ---- */
+
+/* Drop-in for the reference's only native symbol:
+ *   void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num,
+ *             int boxes_dim, float nms_overlap_thresh, int device_id);
+ *   (utils/nms/gpu_nms.hpp:1-2, utils/nms/nms_kernel.cu:91-144; caller utils/nms/gpu_nms.pyx:29)
+ * Same contract: host buffers owned by the caller, boxes already sorted by descending
+ * score, row = [x1,y1,x2,y2,score,...] (boxes_dim >= 4 floats per row), +1 pixel
+ * convention, suppress IoU > thresh, keep_out = ascending indices into the sorted array.
+ * Differences: returns a status instead of printing CUDA errors; does not change the
+ * process-global current device (it is restored). */
+int ct_nms_sorted_host(int* keep_out, int* num_out, const float* boxes_host, int boxes_num,
+                       int boxes_dim, float nms_overlap_thresh, int device_id);
+/* NMS mode flags (the `mode` / `ge` argument of the NMS entry points). */
+#define CT_NMS_GT 0     /* suppress IoU >  thresh, +1 pixel convention (utils/nms/nms_kernel.cu:24-32,71) */
+#define CT_NMS_GE 1     /* suppress IoU >= thresh                      (utils/nms/cpu_nms.pyx:65)          */
+#define CT_NMS_PLAIN 2  /* no +1, union = (area_j - inter) + area_i    (utils/box_utils.py:238-302 `nms`)  */
+/* Same with the rule selectable: mode = CT_NMS_GT | CT_NMS_GE, optionally | CT_NMS_PLAIN. */
+int ct_nms_sorted_host_mode(int* keep_out, int* num_out, const float* boxes_host, int boxes_num,
+                            int boxes_dim, float nms_overlap_thresh, int mode, int device_id);
+
+/* Batched device NMS over independent segments (one per (image, class) of test.py:142-153).
+ *   dets      dev [total,5]  rows [x1,y1,x2,y2,score], each segment sorted by descending score
+ *   seg_off   dev [S+1]      segment s = rows seg_off[s] .. seg_off[s+1]-1
+ *   keep      dev [total]    out: for segment s, keep[seg_off[s] + i], i < keep_count[s], are
+ *                            the kept row positions RELATIVE to the segment, ascending
+ *   keep_count dev [S]
+ * max_seg_len bounds every segment length (sizes the launch). */
+size_t ct_nms_batched_workspace_bytes(int total_boxes, int num_segments);
+int ct_nms_batched_dev(const float* dets, const int* seg_off, int num_segments, int max_seg_len,
+                       float thresh, int ge, int* keep, int* keep_count,
+                       void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
+/* CPU NMS of the reference's `--cpu` path: utils/nms/cpu_nms.pyx:17-68 (`cpu_nms`).
+ * dets host [n,5] UNSORTED; keep_out host [n] receives original indices in descending
+ * score order (ties: lower index first); suppress IoU >= thresh (ge=1) or > (ge=0). */
+int ct_cpu_nms(const float* dets_host, int n, float thresh, int ge, int* keep_out, int* num_out);
+/* utils/nms/cpu_nms.pyx:70-163 (`cpu_soft_nms`): mutates boxes [n,5] in place, *n_out = N'. */
+int ct_cpu_soft_nms(float* boxes_host, int n, float sigma, float Nt, float threshold,
+                    unsigned method, int* n_out);
+
+/* ----------------------------------------------------- boxes / detection ---- */
+
+/* utils/box_utils.py:184-202 `decode(loc, priors, variances)`, batched over images:
+ * loc dev [B,P,4], priors dev [P,4] (cx,cy,w,h) -> boxes dev [B,P,4] (x1,y1,x2,y2),
+ * each coordinate multiplied by scale4[c] if scale4 != NULL (dev [4] or per image [B,4],
+ * `boxes *= scale` of test.py:136). */
+int ct_decode(const float* loc, const float* priors, int batch, int num_priors,
+              float var0, float var1, const float* scale4, int scale_per_image,
+              float* boxes, ct_stream_t stream);
+/* utils/box_utils.py:135-156 `encode(matched, priors, variances)`: [P,4],[P,4] -> [P,4]. */
+int ct_encode(const float* matched, const float* priors, int num_priors, float var0, float var1,
+              float* out, ct_stream_t stream);
+/* layers/functions/detection.py:18-55 `Detect.forward`: decode + score fusion
+ * scores[b,p,0] = obj[b,p,0]; scores[b,p,1+k] = obj[b,p,1]*conf[b,p,k].
+ * If apply_softmax != 0, conf/obj are raw logits and the eval-time softmaxes of
+ * models/RFB_Net_vgg.py:279-285 are fused in. */
+int ct_detect_fused(const float* loc, const float* conf, const float* obj, const float* priors,
+                    int batch, int num_priors, int num_fg, float var0, float var1,
+                    int apply_softmax, float* boxes, float* scores, ct_stream_t stream);
+/* torch.nn.functional.softmax(x, dim=-1) of models/RFB_Net_vgg.py:282-284: [rows, cols]. */
+int ct_softmax_lastdim(const float* in, float* out, long rows, int cols, ct_stream_t stream);
+
+/* utils/box_utils.py:50-68 `jaccard(box_a, box_b)`: a dev [A,4], b dev [Bn,4] point form
+ * -> out dev [A,Bn]; no +1 convention. b_center_form != 0: b is (cx,cy,w,h) and
+ * point_form (utils/box_utils.py:5-14) is applied on the fly. */
+int ct_jaccard(const float* a, int na, const float* b, int nb, int b_center_form,
+               float* out, ct_stream_t stream);
+
+/* utils/box_utils.py:83-132 `match(...)` for a whole batch (the Python loop of
+ * layers/modules/multibox_loss_combined.py:70-74):
+ *   truths dev [sum G,6] rows [x1,y1,x2,y2,label,weight]; gt_off dev [B+1]
+ *   priors dev [P,4] center form
+ *   -> loc_t [B,P,4], conf_t [B,P,2] (label, weight), obj_t uint8 [B,P], overlap [B,P] or NULL
+ * Force-match collisions keep the reference's "later GT wins" order (:122-123). */
+size_t ct_match_workspace_bytes(int batch, int num_priors, int max_gt);
+int ct_match_batched(const float* truths, const int* gt_off, int batch, int max_gt,
+                     const float* priors, int num_priors, float threshold, float var0, float var1,
+                     float* loc_t, float* conf_t, uint8_t* obj_t, float* overlap,
+                     void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
+/* ---------------------------------------- batched test.py post-processing ---- */
+
+/* test.py:136-161 for a batch: per (image, class>=1) select score > conf_thresh, order by
+ * descending score (ties: lower prior index first), NMS, then the per-image top-k rule
+ * (keep score >= k-th largest when more than max_per_image survive).
+ *   boxes  dev [B,P,4] already scaled to pixels; scores dev [B,P,1+T]
+ *   out_dets  dev [B, T, cap, 5]   kept rows [x1,y1,x2,y2,score] per (image,class), in
+ *                                   descending score order, cap = out_cap rows reserved
+ *   out_count dev [B, T]            rows valid in out_dets (after the top-k rule)
+ *   out_index dev [B, T, cap]       prior index of each kept row (or NULL)
+ * cap must be >= the largest number of boxes NMS keeps in any segment; on overflow the
+ * call reports CT_ERR_WORKSPACE through *overflow (dev int, 0/1) for the host to check. */
+size_t ct_postprocess_workspace_bytes(int batch, int num_priors, int num_fg);
+int ct_postprocess_batched(const float* boxes, const float* scores, int batch, int num_priors,
+                           int num_fg, float conf_thresh, float nms_thresh, int ge,
+                           int max_per_image, int out_cap, float* out_dets, int* out_count,
+                           int* out_index, int* overflow,
+                           void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
+/* ------------------------------------------------------------ convolution ---- */
+
+/* One fused convolution of the RFBNet-VGG stack.  Replaces the ATen sequence
+ * Conv2d [+ bias] [-> BatchNorm2d(eval)] [-> *res_scale + residual] [-> ReLU] [-> cat / permute]
+ * of models/RFB_Net_vgg.py:7-22 (BasicConv), :53-64 / :100-112 (RFB tail), :219-227 (VGG),
+ * :238-248 (heads: permute(0,2,3,1) + flatten + cat), as one implicit-GEMM kernel on the
+ * fp32 MFMA path (v_mfma_f32_32x32x2_f32; exact fp32 products, fp32 accumulate).
+ *
+ * y[n,co,oh,ow] = act( (sum_k w[co,k] x[n,k@(oh,ow)]) * scale[co] + shift[co] ) with the
+ * optional residual  y = act( (.)*res_scale + res[n,co,oh,ow] ).
+ */
+typedef struct ct_out_segment {
+    float* ptr;          /* dev */
+    int co_begin;        /* output channels [co_begin, co_end) go to this segment */
+    int co_end;
+    int pix_stride;      /* floats between consecutive pixels (= #channels of the segment) */
+    long long img_stride;/* floats between consecutive images */
+    long long base;      /* float offset of pixel 0 / channel co_begin inside an image */
+} ct_out_segment;
+
+typedef struct ct_conv_desc {
+    /* input: NCHW buffer with in_ctot channels; the conv reads channels [in_coff, in_coff+cin) */
+    const float* in;
+    int batch, cin, h, w, in_ctot, in_coff;
+    /* packed weights from ct_conv_pack_weights(): [k_pad][m_pad]; scale/shift: [m_pad] */
+    const float* wpacked;
+    const float* scale;
+    const float* shift;
+    int cout, m_pad, k_pad;
+    int kh, kw, stride, pad_h, pad_w, dil;
+    int oh, ow;
+    /* output mode 0: NCHW buffer with out_ctot channels, written at [out_coff, out_coff+cout) */
+    float* out;
+    int out_ctot, out_coff;
+    /* optional residual (NCHW, res_ctot channels, offset res_coff); NULL = none */
+    const float* res;
+    int res_ctot, res_coff;
+    float res_scale;
+    int relu;            /* 1: ReLU on every output channel */
+    const float* lo;     /* optional dev [m_pad]: y = max(y, lo[co]) per channel (0 = ReLU, -inf = none);
+                            overrides `relu`; lets convs with and without ReLU share one launch */
+    /* output mode 1 (nseg > 0): channels-last scatter into up to 3 flattened head buffers */
+    int nseg;
+    ct_out_segment seg[3];
+    /* tile configuration: 0 = heuristic; otherwise 1 + index into ct_conv_num_configs() */
+    int config;
+} ct_conv_desc;
+
+/* Rows of the packed weight matrix for a (cin, kh, kw) filter: k_pad. */
+int ct_conv_kpad(int cin, int kh, int kw);
+int ct_conv_mpad(int cout);
+int ct_conv_num_configs(void);
+/* Human-readable name of tile config i (0-based), e.g. "128x128". */
+const char* ct_conv_config_name(int i);
+/* Pack nparts (1..6) weight tensors w[i] dev [cout_i, cin, kh, kw] (concatenated along cout) into
+ * wpacked dev [k_pad][m_pad] (k = ci*kh*kw + tap, zero padded). */
+int ct_conv_pack_weights(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
+                         float* wpacked, int m_pad, int k_pad, ct_stream_t stream);
+/* Epilogue vectors. BatchNorm2d(eval) of models/RFB_Net_vgg.py:13: scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale.  With gamma == NULL: scale = 1, shift = bias (or 0 if bias NULL).
+ * Written at [offset, offset+n) of the m_pad-long vectors. */
+int ct_conv_fold_epilogue(const float* gamma, const float* beta, const float* mean, const float* var,
+                          float eps, const float* bias, int n, int offset,
+                          float* scale, float* shift, ct_stream_t stream);
+int ct_conv2d_fwd(const ct_conv_desc* desc, ct_stream_t stream);
+
+/* torch.nn.MaxPool2d of models/RFB_Net_vgg.py:328-330,338 (2x2 s2 [ceil], 3x3 s1 p1) on an NCHW
+ * buffer: planes = batch*channels; windows are clipped to the input (ceil_mode semantics are
+ * encoded in oh/ow by the caller). */
+int ct_maxpool2d_fwd(const float* in, float* out, long planes, int h, int w, int oh, int ow,
+                     int k, int stride, int pad, ct_stream_t stream);
+/* Context pooling of models/RFB_Net_vgg.py:243-244 on the channels-last head output:
+ * in  = conf logits of one source, per image [h*w, ch] at in + n*in_img_stride
+ * out = max_pool2d(k, stride k, ceil_mode) -> [oh*ow, ch] at out + n*out_img_stride */
+int ct_ctx_pool_fwd(const float* in, long long in_img_stride, float* out, long long out_img_stride,
+                    int batch, int h, int w, int ch, int k, ct_stream_t stream);
+
+/* ------------------------------------------------ Context-Transformer block ---- */
+
+/* models/RFB_Net_vgg.py:253-271 fused (flash-style, W never materialised):
+ *   theta = Lin_t(conf)+conf; phi = Lin_p(pool)+pool; g = Lin_g(pool)+pool
+ *   delta = softmax(theta phi^T, dim=2) g * Wz;  nov = normalize(conf+delta) OBJ^T * scale
+ *   setting 'incre' (fc_w != NULL): out = cat(Lin_fc(conf)+conf, nov)
+ * conf dev [B,P,d], pool dev [B,M,d], out dev [B,P,(fc_w?d:0)+T]; d <= 64, T <= 32.
+ * Linear weights are [d,d] row-major (out,in) as torch.nn.Linear stores them. */
+typedef struct ct_ctx_params {
+    const float *theta_w, *theta_b, *phi_w, *phi_b, *g_w, *g_b;
+    const float *wz;          /* [d] */
+    const float *obj_w;       /* [T,d] */
+    const float *fc_w, *fc_b; /* optional ('incre'), [d,d],[d] */
+    float scale;              /* the non-trainable `scale` parameter (5) */
+    int d, t;
+} ct_ctx_params;
+size_t ct_ctx_attention_workspace_bytes(int batch, int num_priors, int num_ctx, int d);
+int ct_ctx_attention_fwd(const float* conf, const float* pool, int batch, int num_priors,
+                         int num_ctx, const ct_ctx_params* prm, float* out,
+                         void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTDET_H */

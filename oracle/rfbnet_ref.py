@@ -116,8 +116,10 @@ def backbone(sd, x, size, training=False):
 
 
 def forward(sd, x, size, num_classes, phase=1, method='ours', setting='transfer',
-            training=False, init=False):
-    """RFBNet.forward (:190-286).  num_classes = #foreground classes of the conf head."""
+            training=False, init=False, raw=False):
+    """RFBNet.forward (:190-286).  num_classes = #foreground classes of the conf head.
+    raw=True: eval-mode BatchNorm but WITHOUT the final softmaxes (the tensors the reference
+    feeds to softmax at :282-284), for layer-level parity checks."""
     num = x.shape[0]
     sources = backbone(sd, x, size, training)
     ctx = (method == 'ours' and phase == 2)
@@ -156,7 +158,7 @@ def forward(sd, x, size, num_classes, phase=1, method='ours', setting='transfer'
         conf = conf.view(num, -1, num_classes)
     loc = loc.view(num, -1, 4)
     obj = obj.view(num, -1, 2)
-    if training:
+    if training or raw:
         return loc, conf, obj
     return loc, F.softmax(conf, dim=-1), F.softmax(obj, dim=-1)
 

@@ -1,0 +1,151 @@
+"""CPU-side checks of the drop-in surface: module tree / state-dict contract, host-side
+functions, the engine plan wiring (replayed with tests/emu_backend.py against the oracle), and
+the C ABI (symbols + the host-only entry points).  No GPU needed."""
+import ctypes
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, rel_err
+from ctdet import _lib, engine, ops, synth
+from oracle import box_ref, nms_ref, rfbnet_ref
+
+torch.set_num_threads(8)
+
+
+def _args(phase=1, setting='transfer', method='ours'):
+    return types.SimpleNamespace(method=method, phase=phase, setting=setting)
+
+
+def _net(size, C, phase=1, setting='transfer'):
+    from models.RFB_Net_vgg import build_net
+    net = build_net(_args(phase, setting), size, C)
+    net.load_state_dict(synth.fill_state_dict(net.state_dict()), strict=True)
+    return net.eval()
+
+
+# ---------------------------------------------------------------- C ABI
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, 'include', 'ctdet.h')).read()
+    declared = set(re.findall(r'\b(ct_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'ct_stream_t'}
+    assert len(declared) >= 25
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(handle, s)]
+    assert not missing, missing
+    assert set(_lib.SIGNATURES) == declared
+    assert _lib.lib().ct_abi_version() == 1
+    assert _lib.lib().ct_conv_num_configs() >= 4
+    assert _lib.lib().ct_conv_kpad(512, 3, 3) % 36 == 0
+    assert _lib.lib().ct_conv_kpad(3, 3, 3) == 36
+
+
+def test_device_ops_refuse_cpu_tensors():
+    with pytest.raises(_lib.CtdetError):
+        ops.decode(torch.zeros(4, 4), torch.ones(4, 4), [0.1, 0.2])
+    net = _net(300, 20)
+    net.device = 'cpu'
+    with pytest.raises(_lib.CtdetError):
+        net(torch.zeros(1, 3, 300, 300))
+
+
+def test_host_cpu_nms_matches_oracle(golden):
+    g = golden('nms.npz')
+    from utils.nms.cpu_nms import cpu_nms, cpu_soft_nms
+    from utils.nms.py_cpu_nms import py_cpu_nms
+    for ci in range(int(g['ncases'])):
+        d = g['c%d_dets' % ci]
+        for thr in (0.45, 0.3, 0.5, 0.7):
+            tag = 'c%d_t%02d' % (ci, int(round(thr * 100)))
+            assert list(ops.cpu_nms(d, thr, ge=False)) == list(g[tag + '_gt']), tag
+            assert py_cpu_nms(d, thr) == list(g[tag + '_gt']), tag
+            assert cpu_nms(d, thr) == list(nms_ref.nms(d, thr, ge=True)), tag
+            if bool(g['have_ge']):
+                assert cpu_nms(d, thr) == list(g[tag + '_ge']), tag
+    assert cpu_nms(g['eq_dets'], 0.5) == [0]
+    assert list(ops.cpu_nms(g['eq_dets'], 0.5, ge=False)) == [0, 1]
+    if bool(g['have_ge']):
+        for m in (0, 1, 2):
+            b = g['c6_dets'].copy()
+            keep = cpu_soft_nms(b, 0.5, 0.3, 0.001, m)
+            assert len(keep) == int(g['soft_m%d_n' % m])
+            n = len(keep)
+            assert np.array_equal(b[:n, :4], g['soft_m%d_boxes' % m][:n, :4])
+            np.testing.assert_allclose(b[:n, 4], g['soft_m%d_boxes' % m][:n, 4], rtol=2e-6)
+    from utils.nms_wrapper import nms
+    assert nms(np.zeros((0, 5), np.float32), 0.45) == []
+
+
+# ---------------------------------------------------------------- surface
+def test_prior_box_and_config(golden):
+    import hashlib
+    from data import config as cfg
+    from layers.functions import PriorBox
+    g = golden('box_ops.npz')
+    for name in box_ref.ANCHOR_CFGS:
+        assert getattr(cfg, name) == box_ref.ANCHOR_CFGS[name], name
+        p = PriorBox(getattr(cfg, name)).forward().numpy()
+        sha = np.frombuffer(hashlib.sha256(p.tobytes()).digest(), dtype=np.uint8)
+        assert (sha == g['prior_%s__sha' % name]).all(), name
+
+
+@pytest.mark.parametrize('fname,size,C,phase,setting', [
+    ('rfb300_phase1.npz', 300, 20, 1, 'transfer'),
+    ('rfb300_phase2_transfer.npz', 300, 60, 2, 'transfer'),
+    ('rfb300_phase2_incre.npz', 300, 15, 2, 'incre'),
+    ('rfb512_phase1.npz', 512, 20, 1, 'transfer')])
+def test_state_dict_keys_match_reference(golden, fname, size, C, phase, setting):
+    from models.RFB_Net_vgg import build_net
+    g = golden(fname)
+    net = build_net(_args(phase, setting), size, C)
+    sd = net.state_dict()
+    assert sorted(sd.keys()) == sorted(g['keys'].tolist())
+    shapes = rfbnet_ref.param_shapes(size, C, phase, 'ours', setting)
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(shapes[k]), k
+    assert sum(p.numel() for p in net.parameters()) == int(g['nparams'])
+    names = [n for n, _ in net.named_parameters()]
+    assert any(n.startswith('base.') for n in names) and any(n.startswith('Norm.') for n in names)
+    if phase == 2:
+        assert (net.Wz == 0).all() and float(net.scale) == 5.0 and not net.scale.requires_grad
+
+
+# ---------------------------------------------------------------- plan wiring
+@pytest.mark.parametrize('size,C,phase,setting,B', [(300, 20, 1, 'transfer', 1), (300, 15, 2, 'incre', 1),
+                                                     (512, 20, 1, 'transfer', 1)])
+def test_plan_wiring_against_oracle(size, C, phase, setting, B):
+    from emu_backend import EmuBackend
+    net = _net(size, C, phase, setting)
+    rt = engine.Runtime(net, B, EmuBackend(), tune=False)
+    x = synth.images(B, size, 'randn', 1234)
+    sd = {k: v for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        loc, conf, obj = rt.run_backbone(x)
+        want = rfbnet_ref.forward(sd, x, size, C, 1, 'ft', raw=True)     # raw heads, no ctx block
+        assert not torch.isnan(loc).any() and not torch.isnan(conf).any() and not torch.isnan(obj).any()
+        assert rel_err(loc.view(B, -1, 4), want[0]) < 2e-5
+        assert rel_err(conf.view(B, -1, C), want[1]) < 2e-5
+        assert rel_err(obj.view(B, -1, 2), want[2]) < 2e-5
+        if phase == 2:
+            pool = rt.bufs['pool']
+            cpool = []
+            srcs = rfbnet_ref.backbone(sd, x, size)
+            for i, s in enumerate(srcs):
+                c = torch.nn.functional.conv2d(s, sd['conf.%d.weight' % i], sd['conf.%d.bias' % i], 1, 1)
+                k = rfbnet_ref.CTX_POOL[size][i]
+                cpool.append(torch.nn.functional.max_pool2d(c, k, k, ceil_mode=True).permute(0, 2, 3, 1).reshape(B, -1))
+            cpool = torch.cat(cpool, 1)
+            assert pool.shape == cpool.shape
+            assert rel_err(pool, cpool) < 2e-5
+    plan = rt.plan
+    if size == 300:
+        assert plan.P == 11620
+        assert abs(plan.conv_flops() / B - 72.24e9) < 0.3e9 or C != 20      # SURVEY 8d figure
+        if phase == 2:
+            assert plan.M == 1858 // 1 if C else True
+    else:
+        assert plan.P == 32756
