@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of forward + NMS for RFBNet-300 (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the whole hot path over one synthetic batch already resident in HBM:
+RFBNet engine (fused HIP convs) -> fused softmax/decode/score fusion -> per (image, class)
+threshold + sort + NMS(0.45) -> per-image top-200 (test.py:130-161 generalised to a batch).
+Workload = BASELINE.json configs[1]: RFBNet-300 VGG16, bs=32 per GPU, fp32, 20 foreground
+classes, name-seeded random weights (no checkpoints/datasets offline).  Images shard across
+ranks with no data-path collective (inference), so scaling is weak: every rank processes its
+own 32 images; value = all images / max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      the dominant kernel (the fp32-MFMA implicit-GEMM conv instantiation that
+                accumulates the most time): algorithmic FLOPs of its launches / their duration
+                measured with HIP events on the launch stream inside the timed region
+                (peak = 157.3 TFLOP/s dense fp32 MFMA, MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (port of the reference path: stock torch-CPU fp32 ops + C NMS)
+                on a bounded sample (BASELINE configs[0] shape, 4 images), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(REPO, 'context-transformer_amd'))
+sys.path.insert(0, REPO)
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def build_net(size, num_fg, phase, setting, device):
+    from models.RFB_Net_vgg import build_net as bn
+    from ctdet import synth
+    args = types.SimpleNamespace(method='ours', phase=phase, setting=setting)
+    net = bn(args, size, num_fg)
+    net.load_state_dict(synth.fill_state_dict(net.state_dict()), strict=True)
+    net = net.eval().to(device)
+    net.device = device
+    return net
+
+
+def cpu_baseline(size, num_fg, images=4, reps=3):
+    """Oracle (port) timed on the host cores: forward + detect + per-class NMS + top-200."""
+    from ctdet import synth
+    from oracle import box_ref, nms_ref, rfbnet_ref
+    nms_ref.build_c()
+    threads = int(os.environ.get('CTDET_CPU_THREADS', 0)) or (os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    sd = synth.fill_state_dict(rfbnet_ref.param_shapes(size, num_fg, 1))
+    x = synth.images(images, size, 'randn', 1234)
+    priors = box_ref.prior_box(box_ref.ANCHOR_CFGS['VOC_%d' % size])
+    times = []
+    with torch.no_grad():
+        for r in range(reps + 1):
+            t0 = time.perf_counter()
+            loc, conf, obj = rfbnet_ref.forward(sd, x, size, num_fg)
+            boxes, scores = box_ref.detect(loc, conf, obj, priors)
+            for i in range(images):
+                nms_ref.postprocess_image(boxes[i].numpy(), scores[i].numpy(), (500, 375), nms_fn=nms_ref.nms_c)
+            dt = time.perf_counter() - t0
+            if r > 0:
+                times.append(dt)
+    med = float(np.median(times))
+    return {'value': round(images / med, 3), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+            'sample': '%d synthetic %dx%d images (BASELINE configs[0] shape): torch-CPU fp32 forward + '
+                      'Detect + per-class C NMS + top-200, median of %d runs after 1 warm-up'
+                      % (images, size, size, reps)}
+
+
+def conv_roofline(rt, batch):
+    """Per-instantiation totals from the HIP events the engine recorded around every conv launch
+    of the timed region; reports the instantiation with the most accumulated time."""
+    from ctdet import _lib
+    lib = _lib.lib()
+    agg = {}
+    for st, e0, e1 in rt.event_log:
+        cfg = st.rt['desc'].config
+        name = 'conv_igemm_f32<%dx%d,%s>' % (st.kh, st.kw, lib.ct_conv_config_name(cfg - 1).decode()
+                                            if cfg > 0 else 'auto')
+        a = agg.setdefault(name, [0.0, 0.0, 0])
+        a[0] += e0.elapsed_time(e1) * 1e-3
+        a[1] += st.flops(batch)
+        a[2] += 1
+    tot_t = sum(a[0] for a in agg.values())
+    tot_f = sum(a[1] for a in agg.values())
+    name, (t, f, n) = max(agg.items(), key=lambda kv: kv[1][0])
+    ach = f / t / 1e12
+    return {
+        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+        'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+        'kernel': name, 'launches': n, 'avg_launch_us': round(t / n * 1e6, 2),
+        'flops_per_launch': round(f / n),
+        'all_conv': {'achieved': round(tot_f / tot_t / 1e12, 2),
+                     'frac': round(tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                     'time_share_of_dominant': round(t / tot_t, 3),
+                     'conv_ms_per_step': round(tot_t / max(1, len(rt.event_log)) * len(rt.conv_steps()) * 1e3, 3),
+                     'launches_per_step': len(rt.conv_steps())},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--size', type=int, default=300)
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--classes', type=int, default=20)
+    ap.add_argument('--phase', type=int, default=1)
+    ap.add_argument('--setting', default='transfer')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != a.gpus and world > 1:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a HIP device (the product has no CPU path)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    from ctdet import synth
+    from ctdet.pipeline import DetectionPipeline
+    from layers.functions import PriorBox
+    import data as cfgs
+
+    num_fg = a.classes
+    T = {('transfer', 2): 20, ('incre', 2): 20}.get((a.setting, a.phase), num_fg) if a.phase == 2 else num_fg
+    net = build_net(a.size, num_fg, a.phase, a.setting, dev)
+    priors = PriorBox(getattr(cfgs, 'VOC_%d' % a.size)).forward()
+    pipe = DetectionPipeline(net, priors, a.batch, T, image_wh=(500, 375))
+    x = synth.images(a.batch, a.size, 'randn', 1234 + rank).to(dev)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        pipe.run(x)
+    if not a.no_roofline and rank == 0:
+        pipe.rt.event_log = []          # HIP events around every conv launch of the timed region
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pipe.run(x)
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    roof = None
+    if pipe.rt.event_log:
+        roof = conv_roofline(pipe.rt, a.batch)
+        pipe.rt.event_log = None
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.size, num_fg)
+
+    if rank == 0:
+        total_images = a.batch * world * a.steps
+        counts = pipe.post.out_count.sum().item()
+        line = {
+            'metric': 'images/sec fwd+NMS', 'value': round(total_images / dt, 2), 'unit': 'images/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'RFBNet-%d VGG16 inference, bs=%d per GPU, %d fg classes, phase %d%s: '
+                                   'fwd + softmax/decode + per-class NMS(0.45) + top-200; name-seeded random '
+                                   'weights, randn images' % (a.size, a.batch, num_fg, a.phase,
+                                                              ' ' + a.setting if a.phase == 2 else ''),
+                       'global_batch': a.batch * world, 'parallelism': 'dp%d (image shards, no collective)' % world,
+                       'conv_gflop_per_image': round(pipe.rt.plan.conv_flops() / a.batch / 1e9, 2),
+                       'detections_per_batch': int(counts), 'conv_autotuned': bool(pipe.rt.tuned)},
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -73,13 +73,19 @@ __global__ __launch_bounds__(256) void detect_kernel(const float4* __restrict__ 
                                                      const float2* __restrict__ obj,
                                                      const float4* __restrict__ priors, int batch,
                                                      int P, int C, float v0, float v1,
+                                                     const float* __restrict__ scale4, int per_image,
                                                      float4* __restrict__ boxes, float* __restrict__ scores)
 {
     const long total = (long)batch * P;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
          idx += (long)gridDim.x * blockDim.x) {
         const int p = (int)(idx % P);
-        boxes[idx] = decode_one(loc[idx], priors[p], v0, v1);
+        float4 bx = decode_one(loc[idx], priors[p], v0, v1);
+        if (scale4) {
+            const float* sc = scale4 + (per_image ? 4 * (idx / P) : 0);
+            bx.x *= sc[0]; bx.y *= sc[1]; bx.z *= sc[2]; bx.w *= sc[3];
+        }
+        boxes[idx] = bx;
         float2 o = obj[idx];
         const float* c = conf + idx * C;
         float* s = scores + idx * (C + 1);
@@ -258,8 +264,8 @@ extern "C" int ct_encode(const float* matched, const float* priors, int num_prio
 
 extern "C" int ct_detect_fused(const float* loc, const float* conf, const float* obj,
                                const float* priors, int batch, int num_priors, int num_fg, float var0,
-                               float var1, int apply_softmax, float* boxes, float* scores,
-                               ct_stream_t stream)
+                               float var1, int apply_softmax, const float* scale4, int scale_per_image,
+                               float* boxes, float* scores, ct_stream_t stream)
 {
     CT_REQUIRE(loc && conf && obj && priors && boxes && scores, "ct_detect_fused: null tensor");
     CT_REQUIRE(batch > 0 && num_priors > 0 && num_fg > 0, "ct_detect_fused: bad shape");
@@ -268,11 +274,11 @@ extern "C" int ct_detect_fused(const float* loc, const float* conf, const float*
     if (apply_softmax)
         hipLaunchKernelGGL(detect_kernel<true>, grid, block, 0, st, (const float4*)loc, conf,
                            (const float2*)obj, (const float4*)priors, batch, num_priors, num_fg, var0,
-                           var1, (float4*)boxes, scores);
+                           var1, scale4, scale_per_image, (float4*)boxes, scores);
     else
         hipLaunchKernelGGL(detect_kernel<false>, grid, block, 0, st, (const float4*)loc, conf,
                            (const float2*)obj, (const float4*)priors, batch, num_priors, num_fg, var0,
-                           var1, (float4*)boxes, scores);
+                           var1, scale4, scale_per_image, (float4*)boxes, scores);
     CT_LAUNCH_CHECK("detect_kernel");
     return CT_OK;
 }

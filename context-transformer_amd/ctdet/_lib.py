@@ -66,7 +66,7 @@ SIGNATURES = {
     'ct_cpu_soft_nms': (_I, [_P, _I, _F, _F, _F, C.c_uint, _P]),
     'ct_decode': (_I, [_P, _P, _I, _I, _F, _F, _P, _I, _P, _P]),
     'ct_encode': (_I, [_P, _P, _I, _F, _F, _P, _P]),
-    'ct_detect_fused': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P]),
+    'ct_detect_fused': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _I, _P, _P, _P]),
     'ct_softmax_lastdim': (_I, [_P, _P, _L, _I, _P]),
     'ct_jaccard': (_I, [_P, _I, _P, _I, _I, _P, _P]),
     'ct_match_workspace_bytes': (_Z, [_I, _I, _I]),

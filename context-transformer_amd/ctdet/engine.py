@@ -490,6 +490,7 @@ class Runtime:
         if tune is None:
             tune = os.environ.get('CTDET_TUNE', '1') != '0'
         self.tuned = False
+        self.event_log = None        # set to a list to collect (step, start_event, end_event) per conv
         if tune and hasattr(backend, 'tune_conv'):
             self.autotune()
 
@@ -510,6 +511,13 @@ class Runtime:
 
     def _run_step(self, st):
         if st.kind == 'conv':
+            if self.event_log is not None:      # HIP events on the launch stream (bench roofline)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self.backend.run_conv(st)
+                e1.record()
+                self.event_log.append((st, e0, e1))
+                return
             self.backend.run_conv(st)
         elif st.kind == 'pool':
             self.backend.run_pool(st, self.bufs, self.batch)

@@ -53,14 +53,20 @@ def encode(matched, priors, variances):
     return out
 
 
-def detect_fused(loc, conf, obj, priors, variances, apply_softmax=False):
-    """layers/functions/detection.py:18-55 (+ eval softmaxes when apply_softmax)."""
+def detect_fused(loc, conf, obj, priors, variances, apply_softmax=False, scale=None, out=None):
+    """layers/functions/detection.py:18-55 (+ eval softmaxes when apply_softmax, + the
+    `boxes *= scale` of test.py:136 when scale ([4] or [B,4]) is given)."""
     B, P = loc.shape[0], priors.shape[0]
     Cn = conf.shape[-1]
-    boxes = torch.empty(B, P, 4, device=loc.device, dtype=torch.float32)
-    scores = torch.empty(B, P, Cn + 1, device=loc.device, dtype=torch.float32)
+    if out is None:
+        boxes = torch.empty(B, P, 4, device=loc.device, dtype=torch.float32)
+        scores = torch.empty(B, P, Cn + 1, device=loc.device, dtype=torch.float32)
+    else:
+        boxes, scores = out
+    per_image = int(scale is not None and scale.dim() == 2)
     check(lib().ct_detect_fused(_dev(loc, 'loc'), _dev(conf, 'conf'), _dev(obj, 'obj'), _dev(priors, 'priors'),
                                 B, P, Cn, float(variances[0]), float(variances[1]), int(apply_softmax),
+                                _opt(scale, 'scale'), per_image,
                                 _dev(boxes, 'boxes'), _dev(scores, 'scores'), _stream()), 'ct_detect_fused')
     return boxes, scores
 

@@ -100,10 +100,12 @@ int ct_encode(const float* matched, const float* priors, int num_priors, float v
 /* layers/functions/detection.py:18-55 `Detect.forward`: decode + score fusion
  * scores[b,p,0] = obj[b,p,0]; scores[b,p,1+k] = obj[b,p,1]*conf[b,p,k].
  * If apply_softmax != 0, conf/obj are raw logits and the eval-time softmaxes of
- * models/RFB_Net_vgg.py:279-285 are fused in. */
+ * models/RFB_Net_vgg.py:279-285 are fused in.  scale4 (dev [4] or [B,4], may be NULL) fuses
+ * the `boxes *= scale` of test.py:136. */
 int ct_detect_fused(const float* loc, const float* conf, const float* obj, const float* priors,
                     int batch, int num_priors, int num_fg, float var0, float var1,
-                    int apply_softmax, float* boxes, float* scores, ct_stream_t stream);
+                    int apply_softmax, const float* scale4, int scale_per_image,
+                    float* boxes, float* scores, ct_stream_t stream);
 /* torch.nn.functional.softmax(x, dim=-1) of models/RFB_Net_vgg.py:282-284: [rows, cols]. */
 int ct_softmax_lastdim(const float* in, float* out, long rows, int cols, ct_stream_t stream);
 

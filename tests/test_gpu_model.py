@@ -1,0 +1,170 @@
+"""End-to-end parity on the MI355X: the full RFBNet engine (HIP convs / pools / attention) and the
+batched detection pipeline against the CPU oracle and the committed goldens."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err, sampled
+from ctdet import ops, synth
+from ctdet.pipeline import DetectionPipeline
+from oracle import box_ref, nms_ref, rfbnet_ref
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL = 1e-4
+
+
+def _net(size, C, phase=1, setting='transfer'):
+    from models.RFB_Net_vgg import build_net
+    args = types.SimpleNamespace(method='ours', phase=phase, setting=setting)
+    net = build_net(args, size, C)
+    net.load_state_dict(synth.fill_state_dict(net.state_dict()), strict=True)
+    net = net.eval().cuda()
+    net.device = 'cuda'
+    return net
+
+
+def _layer_report(net, x, size):
+    """Per-source error table (printed when a model-level assertion fails)."""
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        srcs = rfbnet_ref.backbone(sd, x, size)
+    rt = net.runtime(x.shape[0])
+    names = ['Norm.out'] + ['extras.%d.out' % k if ('extras.%d.out' % k) in rt.bufs else 'a_extras.%d' % k
+                            for k in range(len(net.extras)) if k < net.indicator or k % 2 == 0]
+    rows = []
+    for nme, s in zip(names, srcs):
+        rows.append('%s: %.3e' % (nme, rel_err(rt.bufs[nme].cpu(), s)))
+    return '; '.join(rows)
+
+
+def test_rfb300_phase1_vs_oracle_and_golden(golden):
+    g = golden('rfb300_phase1.npz')
+    net = _net(300, 20)
+    x = synth.images(2, 300, 'randn', 1234)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        want_raw = rfbnet_ref.forward(sd, x, 300, 20, raw=True)
+        got_raw = [t.cpu() for t in net.forward_raw(x.cuda())]
+        errs = [rel_err(a, b) for a, b in zip(got_raw, want_raw)]
+        assert max(errs) < TOL, (errs, _layer_report(net, x, 300))
+        loc, conf, obj = [t.cpu() for t in net(x)]
+    for t, name in ((loc, 'p1_loc'), (conf, 'p1_conf'), (obj, 'p1_obj')):
+        a, b, _, _ = sampled(t, g, name)
+        assert rel_err(a, b) < TOL, name
+    with torch.no_grad():
+        init_conf = net(x, init=True).cpu()
+    a, b, _, _ = sampled(init_conf, g, 'p1_init_conf')
+    assert rel_err(a, b) < TOL
+    # Detect on the device outputs (reference call sequence test.py:130-131)
+    from layers.functions import Detect, PriorBox
+    from data import VOC_300
+    priors = PriorBox(VOC_300).forward().cuda()
+    boxes, scores = Detect(21, 0, VOC_300).forward(net(x), priors)
+    for t, name in ((boxes.cpu(), 'p1_boxes'), (scores.cpu(), 'p1_scores')):
+        a, b, _, _ = sampled(t, g, name)
+        assert rel_err(a, b) < TOL, name
+    # image-like input
+    with torch.no_grad():
+        loc, conf, obj = [t.cpu() for t in net(synth.images(1, 300, 'u8', 1234))]
+    for t, name in ((loc, 'p1u8_loc'), (conf, 'p1u8_conf'), (obj, 'p1u8_obj')):
+        a, b, _, _ = sampled(t, g, name)
+        assert rel_err(a, b) < TOL, name
+
+
+@pytest.mark.parametrize('setting,C', [('transfer', 60), ('incre', 15)])
+def test_rfb300_phase2_context_transformer(golden, setting, C):
+    g = golden('rfb300_phase2_%s.npz' % setting)
+    net = _net(300, C, 2, setting)
+    x = synth.images(2, 300, 'randn', 1234)
+    with torch.no_grad():
+        loc, conf, obj = [t.cpu() for t in net(x)]
+        init_conf = net(x, init=True).cpu()
+    for t, name in ((loc, 'loc'), (conf, 'conf'), (obj, 'obj'), (init_conf, 'init_conf')):
+        a, b, _, _ = sampled(t, g, name)
+        assert rel_err(a, b) < TOL, (name, rel_err(a, b))
+    assert conf.shape[-1] == (20 if setting == 'transfer' else 20)
+
+
+def test_rfb512_phase1(golden):
+    g = golden('rfb512_phase1.npz')
+    net = _net(512, 20)
+    x = synth.images(1, 512, 'randn', 1234)
+    with torch.no_grad():
+        loc, conf, obj = [t.cpu() for t in net(x)]
+    assert loc.shape == (1, 32756, 4)
+    for t, name in ((loc, 'p1_loc'), (conf, 'p1_conf'), (obj, 'p1_obj')):
+        a, b, _, _ = sampled(t, g, name)
+        assert rel_err(a, b) < TOL, (name, rel_err(a, b), _layer_report(net, x, 512))
+
+
+def test_rfb512_context_transformer_build_defined():
+    """parity unpinned: the reference raises IndexError at 512 (models/RFB_Net_vgg.py:235-244);
+    the build's 7-entry pooling list is checked against the build's own CPU restatement only."""
+    net = _net(512, 60, 2, 'transfer')
+    x = synth.images(1, 512, 'randn', 1234)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        want = rfbnet_ref.forward(sd, x, 512, 60, 2, 'ours', 'transfer')
+        got = [t.cpu() for t in net(x)]
+    assert net.runtime(1).plan.M == 4964
+    for a, b in zip(got, want):
+        assert rel_err(a, b) < TOL
+
+
+def test_batched_pipeline_equals_sequential_reference_loop():
+    """DetectionPipeline (bs=4) == the reference's per-image / per-class loop (test.py:121-161)
+    applied to the SAME device-produced boxes/scores: bit-exact rows; and the boxes/scores
+    themselves match the CPU oracle within the fp32 tolerance."""
+    from layers.functions import PriorBox
+    from data import VOC_300
+    from utils.nms_wrapper import nms
+    B, T = 4, 20
+    net = _net(300, 20)
+    priors = PriorBox(VOC_300).forward()
+    x = synth.images(B, 300, 'randn', 1234)
+    pipe = DetectionPipeline(net, priors, B, T, image_wh=(500, 375))
+    pipe.run(x.cuda())
+    got = pipe.results()
+    boxes, scores = pipe.boxes.cpu().numpy(), pipe.scores.cpu().numpy()
+    ncand = 0
+    for i in range(B):
+        want = nms_ref.postprocess_image(boxes[i], scores[i], (1, 1), nms_fn=nms_ref.nms_c)
+        for j in range(1, T + 1):
+            ncand += int((scores[i, :, j] > 0.01).sum())
+            assert np.array_equal(got[i][j], want[j]), (i, j, got[i][j].shape, want[j].shape)
+    assert ncand > 1000, 'degenerate case: no candidates'
+    # the reference call sequence on one image through the drop-in `nms` (device kernel, '>' rule)
+    i = 1
+    per_cls = []
+    for j in range(1, T + 1):
+        inds = np.where(scores[i, :, j] > 0.01)[0]
+        c_dets = np.hstack((boxes[i][inds], scores[i][inds, j][:, None])).astype(np.float32)
+        keep = nms(c_dets, 0.45) if len(inds) else []
+        per_cls.append(c_dets[keep, :] if len(inds) else np.empty((0, 5), np.float32))
+    sc = np.hstack([d[:, -1] for d in per_cls])
+    if len(sc) > 200:
+        th = np.sort(sc)[-200]
+        per_cls = [d[d[:, -1] >= th] for d in per_cls]
+    for j in range(T):
+        assert np.array_equal(per_cls[j], got[i][j + 1]), j
+    # numerics of the fused softmax/decode stage against the oracle
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        loc, conf, obj = rfbnet_ref.forward(sd, x, 300, 20)
+    wb, ws = box_ref.detect(loc, conf, obj, priors)
+    assert rel_err(boxes, (wb * torch.tensor([500., 375., 500., 375.])).numpy()) < TOL
+    assert rel_err(scores, ws.numpy()) < TOL
+
+
+def test_weights_repacked_after_update():
+    net = _net(300, 20)
+    x = synth.images(1, 300, 'randn', 7).cuda()
+    with torch.no_grad():
+        a = net.forward_raw(x)[1].clone()
+        net.conf[0].bias.add_(0.5)
+        b = net.forward_raw(x)[1].clone()
+    d = (b - a).view(-1)[:38 * 38 * 6 * 20]
+    assert torch.allclose(d, torch.full_like(d, 0.5), atol=1e-4)
