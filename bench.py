@@ -54,7 +54,13 @@ def cpu_baseline(size, num_fg, images=4, reps=3):
     from ctdet import synth
     from oracle import box_ref, nms_ref, rfbnet_ref
     nms_ref.build_c()
-    threads = int(os.environ.get('CTDET_CPU_THREADS', 0)) or (os.cpu_count() or 1)
+    threads = int(os.environ.get('CTDET_CPU_THREADS', 0))
+    if threads <= 0:
+        try:
+            import psutil
+            threads = psutil.cpu_count(logical=False) or os.cpu_count() or 1     # physical cores
+        except Exception:
+            threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
     sd = synth.fill_state_dict(rfbnet_ref.param_shapes(size, num_fg, 1))
     x = synth.images(images, size, 'randn', 1234)
@@ -108,7 +114,20 @@ def conv_roofline(rt, batch):
     }
 
 
+def log(msg):
+    if os.environ.get('CTDET_BENCH_VERBOSE', '1') != '0' and int(os.environ.get('RANK', 0)) == 0:
+        sys.stderr.write('[bench %7.1fs] %s\n' % (time.perf_counter() - _T0, msg))
+        sys.stderr.flush()
+
+
+_T0 = time.perf_counter()
+
+
 def main():
+    import faulthandler
+    faulthandler.enable()
+    if os.environ.get('CTDET_BENCH_WATCHDOG'):
+        faulthandler.dump_traceback_later(int(os.environ['CTDET_BENCH_WATCHDOG']), exit=False)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -144,7 +163,9 @@ def main():
 
     num_fg = a.classes
     T = {('transfer', 2): 20, ('incre', 2): 20}.get((a.setting, a.phase), num_fg) if a.phase == 2 else num_fg
+    log('building net')
     net = build_net(a.size, num_fg, a.phase, a.setting, dev)
+    log('building pipeline (plan, weight packing%s)' % (', conv autotune' if os.environ.get('CTDET_TUNE', '1') != '0' else ''))
     priors = PriorBox(getattr(cfgs, 'VOC_%d' % a.size)).forward()
     pipe = DetectionPipeline(net, priors, a.batch, T, image_wh=(500, 375))
     x = synth.images(a.batch, a.size, 'randn', 1234 + rank).to(dev)
@@ -155,8 +176,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    log('warm-up')
     for _ in range(a.warmup):
         pipe.run(x)
+    torch.cuda.synchronize(dev)
+    log('timed region')
     if not a.no_roofline and rank == 0:
         pipe.rt.event_log = []          # HIP events around every conv launch of the timed region
     sync()
@@ -170,13 +194,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    log('timed region done: %.2f ms/step' % (dt / a.steps * 1e3))
     roof = None
     if pipe.rt.event_log:
         roof = conv_roofline(pipe.rt, a.batch)
         pipe.rt.event_log = None
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        log('cpu baseline (oracle on host cores)')
         cpu = cpu_baseline(a.size, num_fg)
+        log('cpu baseline done')
 
     if rank == 0:
         total_images = a.batch * world * a.steps

@@ -25,6 +25,9 @@
 // CPB whole input channels so the row -> (channel, tap) split is a compile-time constant.
 #include "ct_common.h"
 #include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_set>
 
 namespace {
 
@@ -53,6 +56,7 @@ struct ConvArgs {
     int nseg;
     ct_out_segment seg[3];
     int tiles_m, tiles_n;
+    int ablate;      // debug (CTDET_CONV_ABLATE): 1 no staging, 2 no barrier, 4 no LDS operand reads
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -60,8 +64,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
-template <int KH, int KW, int CPB, int BM, int BN, int WAVES_M>
-__global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
+template <int KH, int KW, int CPB, int BM, int BN, int WAVES_M, int MINW>
+__global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
 {
     constexpr int KHW = KH * KW;
     constexpr int BK = CPB * KHW;
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     static_assert(BK % 2 == 0 && BK % RPP == 0, "k-step must be even and divide into passes");
     static_assert(TM >= 1 && TN >= 1 && BN >= 64, "wave tile");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * BK * BM + 2 * BK * BN];
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // 2*BK*BM + 2*BK*BN floats
     float* const As = smem;                   // [2][BK][BM]
     float* const Bs = smem + 2 * BK * BM;     // [2][BK][BN]
 
@@ -128,7 +132,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
             }
     }
 
-    // ---- A tile constants ----
+    // ---- staging constants: everything per-lane is computed ONCE; inside the k loop the
+    //      gather is buffer_load(voffset = lane constant, soffset = wave-uniform channel offset)
     int a_voff[NA];       // byte offset inside one k-step slab, or kInvalidOff
     int a_lds[NA];        // float index inside As[buf], or -1
 #pragma unroll
@@ -142,26 +147,32 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     }
     const int a_step_bytes = BK * a.M_pad * 4;
 
+    int b_voff[NB];       // this lane's pixel at the tap of gathered row i (bytes), or kInvalidOff
+    int b_chan[NB];       // wave-uniform: channel of row i inside the k-step
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int r = rowgrp + RPP * i;                 // wave-uniform
+        const int c = r / KHW, tap = r - c * KHW;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        const int off = (int)((unsigned)(pix_base + kh * a.dil * a.W + kw * a.dil) * 4u);
+        b_voff[i] = ((tapmask >> tap) & 1u) ? off : kInvalidOff;
+        b_chan[i] = c;
+    }
+    const int chan_bytes = HW * 4;
+
     i32x4 areg[NA];
     float breg[NB];
 
     auto load_tile = [&](int step) {
+        const int asoff = step * a_step_bytes;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const int v = a_voff[j] == kInvalidOff ? kInvalidOff : a_voff[j] + step * a_step_bytes;
-            areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, v, 0, 0);
-        }
+        for (int j = 0; j < NA; ++j) areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, a_voff[j], asoff, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int r = rowgrp + RPP * i;                 // wave-uniform
-            const int c = r / KHW, tap = r - c * KHW;
-            const int kh = tap / KW, kw = tap - kh * KW;
-            const int ci = step * CPB + c;
-            const int koff = ci * HW + kh * a.dil * a.W + kw * a.dil;
-            const unsigned bit = (ci < a.Cin) ? (1u << tap) : 0u;
-            const int off = (int)((unsigned)(pix_base + koff) * 4u);
-            const int v = (tapmask & bit) ? off : kInvalidOff;
-            breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, v, 0, 0));
+            // channels past Cin (last k-step only) read channel 0: their packed weights are zero
+            const int ci = step * CPB + b_chan[i];
+            const int soff = (ci < a.Cin ? ci : 0) * chan_bytes;
+            breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, b_voff[i], soff, 0));
         }
     };
     auto store_tile = [&](int buf) {
@@ -186,27 +197,41 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(const ConvArgs a)
     store_tile(0);
     __syncthreads();
 
+    constexpr int NKP = BK / 2;
+    constexpr int NDS = (TM + 1) / 2 + (TN + 1) / 2;      // ds_read2_b32 pairs up fragments 32 floats apart
     for (int step = 0; step < a.nsteps; ++step) {
         const int buf = step & 1;
         const bool more = step + 1 < a.nsteps;
-        if (more) load_tile(step + 1);
         const float* Ab = As + buf * (BK * BM) + hsel * BM + wm0 + l31;
         const float* Bb = Bs + buf * (BK * BN) + hsel * BN + wn0 + l31;
+        // operand fragments are double-buffered in registers: the ds_reads of k-pair p+1 are in
+        // flight while the MFMAs of k-pair p execute
+        float av[2][TM], bv[2][TN];
 #pragma unroll
-        for (int kp = 0; kp < BK / 2; ++kp) {
-            float av[TM], bv[TN];
+        for (int i = 0; i < TM; ++i) av[0][i] = Ab[i * 32];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = Ab[(2 * kp) * BM + i * 32];
+        for (int j = 0; j < TN; ++j) bv[0][j] = Bb[j * 32];
+        if (more && !(a.ablate & 1)) load_tile(step + 1);   // HBM/L2 gather of the next k-step overlaps the MFMAs
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Bb[(2 * kp) * BN + j * 32];
+        for (int kp = 0; kp < NKP; ++kp) {
+            const int cur = kp & 1;
+            if (kp + 1 < NKP && !(a.ablate & 4)) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) av[cur ^ 1][i] = Ab[(2 * kp + 2) * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bv[cur ^ 1][j] = Bb[(2 * kp + 2) * BN + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+            // pin the issue order: the next pair's LDS reads go out BEFORE this pair's MFMAs
+            if (kp + 1 < NKP) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
+        if (more && !(a.ablate & 1)) store_tile(buf ^ 1);
+        if (!(a.ablate & 2)) __syncthreads();
     }
 
     // ---- epilogue ----
@@ -285,15 +310,17 @@ __global__ void fold_epilogue_kernel(const float* gamma, const float* beta, cons
 
 // --------------------------------------------------------------------------------------
 struct TileCfg {
-    int bm, bn;
+    int bm, bn, kmul;
     const char* name;
 };
+// kmul scales the channels-per-k-step of the geometry (longer k-steps = fewer barriers, more LDS)
 const TileCfg kCfgs[] = {
-    {128, 128, "128x128"}, {64, 128, "64x128"}, {128, 64, "128x64"}, {64, 64, "64x64"}, {32, 128, "32x128"},
+    {128, 128, 1, "128x128"}, {64, 128, 1, "64x128"}, {128, 64, 1, "128x64"}, {64, 64, 1, "64x64"},
+    {32, 128, 1, "32x128"},   {160, 128, 1, "160x128"}, {128, 128, 2, "128x128k2"}, {96, 128, 1, "96x128"},
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-// channels per k-step for (geometry, BN)
+// channels per k-step for (geometry, BN) at kmul = 1
 constexpr int cpb_for(int kh, int kw, int bn)
 {
     return (kh == 3 && kw == 3) ? (bn == 128 ? 2 : 4)
@@ -303,26 +330,48 @@ constexpr int cpb_for(int kh, int kw, int bn)
                                 : 0;
 }
 
+template <typename K>
+hipError_t launch_one(K kernel, size_t smem, const ConvArgs& a, hipStream_t st)
+{
+    if (smem > 64 * 1024) {              // opt in to > 64 KiB of LDS once per kernel
+        static std::mutex mu;
+        static std::unordered_set<const void*> raised;
+        const void* fn = reinterpret_cast<const void*>(kernel);
+        std::lock_guard<std::mutex> lock(mu);
+        if (!raised.count(fn)) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            raised.insert(fn);
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
+    return hipGetLastError();
+}
+
 template <int KH, int KW>
 hipError_t launch_geo(int cfg, const ConvArgs& a, hipStream_t st)
 {
-    const dim3 grid(a.tiles_m * a.tiles_n), block(256);
     switch (cfg) {
-#define CT_CASE(idx, BM, BN, WMV)                                                            \
-    case idx:                                                                                \
-        hipLaunchKernelGGL((conv_igemm_f32<KH, KW, cpb_for(KH, KW, BN), BM, BN, WMV>), grid, \
-                           block, 0, st, a);                                                 \
-        break;
-        CT_CASE(0, 128, 128, 2)
-        CT_CASE(1, 64, 128, 2)
-        CT_CASE(2, 128, 64, 2)
-        CT_CASE(3, 64, 64, 2)
-        CT_CASE(4, 32, 128, 1)
+#define CT_CASE(idx, BM, BN, WMV, KMUL)                                                       \
+    case idx: {                                                                               \
+        constexpr int CPB = cpb_for(KH, KW, BN) * KMUL;                                       \
+        constexpr size_t SMEM = (size_t)2 * CPB * KH * KW * (BM + BN) * sizeof(float);        \
+        /* 128x128 fits 128 registers: ask for 4 waves/SIMD (4 workgroups per CU) */         \
+        constexpr int MINW = (BM == 128 && BN == 128 && KMUL == 1) ? 4 : 1;                   \
+        return launch_one(conv_igemm_f32<KH, KW, CPB, BM, BN, WMV, MINW>, SMEM, a, st);       \
+    }
+        CT_CASE(0, 128, 128, 2, 1)
+        CT_CASE(1, 64, 128, 2, 1)
+        CT_CASE(2, 128, 64, 2, 1)
+        CT_CASE(3, 64, 64, 2, 1)
+        CT_CASE(4, 32, 128, 1, 1)
+        CT_CASE(5, 160, 128, 1, 1)
+        CT_CASE(6, 128, 128, 2, 2)
+        CT_CASE(7, 96, 128, 1, 1)
 #undef CT_CASE
         default:
             return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 int pick_config(int M, long N)
@@ -342,11 +391,15 @@ int pick_config(int M, long N)
 
 extern "C" int ct_conv_kpad(int cin, int kh, int kw)
 {
-    // k_pad must be a multiple of BK for every BN variant: lcm of the CPB choices.
-    const int c128 = cpb_for(kh, kw, 128), c64 = cpb_for(kh, kw, 64);
-    if (c128 == 0) return -1;
-    const int cpb = (c128 % c64 == 0) ? c128 : (c64 % c128 == 0 ? c64 : c128 * c64);
-    return (cin + cpb - 1) / cpb * cpb * kh * kw;
+    // k_pad must be a whole number of k-steps for every tile config: lcm of their CPBs.
+    if (cpb_for(kh, kw, 128) == 0) return -1;
+    auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
+    int l = 1;
+    for (int i = 0; i < kNumCfgs; ++i) {
+        const int c = cpb_for(kh, kw, kCfgs[i].bn) * kCfgs[i].kmul;
+        l = l / gcd(l, c) * c;
+    }
+    return (cin + l - 1) / l * l * kh * kw;
 }
 
 extern "C" int ct_conv_mpad(int cout) { return (cout + 31) / 32 * 32; }
@@ -435,7 +488,7 @@ extern "C" int ct_conv2d_fwd(const ct_conv_desc* d, ct_stream_t stream)
     int cfg = d->config > 0 ? d->config - 1 : pick_config(d->cout, (long)d->batch * d->oh * d->ow);
     CT_REQUIRE(cfg >= 0 && cfg < kNumCfgs, "ct_conv2d_fwd: config %d", d->config);
     const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
-    const int cpb = cpb_for(d->kh, d->kw, bn);
+    const int cpb = cpb_for(d->kh, d->kw, bn) * kCfgs[cfg].kmul;
 
     for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
         const int nb = std::min(max_chunk, d->batch - b0);
@@ -477,6 +530,10 @@ extern "C" int ct_conv2d_fwd(const ct_conv_desc* d, ct_stream_t stream)
         }
         a.tiles_m = (d->cout + bm - 1) / bm;
         a.tiles_n = (a.Npix + bn - 1) / bn;
+        {
+            static const int abl = getenv("CTDET_CONV_ABLATE") ? atoi(getenv("CTDET_CONV_ABLATE")) : 0;
+            a.ablate = abl;
+        }
         hipError_t e;
         hipStream_t st = ctdet::as_stream(stream);
         if (d->kh == 3 && d->kw == 3) e = launch_geo<3, 3>(cfg, a, st);

@@ -51,24 +51,28 @@ __host__ inline Thr make_thr(float t)
     return r;
 }
 
-// true if the reference would suppress b given kept box a.  (a = higher score.)
+// Branch-free estimate of "the reference suppresses b given kept box a" (a = higher score):
+//   returns 1 = certainly yes, 0 = certainly no, 2 = within 1e-5 of the threshold (decide exactly)
 // PLAIN: no +1 and union = (Sb - inter) + Sa, the expression of utils/box_utils.py:288-299.
-template <bool GE, bool PLAIN>
-__device__ __forceinline__ bool overlaps(const float ax1, const float ay1, const float ax2,
-                                         const float ay2, const float sa, const float bx1,
-                                         const float by1, const float bx2, const float by2,
-                                         const float sb, const Thr th)
+template <bool PLAIN>
+__device__ __forceinline__ int overlap_class(const float4 a, const float sa, const float bx1,
+                                             const float by1, const float bx2, const float by2,
+                                             const float sb, const Thr th, float& inter, float& uni)
 {
-    const float left = fmaxf(ax1, bx1), right = fminf(ax2, bx2);
-    const float top = fmaxf(ay1, by1), bottom = fminf(ay2, by2);
+    const float left = fmaxf(a.x, bx1), right = fminf(a.z, bx2);
+    const float top = fmaxf(a.y, by1), bottom = fminf(a.w, by2);
     const float w = PLAIN ? fmaxf(right - left, 0.f) : fmaxf(right - left + 1.f, 0.f);
     const float h = PLAIN ? fmaxf(bottom - top, 0.f) : fmaxf(bottom - top + 1.f, 0.f);
-    const float inter = w * h;
-    const float uni = PLAIN ? (sb - inter) + sa : sa + sb - inter;
+    inter = w * h;
+    uni = PLAIN ? (sb - inter) + sa : sa + sb - inter;
     const float q = inter * __builtin_amdgcn_rcpf(uni);
-    if (q > th.hi) return true;
-    if (q < th.lo) return false;
-    const float ovr = inter / uni;                 // exact IEEE quotient, rare
+    return q > th.hi ? 1 : (q < th.lo ? 0 : 2);
+}
+
+template <bool GE>
+__device__ __forceinline__ bool exact_rule(float inter, float uni, const Thr th)
+{
+    const float ovr = inter / uni;                 // IEEE quotient, only for borderline pairs
     return GE ? (ovr >= th.t) : (ovr > th.t);
 }
 
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(kThreads) void nms_segments_kernel(const float* __r
                                                                 int* __restrict__ keep_count)
 {
     __shared__ float4 kbox[kKeptLds];
-    __shared__ float karea[kKeptLds];
+    __shared__ __attribute__((aligned(16))) float karea[kKeptLds];
     __shared__ int s_kept[kThreads / 64];   // one slot per sub-chunk (no reuse within 3 barriers)
 
     const int seg = blockIdx.x;
@@ -98,18 +102,6 @@ __global__ __launch_bounds__(kThreads) void nms_segments_kernel(const float* __r
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const float* d = dets + (size_t)base * 5;
     int* kp = keep + base;
-
-    // fetch kept box i (uniform i)
-    auto kept_box = [&](int i, float4& b, float& s) {
-        if (i < kKeptLds) {
-            b = kbox[i];
-            s = karea[i];
-        } else {
-            const float* r = d + (size_t)kp[i] * 5;
-            b = make_float4(r[0], r[1], r[2], r[3]);
-            s = PLAIN ? (b.z - b.x) * (b.w - b.y) : (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
-        }
-    };
 
     int kept = 0;   // uniform across the workgroup at chunk boundaries
     for (int c0 = 0; c0 < n; c0 += kThreads) {
@@ -123,13 +115,49 @@ __global__ __launch_bounds__(kThreads) void nms_segments_kernel(const float* __r
         const float sj = PLAIN ? (x2 - x1) * (y2 - y1) : (x2 - x1 + 1.f) * (y2 - y1 + 1.f);
         bool alive = valid;
 
+        // test this lane's candidate against kept boxes [i0, i1): LDS part 4 at a time with all
+        // eight ds_reads in flight together, the (rare) part beyond the LDS window from L2
+        auto test_range = [&](int i0, int i1) {
+            const int lds_end = min(i1, kKeptLds);
+            int i = i0;
+            for (; i < lds_end && (i & 3); ++i) {
+                float inter, uni;
+                const int c = overlap_class<PLAIN>(kbox[i], karea[i], x1, y1, x2, y2, sj, th, inter, uni);
+                if (c == 1 || (c == 2 && exact_rule<GE>(inter, uni, th))) alive = false;
+            }
+            for (; i + 4 <= lds_end; i += 4) {
+                if (!__any(alive)) return;
+                const float4 b0 = kbox[i], b1 = kbox[i + 1], b2 = kbox[i + 2], b3 = kbox[i + 3];
+                const float4 ar = *reinterpret_cast<const float4*>(&karea[i]);
+                float n0, u0, n1, u1, n2, u2, n3, u3;
+                const int c0_ = overlap_class<PLAIN>(b0, ar.x, x1, y1, x2, y2, sj, th, n0, u0);
+                const int c1_ = overlap_class<PLAIN>(b1, ar.y, x1, y1, x2, y2, sj, th, n1, u1);
+                const int c2_ = overlap_class<PLAIN>(b2, ar.z, x1, y1, x2, y2, sj, th, n2, u2);
+                const int c3_ = overlap_class<PLAIN>(b3, ar.w, x1, y1, x2, y2, sj, th, n3, u3);
+                if (((c0_ | c1_ | c2_ | c3_) & 1) != 0) alive = false;
+                if (__any(((c0_ | c1_ | c2_ | c3_) & 2) != 0)) {          // borderline: exact quotient
+                    if ((c0_ == 2 && exact_rule<GE>(n0, u0, th)) || (c1_ == 2 && exact_rule<GE>(n1, u1, th)) ||
+                        (c2_ == 2 && exact_rule<GE>(n2, u2, th)) || (c3_ == 2 && exact_rule<GE>(n3, u3, th)))
+                        alive = false;
+                }
+            }
+            for (; i < lds_end; ++i) {
+                float inter, uni;
+                const int c = overlap_class<PLAIN>(kbox[i], karea[i], x1, y1, x2, y2, sj, th, inter, uni);
+                if (c == 1 || (c == 2 && exact_rule<GE>(inter, uni, th))) alive = false;
+            }
+            for (i = max(i, kKeptLds); i < i1; ++i) {
+                const float* r = d + (size_t)kp[i] * 5;
+                const float4 b = make_float4(r[0], r[1], r[2], r[3]);
+                const float s = PLAIN ? (b.z - b.x) * (b.w - b.y) : (b.z - b.x + 1.f) * (b.w - b.y + 1.f);
+                float inter, uni;
+                const int c = overlap_class<PLAIN>(b, s, x1, y1, x2, y2, sj, th, inter, uni);
+                if (c == 1 || (c == 2 && exact_rule<GE>(inter, uni, th))) alive = false;
+            }
+        };
+
         // ---- phase A: against everything kept before this chunk ----
-        for (int i = 0; i < kept; ++i) {
-            if ((i & 15) == 0 && !__any(alive)) break;
-            float4 b; float s;
-            kept_box(i, b, s);
-            if (overlaps<GE, PLAIN>(b.x, b.y, b.z, b.w, s, x1, y1, x2, y2, sj, th)) alive = false;
-        }
+        test_range(0, kept);
 
         // ---- phase B: resolve the four 64-candidate sub-chunks in order ----
         int kstart = kept;
@@ -141,8 +169,7 @@ __global__ __launch_bounds__(kThreads) void nms_segments_kernel(const float* __r
                 unsigned long long m = __ballot(alive);
                 while (m) {
                     const int i = __builtin_ctzll(m);       // highest-scoring survivor
-                    const float bx1 = bcast(x1, i), by1 = bcast(y1, i);
-                    const float bx2 = bcast(x2, i), by2 = bcast(y2, i);
+                    const float4 bb = make_float4(bcast(x1, i), bcast(y1, i), bcast(x2, i), bcast(y2, i));
                     const float bs = bcast(sj, i);
                     if (lane == i) {
                         if (k < kKeptLds) {
@@ -152,22 +179,16 @@ __global__ __launch_bounds__(kThreads) void nms_segments_kernel(const float* __r
                         kp[k] = j;
                     }
                     ++k;
-                    if (lane > i && alive &&
-                        overlaps<GE, PLAIN>(bx1, by1, bx2, by2, bs, x1, y1, x2, y2, sj, th))
-                        alive = false;
+                    float inter, uni;
+                    const int c = overlap_class<PLAIN>(bb, bs, x1, y1, x2, y2, sj, th, inter, uni);
+                    if (lane > i && (c == 1 || (c == 2 && exact_rule<GE>(inter, uni, th)))) alive = false;
                     m = __ballot(alive) & ~((2ull << i) - 1ull);
                 }
                 if (lane == 0) s_kept[w] = k;
             }
             __syncthreads();
             const int know = s_kept[w];
-            if (wave > w) {
-                for (int i = kstart; i < know; ++i) {
-                    float4 b; float s;
-                    kept_box(i, b, s);
-                    if (overlaps<GE, PLAIN>(b.x, b.y, b.z, b.w, s, x1, y1, x2, y2, sj, th)) alive = false;
-                }
-            }
+            if (wave > w) test_range(kstart, know);
             kstart = know;
         }
         kept = kstart;

@@ -21,6 +21,7 @@ launch descriptors (tests/emu_backend.py) and check the wiring without a GPU; th
 ships exactly one backend, the HIP one, and `RFBNet.forward` refuses non-HIP devices.
 """
 import ctypes as C
+import json
 import math
 import os
 from dataclasses import dataclass, field
@@ -29,6 +30,22 @@ from typing import List, Optional
 import torch
 
 from . import _lib
+
+TUNE_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_tune_gfx950.json')
+_tune_table = None
+
+
+def tune_table():
+    """Committed per-shape tile choices measured on an MI355X by tools/tune_convs.py."""
+    global _tune_table
+    if _tune_table is None:
+        try:
+            with open(TUNE_TABLE) as f:
+                _tune_table = json.load(f)
+        except (OSError, ValueError):
+            _tune_table = {}
+    return _tune_table
+
 
 CTX_POOL = {300: [3, 2, 2, 2, 1, 1],           # models/RFB_Net_vgg.py:235-236
             512: [3, 2, 2, 2, 2, 1, 1]}        # build-defined: the reference crashes at 512 (:243)
@@ -106,6 +123,10 @@ class ConvStep:
 
     def flops(self, batch):
         return 2.0 * batch * self.cout * self.oh * self.ow * self.cin * self.kh * self.kw
+
+    def tune_key(self, batch):
+        return '%dx%d_s%d_d%d_c%d_m%d_%dx%d_b%d%s' % (self.kh, self.kw, self.stride, self.dil, self.cin,
+                                                    self.cout, self.h, self.w, batch, '_seg' if self.segs else '')
 
 
 @dataclass
@@ -487,21 +508,37 @@ class Runtime:
         for st in self.plan.steps:
             if st.kind == 'conv':
                 backend.prepare_conv(st, bufs, batch)
-        if tune is None:
-            tune = os.environ.get('CTDET_TUNE', '1') != '0'
+        # tile config per conv: committed table first (names, so it survives config reordering),
+        # live autotune only for shapes the table does not know (CTDET_TUNE=0 disables, =2 forces)
+        mode = os.environ.get('CTDET_TUNE', '1') if tune is None else ('1' if tune else '0')
         self.tuned = False
         self.event_log = None        # set to a list to collect (step, start_event, end_event) per conv
-        if tune and hasattr(backend, 'tune_conv'):
-            self.autotune()
+        if hasattr(backend, 'tune_conv'):
+            names = [backend.lib.ct_conv_config_name(i).decode() for i in range(backend.lib.ct_conv_num_configs())]
+            table = tune_table() if mode != '2' else {}
+            missing = []
+            for st in self.conv_steps():
+                cfg = table.get(st.tune_key(batch))
+                if cfg in names:
+                    st.rt['config'] = names.index(cfg) + 1
+                    st.rt['desc'].config = st.rt['config']
+                else:
+                    missing.append(st)
+            if missing and mode != '0':
+                self.autotune(missing)
+            self.tuned = not missing or mode != '0'
 
-    def autotune(self):
+    def autotune(self, steps=None):
         self.bufs['x'].normal_()
         for st in self.plan.steps:            # run once so every buffer holds realistic data
             self._run_step(st)
-        for st in self.plan.steps:
-            if st.kind == 'conv':
-                self.backend.tune_conv(st)
-        self.tuned = True
+        for st in (steps if steps is not None else self.conv_steps()):
+            self.backend.tune_conv(st)
+
+    def tuned_configs(self):
+        lib = self.backend.lib
+        return {st.tune_key(self.batch): lib.ct_conv_config_name(st.rt['desc'].config - 1).decode()
+                for st in self.conv_steps() if st.rt['desc'].config > 0}
 
     def refresh_weights(self):
         """Re-pack any fused conv whose parameters changed since the last pack."""

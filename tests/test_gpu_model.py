@@ -67,11 +67,17 @@ def test_rfb300_phase1_vs_oracle_and_golden(golden):
         a, b, _, _ = sampled(t, g, name)
         assert rel_err(a, b) < TOL, name
     # image-like input
+    xu = synth.images(1, 300, 'u8', 1234)
     with torch.no_grad():
-        loc, conf, obj = [t.cpu() for t in net(synth.images(1, 300, 'u8', 1234))]
+        want_raw = rfbnet_ref.forward(sd, xu, 300, 20, raw=True)
+        got_raw = [t.cpu() for t in net.forward_raw(xu.cuda())]
+        assert max(rel_err(a, b) for a, b in zip(got_raw, want_raw)) < TOL      # activations: 1e-4
+        loc, conf, obj = [t.cpu() for t in net(xu)]
+    # 0..255 pixel inputs give |logit| ~ 1e2; softmax turns a 1e-5 relative logit error into
+    # up to ~|logit|*1e-5 in the probabilities, so the post-softmax goldens get 2e-3
     for t, name in ((loc, 'p1u8_loc'), (conf, 'p1u8_conf'), (obj, 'p1u8_obj')):
         a, b, _, _ = sampled(t, g, name)
-        assert rel_err(a, b) < TOL, name
+        assert rel_err(a, b) < (TOL if name.endswith('loc') else 2e-3), name
 
 
 @pytest.mark.parametrize('setting,C', [('transfer', 60), ('incre', 15)])
@@ -106,12 +112,17 @@ def test_rfb512_context_transformer_build_defined():
     net = _net(512, 60, 2, 'transfer')
     x = synth.images(1, 512, 'randn', 1234)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
     with torch.no_grad():
-        want = rfbnet_ref.forward(sd, x, 512, 60, 2, 'ours', 'transfer')
-        got = [t.cpu() for t in net(x)]
+        want = rfbnet_ref.forward(sd, x, 512, 60, 2, 'ours', 'transfer', raw=True)
+        want64 = rfbnet_ref.forward(sd64, x.double(), 512, 60, 2, 'ours', 'transfer', raw=True)
+        got = [t.cpu() for t in net.forward_raw(x.cuda())]
     assert net.runtime(1).plan.M == 4964
-    for a, b in zip(got, want):
-        assert rel_err(a, b) < TOL
+    # The un-scaled theta.phi^T logits reach |x| ~ 1e2-1e3 here, so fp32 itself (CPU or GPU) is
+    # only good to ~1e-3 after the softmax; judge both fp32 paths against an fp64 evaluation.
+    for name, a, b, c in zip(('loc', 'conf', 'obj'), got, want, want64):
+        e_gpu, e_cpu = rel_err(a, c), rel_err(b, c)
+        assert e_gpu < max(TOL, 5 * e_cpu), (name, e_gpu, e_cpu)
 
 
 def test_batched_pipeline_equals_sequential_reference_loop():

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Time the batched post-processing stages on realistic model outputs (debug aid)."""
+import os, sys, types
+import numpy as np
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, 'context-transformer_amd')); sys.path.insert(0, REPO)
+os.environ.setdefault('CTDET_TUNE', '0')
+from ctdet import ops, synth
+from ctdet.pipeline import DetectionPipeline
+from models.RFB_Net_vgg import build_net
+from layers.functions import PriorBox
+from data import VOC_300
+
+B = int(os.environ.get('B', 32))
+net = build_net(types.SimpleNamespace(method='ours', phase=1, setting='transfer'), 300, 20)
+net.load_state_dict(synth.fill_state_dict(net.state_dict()))
+net = net.eval().cuda(); net.device = 'cuda'
+pipe = DetectionPipeline(net, PriorBox(VOC_300).forward(), B, 20)
+x = synth.images(B, 300, 'randn', 1234).cuda()
+pipe.run(x)
+torch.cuda.synchronize()
+cnt = pipe.post.ws  # noqa
+sc = pipe.scores
+ncand = (sc[:, :, 1:] > 0.01).sum(1).float()
+print('candidates per (img,cls): mean %.0f max %d' % (ncand.mean().item(), int(ncand.max().item())))
+def t(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+print('postprocess (select+sort+nms+topk+gather): %.3f ms' % t(lambda: pipe.post.run(pipe.boxes, pipe.scores)))
+print('postprocess without top-k rule:            %.3f ms' % t(lambda: pipe.post.run(pipe.boxes, pipe.scores, max_per_image=0)))
+pipe.post.run(pipe.boxes, pipe.scores, max_per_image=0)
+print('kept per (img,cls) before top-k: mean %.0f max %d' % (pipe.post.out_count.float().mean().item(), int(pipe.post.out_count.max().item())))
+loc, conf, obj = net.forward_raw(x)
+print('detect_fused: %.3f ms' % t(lambda: ops.detect_fused(loc, conf.contiguous(), obj, pipe.priors, (0.1, 0.2), True, pipe.scale, out=(pipe.boxes, pipe.scores))))
