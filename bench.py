@@ -83,6 +83,29 @@ def cpu_baseline(size, num_fg, images=4, reps=3):
                       % (images, size, size, reps)}
 
 
+def pmc_traffic(event_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same
+    workload, 2*FETCH+WRITE per MI355X_MICROARCH.md); None when no pass covers this kernel."""
+    import glob
+    import re
+    m = re.match(r'conv_igemm_f32<(\d+)x(\d+),(\d+)x(\d+)', event_name)
+    if not m:
+        return None
+    kh, kw, bm, bn = m.groups()
+    best = None
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_pmc_traffic.json'))):
+        try:
+            table = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for k, v in table.items():
+            f = [x.strip() for x in k[k.find('<') + 1:k.find('>')].split(',')] if '<' in k else []
+            if k.startswith('conv_igemm_f32') and len(f) >= 5 and f[0] == kh and f[1] == kw and f[3] == bm and f[4] == bn:
+                best = v['hbm_bytes']
+    return best
+
+
 def conv_roofline(rt, batch):
     """Per-instantiation totals from the HIP events the engine recorded around every conv launch
     of the timed region; reports the instantiation with the most accumulated time."""
@@ -101,9 +124,10 @@ def conv_roofline(rt, batch):
     tot_f = sum(a[1] for a in agg.values())
     name, (t, f, n) = max(agg.items(), key=lambda kv: kv[1][0])
     ach = f / t / 1e12
+    traffic = pmc_traffic(name)
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+        'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
         'kernel': name, 'launches': n, 'avg_launch_us': round(t / n * 1e6, 2),
         'flops_per_launch': round(f / n),
         'all_conv': {'achieved': round(tot_f / tot_t / 1e12, 2),
@@ -141,20 +165,15 @@ def main():
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', 0))
-    local = int(os.environ.get('LOCAL_RANK', 0))
-    world = int(os.environ.get('WORLD_SIZE', 1))
+    from ctdet import dist as cdist
+    rank, local, world = cdist.env_world()
     if world != a.gpus and world > 1:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product has no CPU path)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+    cdist.init('nccl')           # RCCL; only used for the timing barrier / max-over-ranks
 
     from ctdet import synth
     from ctdet.pipeline import DetectionPipeline
@@ -171,10 +190,7 @@ def main():
     x = synth.images(a.batch, a.size, 'randn', 1234 + rank).to(dev)
 
     def sync():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
+        cdist.barrier(dev)
 
     log('warm-up')
     for _ in range(a.warmup):
@@ -189,10 +205,7 @@ def main():
         pipe.run(x)
     sync()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = cdist.max_over_ranks(dt, dev)
 
     log('timed region done: %.2f ms/step' % (dt / a.steps * 1e3))
     roof = None
@@ -223,8 +236,9 @@ def main():
             'roofline': roof, 'cpu_baseline': cpu,
         }
         print(json.dumps(line))
-    if dist is not None:
-        dist.destroy_process_group()
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -25,6 +25,7 @@
 // CPB whole input channels so the row -> (channel, tap) split is a compile-time constant.
 #include "ct_common.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_set>
@@ -56,7 +57,6 @@ struct ConvArgs {
     int nseg;
     ct_out_segment seg[3];
     int tiles_m, tiles_n;
-    int ablate;      // debug (CTDET_CONV_ABLATE): 1 no staging, 2 no barrier, 4 no LDS operand reads
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -135,15 +135,16 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
     // ---- staging constants: everything per-lane is computed ONCE; inside the k loop the
     //      gather is buffer_load(voffset = lane constant, soffset = wave-uniform channel offset)
     int a_voff[NA];       // byte offset inside one k-step slab, or kInvalidOff
-    int a_lds[NA];        // float index inside As[buf], or -1
+    int a_lds[NA];        // float index inside As[buf]
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int f = tid + 256 * j;
+        int f = tid + 256 * j;
+        if (f >= A_F4) f %= A_F4;         // surplus lanes of the last pass duplicate another element
+                                          // (same data, same LDS slot): no exec masking needed
         const int arow = f / (BM / 4), ac4 = f % (BM / 4);
         const int col = m0 + ac4 * 4;
-        const bool ok = (f < A_F4) && (col < a.M_pad);
-        a_voff[j] = ok ? (arow * a.M_pad + col) * 4 : kInvalidOff;
-        a_lds[j] = (f < A_F4) ? arow * BM + ac4 * 4 : -1;
+        a_voff[j] = (col < a.M_pad) ? (arow * a.M_pad + col) * 4 : kInvalidOff;
+        a_lds[j] = arow * BM + ac4 * 4;
     }
     const int a_step_bytes = BK * a.M_pad * 4;
 
@@ -163,26 +164,33 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
     i32x4 areg[NA];
     float breg[NB];
 
-    auto load_tile = [&](int step) {
-        const int asoff = step * a_step_bytes;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, a_voff[j], asoff, 0);
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
+    // staging element e: e < NA -> A float4 j = e, else B dword i = e - NA
+    auto load_elem = [&](int e, int step) {
+        if (e < NA) {
+            areg[e] = __builtin_amdgcn_raw_buffer_load_b128(rw, a_voff[e], step * a_step_bytes, 0);
+        } else {
+            const int i = e - NA;
             // channels past Cin (last k-step only) read channel 0: their packed weights are zero
             const int ci = step * CPB + b_chan[i];
             const int soff = (ci < a.Cin ? ci : 0) * chan_bytes;
             breg[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, b_voff[i], soff, 0));
         }
     };
+    auto store_elem = [&](int e, int buf) {
+        if (e < NA) {
+            *reinterpret_cast<i32x4*>(As + buf * (BK * BM) + a_lds[e]) = areg[e];
+        } else {
+            const int i = e - NA;
+            Bs[buf * (BK * BN) + (rowgrp + RPP * i) * BN + bp] = breg[i];
+        }
+    };
+    auto load_tile = [&](int step) {
+#pragma unroll
+        for (int e = 0; e < NA + NB; ++e) load_elem(e, step);
+    };
     auto store_tile = [&](int buf) {
-        float* Ab = As + buf * (BK * BM);
-        float* Bb = Bs + buf * (BK * BN);
 #pragma unroll
-        for (int j = 0; j < NA; ++j)
-            if (a_lds[j] >= 0) *reinterpret_cast<i32x4*>(Ab + a_lds[j]) = areg[j];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) Bb[(rowgrp + RPP * i) * BN + bp] = breg[i];
+        for (int e = 0; e < NA + NB; ++e) store_elem(e, buf);
     };
 
     f32x16 acc[TM][TN];
@@ -193,46 +201,63 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     constexpr int NKP = BK / 2;
-    constexpr int NDS = (TM + 1) / 2 + (TN + 1) / 2;      // ds_read2_b32 pairs up fragments 32 floats apart
-    for (int step = 0; step < a.nsteps; ++step) {
+    constexpr int NST = NA + NB;                          // staging elements per lane per k-step
+    constexpr int NSLOT = NKP - 1;                        // k-pairs that carry staging work
+    constexpr int WPS = (NST + NSLOT - 1) / NSLOT;        // staging elements per k-pair slot
+
+    // One k-step.  Software pipeline (registers hold tile step+1 on entry); per k-pair slot:
+    //   ds_read the NEXT pair's operand fragments, ds_write a slice of tile step+1 into the other
+    //   LDS buffer, re-issue the gather of the same slice for tile step+2 (a whole k-step to land),
+    //   then this pair's MFMAs.  sched_barrier(0) keeps the compiler from regrouping the slots.
+    auto k_step = [&](int step, auto store_c, auto load_c) {
+        constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
         const int buf = step & 1;
-        const bool more = step + 1 < a.nsteps;
         const float* Ab = As + buf * (BK * BM) + hsel * BM + wm0 + l31;
         const float* Bb = Bs + buf * (BK * BN) + hsel * BN + wn0 + l31;
-        // operand fragments are double-buffered in registers: the ds_reads of k-pair p+1 are in
-        // flight while the MFMAs of k-pair p execute
         float av[2][TM], bv[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) av[0][i] = Ab[i * 32];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bv[0][j] = Bb[j * 32];
-        if (more && !(a.ablate & 1)) load_tile(step + 1);   // HBM/L2 gather of the next k-step overlaps the MFMAs
 #pragma unroll
         for (int kp = 0; kp < NKP; ++kp) {
             const int cur = kp & 1;
-            if (kp + 1 < NKP && !(a.ablate & 4)) {
+            if (kp + 1 < NKP) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i) av[cur ^ 1][i] = Ab[(2 * kp + 2) * BM + i * 32];
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bv[cur ^ 1][j] = Bb[(2 * kp + 2) * BN + j * 32];
             }
 #pragma unroll
+            for (int q = 0; q < WPS; ++q) {
+                const int e = kp * WPS + q;
+                if (e < NST) {
+                    if (STORE) store_elem(e, buf ^ 1);
+                    if (LOAD) load_elem(e, step + 2);
+                }
+            }
+#pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
-            // pin the issue order: the next pair's LDS reads go out BEFORE this pair's MFMAs
-            if (kp + 1 < NKP) __builtin_amdgcn_sched_group_barrier(0x100, NDS, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more && !(a.ablate & 1)) store_tile(buf ^ 1);
-        if (!(a.ablate & 2)) __syncthreads();
-    }
+        __syncthreads();
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    const int nsteps = a.nsteps;
+    load_tile(0);
+    store_tile(0);
+    if (nsteps > 1) load_tile(1);
+    __syncthreads();
+    int step = 0;
+    for (; step + 2 < nsteps; ++step) k_step(step, T_{}, T_{});
+    if (step + 1 < nsteps) { k_step(step, T_{}, F_{}); ++step; }
+    k_step(step, F_{}, F_{});
 
     // ---- epilogue ----
 #pragma unroll
@@ -530,10 +555,6 @@ extern "C" int ct_conv2d_fwd(const ct_conv_desc* d, ct_stream_t stream)
         }
         a.tiles_m = (d->cout + bm - 1) / bm;
         a.tiles_n = (a.Npix + bn - 1) / bn;
-        {
-            static const int abl = getenv("CTDET_CONV_ABLATE") ? atoi(getenv("CTDET_CONV_ABLATE")) : 0;
-            a.ablate = abl;
-        }
         hipError_t e;
         hipStream_t st = ctdet::as_stream(stream);
         if (d->kh == 3 && d->kw == 3) e = launch_geo<3, 3>(cfg, a, st);

@@ -1,0 +1,60 @@
+"""world_size-2 gloo test of the multi-GPU path's host logic (sharding, barrier, max-over-ranks
+timing, detection gather).  The data path itself has no collective (images shard by rank)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from ctdet import dist as cdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    r, l, w = cdist.init('gloo')
+    assert (r, w) == (rank, world)
+    b, e = cdist.shard(7, rank, world)
+    cdist.barrier('cpu')
+    t = cdist.max_over_ranks(0.010 * (rank + 1))
+    n = cdist.sum_over_ranks(e - b)
+    dets = [[np.full((rank + 1, 5), i, np.float32)] for i in range(b, e)]
+    allb = cdist.gather_detections(dets)
+    q.put((rank, (b, e), t, n, None if allb is None else [int(a[0][0, 0]) for a in allb]))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == (0, 4) and res[1][1] == (4, 7)            # contiguous, sizes differ by <= 1
+    assert abs(res[0][2] - 0.020) < 1e-12 and abs(res[1][2] - 0.020) < 1e-12   # max over ranks
+    assert res[0][3] == 7 and res[1][3] == 7
+    assert res[0][4] == list(range(7)) and res[1][4] is None        # global image order on rank 0
+
+
+def test_shard_covers_everything():
+    for total in (1, 5, 32, 33, 257):
+        for world in (1, 2, 3, 8):
+            spans = [cdist.shard(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -14,7 +14,7 @@ SHAPES = [  # name, B, Cin, H, W, Cout, k, pad, dil
     ('base.2', 32, 64, 300, 300, 64, 3, 1, 1),
     ('base.24', 32, 512, 19, 19, 512, 3, 1, 1),
 ]
-cfgs = [int(c) for c in os.environ.get('PROBE_CFGS', '1,2,3,4').split(',')]
+cfgs = [int(c) for c in os.environ.get('PROBE_CFGS', '1,2,3,4,7,8').split(',')]
 be = engine.HipBackend(DEV)
 lib = _lib.lib()
 for (name, B, Cin, H, W, Cout, k, pad, dil) in SHAPES:
