@@ -51,6 +51,21 @@ __host__ inline Thr make_thr(float t)
     return r;
 }
 
+// v_max_f32 / v_min_f32 without the canonicalising self-max the compiler puts in front of
+// fmaxf/fminf on loaded values (inputs are finite; result for finite inputs is identical).
+__device__ __forceinline__ float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Branch-free estimate of "the reference suppresses b given kept box a" (a = higher score):
 //   returns 1 = certainly yes, 0 = certainly no, 2 = within 1e-5 of the threshold (decide exactly)
 // PLAIN: no +1 and union = (Sb - inter) + Sa, the expression of utils/box_utils.py:288-299.
@@ -59,14 +74,29 @@ __device__ __forceinline__ int overlap_class(const float4 a, const float sa, con
                                              const float by1, const float bx2, const float by2,
                                              const float sb, const Thr th, float& inter, float& uni)
 {
-    const float left = fmaxf(a.x, bx1), right = fminf(a.z, bx2);
-    const float top = fmaxf(a.y, by1), bottom = fminf(a.w, by2);
-    const float w = PLAIN ? fmaxf(right - left, 0.f) : fmaxf(right - left + 1.f, 0.f);
-    const float h = PLAIN ? fmaxf(bottom - top, 0.f) : fmaxf(bottom - top + 1.f, 0.f);
+    const float left = vmax(a.x, bx1), right = vmin(a.z, bx2);
+    const float top = vmax(a.y, by1), bottom = vmin(a.w, by2);
+    const float w = PLAIN ? vmax(right - left, 0.f) : vmax(right - left + 1.f, 0.f);
+    const float h = PLAIN ? vmax(bottom - top, 0.f) : vmax(bottom - top + 1.f, 0.f);
     inter = w * h;
     uni = PLAIN ? (sb - inter) + sa : sa + sb - inter;
     const float q = inter * __builtin_amdgcn_rcpf(uni);
     return q > th.hi ? 1 : (q < th.lo ? 0 : 2);
+}
+
+// reciprocal-estimate of inter/union only (inter, uni returned for the exact path)
+template <bool PLAIN>
+__device__ __forceinline__ float ratio(const float4 a, const float sa, const float bx1, const float by1,
+                                       const float bx2, const float by2, const float sb, float& inter,
+                                       float& uni)
+{
+    const float left = vmax(a.x, bx1), right = vmin(a.z, bx2);
+    const float top = vmax(a.y, by1), bottom = vmin(a.w, by2);
+    const float w = PLAIN ? vmax(right - left, 0.f) : vmax(right - left + 1.f, 0.f);
+    const float h = PLAIN ? vmax(bottom - top, 0.f) : vmax(bottom - top + 1.f, 0.f);
+    inter = w * h;
+    uni = PLAIN ? (sb - inter) + sa : sa + sb - inter;
+    return inter * __builtin_amdgcn_rcpf(uni);
 }
 
 template <bool GE>
@@ -130,14 +160,18 @@ __global__ __launch_bounds__(kThreads) void nms_segments_kernel(const float* __r
                 const float4 b0 = kbox[i], b1 = kbox[i + 1], b2 = kbox[i + 2], b3 = kbox[i + 3];
                 const float4 ar = *reinterpret_cast<const float4*>(&karea[i]);
                 float n0, u0, n1, u1, n2, u2, n3, u3;
-                const int c0_ = overlap_class<PLAIN>(b0, ar.x, x1, y1, x2, y2, sj, th, n0, u0);
-                const int c1_ = overlap_class<PLAIN>(b1, ar.y, x1, y1, x2, y2, sj, th, n1, u1);
-                const int c2_ = overlap_class<PLAIN>(b2, ar.z, x1, y1, x2, y2, sj, th, n2, u2);
-                const int c3_ = overlap_class<PLAIN>(b3, ar.w, x1, y1, x2, y2, sj, th, n3, u3);
-                if (((c0_ | c1_ | c2_ | c3_) & 1) != 0) alive = false;
-                if (__any(((c0_ | c1_ | c2_ | c3_) & 2) != 0)) {          // borderline: exact quotient
-                    if ((c0_ == 2 && exact_rule<GE>(n0, u0, th)) || (c1_ == 2 && exact_rule<GE>(n1, u1, th)) ||
-                        (c2_ == 2 && exact_rule<GE>(n2, u2, th)) || (c3_ == 2 && exact_rule<GE>(n3, u3, th)))
+                const float q0 = ratio<PLAIN>(b0, ar.x, x1, y1, x2, y2, sj, n0, u0);
+                const float q1 = ratio<PLAIN>(b1, ar.y, x1, y1, x2, y2, sj, n1, u1);
+                const float q2 = ratio<PLAIN>(b2, ar.z, x1, y1, x2, y2, sj, n2, u2);
+                const float q3 = ratio<PLAIN>(b3, ar.w, x1, y1, x2, y2, sj, n3, u3);
+                const bool yes = (q0 > th.hi) | (q1 > th.hi) | (q2 > th.hi) | (q3 > th.hi);
+                const bool no = (q0 < th.lo) & (q1 < th.lo) & (q2 < th.lo) & (q3 < th.lo);
+                if (yes) alive = false;
+                if (__any(!yes && !no)) {                  // some pair within 1e-5 of the threshold
+                    const bool m0 = !(q0 > th.hi) && !(q0 < th.lo), m1 = !(q1 > th.hi) && !(q1 < th.lo);
+                    const bool m2 = !(q2 > th.hi) && !(q2 < th.lo), m3 = !(q3 > th.hi) && !(q3 < th.lo);
+                    if ((m0 && exact_rule<GE>(n0, u0, th)) || (m1 && exact_rule<GE>(n1, u1, th)) ||
+                        (m2 && exact_rule<GE>(n2, u2, th)) || (m3 && exact_rule<GE>(n3, u3, th)))
                         alive = false;
                 }
             }

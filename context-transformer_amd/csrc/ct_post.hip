@@ -148,6 +148,89 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
     }
 }
 
+// k-th largest kept score of image b (as uint bits; all scores are positive floats), or 0 when
+// at most k boxes are kept.  256 threads; hist/s_* are workgroup scratch.
+__device__ unsigned kth_largest_kept(const float* __restrict__ dets_sorted, const int* __restrict__ keep,
+                                     const int* __restrict__ keep_count, int P, int T, int b, int k,
+                                     int* hist, int* s_scalars)
+{
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        int t = 0;
+        for (int c = 0; c < T; ++c) t += keep_count[b * T + c];
+        s_scalars[0] = t;
+    }
+    __syncthreads();
+    const int total = s_scalars[0];
+    __syncthreads();
+    if (k <= 0 || total <= k) return 0u;
+    unsigned prefix = 0, pmask = 0;
+    int krem = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (int c = 0; c < T; ++c) {
+            const int seg = b * T + c, kc = keep_count[seg];
+            const float* d = dets_sorted + (size_t)seg * P * 5;
+            const int* kp = keep + (size_t)seg * P;
+            for (int i = tid; i < kc; i += 256) {
+                const unsigned u = __float_as_uint(d[(size_t)kp[i] * 5 + 4]);
+                if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, x = 255;
+            for (; x > 0; --x) {
+                if (cum + hist[x] >= krem) break;
+                cum += hist[x];
+            }
+            s_scalars[1] = x;
+            s_scalars[2] = krem - cum;
+        }
+        __syncthreads();
+        prefix |= (unsigned)s_scalars[1] << shift;
+        pmask |= 255u << shift;
+        krem = s_scalars[2];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// Exact early cut for the top-k rule.  NMS is prefix-consistent (whether a box is kept depends
+// only on higher-scoring boxes), so after NMS of every class's first `prefix_len` candidates the
+// k-th largest kept score t_est of the image is a LOWER bound of the final threshold: no candidate
+// below t_est can appear in the output, and the kept set above it is determined by the candidates
+// above it alone.  This kernel shortens every segment to its candidates with score >= t_est.
+__global__ __launch_bounds__(256) void prefix_cut_kernel(const float* __restrict__ dets_sorted,
+                                                         const int* __restrict__ keep,
+                                                         const int* __restrict__ keep_count,
+                                                         const int* __restrict__ seg_count, int P, int T,
+                                                         int max_per_image, int* __restrict__ seg_len_out)
+{
+    __shared__ int hist[256];
+    __shared__ int s_scalars[4];
+    const int b = blockIdx.x;
+    const unsigned thr = kth_largest_kept(dets_sorted, keep, keep_count, P, T, b, max_per_image, hist, s_scalars);
+    for (int c = threadIdx.x; c < T; c += 256) {
+        const int seg = b * T + c, n = seg_count[seg];
+        const float* d = dets_sorted + (size_t)seg * P * 5;
+        int lo = 0, hi = n;                // first candidate with score < thr (descending order)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (__float_as_uint(d[(size_t)mid * 5 + 4]) >= thr) lo = mid + 1;
+            else hi = mid;
+        }
+        seg_len_out[seg] = lo;
+    }
+}
+
+__global__ void clamp_len_kernel(const int* __restrict__ in, int n, int cap, int* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = min(in[i], cap);
+}
+
 // per image: the `>= k-th largest score` rule of test.py:155-161
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ dets_sorted,
                                                    const int* __restrict__ keep,
@@ -156,49 +239,9 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ det
                                                    int* __restrict__ out_count, int* __restrict__ overflow)
 {
     __shared__ int hist[256];
-    __shared__ int s_total, s_digit, s_krem;
+    __shared__ int s_scalars[4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) {
-        int t = 0;
-        for (int c = 0; c < T; ++c) t += keep_count[b * T + c];
-        s_total = t;
-    }
-    __syncthreads();
-    const int total = s_total;
-    unsigned thr_bits = 0;    // every positive score passes
-    if (max_per_image > 0 && total > max_per_image) {
-        unsigned prefix = 0, pmask = 0;
-        int krem = max_per_image;
-        for (int shift = 24; shift >= 0; shift -= 8) {
-            hist[tid] = 0;
-            __syncthreads();
-            for (int c = 0; c < T; ++c) {
-                const int seg = b * T + c, kc = keep_count[seg];
-                const float* d = dets_sorted + (size_t)seg * P * 5;
-                const int* kp = keep + (size_t)seg * P;
-                for (int i = tid; i < kc; i += 256) {
-                    const unsigned u = __float_as_uint(d[(size_t)kp[i] * 5 + 4]);
-                    if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
-                }
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int cum = 0, x = 255;
-                for (; x > 0; --x) {
-                    if (cum + hist[x] >= krem) break;
-                    cum += hist[x];
-                }
-                s_digit = x;
-                s_krem = krem - cum;
-            }
-            __syncthreads();
-            prefix |= (unsigned)s_digit << shift;
-            pmask |= 255u << shift;
-            krem = s_krem;
-            __syncthreads();
-        }
-        thr_bits = prefix;
-    }
+    const unsigned thr_bits = kth_largest_kept(dets_sorted, keep, keep_count, P, T, b, max_per_image, hist, s_scalars);
     // survivors of every class are a prefix of its descending kept list
     for (int c = tid; c < T; c += 256) {
         const int seg = b * T + c, kc = keep_count[seg];
@@ -252,6 +295,7 @@ struct PostWs {
     int* keep;
     int* seg_count;
     int* keep_count;
+    int* seg_len;      // working segment lengths (prefix pass / cut pass)
     size_t total;
 };
 
@@ -272,6 +316,7 @@ PostWs carve(char* base, int batch, int P, int T)
     w.keep = (int*)take(S * P * 4);
     w.seg_count = (int*)take(S * 4);
     w.keep_count = (int*)take(S * 4);
+    w.seg_len = (int*)take(S * 4);
     w.total = off;
     return w;
 }
@@ -303,8 +348,22 @@ extern "C" int ct_postprocess_batched(const float* boxes, const float* scores, i
     hipLaunchKernelGGL(select_sort_kernel, dim3(S), dim3(kSortThreads), 0, st, boxes, scores, num_priors,
                        num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count);
     CT_LAUNCH_CHECK("select_sort_kernel");
-    int rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_count, num_priors, S, nms_thresh, ge, w.keep,
-                                       w.keep_count, st);
+    int rc;
+    constexpr int kPrefix = 256;          // candidates per class in the bounding pass
+    if (max_per_image > 0 && num_priors > kPrefix) {
+        // pass 1: NMS of every class's best kPrefix candidates -> exact lower bound of the top-k
+        // threshold -> cut every segment there (see prefix_cut_kernel); pass 2: NMS of what is left
+        hipLaunchKernelGGL(clamp_len_kernel, dim3((S + 255) / 256), dim3(256), 0, st, w.seg_count, S, kPrefix, w.seg_len);
+        CT_LAUNCH_CHECK("clamp_len_kernel");
+        rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_len, num_priors, S, nms_thresh, ge, w.keep, w.keep_count, st);
+        if (rc != CT_OK) return rc;
+        hipLaunchKernelGGL(prefix_cut_kernel, dim3(batch), dim3(256), 0, st, w.dets_sorted, w.keep, w.keep_count,
+                           w.seg_count, num_priors, num_fg, max_per_image, w.seg_len);
+        CT_LAUNCH_CHECK("prefix_cut_kernel");
+        rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_len, num_priors, S, nms_thresh, ge, w.keep, w.keep_count, st);
+    } else {
+        rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_count, num_priors, S, nms_thresh, ge, w.keep, w.keep_count, st);
+    }
     if (rc != CT_OK) return rc;
     hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(256), 0, st, w.dets_sorted, w.keep, w.keep_count,
                        num_priors, num_fg, max_per_image, out_cap, out_count, overflow);

@@ -179,3 +179,20 @@ def test_weights_repacked_after_update():
         b = net.forward_raw(x)[1].clone()
     d = (b - a).view(-1)[:38 * 38 * 6 * 20]
     assert torch.allclose(d, torch.full_like(d, 0.5), atol=1e-4)
+
+
+def test_large_batch_512_matches_small_batches():
+    """bs=32 at 512x512 makes base.2's input 2.1 GB, i.e. more than one buffer descriptor can
+    address: ct_conv2d_fwd splits the batch.  Every image must come out exactly as it does in a
+    bs=4 run of the same engine (both use the same tile configs only if tuned alike, so compare
+    within the fp32 tolerance)."""
+    net = _net(512, 20)
+    x = synth.images(32, 512, 'randn', 99)
+    with torch.no_grad():
+        big = [t.clone() for t in net.forward_raw(x.cuda())]
+        for i0 in (0, 12, 28):
+            small = net.forward_raw(x[i0:i0 + 4].cuda())
+            for a, b in zip(big, small):
+                assert rel_err(a[i0:i0 + 4].cpu(), b.cpu()) < 1e-5
+    del net
+    torch.cuda.empty_cache()
