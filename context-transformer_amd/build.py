@@ -27,6 +27,7 @@ SOURCES = {
     'ct_conv.hip': [],
     'ct_pool.hip': [],
     'ct_attn.hip': [],
+    'ct_train.hip': [],
     'ct_box.hip': ['-ffp-contract=off'],
     'ct_nms.hip': ['-ffp-contract=off'],
     'ct_post.hip': ['-ffp-contract=off'],

@@ -57,6 +57,7 @@ struct ConvArgs {
     int nseg;
     ct_out_segment seg[3];
     int tiles_m, tiles_n;
+    int transposed;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -111,26 +112,37 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
     const int bp = tid % BN;
     const int rowgrp = __builtin_amdgcn_readfirstlane(tid / BN);
     const int HW = a.H * a.W;
-    int pix_base;
-    unsigned tapmask = 0;
+    // source pixel of tap (kh,kw) for this lane's output pixel, as an element offset, or -1:
+    //   forward     (oh,ow) reads  ih = oh*stride - pad + kh*dil
+    //   transposed  (data gradient, out pixel = input pixel (ih,iw) of the forward conv; the
+    //               "input" here is dY):  oh = (ih + pad - kh*dil) / stride when divisible
+    int img_base, oh_, ow_;
+    bool pvalid;
     {
         const int P = n0 + bp;
-        const bool pvalid = P < a.Npix;
+        pvalid = P < a.Npix;
         const int Pc = pvalid ? P : 0;
         const int n = Pc / a.OHW;
         const int s = Pc - n * a.OHW;
-        const int oh = s / a.OW, ow = s - oh * a.OW;
-        const int ih0 = oh * a.stride - a.pad_h, iw0 = ow * a.stride - a.pad_w;
-        pix_base = ((n * a.in_ctot + a.in_coff) * a.H + ih0) * a.W + iw0;
-#pragma unroll
-        for (int kh = 0; kh < KH; ++kh)
-#pragma unroll
-            for (int kw = 0; kw < KW; ++kw) {
-                const int ih = ih0 + kh * a.dil, iw = iw0 + kw * a.dil;
-                const bool ok = pvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-                tapmask |= (ok ? 1u : 0u) << (kh * KW + kw);
-            }
+        oh_ = s / a.OW;
+        ow_ = s - oh_ * a.OW;
+        img_base = (n * a.in_ctot + a.in_coff) * HW;
     }
+    auto tap_offset = [&](int kh, int kw) -> int {
+        int ih, iw;
+        bool ok = pvalid;
+        if (!a.transposed) {
+            ih = oh_ * a.stride - a.pad_h + kh * a.dil;
+            iw = ow_ * a.stride - a.pad_w + kw * a.dil;
+        } else {
+            const int th = oh_ + a.pad_h - kh * a.dil, tw = ow_ + a.pad_w - kw * a.dil;
+            ih = th / a.stride;
+            iw = tw / a.stride;
+            ok = ok && th >= 0 && tw >= 0 && ih * a.stride == th && iw * a.stride == tw;
+        }
+        ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        return ok ? img_base + ih * a.W + iw : -1;
+    };
 
     // ---- staging constants: everything per-lane is computed ONCE; inside the k loop the
     //      gather is buffer_load(voffset = lane constant, soffset = wave-uniform channel offset)
@@ -155,8 +167,8 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
         const int r = rowgrp + RPP * i;                 // wave-uniform
         const int c = r / KHW, tap = r - c * KHW;
         const int kh = tap / KW, kw = tap - kh * KW;
-        const int off = (int)((unsigned)(pix_base + kh * a.dil * a.W + kw * a.dil) * 4u);
-        b_voff[i] = ((tapmask >> tap) & 1u) ? off : kInvalidOff;
+        const int off = tap_offset(kh, kw);
+        b_voff[i] = off >= 0 ? off * 4 : kInvalidOff;
         b_chan[i] = c;
     }
     const int chan_bytes = HW * 4;
@@ -297,6 +309,7 @@ struct PackArgs {
     const float* w[6];
     int mbeg[7];
     int nparts, K, K_pad, M_pad;
+    int dgrad, cin, khw;      // dgrad: out[k = co*khw + tap][m = ci] = w[co][ci][tap]
     float* out;
 };
 
@@ -307,11 +320,19 @@ __global__ void pack_weights_kernel(const PackArgs p)
          idx += (long)gridDim.x * blockDim.x) {
         const int k = (int)(idx / p.M_pad), m = (int)(idx - (long)k * p.M_pad);
         float v = 0.f;
-        if (k < p.K) {
+        if (!p.dgrad) {
+            if (k < p.K) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if (i < p.nparts && m >= p.mbeg[i] && m < p.mbeg[i + 1])
+                        v = p.w[i][(size_t)(m - p.mbeg[i]) * p.K + k];
+            }
+        } else if (k < p.K && m < p.cin) {
+            const int co = k / p.khw, tap = k - co * p.khw;
 #pragma unroll
             for (int i = 0; i < 6; ++i)
-                if (i < p.nparts && m >= p.mbeg[i] && m < p.mbeg[i + 1])
-                    v = p.w[i][(size_t)(m - p.mbeg[i]) * p.K + k];
+                if (i < p.nparts && co >= p.mbeg[i] && co < p.mbeg[i + 1])
+                    v = p.w[i][((size_t)(co - p.mbeg[i]) * p.cin + m) * p.khw + tap];
         }
         p.out[idx] = v;
     }
@@ -436,9 +457,8 @@ extern "C" const char* ct_conv_config_name(int i)
     return (i >= 0 && i < kNumCfgs) ? kCfgs[i].name : "?";
 }
 
-extern "C" int ct_conv_pack_weights(const float* const* w, const int* cout, int nparts, int cin,
-                                    int kh, int kw, float* wpacked, int m_pad, int k_pad,
-                                    ct_stream_t stream)
+static int pack_impl(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
+                     float* wpacked, int m_pad, int k_pad, int dgrad, ct_stream_t stream)
 {
     CT_REQUIRE(nparts >= 1 && nparts <= 6, "ct_conv_pack_weights: nparts=%d (1..6)", nparts);
     PackArgs p{};
@@ -450,10 +470,18 @@ extern "C" int ct_conv_pack_weights(const float* const* w, const int* cout, int 
     }
     p.mbeg[nparts] = mtot;
     for (int i = nparts + 1; i < 7; ++i) p.mbeg[i] = mtot;
-    CT_REQUIRE(mtot <= m_pad, "ct_conv_pack_weights: sum(cout)=%d > m_pad=%d", mtot, m_pad);
-    CT_REQUIRE(k_pad >= cin * kh * kw, "ct_conv_pack_weights: k_pad=%d < K=%d", k_pad, cin * kh * kw);
     p.nparts = nparts;
-    p.K = cin * kh * kw;
+    p.dgrad = dgrad;
+    p.cin = cin;
+    p.khw = kh * kw;
+    if (!dgrad) {
+        CT_REQUIRE(mtot <= m_pad, "ct_conv_pack_weights: sum(cout)=%d > m_pad=%d", mtot, m_pad);
+        p.K = cin * kh * kw;
+    } else {
+        CT_REQUIRE(cin <= m_pad, "ct_conv_pack_weights_dgrad: cin=%d > m_pad=%d", cin, m_pad);
+        p.K = mtot * kh * kw;
+    }
+    CT_REQUIRE(k_pad >= p.K, "ct_conv_pack_weights: k_pad=%d < K=%d", k_pad, p.K);
     p.K_pad = k_pad;
     p.M_pad = m_pad;
     p.out = wpacked;
@@ -462,6 +490,20 @@ extern "C" int ct_conv_pack_weights(const float* const* w, const int* cout, int 
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, ctdet::as_stream(stream), p);
     CT_LAUNCH_CHECK("pack_weights_kernel");
     return CT_OK;
+}
+
+extern "C" int ct_conv_pack_weights(const float* const* w, const int* cout, int nparts, int cin,
+                                    int kh, int kw, float* wpacked, int m_pad, int k_pad,
+                                    ct_stream_t stream)
+{
+    return pack_impl(w, cout, nparts, cin, kh, kw, wpacked, m_pad, k_pad, 0, stream);
+}
+
+extern "C" int ct_conv_pack_weights_dgrad(const float* const* w, const int* cout, int nparts, int cin,
+                                          int kh, int kw, float* wpacked, int m_pad, int k_pad,
+                                          ct_stream_t stream)
+{
+    return pack_impl(w, cout, nparts, cin, kh, kw, wpacked, m_pad, k_pad, 1, stream);
 }
 
 extern "C" int ct_conv_fold_epilogue(const float* gamma, const float* beta, const float* mean,
@@ -484,10 +526,17 @@ extern "C" int ct_conv2d_fwd(const ct_conv_desc* d, ct_stream_t stream)
     CT_REQUIRE(d->batch > 0 && d->cin > 0 && d->cout > 0 && d->h > 0 && d->w > 0,
                "ct_conv2d_fwd: bad shape");
     CT_REQUIRE(d->stride >= 1 && d->dil >= 1, "ct_conv2d_fwd: stride/dilation");
-    const int eoh = (d->h + 2 * d->pad_h - d->dil * (d->kh - 1) - 1) / d->stride + 1;
-    const int eow = (d->w + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
-    CT_REQUIRE(eoh == d->oh && eow == d->ow, "ct_conv2d_fwd: oh/ow %dx%d != expected %dx%d", d->oh,
-               d->ow, eoh, eow);
+    if (!d->transposed) {
+        const int eoh = (d->h + 2 * d->pad_h - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+        const int eow = (d->w + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+        CT_REQUIRE(eoh == d->oh && eow == d->ow, "ct_conv2d_fwd: oh/ow %dx%d != expected %dx%d", d->oh,
+                   d->ow, eoh, eow);
+    } else {    // data gradient: (h,w) = spatial size of dY, (oh,ow) = spatial size of dX
+        const int fh = (d->oh + 2 * d->pad_h - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+        const int fw = (d->ow + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+        CT_REQUIRE(fh == d->h && fw == d->w, "ct_conv2d_fwd(transposed): dY %dx%d != forward output %dx%d of a %dx%d input",
+                   d->h, d->w, fh, fw, d->oh, d->ow);
+    }
     CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "ct_conv2d_fwd: input slice");
     CT_REQUIRE(d->m_pad >= d->cout && d->m_pad % 4 == 0, "ct_conv2d_fwd: m_pad");
     const int kpad = ct_conv_kpad(d->cin, d->kh, d->kw);
@@ -541,6 +590,7 @@ extern "C" int ct_conv2d_fwd(const ct_conv_desc* d, ct_stream_t stream)
         a.pad_h = d->pad_h;
         a.pad_w = d->pad_w;
         a.dil = d->dil;
+        a.transposed = d->transposed;
         a.Npix = nb * a.OHW;
         a.out_ctot = d->out_ctot;
         a.out_coff = d->out_coff;

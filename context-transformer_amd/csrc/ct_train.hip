@@ -1,0 +1,509 @@
+// libctdet: training-side kernels of the RFBNet stack (what autograd + cuDNN do for the reference
+// in train.py:222-229): weight gradient of a convolution, batch-statistics BatchNorm forward /
+// backward, bias+ReLU backward, max-pool backward and the head-gradient gather.  The data gradient
+// of a convolution is the `transposed` mode of ct_conv2d_fwd (ct_conv.hip).
+#include "ct_common.h"
+#include <algorithm>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kInvalidOff = 0x7FFFFFF0;
+constexpr long long kMaxBufBytes = 0x7FFFFF00LL;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient:  dW[co][ci][kh][kw] = sum_{n,oh,ow} dZ[n][co][oh][ow] * X[n][ci][ih][iw]
+// GEMM  M = cout, N = cin*kh*kw, K = batch*oh*ow (pixels), fp32 MFMA 32x32x2, 64x64 tile,
+// split over pixel ranges across workgroups (fp32 atomicAdd into a zeroed dW).
+// Lanes run along pixels (coalesced rows of dZ and of the shifted X), tiles are staged to LDS
+// transposed ([pixel][row], stride 65) so the MFMA fragments read conflict-free.
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;
+    const float* dz;
+    float* dw;
+    unsigned x_bytes, dz_bytes;
+    int Cin, H, W, x_ctot, x_coff;
+    int Cout, OW, OHW, dz_ctot, dz_coff;
+    int stride, pad_h, pad_w, dil;
+    int Npix, Ncols;
+    int tiles_m, tiles_n, pix_per_split;
+};
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
+{
+    constexpr int KHW = KH * KW;
+    constexpr int BM = 64, BN = 64, BKP = 64, LD = 65;
+    __shared__ float As[BKP * LD];
+    __shared__ float Bs[BKP * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave & 1) * 32, wn0 = (wave >> 1) * 32;
+    const int tile = blockIdx.x;
+    const int m0 = (tile % a.tiles_m) * BM;
+    const int c0 = (tile / a.tiles_m) * BN;
+    const int p_begin = blockIdx.y * a.pix_per_split;
+    const int p_end = min(p_begin + a.pix_per_split, a.Npix);
+    if (p_begin >= p_end) return;
+
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+    const __amdgpu_buffer_rsrc_t rz = make_rsrc(a.dz, a.dz_bytes);
+    const int HW = a.H * a.W;
+
+    // wave-uniform row descriptors: A rows = cout m0 + wave + 4j, B rows = column c0 + wave + 4j
+    int a_soff[16], b_soff[16], b_dh[16], b_dw[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int m = m0 + wave + 4 * j;
+        a_soff[j] = m < a.Cout ? m * a.OHW * 4 : -1;
+        const int col = c0 + wave + 4 * j;
+        const int ci = col / KHW, tap = col - ci * KHW;
+        const int kh = tap / KW, kw = tap - kh * KW;
+        b_soff[j] = col < a.Ncols ? ci * HW * 4 : -1;
+        b_dh[j] = kh * a.dil - a.pad_h;
+        b_dw[j] = kw * a.dil - a.pad_w;
+    }
+
+    float areg[16], breg[16];
+    auto load_chunk = [&](int p0) {
+        const int P = p0 + lane;
+        const bool pv = P < p_end;
+        const int Pc = pv ? P : 0;
+        const int n = Pc / a.OHW;
+        const int s = Pc - n * a.OHW;
+        const int oh = s / a.OW, ow = s - oh * a.OW;
+        const int zoff = pv ? ((n * a.dz_ctot + a.dz_coff) * a.OHW + s) * 4 : kInvalidOff;
+        const int xbase = (n * a.x_ctot + a.x_coff) * HW;
+        const int ih0 = oh * a.stride, iw0 = ow * a.stride;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            areg[j] = a_soff[j] >= 0
+                          ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff, a_soff[j], 0))
+                          : 0.f;
+            const int ih = ih0 + b_dh[j], iw = iw0 + b_dw[j];
+            const bool ok = pv && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const int xoff = ok ? (xbase + ih * a.W + iw) * 4 : kInvalidOff;
+            breg[j] = b_soff[j] >= 0
+                          ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff, b_soff[j], 0))
+                          : 0.f;
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    load_chunk(p_begin);
+    for (int p0 = p_begin; p0 < p_end; p0 += BKP) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            As[lane * LD + wave + 4 * j] = areg[j];
+            Bs[lane * LD + wave + 4 * j] = breg[j];
+        }
+        __syncthreads();
+        if (p0 + BKP < p_end) load_chunk(p0 + BKP);
+        const float* Ab = As + hsel * LD + wm0 + l31;
+        const float* Bb = Bs + hsel * LD + wn0 + l31;
+#pragma unroll
+        for (int s = 0; s < BKP / 2; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[(2 * s) * LD], Bb[(2 * s) * LD], acc, 0, 0, 0);
+        __syncthreads();
+    }
+
+    const int col = c0 + wn0 + l31;
+    if (col < a.Ncols) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+            if (m < a.Cout) atomicAdd(a.dw + (size_t)m * a.Ncols + col, acc[r]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// BatchNorm2d training statistics over (batch, h, w) of a channel slice of an NCHW buffer
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* red)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int batch, int ctot,
+                                                       int coff, int HW, float* __restrict__ mean,
+                                                       float* __restrict__ var)
+{
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    double s = 0.0, ss = 0.0;
+    for (int n = 0; n < batch; ++n) {
+        const float* p = z + ((size_t)n * ctot + coff + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const double v = p[i];
+            s += v;
+            ss += v * v;
+        }
+    }
+    s = block_sum(s, red);
+    ss = block_sum(ss, red);
+    if (threadIdx.x == 0) {
+        const double cnt = (double)batch * HW;
+        const double m = s / cnt;
+        mean[c] = (float)m;
+        var[c] = (float)fmax(ss / cnt - m * m, 0.0);       // biased variance (normalisation)
+    }
+}
+
+// running_mean/var update of nn.BatchNorm2d (momentum m, unbiased variance), count = batch*HW
+__global__ void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var, int C,
+                                  float momentum, float unbias, float* __restrict__ rmean,
+                                  float* __restrict__ rvar)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (var[c] * unbias);
+}
+
+struct BnApplyArgs {
+    const float* z;          // conv output, channel slice [z_coff, z_coff+C) of z_ctot
+    const float* mean;
+    const float* var;
+    const float* gamma;
+    const float* beta;
+    const float* lo;         // per-channel clamp (0 / -inf) or null
+    const float* res;        // residual slice or null
+    float* y;
+    int batch, C, HW, y_ctot, y_coff, res_ctot, res_coff, z_ctot, z_coff;
+    float eps, rscale;
+    int relu;
+};
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a)
+{
+    const long total = (long)a.batch * a.C * a.HW;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % a.HW);
+        const long t = idx / a.HW;
+        const int c = (int)(t % a.C);
+        const int n = (int)(t / a.C);
+        const float inv = 1.f / sqrtf(a.var[c] + a.eps);
+        float v = (a.z[((size_t)n * a.z_ctot + a.z_coff + c) * a.HW + i] - a.mean[c]) * inv * a.gamma[c] + a.beta[c];
+        if (a.res) v = v * a.rscale + a.res[((size_t)n * a.res_ctot + a.res_coff + c) * a.HW + i];
+        if (a.lo) v = fmaxf(v, a.lo[c]);
+        else if (a.relu) v = fmaxf(v, 0.f);
+        a.y[((size_t)n * a.y_ctot + a.y_coff + c) * a.HW + i] = v;
+    }
+}
+
+struct BnBwdArgs {
+    const float* dy;         // slice of the consumer-side gradient buffer
+    const float* y;          // slice of the forward output (ReLU mask) or null
+    const float* z;          // conv output slice (z_ctot / z_coff); dz uses the same slicing
+    const float* mean;
+    const float* var;
+    const float* gamma;
+    const float* lo;
+    float* dz;               // dense
+    float* dgamma;
+    float* dbeta;
+    float* dres;             // where the residual branch's gradient goes (slice) or null
+    int batch, C, HW, dy_ctot, dy_coff, y_ctot, y_coff, dres_ctot, dres_coff, dres_accumulate, z_ctot, z_coff;
+    float eps, rscale;
+    int relu;
+};
+
+__device__ __forceinline__ float masked_dy(const BnBwdArgs& a, int n, int c, int i)
+{
+    float g = a.dy[((size_t)n * a.dy_ctot + a.dy_coff + c) * a.HW + i];
+    const bool act = a.lo ? (a.lo[c] == 0.f) : (a.relu != 0);
+    if (act && a.y[((size_t)n * a.y_ctot + a.y_coff + c) * a.HW + i] <= 0.f) g = 0.f;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a)
+{
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const float inv = 1.f / sqrtf(a.var[c] + a.eps), mu = a.mean[c];
+    double sb = 0.0, sg = 0.0;
+    for (int n = 0; n < a.batch; ++n) {
+        const float* zp = a.z + ((size_t)n * a.z_ctot + a.z_coff + c) * a.HW;
+        for (int i = threadIdx.x; i < a.HW; i += 256) {
+            const float g = masked_dy(a, n, c, i) * a.rscale;
+            sb += g;
+            sg += (double)g * ((zp[i] - mu) * inv);
+        }
+    }
+    sb = block_sum(sb, red);
+    sg = block_sum(sg, red);
+    if (threadIdx.x == 0) {
+        a.dbeta[c] = (float)sb;
+        a.dgamma[c] = (float)sg;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a)
+{
+    const long total = (long)a.batch * a.C * a.HW;
+    const float cnt = (float)a.batch * a.HW;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % a.HW);
+        const long t = idx / a.HW;
+        const int c = (int)(t % a.C);
+        const int n = (int)(t / a.C);
+        const float inv = 1.f / sqrtf(a.var[c] + a.eps);
+        const float gm = masked_dy(a, n, c, i);
+        if (a.dres) {
+            float* d = a.dres + ((size_t)n * a.dres_ctot + a.dres_coff + c) * a.HW + i;
+            *d = a.dres_accumulate ? *d + gm : gm;
+        }
+        const float g = gm * a.rscale;
+        const size_t zi = ((size_t)n * a.z_ctot + a.z_coff + c) * a.HW + i;
+        const float xh = (a.z[zi] - a.mean[c]) * inv;
+        a.dz[zi] = a.gamma[c] * inv * (g - a.dbeta[c] / cnt - xh * a.dgamma[c] / cnt);
+    }
+}
+
+// y = act(conv + bias):  dz = dy * (y > 0 if relu),  dbias = sum dz   (VGG convs, heads)
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ dy, int dy_ctot,
+                                                           int dy_coff, const float* __restrict__ y,
+                                                           int y_ctot, int y_coff, int relu, int batch,
+                                                           int C, int HW, float* __restrict__ dz,
+                                                           int dz_ctot, int dz_coff,
+                                                           float* __restrict__ dbias)
+{
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    double sb = 0.0;
+    for (int n = 0; n < batch; ++n) {
+        const float* g = dy + ((size_t)n * dy_ctot + dy_coff + c) * HW;
+        const float* yy = y ? y + ((size_t)n * y_ctot + y_coff + c) * HW : nullptr;
+        float* o = dz + ((size_t)n * dz_ctot + dz_coff + c) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float v = g[i];
+            if (relu && yy[i] <= 0.f) v = 0.f;
+            o[i] = v;
+            sb += v;
+        }
+    }
+    sb = block_sum(sb, red);
+    if (threadIdx.x == 0 && dbias) dbias[c] = (float)sb;
+}
+
+// max-pool backward (gather form): every input element collects dy of the windows whose FIRST
+// maximum (row-major scan, torch's tie rule) it is.
+__global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ dy,
+                                                            float* __restrict__ dx, long planes, int H,
+                                                            int W, int OH, int OW, int k, int stride,
+                                                            int pad, int accumulate)
+{
+    const long total = planes * H * W;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int w = (int)(idx % W);
+        const long t = idx / W;
+        const int h = (int)(t % H);
+        const long pl = t / H;
+        const float* xp = x + pl * (long)H * W;
+        const float* gp = dy + pl * (long)OH * OW;
+        float g = 0.f;
+        const int oh_lo = max(0, (h + pad - k + stride) / stride), oh_hi = min(OH - 1, (h + pad) / stride);
+        const int ow_lo = max(0, (w + pad - k + stride) / stride), ow_hi = min(OW - 1, (w + pad) / stride);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const int h0 = oh * stride - pad, w0 = ow * stride - pad;
+                float m = -INFINITY;
+                int mh = -1, mw = -1;
+                for (int hh = max(h0, 0); hh < min(h0 + k, H); ++hh)
+                    for (int ww = max(w0, 0); ww < min(w0 + k, W); ++ww) {
+                        const float v = xp[(long)hh * W + ww];
+                        if (v > m) { m = v; mh = hh; mw = ww; }
+                    }
+                if (mh == h && mw == w) g += gp[(long)oh * OW + ow];
+            }
+        dx[idx] = accumulate ? dx[idx] + g : g;
+    }
+}
+
+// gradient of the channels-last head scatter: dz[n][co][pix] = dflat[n*img_stride + base + pix*ps + (co-co0)]
+struct HeadGatherArgs {
+    ct_out_segment seg[3];
+    int nseg;
+    float* dz;
+    int batch, C, HW;
+};
+
+__global__ __launch_bounds__(256) void head_grad_gather_kernel(const HeadGatherArgs a)
+{
+    const long total = (long)a.batch * a.C * a.HW;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(idx % a.HW);
+        const long t = idx / a.HW;
+        const int c = (int)(t % a.C);
+        const int n = (int)(t / a.C);
+        float v = 0.f;
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            if (g < a.nseg && c >= a.seg[g].co_begin && c < a.seg[g].co_end)
+                v = a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                 (size_t)i * a.seg[g].pix_stride + (c - a.seg[g].co_begin)];
+        a.dz[idx] = v;
+    }
+}
+
+inline int grid_for(long total) { return (int)std::min<long>((total + 255) / 256, 256 * 16); }
+
+}  // namespace
+
+extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ctot, int dz_coff,
+                               float* dw, ct_stream_t stream)
+{
+    CT_REQUIRE(d && d->in && dz && dw, "ct_conv2d_wgrad: null pointer");
+    CT_REQUIRE(d->batch > 0 && d->cin > 0 && d->cout > 0, "ct_conv2d_wgrad: bad shape");
+    CT_REQUIRE(dz_coff >= 0 && dz_coff + d->cout <= dz_ctot, "ct_conv2d_wgrad: dZ slice");
+    const int eoh = (d->h + 2 * d->pad_h - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+    const int eow = (d->w + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    CT_REQUIRE(eoh == d->oh && eow == d->ow, "ct_conv2d_wgrad: oh/ow mismatch");
+    const long long x_bytes = (long long)d->batch * d->in_ctot * d->h * d->w * 4;
+    const long long z_bytes = (long long)d->batch * dz_ctot * d->oh * d->ow * 4;
+    CT_REQUIRE(x_bytes < kMaxBufBytes && z_bytes < kMaxBufBytes,
+               "ct_conv2d_wgrad: buffers above 2 GiB are not supported yet (split the batch)");
+    WgradArgs a{};
+    a.x = d->in; a.dz = dz; a.dw = dw;
+    a.x_bytes = (unsigned)x_bytes; a.dz_bytes = (unsigned)z_bytes;
+    a.Cin = d->cin; a.H = d->h; a.W = d->w; a.x_ctot = d->in_ctot; a.x_coff = d->in_coff;
+    a.Cout = d->cout; a.OW = d->ow; a.OHW = d->oh * d->ow; a.dz_ctot = dz_ctot; a.dz_coff = dz_coff;
+    a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.dil = d->dil;
+    a.Npix = d->batch * a.OHW;
+    a.Ncols = d->cin * d->kh * d->kw;
+    a.tiles_m = (d->cout + 63) / 64;
+    a.tiles_n = (a.Ncols + 63) / 64;
+    const int tiles = a.tiles_m * a.tiles_n;
+    int splits = std::max(1, std::min((a.Npix + 255) / 256, (2048 + tiles - 1) / tiles));
+    a.pix_per_split = ((a.Npix + splits - 1) / splits + 63) / 64 * 64;
+    splits = (a.Npix + a.pix_per_split - 1) / a.pix_per_split;
+    hipStream_t st = ctdet::as_stream(stream);
+    CT_HIP(hipMemsetAsync(dw, 0, (size_t)d->cout * a.Ncols * 4, st));
+    const dim3 grid(tiles, splits), block(256);
+    if (d->kh == 3 && d->kw == 3) hipLaunchKernelGGL((conv_wgrad_f32<3, 3>), grid, block, 0, st, a);
+    else if (d->kh == 1 && d->kw == 1) hipLaunchKernelGGL((conv_wgrad_f32<1, 1>), grid, block, 0, st, a);
+    else if (d->kh == 1 && d->kw == 3) hipLaunchKernelGGL((conv_wgrad_f32<1, 3>), grid, block, 0, st, a);
+    else if (d->kh == 3 && d->kw == 1) hipLaunchKernelGGL((conv_wgrad_f32<3, 1>), grid, block, 0, st, a);
+    else if (d->kh == 4 && d->kw == 4) hipLaunchKernelGGL((conv_wgrad_f32<4, 4>), grid, block, 0, st, a);
+    else return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wgrad: %dx%d filters not built", d->kh, d->kw);
+    CT_LAUNCH_CHECK("conv_wgrad_f32");
+    return CT_OK;
+}
+
+extern "C" int ct_bn_train_stats(const float* z, int batch, int ctot, int coff, int channels, int hw,
+                                 float* mean, float* var, float momentum, float* running_mean,
+                                 float* running_var, ct_stream_t stream)
+{
+    CT_REQUIRE(z && mean && var && batch > 0 && channels > 0 && hw > 0, "ct_bn_train_stats: bad arguments");
+    hipStream_t st = ctdet::as_stream(stream);
+    hipLaunchKernelGGL(bn_stats_kernel, dim3(channels), dim3(256), 0, st, z, batch, ctot, coff, hw, mean, var);
+    CT_LAUNCH_CHECK("bn_stats_kernel");
+    if (running_mean && running_var) {
+        const float cnt = (float)batch * hw;
+        hipLaunchKernelGGL(bn_running_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, mean, var,
+                           channels, momentum, cnt > 1.f ? cnt / (cnt - 1.f) : 1.f, running_mean, running_var);
+        CT_LAUNCH_CHECK("bn_running_kernel");
+    }
+    return CT_OK;
+}
+
+extern "C" int ct_bn_train_apply(const float* z, const float* mean, const float* var, const float* gamma,
+                                 const float* beta, float eps, int relu, const float* lo, const float* res,
+                                 int res_ctot, int res_coff, float res_scale, float* y, int y_ctot,
+                                 int y_coff, int z_ctot, int z_coff, int batch, int channels, int hw,
+                                 ct_stream_t stream)
+{
+    CT_REQUIRE(z && mean && var && gamma && beta && y, "ct_bn_train_apply: null pointer");
+    BnApplyArgs a{};
+    a.z = z; a.mean = mean; a.var = var; a.gamma = gamma; a.beta = beta; a.lo = lo; a.res = res; a.y = y;
+    a.batch = batch; a.C = channels; a.HW = hw; a.y_ctot = y_ctot; a.y_coff = y_coff;
+    a.res_ctot = res_ctot; a.res_coff = res_coff; a.eps = eps; a.rscale = res_scale; a.relu = relu;
+    a.z_ctot = z_ctot; a.z_coff = z_coff;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((long)batch * channels * hw)), dim3(256), 0,
+                       ctdet::as_stream(stream), a);
+    CT_LAUNCH_CHECK("bn_apply_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_bn_train_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot,
+                                    int y_coff, const float* z, const float* mean, const float* var,
+                                    const float* gamma, float eps, int relu, const float* lo,
+                                    float res_scale, float* dres, int dres_ctot, int dres_coff,
+                                    int dres_accumulate, float* dz, float* dgamma, float* dbeta,
+                                    int z_ctot, int z_coff, int batch, int channels, int hw,
+                                    ct_stream_t stream)
+{
+    CT_REQUIRE(dy && z && mean && var && gamma && dz && dgamma && dbeta, "ct_bn_train_backward: null pointer");
+    CT_REQUIRE(!(relu || lo) || y, "ct_bn_train_backward: ReLU mask needs the forward output");
+    BnBwdArgs a{};
+    a.dy = dy; a.y = y; a.z = z; a.mean = mean; a.var = var; a.gamma = gamma; a.lo = lo;
+    a.dz = dz; a.dgamma = dgamma; a.dbeta = dbeta; a.dres = dres;
+    a.batch = batch; a.C = channels; a.HW = hw; a.dy_ctot = dy_ctot; a.dy_coff = dy_coff;
+    a.y_ctot = y_ctot; a.y_coff = y_coff; a.dres_ctot = dres_ctot; a.dres_coff = dres_coff;
+    a.dres_accumulate = dres_accumulate; a.eps = eps; a.rscale = res_scale; a.relu = relu;
+    a.z_ctot = z_ctot; a.z_coff = z_coff;
+    hipStream_t st = ctdet::as_stream(stream);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(channels), dim3(256), 0, st, a);
+    CT_LAUNCH_CHECK("bn_bwd_reduce_kernel");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long)batch * channels * hw)), dim3(256), 0, st, a);
+    CT_LAUNCH_CHECK("bn_bwd_apply_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot,
+                                    int y_coff, int relu, int batch, int channels, int hw, float* dz,
+                                    int dz_ctot, int dz_coff, float* dbias, ct_stream_t stream)
+{
+    CT_REQUIRE(dy && dz && (!relu || y), "ct_bias_act_backward: null pointer");
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(channels), dim3(256), 0, ctdet::as_stream(stream), dy,
+                       dy_ctot, dy_coff, y, y_ctot, y_coff, relu, batch, channels, hw, dz, dz_ctot, dz_coff, dbias);
+    CT_LAUNCH_CHECK("bias_act_bwd_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_maxpool2d_bwd(const float* x, const float* dy, float* dx, long planes, int h, int w,
+                                int oh, int ow, int k, int stride, int pad, int accumulate,
+                                ct_stream_t stream)
+{
+    CT_REQUIRE(x && dy && dx && planes > 0, "ct_maxpool2d_bwd: bad arguments");
+    hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0,
+                       ctdet::as_stream(stream), x, dy, dx, planes, h, w, oh, ow, k, stride, pad, accumulate);
+    CT_LAUNCH_CHECK("maxpool2d_bwd_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_head_grad_gather(const ct_out_segment* segs, int nseg, int batch, int channels, int hw,
+                                   float* dz, ct_stream_t stream)
+{
+    CT_REQUIRE(segs && dz && nseg >= 1 && nseg <= 3, "ct_head_grad_gather: bad arguments");
+    HeadGatherArgs a{};
+    for (int g = 0; g < nseg; ++g) a.seg[g] = segs[g];
+    a.nseg = nseg; a.dz = dz; a.batch = batch; a.C = channels; a.HW = hw;
+    hipLaunchKernelGGL(head_grad_gather_kernel, dim3(grid_for((long)batch * channels * hw)), dim3(256), 0,
+                       ctdet::as_stream(stream), a);
+    CT_LAUNCH_CHECK("head_grad_gather_kernel");
+    return CT_OK;
+}

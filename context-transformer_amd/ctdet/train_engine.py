@@ -1,0 +1,257 @@
+"""Training engine: forward with batch-statistics BatchNorm + the full backward pass of the RFBNet
+backbone and heads as HIP launches, exposed to autograd as ONE function.
+
+What the reference gets from autograd + cuDNN in `train.py:222-229` (`model(data)` ...
+`losses.backward()`) is rebuilt on the same fused launch plan as inference (ctdet.engine.Plan):
+
+  forward   conv (identity epilogue) -> ct_bn_train_stats (batch mean / biased var, running-stat
+            update with momentum 0.01) -> ct_bn_train_apply (+ReLU, + `out*scale + shortcut`) for
+            BasicConv layers; the fused bias+ReLU conv for the VGG trunk and the heads.
+  backward  reverse walk: ct_bn_train_backward / ct_bias_act_backward -> dZ, then per fused conv ONE
+            weight-gradient launch (ct_conv2d_wgrad) and ONE data-gradient launch (ct_conv2d_fwd,
+            transposed mode, accumulating into the producer's gradient buffer through the residual
+            input), ct_maxpool2d_bwd for the pools, ct_head_grad_gather for the head scatter.
+
+Buffers are owned by the runtime and reused every step (call backward before the next forward).
+Not covered yet: the Context-Transformer block's backward (phase-2 'ours' training raises).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .engine import ConvPart, ConvStep, HipBackend, Plan
+
+
+class _StepState:
+    pass
+
+
+class TrainRuntime:
+    def __init__(self, net, batch, backend):
+        if net.method == 'ours' and net.phase == 2:
+            raise _lib.CtdetError('training the Context-Transformer block (phase 2, method "ours") is not '
+                                  'implemented yet: its backward kernel is missing')
+        self.net, self.batch, self.be = net, batch, backend
+        self.lib = backend.lib
+        self.plan = Plan(net, batch)
+        al = backend.alloc
+        self.bufs = {n: al((batch,) + tuple(s)) for n, s in self.plan.buf_shapes.items()}
+        self.grads = {n: al((batch,) + tuple(s)) for n, s in self.plan.buf_shapes.items() if n != 'x'}
+        self.state = {}
+        self.params = []            # ordered parameters that receive gradients
+        self._pindex = {}
+        for st in self.plan.steps:
+            if st.kind != 'conv':
+                continue
+            s = _StepState()
+            self.state[st.name] = s
+            s.is_bn = st.parts[0].bn is not None
+            assert all((p.bn is not None) == s.is_bn for p in st.parts), st.name
+            ctot = st.cout
+            s.dz = al((batch, ctot, st.oh, st.ow))
+            s.dw = al((ctot, st.cin, st.kh, st.kw))
+            if s.is_bn:
+                # conv with identity epilogue into a dense Z buffer
+                zname = 'z.' + st.name
+                self.bufs[zname] = al((batch, ctot, st.oh, st.ow))
+                s.zstep = ConvStep(zname, [ConvPart(p.weight, None, None, False) for p in st.parts], st.cin,
+                                   st.kh, st.kw, st.stride, st.ph, st.pw, st.dil, st.src, st.src_coff, st.h,
+                                   st.w, zname, 0)
+                backend.prepare_conv(s.zstep, self.bufs, batch)
+                s.fwd = s.zstep
+                s.mean = [al((p.cout,)) for p in st.parts]
+                s.var = [al((p.cout,)) for p in st.parts]
+                s.dgamma = [al((p.cout,)) for p in st.parts]
+                s.dbeta = [al((p.cout,)) for p in st.parts]
+            else:
+                backend.prepare_conv(st, self.bufs, batch)
+                s.fwd = st
+                s.dbias = [al((p.cout,)) for p in st.parts]
+            # data-gradient launch (not needed for the image itself)
+            s.dgrad = None
+            if st.src != 'x':
+                kpad = self.lib.ct_conv_kpad(ctot, st.kh, st.kw)
+                mpad = self.lib.ct_conv_mpad(st.cin)
+                s.wpk_d = al((kpad, mpad))
+                s.ones = torch.ones(mpad, device=backend.device)
+                s.zeros = torch.zeros(mpad, device=backend.device)
+                d = _lib.ConvDesc()
+                d.in_ = s.dz.data_ptr()
+                d.batch, d.cin, d.h, d.w, d.in_ctot, d.in_coff = batch, ctot, st.oh, st.ow, ctot, 0
+                d.wpacked, d.scale, d.shift = s.wpk_d.data_ptr(), s.ones.data_ptr(), s.zeros.data_ptr()
+                d.cout, d.m_pad, d.k_pad = st.cin, mpad, kpad
+                d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil = st.kh, st.kw, st.stride, st.ph, st.pw, st.dil
+                d.oh, d.ow = st.h, st.w
+                g = self.grads[st.src]
+                d.out, d.out_ctot, d.out_coff = g.data_ptr(), g.shape[1], st.src_coff
+                d.res_ctot, d.res_coff, d.res_scale = g.shape[1], st.src_coff, 1.0
+                d.transposed = 1
+                s.dgrad = d
+                s.kpad_d, s.mpad_d = kpad, mpad
+            # weight-gradient descriptor = forward geometry on the forward input
+            w = _lib.ConvDesc()
+            src = self.bufs[st.src]
+            w.in_ = src.data_ptr()
+            w.batch, w.cin, w.h, w.w, w.in_ctot, w.in_coff = batch, st.cin, st.h, st.w, src.shape[1], st.src_coff
+            w.cout = ctot
+            w.kh, w.kw, w.stride, w.pad_h, w.pad_w, w.dil = st.kh, st.kw, st.stride, st.ph, st.pw, st.dil
+            w.oh, w.ow = st.oh, st.ow
+            s.wgrad = w
+            for p in st.parts:
+                self._reg(p.weight)
+                if p.bn is not None:
+                    self._reg(p.bn.weight)
+                    self._reg(p.bn.bias)
+                elif p.bias is not None:
+                    self._reg(p.bias)
+
+    def _reg(self, prm):
+        if id(prm) not in self._pindex:
+            self._pindex[id(prm)] = len(self.params)
+            self.params.append(prm)
+
+    def _s(self):
+        return C.c_void_p(torch.cuda.current_stream(self.be.device).cuda_stream)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        lib, B = self.lib, self.batch
+        if tuple(x.shape) != tuple(self.bufs['x'].shape):
+            raise _lib.CtdetError('training plan was built for input %s, got %s'
+                                  % (tuple(self.bufs['x'].shape), tuple(x.shape)))
+        self.bufs['x'].copy_(x)
+        for st in self.plan.steps:
+            if st.kind == 'pool':
+                self.be.run_pool(st, self.bufs, B)
+                continue
+            if st.kind != 'conv':
+                raise _lib.CtdetError('step %s has no training implementation' % st.name)
+            s = self.state[st.name]
+            self.be.pack_conv(s.fwd)
+            self.be.run_conv(s.fwd)
+            if not s.is_bn:
+                continue
+            z = self.bufs[s.zstep.dst]
+            hw = st.oh * st.ow
+            dst = self.bufs[st.dst]
+            off = 0
+            for i, p in enumerate(st.parts):
+                bn = p.bn
+                _lib.check(lib.ct_bn_train_stats(z.data_ptr(), B, z.shape[1], off, p.cout, hw,
+                                                 s.mean[i].data_ptr(), s.var[i].data_ptr(), float(bn.momentum),
+                                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self._s()),
+                           st.name + ' bn stats')
+                bn.num_batches_tracked += 1
+                res = self.bufs[st.res] if st.res is not None else None
+                _lib.check(lib.ct_bn_train_apply(
+                    z.data_ptr(), s.mean[i].data_ptr(), s.var[i].data_ptr(), bn.weight.data_ptr(),
+                    bn.bias.data_ptr(), float(bn.eps), int(p.relu), None,
+                    res.data_ptr() if res is not None else None, res.shape[1] if res is not None else 0,
+                    st.res_coff, float(st.res_scale), dst.data_ptr(), dst.shape[1], st.dst_coff + off,
+                    z.shape[1], off, B, p.cout, hw, self._s()), st.name + ' bn apply')
+                off += p.cout
+        return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, dloc, dconf, dobj):
+        lib, B = self.lib, self.batch
+        flat = {'loc': dloc.contiguous(), 'conf': dconf.contiguous(), 'obj': dobj.contiguous()}
+        written = {}
+
+        def overlaps(name, c0, c1):
+            return any(a < c1 and c0 < b for a, b in written.get(name, []))
+
+        grads_out = [None] * len(self.params)
+
+        def put(prm, g):
+            grads_out[self._pindex[id(prm)]] = g
+
+        for st in reversed(self.plan.steps):
+            if st.kind == 'pool':
+                acc = overlaps(st.src, 0, st.ch)
+                _lib.check(lib.ct_maxpool2d_bwd(self.bufs[st.src].data_ptr(), self.grads[st.dst].data_ptr(),
+                                                self.grads[st.src].data_ptr(), B * st.ch, st.h, st.w, st.oh,
+                                                st.ow, st.k, st.stride, st.pad, int(acc), self._s()), st.name)
+                written.setdefault(st.src, []).append((0, st.ch))
+                continue
+            s = self.state[st.name]
+            hw, ctot = st.oh * st.ow, st.cout
+            if st.segs:                                   # heads: gather the flattened gradients
+                segs = (_lib.OutSegment * 3)()
+                for g, sg in enumerate(st.segs):
+                    t = flat[sg.dst]
+                    segs[g].ptr = t.data_ptr()
+                    segs[g].co_begin, segs[g].co_end, segs[g].pix_stride = sg.co_begin, sg.co_end, sg.pix_stride
+                    segs[g].img_stride, segs[g].base = t.shape[1], sg.base
+                _lib.check(lib.ct_head_grad_gather(segs, len(st.segs), B, ctot, hw, s.dz.data_ptr(), self._s()),
+                           st.name + ' head gather')
+                off = 0
+                for i, p in enumerate(st.parts):
+                    _lib.check(lib.ct_bias_act_backward(s.dz.data_ptr(), ctot, off, None, 0, 0, 0, B, p.cout, hw,
+                                                        s.dz.data_ptr(), ctot, off, s.dbias[i].data_ptr(),
+                                                        self._s()), st.name + ' bias bwd')
+                    put(p.bias, s.dbias[i].clone())
+                    off += p.cout
+            else:
+                gy, y = self.grads[st.dst], self.bufs[st.dst]
+                off = 0
+                for i, p in enumerate(st.parts):
+                    if s.is_bn:
+                        z = self.bufs[s.zstep.dst]
+                        dres, dres_ctot, dres_acc = None, 0, 0
+                        if st.res is not None:
+                            dr = self.grads[st.res]
+                            dres, dres_ctot = dr.data_ptr(), dr.shape[1]
+                            dres_acc = int(overlaps(st.res, st.res_coff, st.res_coff + p.cout))
+                            written.setdefault(st.res, []).append((st.res_coff, st.res_coff + p.cout))
+                        _lib.check(lib.ct_bn_train_backward(
+                            gy.data_ptr(), gy.shape[1], st.dst_coff + off, y.data_ptr(), y.shape[1], st.dst_coff + off,
+                            z.data_ptr(), s.mean[i].data_ptr(), s.var[i].data_ptr(), p.bn.weight.data_ptr(),
+                            float(p.bn.eps), int(p.relu), None, float(st.res_scale), dres, dres_ctot, st.res_coff,
+                            dres_acc, s.dz.data_ptr(), s.dgamma[i].data_ptr(), s.dbeta[i].data_ptr(), ctot, off,
+                            B, p.cout, hw, self._s()), st.name + ' bn bwd')
+                        put(p.bn.weight, s.dgamma[i].clone())
+                        put(p.bn.bias, s.dbeta[i].clone())
+                    else:
+                        _lib.check(lib.ct_bias_act_backward(
+                            gy.data_ptr(), gy.shape[1], st.dst_coff + off, y.data_ptr(), y.shape[1], st.dst_coff + off,
+                            int(p.relu), B, p.cout, hw, s.dz.data_ptr(), ctot, off,
+                            s.dbias[i].data_ptr() if p.bias is not None else None, self._s()), st.name + ' bias bwd')
+                        if p.bias is not None:
+                            put(p.bias, s.dbias[i].clone())
+                    off += p.cout
+            # weight gradient of the fused conv, split back to its parts
+            _lib.check(lib.ct_conv2d_wgrad(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(), self._s()),
+                       st.name + ' wgrad')
+            off = 0
+            for p in st.parts:
+                put(p.weight, s.dw[off:off + p.cout].clone())
+                off += p.cout
+            # data gradient into the producer's gradient buffer (accumulate if already written)
+            if s.dgrad is not None:
+                n = len(st.parts)
+                ptrs = (C.c_void_p * n)(*[p.weight.data_ptr() for p in st.parts])
+                couts = (C.c_int * n)(*[p.cout for p in st.parts])
+                _lib.check(lib.ct_conv_pack_weights_dgrad(ptrs, couts, n, st.cin, st.kh, st.kw, s.wpk_d.data_ptr(),
+                                                          s.mpad_d, s.kpad_d, self._s()), st.name + ' pack dgrad')
+                acc = overlaps(st.src, st.src_coff, st.src_coff + st.cin)
+                s.dgrad.res = self.grads[st.src].data_ptr() if acc else None
+                _lib.check(lib.ct_conv2d_fwd(C.byref(s.dgrad), self._s()), st.name + ' dgrad')
+                written.setdefault(st.src, []).append((st.src_coff, st.src_coff + st.cin))
+        return grads_out
+
+
+class BackboneFunction(torch.autograd.Function):
+    """(x, *params) -> (loc, conf, obj) flattened head outputs, differentiable w.r.t. the parameters."""
+
+    @staticmethod
+    def forward(ctx, rt, x, *params):
+        ctx.rt = rt
+        loc, conf, obj = rt.forward(x)
+        return loc.clone(), conf.clone(), obj.clone()
+
+    @staticmethod
+    def backward(ctx, dloc, dconf, dobj):
+        grads = ctx.rt.backward(dloc, dconf, dobj)
+        return (None, None) + tuple(grads)

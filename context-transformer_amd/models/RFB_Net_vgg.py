@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from ctdet import engine as _engine
+from ctdet import train_engine as _train
 from ctdet import ops as _ops
 from ctdet._lib import CtdetError
 
@@ -228,13 +229,17 @@ class RFBNet(nn.Module):
 
     def forward_raw(self, x, init=False):
         """-> (loc [B,P,4], conf logits [B,P,C or T], obj logits [B,P,2]) without the eval softmaxes."""
-        if self.training:
-            raise CtdetError('training-mode forward (batch-statistics BatchNorm + autograd) is not '
-                             'implemented in this build; call .eval()')
         x = x.to(self._device(), torch.float32).contiguous()
+        num = x.shape[0]
+        if self.training:
+            # batch-statistics BatchNorm + autograd: the whole backbone is one autograd function
+            # whose backward is the HIP backward pass (ctdet.train_engine)
+            trt = self.train_runtime(num)
+            loc, conf, obj = _train.BackboneFunction.apply(trt, x, *trt.params)
+            conf = conf.view(num, -1, self.num_classes)
+            return (conf if init else (loc.view(num, -1, 4), conf, obj.view(num, -1, 2)))
         rt = self.runtime(x.shape[0])
         loc, conf, obj = rt.run_backbone(x)
-        num = x.shape[0]
         conf = conf.view(num, -1, self.num_classes)
         if init:
             return conf
@@ -243,7 +248,19 @@ class RFBNet(nn.Module):
             conf = _ops.ctx_attention(conf, pool, self._ctx_params(), self.setting == 'incre')
         return loc.view(num, -1, 4), conf, obj.view(num, -1, 2)
 
+    def train_runtime(self, batch, device=None):
+        """The training engine (forward with batch-stat BN + HIP backward) for this batch size."""
+        device = device or self._device()
+        if device.type != 'cuda':
+            raise CtdetError('RFBNet trains on the MI355X through libctdet only (device %s)' % device)
+        key = ('train', batch, str(device))
+        if key not in self._runtimes:
+            self._runtimes[key] = _train.TrainRuntime(self, batch, _engine.HipBackend(device))
+        return self._runtimes[key]
+
     def forward(self, x, init=False):
+        if self.training:
+            return self.forward_raw(x, init)
         with torch.no_grad():
             out = self.forward_raw(x, init)
             if init:

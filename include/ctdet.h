@@ -192,6 +192,11 @@ typedef struct ct_conv_desc {
     ct_out_segment seg[3];
     /* tile configuration: 0 = heuristic; otherwise 1 + index into ct_conv_num_configs() */
     int config;
+    /* 1: data gradient of the convolution (conv_transpose): `in` = dY [batch,cin=cout_fwd,h,w],
+     * output = dX [batch,cout=cin_fwd,oh,ow] with (oh,ow) the forward INPUT size, weights packed by
+     * ct_conv_pack_weights_dgrad; stride/pad/dil are the forward convolution's.  What autograd's
+     * conv backward-data does for every Conv2d of models/RFB_Net_vgg.py in train.py:228. */
+    int transposed;
 } ct_conv_desc;
 
 /* Rows of the packed weight matrix for a (cin, kh, kw) filter: k_pad. */
@@ -204,6 +209,10 @@ const char* ct_conv_config_name(int i);
  * wpacked dev [k_pad][m_pad] (k = ci*kh*kw + tap, zero padded). */
 int ct_conv_pack_weights(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
                          float* wpacked, int m_pad, int k_pad, ct_stream_t stream);
+/* Same for the data-gradient launch: wpacked [k_pad][m_pad] with k = co*kh*kw + tap over the
+ * concatenated couts and m = ci;  k_pad = ct_conv_kpad(sum cout, kh, kw), m_pad = ct_conv_mpad(cin). */
+int ct_conv_pack_weights_dgrad(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
+                               float* wpacked, int m_pad, int k_pad, ct_stream_t stream);
 /* Epilogue vectors. BatchNorm2d(eval) of models/RFB_Net_vgg.py:13: scale = gamma/sqrt(var+eps),
  * shift = beta - mean*scale.  With gamma == NULL: scale = 1, shift = bias (or 0 if bias NULL).
  * Written at [offset, offset+n) of the m_pad-long vectors. */
@@ -211,6 +220,49 @@ int ct_conv_fold_epilogue(const float* gamma, const float* beta, const float* me
                           float eps, const float* bias, int n, int offset,
                           float* scale, float* shift, ct_stream_t stream);
 int ct_conv2d_fwd(const ct_conv_desc* desc, ct_stream_t stream);
+
+/* ------------------------------------------------------------ training side ---- */
+/* What `losses.backward()` (train.py:228) makes autograd/cuDNN do for the layers above.  The data
+ * gradient of a convolution is ct_conv2d_fwd with desc.transposed = 1. */
+
+/* Weight gradient of the convolution described by `d` (forward geometry; d->in = the forward input
+ * X, d->wpacked/scale/shift/out unused):  dw[cout][cin][kh][kw] (dense fp32, overwritten) =
+ * sum over batch and output pixels of dz[n][co][oh][ow] * X[n][ci][ih][iw];  dz is the channel slice
+ * [dz_coff, dz_coff+cout) of an NCHW buffer with dz_ctot channels. */
+int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ctot, int dz_coff, float* dw,
+                    ct_stream_t stream);
+
+/* nn.BatchNorm2d(eps 1e-5, momentum 0.01) in training mode (models/RFB_Net_vgg.py:13,19), split in
+ * three launches around the conv output z (channel slice [z_coff, z_coff+channels) of an NCHW buffer
+ * with z_ctot channels; dz uses the same slicing):
+ *   stats    per-channel batch mean / biased variance (+ running-stat update with the unbiased
+ *            variance when running_mean/var are given)
+ *   apply    y = act( ((z-mean)/sqrt(var+eps)*gamma + beta) [* res_scale + res] ) into a channel slice
+ *   backward dz, dgamma, dbeta (and the residual branch's gradient) from dy */
+int ct_bn_train_stats(const float* z, int batch, int ctot, int coff, int channels, int hw,
+                      float* mean, float* var, float momentum, float* running_mean, float* running_var,
+                      ct_stream_t stream);
+int ct_bn_train_apply(const float* z, const float* mean, const float* var, const float* gamma,
+                      const float* beta, float eps, int relu, const float* lo, const float* res,
+                      int res_ctot, int res_coff, float res_scale, float* y, int y_ctot, int y_coff,
+                      int z_ctot, int z_coff, int batch, int channels, int hw, ct_stream_t stream);
+int ct_bn_train_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot, int y_coff,
+                         const float* z, const float* mean, const float* var, const float* gamma,
+                         float eps, int relu, const float* lo, float res_scale,
+                         float* dres, int dres_ctot, int dres_coff, int dres_accumulate,
+                         float* dz, float* dgamma, float* dbeta, int z_ctot, int z_coff,
+                         int batch, int channels, int hw, ct_stream_t stream);
+/* y = act(conv + bias): dz = dy * (y > 0 if relu) into a channel slice, dbias[c] = sum dz (may be NULL). */
+int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot, int y_coff,
+                         int relu, int batch, int channels, int hw, float* dz, int dz_ctot, int dz_coff,
+                         float* dbias, ct_stream_t stream);
+/* max_pool2d backward: the gradient goes to the first maximum of each window (torch's rule). */
+int ct_maxpool2d_bwd(const float* x, const float* dy, float* dx, long planes, int h, int w, int oh, int ow,
+                     int k, int stride, int pad, int accumulate, ct_stream_t stream);
+/* Gradient of the channels-last head scatter (models/RFB_Net_vgg.py:239-248 permute/view/cat):
+ * dz[n][co][pix] gathered from the flattened loc/conf/obj gradient buffers described by segs. */
+int ct_head_grad_gather(const ct_out_segment* segs, int nseg, int batch, int channels, int hw,
+                        float* dz, ct_stream_t stream);
 
 /* torch.nn.MaxPool2d of models/RFB_Net_vgg.py:328-330,338 (2x2 s2 [ceil], 3x3 s1 p1) on an NCHW
  * buffer: planes = batch*channels; windows are clipped to the input (ceil_mode semantics are

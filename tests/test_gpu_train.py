@@ -1,0 +1,209 @@
+"""Training-side parity on the MI355X: weight/data gradients, batch-stat BatchNorm, pool backward
+and the whole-backbone backward pass against torch-CPU autograd over the oracle."""
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err, sampled
+from ctdet import _lib, engine, synth
+from oracle import box_ref, loss_ref, rfbnet_ref
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+import ctypes as C
+
+
+def _cuda(t):
+    return t.to(DEV).contiguous()
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+GEOMS = [  # B, Cin, H, W, Cout, k, stride, pad, dil
+    (2, 16, 19, 19, 40, 3, 1, 1, 1), (2, 24, 19, 17, 33, 3, 2, 1, 1), (1, 32, 10, 10, 64, 3, 1, 5, 5),
+    (2, 64, 19, 19, 96, 1, 1, 0, 1), (2, 64, 19, 19, 96, 1, 2, 0, 1), (2, 20, 12, 12, 24, (1, 3), 1, (0, 1), 1),
+    (2, 20, 12, 12, 24, (3, 1), 1, (1, 0), 1), (2, 16, 5, 5, 32, 3, 1, 0, 1), (2, 16, 2, 2, 32, 4, 1, 1, 1),
+    (3, 3, 30, 30, 16, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize('g', GEOMS, ids=[str(i) for i in range(len(GEOMS))])
+def test_conv_dgrad_wgrad_vs_autograd(g):
+    B, Cin, H, W, Cout, k, stride, pad, dil = g
+    kh, kw = (k, k) if isinstance(k, int) else k
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    gen = torch.Generator().manual_seed(sum(map(hash, map(str, g))) % 997)
+    x = torch.randn(B, Cin, H, W, generator=gen, requires_grad=True)
+    w = (torch.randn(Cout, Cin, kh, kw, generator=gen) * 0.2).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, (ph, pw), dil)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    lib = _lib.lib()
+    OH, OW = y.shape[2:]
+    xd, wd, dyd = _cuda(x.detach()), _cuda(w.detach()), _cuda(dy)
+    # weight gradient
+    d = _lib.ConvDesc()
+    d.in_ = xd.data_ptr()
+    d.batch, d.cin, d.h, d.w, d.in_ctot, d.in_coff = B, Cin, H, W, Cin, 0
+    d.cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil, d.oh, d.ow = Cout, kh, kw, stride, ph, pw, dil, OH, OW
+    dw = torch.empty(Cout, Cin, kh, kw, device=DEV)
+    _lib.check(lib.ct_conv2d_wgrad(C.byref(d), dyd.data_ptr(), Cout, 0, dw.data_ptr(), _s()), 'wgrad')
+    assert rel_err(dw.cpu(), w.grad) < 1e-4
+    # data gradient (transposed launch), written into channel slice [2, 2+Cin) of a wider buffer
+    kpad, mpad = lib.ct_conv_kpad(Cout, kh, kw), lib.ct_conv_mpad(Cin)
+    wpk = torch.empty(kpad, mpad, device=DEV)
+    ptrs = (C.c_void_p * 1)(wd.data_ptr()); couts = (C.c_int * 1)(Cout)
+    _lib.check(lib.ct_conv_pack_weights_dgrad(ptrs, couts, 1, Cin, kh, kw, wpk.data_ptr(), mpad, kpad, _s()), 'pack')
+    ones, zeros = torch.ones(mpad, device=DEV), torch.zeros(mpad, device=DEV)
+    dx = torch.full((B, Cin + 4, H, W), 7.0, device=DEV)
+    t = _lib.ConvDesc()
+    t.in_ = dyd.data_ptr()
+    t.batch, t.cin, t.h, t.w, t.in_ctot, t.in_coff = B, Cout, OH, OW, Cout, 0
+    t.wpacked, t.scale, t.shift = wpk.data_ptr(), ones.data_ptr(), zeros.data_ptr()
+    t.cout, t.m_pad, t.k_pad = Cin, mpad, kpad
+    t.kh, t.kw, t.stride, t.pad_h, t.pad_w, t.dil, t.oh, t.ow = kh, kw, stride, ph, pw, dil, H, W
+    t.out, t.out_ctot, t.out_coff = dx.data_ptr(), Cin + 4, 2
+    t.transposed = 1
+    _lib.check(lib.ct_conv2d_fwd(C.byref(t), _s()), 'dgrad')
+    assert rel_err(dx[:, 2:2 + Cin].cpu(), x.grad) < 1e-4
+    assert (dx[:, :2] == 7).all() and (dx[:, 2 + Cin:] == 7).all()
+    # accumulate form: res = out
+    t.res, t.res_ctot, t.res_coff, t.res_scale = dx.data_ptr(), Cin + 4, 2, 1.0
+    _lib.check(lib.ct_conv2d_fwd(C.byref(t), _s()), 'dgrad accumulate')
+    assert rel_err(dx[:, 2:2 + Cin].cpu(), 2 * x.grad) < 1e-4
+
+
+def test_batchnorm_train_forward_backward():
+    lib = _lib.lib()
+    gen = torch.Generator().manual_seed(3)
+    B, Cc, H, W = 3, 10, 7, 5
+    z = (torch.randn(B, Cc + 3, H, W, generator=gen) * 2 + 0.5)
+    zs = z[:, 2:2 + Cc].clone().requires_grad_(True)
+    gamma = (torch.rand(Cc, generator=gen) + 0.5).requires_grad_(True)
+    beta = (torch.rand(Cc, generator=gen) - 0.5).requires_grad_(True)
+    res = torch.randn(B, Cc, H, W, generator=gen).requires_grad_(True)
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    v = F.batch_norm(zs, rm, rv, gamma, beta, True, 0.01, 1e-5)
+    y = F.relu(v * 0.7 + res)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    zd = _cuda(z)
+    mean, var = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+    rmd, rvd = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    _lib.check(lib.ct_bn_train_stats(zd.data_ptr(), B, Cc + 3, 2, Cc, H * W, mean.data_ptr(), var.data_ptr(), 0.01,
+                                     rmd.data_ptr(), rvd.data_ptr(), _s()), 'stats')
+    assert rel_err(rmd.cpu(), rm) < 1e-5 and rel_err(rvd.cpu(), rv) < 1e-5
+    yd = torch.full((B, Cc + 2, H, W), 9.0, device=DEV)
+    gd, bd, resd = _cuda(gamma.detach()), _cuda(beta.detach()), _cuda(res.detach())
+    _lib.check(lib.ct_bn_train_apply(zd.data_ptr(), mean.data_ptr(), var.data_ptr(), gd.data_ptr(), bd.data_ptr(),
+                                     1e-5, 1, None, resd.data_ptr(), Cc, 0, 0.7, yd.data_ptr(), Cc + 2, 1,
+                                     Cc + 3, 2, B, Cc, H * W, _s()), 'apply')
+    assert rel_err(yd[:, 1:1 + Cc].cpu(), y.detach()) < 1e-5
+    dyd = _cuda(dy)
+    dz = torch.zeros(B, Cc + 3, H, W, device=DEV)
+    dres = torch.zeros(B, Cc, H, W, device=DEV)
+    dg, db = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+    _lib.check(lib.ct_bn_train_backward(dyd.data_ptr(), Cc, 0, yd.data_ptr(), Cc + 2, 1, zd.data_ptr(), mean.data_ptr(),
+                                        var.data_ptr(), gd.data_ptr(), 1e-5, 1, None, 0.7, dres.data_ptr(), Cc, 0, 0,
+                                        dz.data_ptr(), dg.data_ptr(), db.data_ptr(), Cc + 3, 2, B, Cc, H * W, _s()),
+               'bn bwd')
+    assert rel_err(dz[:, 2:2 + Cc].cpu(), zs.grad) < 1e-4
+    assert rel_err(dg.cpu(), gamma.grad) < 1e-4 and rel_err(db.cpu(), beta.grad) < 1e-4
+    assert rel_err(dres.cpu(), res.grad) < 1e-5
+
+
+def test_pool_and_bias_backward():
+    lib = _lib.lib()
+    gen = torch.Generator().manual_seed(5)
+    for (H, W, k, s, p, ceil) in [(30, 30, 2, 2, 0, False), (15, 15, 2, 2, 0, True), (9, 9, 3, 1, 1, False)]:
+        x = torch.randn(2, 3, H, W, generator=gen)
+        x[0, 0, :4, :4] = 1.5                       # ties inside windows
+        x = x.requires_grad_(True)
+        y = F.max_pool2d(x, k, s, p, ceil_mode=ceil)
+        dy = torch.randn(y.shape, generator=gen)
+        y.backward(dy)
+        dx = torch.empty(2, 3, H, W, device=DEV)
+        xd, dyd = _cuda(x.detach()), _cuda(dy)          # keep the device copies alive across the launch
+        _lib.check(lib.ct_maxpool2d_bwd(xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), 6, H, W,
+                                        y.shape[2], y.shape[3], k, s, p, 0, _s()), 'pool bwd')
+        torch.cuda.synchronize()
+        assert rel_err(dx.cpu(), x.grad) < 1e-6, (H, k, s)
+    y = torch.randn(2, 6, 5, 5, generator=gen)
+    dy = torch.randn(2, 6, 5, 5, generator=gen)
+    dz, dbias = torch.empty(2, 6, 5, 5, device=DEV), torch.empty(6, device=DEV)
+    dyd, yd = _cuda(dy), _cuda(y)
+    _lib.check(lib.ct_bias_act_backward(dyd.data_ptr(), 6, 0, yd.data_ptr(), 6, 0, 1, 2, 6, 25,
+                                        dz.data_ptr(), 6, 0, dbias.data_ptr(), _s()), 'bias bwd')
+    want = dy * (y > 0)
+    assert torch.equal(dz.cpu(), want) and rel_err(dbias.cpu(), want.sum((0, 2, 3))) < 1e-5
+
+
+def _net(size, C, phase=1, setting='transfer'):
+    from models.RFB_Net_vgg import build_net
+    net = build_net(types.SimpleNamespace(method='ours', phase=phase, setting=setting), size, C)
+    net.load_state_dict(synth.fill_state_dict(net.state_dict()), strict=True)
+    net = net.cuda()
+    net.device = 'cuda'
+    return net
+
+
+def test_train_forward_and_backward_vs_oracle_autograd(golden):
+    """One training step of RFBNet-300 (bs 2): train-mode outputs vs the reference goldens, the
+    MultiBoxLoss values and every parameter gradient vs torch-CPU autograd through the oracle."""
+    from layers.functions import PriorBox
+    from layers.modules.multibox_loss_combined import MultiBoxLoss_combined
+    from data import VOC_300
+    g = golden('rfb300_phase1.npz')
+    net = _net(300, 20).train()
+    x = synth.images(2, 300, 'randn', 1234)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    out = net(x.cuda())
+    for t, name in zip(out, ('p1tr_loc', 'p1tr_conf', 'p1tr_obj')):
+        a, b, _, _ = sampled(t.detach().cpu(), g, name)
+        assert rel_err(a, b) < 1e-4, name
+    priors = PriorBox(VOC_300).forward()
+    targets = synth.targets(2, 21, 99)
+    crit = MultiBoxLoss_combined(21, 0.5, True, 0, True, 3, 0.5, False)
+    ld = crit(out, priors.cuda(), [t.cuda() for t in targets])
+    sum(ld.values()).backward()
+    # oracle: same loss through torch-CPU autograd
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and 'running' not in k}
+    sdo = dict(sd)
+    sdo.update(leaf)
+    oo = rfbnet_ref.forward(sdo, x, 300, 20, training=True)
+    lo = loss_ref.multibox_loss_combined(oo, priors, targets, 21)
+    sum(lo.values()).backward()
+    for k in ld:
+        assert abs(ld[k].item() - lo[k].item()) < 2e-4 * max(1.0, abs(lo[k].item())), k
+    # How exact can this be?  (measured, tools/train_debug.py)  The heads' gradients do not pass a ReLU
+    # or BatchNorm backward and agree to 1e-5.  Everything upstream is a discontinuous function of the
+    # forward activations (ReLU kinks: the two fp32 forwards differ by ~1e-5, which flips a few masks)
+    # and, at batch 2 with 1x1/3x3/5x5 maps, passes BatchNorm backward over 2..50 samples, where
+    # torch-CPU fp32 itself is 1-17 % away from an fp64 evaluation.  So the whole-network check is
+    # structural -- direction and norm of every gradient -- and the per-kernel tests above carry the
+    # 1e-4 numerics.
+    gmax = max(float(v.grad.abs().max()) for v in leaf.values() if v.grad is not None)
+    bad = {}
+    for name, prm in net.named_parameters():
+        assert prm.grad is not None, name
+        a, b = prm.grad.cpu().double().flatten(), leaf[name].grad.double().flatten()
+        na, nb = float(a.norm()), float(b.norm())
+        if nb < 1e-5 * gmax * max(1.0, b.numel() ** 0.5):
+            assert na < 1e-3 * gmax * max(1.0, b.numel() ** 0.5), name       # both ~0 (BN-cancelled terms)
+            continue
+        cos = float(a @ b) / (na * nb)
+        if name.split('.')[0] in ('loc', 'conf', 'obj') and not name.startswith(('loc.5', 'conf.5', 'obj.5')):
+            if float((a - b).abs().max()) > 1e-3 * float(b.abs().max()):     # smooth-L1 / mining kinks
+                bad[name] = ('head', float((a - b).abs().max()) / float(b.abs().max()))
+        elif cos < 0.995 or abs(na / nb - 1) > 0.05:
+            bad[name] = (cos, na / nb)
+    assert not bad, sorted(bad.items())[:12]
+    # running statistics were updated like nn.BatchNorm2d(momentum=0.01)
+    bn = net.Norm.branch0[0].bn
+    assert int(bn.num_batches_tracked) == 1
+    assert not torch.equal(bn.running_mean.cpu(), sd['Norm.branch0.0.bn.running_mean'])

@@ -1,0 +1,33 @@
+import os, sys, types
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, 'context-transformer_amd')); sys.path.insert(0, REPO)
+from ctdet import synth
+from oracle import rfbnet_ref
+from models.RFB_Net_vgg import build_net
+net = build_net(types.SimpleNamespace(method='ours', phase=1, setting='transfer'), 300, 20)
+net.load_state_dict(synth.fill_state_dict(net.state_dict()))
+net = net.cuda().train(); net.device = 'cuda'
+x = synth.images(2, 300, 'randn', 1234)
+sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+g = torch.Generator().manual_seed(0)
+out = net(x.cuda())
+rs = [torch.randn(o.shape, generator=g) for o in out]
+loss = sum((o * r.cuda()).sum() for o, r in zip(out, rs))
+loss.backward()
+leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and 'running' not in k}
+sdo = dict(sd); sdo.update(leaf)
+oo = rfbnet_ref.forward(sdo, x, 300, 20, training=True)
+lo = sum((o * r).sum() for o, r in zip(oo, rs))
+lo.backward()
+leaf64 = {k: v.double().clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and 'running' not in k}
+sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}; sd64.update(leaf64)
+o64 = rfbnet_ref.forward(sd64, x.double(), 300, 20, training=True)
+l64 = sum((o * r.double()).sum() for o, r in zip(o64, rs))
+l64.backward()
+print('loss', loss.item(), lo.item(), l64.item())
+for name, prm in net.named_parameters():
+    a, b, c = prm.grad.cpu().double(), leaf[name].grad.double(), leaf64[name].grad
+    nb = float(c.abs().max())
+    print('%-40s |g|=%.3e gpu_vs_f64=%.2e cpu32_vs_f64=%.2e' % (name, nb, float((a - c).abs().max()) / (nb + 1e-30),
+                                                                 float((b - c).abs().max()) / (nb + 1e-30)))
