@@ -67,3 +67,69 @@ def gather_detections(per_image, dst=0):
     if dist.get_rank() != dst:
         return None
     return [img for part in out for img in part]
+
+
+class GradBucketer:
+    """Gradient all-reduce for the training path (RCCL over xGMI on the GPUs, gloo in CPU tests).
+
+    The reference trains with single-process `torch.nn.DataParallel` (train.py:296-297), i.e. an
+    implicit reduce of every gradient to GPU 0.  Here each GPU runs its own process; gradients are
+    written into ONE flat fp32 buffer laid out in the order the backward pass produces them (heads
+    first, conv1_1 last) and every `bucket_bytes` slice is all-reduced asynchronously as soon as its
+    last gradient exists, so the collective of the late layers overlaps the backward kernels of the
+    early ones.  xGMI is point-to-point (7 links/GPU), so buckets are large (default 32 MiB): a few
+    big ring steps per link instead of hundreds of small ones.
+    """
+
+    def __init__(self, numels, device, bucket_bytes=32 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.offsets = [0]
+        for n in numels:
+            self.offsets.append(self.offsets[-1] + int(n))
+        self.flat = torch.zeros(self.offsets[-1], dtype=torch.float32, device=device)
+        per = max(1, bucket_bytes // 4)
+        self.bucket_of = []              # production index -> bucket id
+        self.bucket_span = []            # bucket id -> (first elem, last elem)
+        start, b = 0, 0
+        for i in range(len(numels)):
+            self.bucket_of.append(b)
+            if self.offsets[i + 1] - start >= per or i == len(numels) - 1:
+                self.bucket_span.append((start, self.offsets[i + 1]))
+                start, b = self.offsets[i + 1], b + 1
+        self.last_in_bucket = {}
+        for i, bid in enumerate(self.bucket_of):
+            self.last_in_bucket[bid] = i
+        self.handles = []
+
+    def view(self, i):
+        return self.flat[self.offsets[i]:self.offsets[i + 1]]
+
+    def begin(self):
+        self.handles = []
+
+    def ready(self, i):
+        """Gradient i (in production order) has been written to view(i)."""
+        bid = self.bucket_of[i]
+        if self.world > 1 and self.last_in_bucket[bid] == i:
+            a, b = self.bucket_span[bid]
+            self.handles.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group,
+                                                async_op=True))
+
+    def finish(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.world > 1:
+            self.flat.div_(self.world)
+
+
+def global_normalizer(n_local, device):
+    """Loss normaliser for data-parallel training: the reference divides by N = sum of positives
+    over the WHOLE batch (multibox_loss_combined.py:119-122 on DataParallel-gathered outputs).  With
+    per-rank losses and mean-reduced gradients that is N_global / world on every rank."""
+    if not dist.is_initialized():
+        return n_local
+    t = n_local.detach().to(device=device, dtype=torch.float64).reshape(1).clone()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return (t / dist.get_world_size()).to(n_local.dtype).reshape(n_local.shape)

@@ -111,6 +111,29 @@ class TrainRuntime:
             self._pindex[id(prm)] = len(self.params)
             self.params.append(prm)
 
+    def production_order(self):
+        """Parameters in the order backward() produces their gradients (heads first)."""
+        order = []
+        for st in reversed(self.plan.steps):
+            if st.kind != 'conv':
+                continue
+            for p in st.parts:
+                if p.bn is not None:
+                    order += [p.bn.weight, p.bn.bias]
+                elif p.bias is not None:
+                    order.append(p.bias)
+            order += [p.weight for p in st.parts]
+        return order
+
+    def enable_grad_sync(self, bucket_bytes=32 << 20, group=None):
+        """Data-parallel training: all-reduce (mean) the gradients over the process group in
+        large buckets, overlapped with the rest of the backward pass (ctdet.dist.GradBucketer)."""
+        from .dist import GradBucketer
+        order = self.production_order()
+        self._prod_index = {id(p): i for i, p in enumerate(order)}
+        self.bucketer = GradBucketer([p.numel() for p in order], self.be.device, bucket_bytes, group)
+        return self.bucketer
+
     def _s(self):
         return C.c_void_p(torch.cuda.current_stream(self.be.device).cuda_stream)
 
@@ -163,8 +186,17 @@ class TrainRuntime:
             return any(a < c1 and c0 < b for a, b in written.get(name, []))
 
         grads_out = [None] * len(self.params)
+        bk = getattr(self, 'bucketer', None)
+        if bk is not None:
+            bk.begin()
 
         def put(prm, g):
+            if bk is not None:                      # stage in the flat buffer, all-reduce per bucket
+                i = self._prod_index[id(prm)]
+                v = bk.view(i)
+                v.copy_(g.reshape(-1))
+                bk.ready(i)
+                g = v.view(g.shape)
             grads_out[self._pindex[id(prm)]] = g
 
         for st in reversed(self.plan.steps):
@@ -239,6 +271,9 @@ class TrainRuntime:
                 s.dgrad.res = self.grads[st.src].data_ptr() if acc else None
                 _lib.check(lib.ct_conv2d_fwd(C.byref(s.dgrad), self._s()), st.name + ' dgrad')
                 written.setdefault(st.src, []).append((st.src_coff, st.src_coff + st.cin))
+        if bk is not None:
+            bk.finish()
+            grads_out = [g.clone() if g is not None else None for g in grads_out]
         return grads_out
 
 

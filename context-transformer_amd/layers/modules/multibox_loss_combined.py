@@ -26,6 +26,7 @@ class MultiBoxLoss_combined(nn.Module):
         self.negpos_ratio = neg_pos
         self.neg_overlap = neg_overlap
         self.variance = [0.1, 0.2]
+        self.sync_normalizer = False      # set True under multi-process data parallelism
 
     def forward(self, predictions, priors, targets):
         loc_data, conf_data, obj_data = predictions
@@ -63,4 +64,7 @@ class MultiBoxLoss_combined(nn.Module):
         loss_c = (F.cross_entropy(logit[mask], labels[mask].long(), reduction='none') * w).sum()
 
         n = num_pos.sum()
+        if self.sync_normalizer:          # data-parallel: N over the global batch (see ctdet.dist)
+            from ctdet.dist import global_normalizer
+            n = global_normalizer(n, dev)
         return {'loss_box_reg': loss_l / n, 'loss_cls': loss_c / n, 'loss_obj': loss_obj / n}

@@ -58,3 +58,47 @@ def test_shard_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [e - b for b, e in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bucket_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    cdist.init('gloo')
+    numels = [5, 1000, 3, 70000, 12, 40000, 7]
+    bk = cdist.GradBucketer(numels, 'cpu', bucket_bytes=200000)       # 50k floats per bucket -> several buckets
+    g = torch.Generator().manual_seed(100 + rank)
+    grads = [torch.randn(n, generator=g) for n in numels]
+    bk.begin()
+    for i, t in enumerate(grads):
+        bk.view(i).copy_(t)
+        bk.ready(i)
+    bk.finish()
+    n = cdist.global_normalizer(torch.tensor(10 + 4 * rank), 'cpu')
+    q.put((rank, [bk.view(i).numpy().copy() for i in range(len(numels))], len(bk.bucket_span), int(n)))
+    torch.distributed.destroy_process_group()
+
+
+def test_grad_bucketer_two_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    numels = [5, 1000, 3, 70000, 12, 40000, 7]
+    want = []
+    for i, n in enumerate(numels):
+        gs = []
+        for rank in range(world):
+            g = torch.Generator().manual_seed(100 + rank)
+            gs.append([torch.randn(m, generator=g) for m in numels][i])
+        want.append(sum(gs) / world)
+    for rank in range(world):
+        assert res[rank][2] >= 2                                 # really bucketed
+        assert res[rank][3] == 12                                # (10 + 14) / 2
+        for a, b in zip(res[rank][1], want):
+            assert np.allclose(a, b.numpy(), atol=1e-6)
