@@ -149,14 +149,28 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
         const bool more = t + 1 < nt;
         if (more) load_tile(t + 1);
 
-        // ---- S^T = K Q^T ----
+        // ---- S^T = K Q^T ----  (A fragments read from LDS four steps ahead of their MFMAs)
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
         const float* kb = &ks[buf][h * KT + l31];
+        {
+            float af[2][4];
 #pragma unroll
-        for (int st = 0; st < 32; ++st)
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[(2 * st) * KT], qreg[st], s, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) af[0][u] = kb[(2 * u) * KT];
+#pragma unroll
+            for (int g4 = 0; g4 < 8; ++g4) {
+                const int cur = g4 & 1;
+                if (g4 + 1 < 8) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) af[cur ^ 1][u] = kb[(2 * (4 * g4 + 4 + u)) * KT];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][u], qreg[4 * g4 + u], s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
 
         // ---- online softmax over this tile's 32 keys (16 in-lane + partner lane^32) ----
         if (t == nt - 1) {
@@ -169,11 +183,15 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float m_new = fmaxf(m_run, mloc);
-        const float alpha = expf(m_run - m_new);
+        // exp(x) = 2^(x*log2 e) on the hardware exp2 (v_exp_f32): only keys within a few units of the
+        // row maximum carry weight, and there (s - m) is exact, so the result is good to ~2 ulp
+        constexpr float kLog2e = 1.4426950408889634f;
+        const float mb = m_new * kLog2e;
+        const float alpha = __builtin_amdgcn_exp2f(m_run * kLog2e - mb);
         float lsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = expf(s[r] - m_new);
+            s[r] = __builtin_amdgcn_exp2f(s[r] * kLog2e - mb);
             lsum += s[r];
         }
         lsum += __shfl_xor(lsum, 32);
@@ -182,13 +200,32 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 
-        // ---- O^T += V^T P^T ----
+        // ---- O^T += V^T P^T ----  (V fragments two key-steps ahead)
         const float* vb = &vs[buf][l31];
+        {
+            float vf[2][4];
 #pragma unroll
-        for (int st = 0; st < 16; ++st) {
-            const int key = acc_row(st, h);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[key * DP], s[st], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb[key * DP + 32], s[st], o1, 0, 0, 0);
+            for (int u = 0; u < 2; ++u) {
+                vf[0][2 * u] = vb[acc_row(u, h) * DP];
+                vf[0][2 * u + 1] = vb[acc_row(u, h) * DP + 32];
+            }
+#pragma unroll
+            for (int g2 = 0; g2 < 8; ++g2) {
+                const int cur = g2 & 1;
+                if (g2 + 1 < 8) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        vf[cur ^ 1][2 * u] = vb[acc_row(2 * g2 + 2 + u, h) * DP];
+                        vf[cur ^ 1][2 * u + 1] = vb[acc_row(2 * g2 + 2 + u, h) * DP + 32];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cur][2 * u], s[2 * g2 + u], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cur][2 * u + 1], s[2 * g2 + u], o1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 
         if (more) store_tile(buf ^ 1);
