@@ -26,6 +26,7 @@ SOURCES = {
     'ct_api.cpp': [],
     'ct_conv.hip': [],
     'ct_pool.hip': [],
+    'ct_preproc.hip': ['-ffp-contract=off'],
     'ct_attn.hip': [],
     'ct_train.hip': [],
     'ct_box.hip': ['-ffp-contract=off'],

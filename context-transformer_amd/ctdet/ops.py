@@ -199,6 +199,55 @@ class PostProcessor:
         return res
 
 
+# ------------------------------------------------------------------ input transform
+class Preprocessor:
+    """Batched BaseTransform (data/data_augment.py:224-266) on the device: uint8 HxWx3 images of
+    any size -> float32 [B,3,S,S] (bilinear resize, minus means, CHW) in one launch.
+    The packed bytes go through one pinned staging buffer and one H2D copy per batch."""
+
+    def __init__(self, size, means, device, max_batch=32, max_pixels=512 * 512):
+        self.size, self.device, self.max_batch = size, torch.device(device), max_batch
+        self.means = (C.c_float * 3)(*[float(m) for m in means])
+        self.cap = max_batch * max_pixels * 3
+        self.stage = torch.empty(self.cap, dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(self.cap, dtype=torch.uint8, device=self.device)
+        self.meta_h = torch.empty(max_batch * 4, dtype=torch.int32).pin_memory()    # offsets (i64) | hw (i32)
+        self.meta_d = torch.empty(max_batch * 4, dtype=torch.int32, device=self.device)
+        self.copied = None                      # event: staging buffers free for reuse
+
+    def __call__(self, images, out=None):
+        n = len(images)
+        if n == 0 or n > self.max_batch:
+            raise ValueError('Preprocessor: batch of %d images (max %d)' % (n, self.max_batch))
+        if self.copied is not None:
+            self.copied.synchronize()
+        offs = self.meta_h[:2 * self.max_batch].view(torch.int64)
+        hw = self.meta_h[2 * self.max_batch:]
+        pos = 0
+        for i, img in enumerate(images):
+            a = np.ascontiguousarray(img)
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError('Preprocessor: image %d is %s %s, expected uint8 HxWx3' % (i, a.dtype, a.shape))
+            if pos + a.size > self.cap:
+                raise _lib.CtdetError('Preprocessor: staging capacity %d bytes exceeded' % self.cap)
+            self.stage[pos:pos + a.size] = torch.from_numpy(a.reshape(-1))
+            offs[i], hw[2 * i], hw[2 * i + 1] = pos, a.shape[0], a.shape[1]
+            pos += (a.size + 15) // 16 * 16
+        self.dev[:pos].copy_(self.stage[:pos], non_blocking=True)
+        self.meta_d.copy_(self.meta_h, non_blocking=True)
+        self.copied = torch.cuda.Event()
+        self.copied.record()
+        if out is None:
+            out = torch.empty(n, 3, self.size, self.size, device=self.device, dtype=torch.float32)
+        offs_d = self.meta_d[:2 * self.max_batch]
+        hw_d = self.meta_d[2 * self.max_batch:]
+        check(lib().ct_preproc_resize(_dev(self.dev, 'src', torch.uint8), _dev(offs_d, 'offsets', torch.int32),
+                                      _dev(hw_d, 'hw', torch.int32), n,
+                                      self.size, C.cast(self.means, C.c_void_p), _dev(out, 'out'), _stream()),
+              'ct_preproc_resize')
+        return out
+
+
 # ------------------------------------------------------------------ pooling / attention
 def maxpool2d(x, k, stride, pad=0, ceil_mode=False):
     B, Cn, H, W = x.shape

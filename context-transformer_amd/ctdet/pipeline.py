@@ -24,19 +24,27 @@ class DetectionPipeline:
         self.variance = variance
         self.conf_thresh, self.nms_thresh, self.max_per_image = conf_thresh, nms_thresh, max_per_image
         self.ge = bool(force_cpu_rule)
-        wh = torch.as_tensor(image_wh, dtype=torch.float32)
-        if wh.dim() == 1:
-            self.scale = torch.stack([wh[0], wh[1], wh[0], wh[1]]).to(self.device)
-        else:                                   # per-image (w, h)
-            self.scale = torch.stack([wh[:, 0], wh[:, 1], wh[:, 0], wh[:, 1]], 1).contiguous().to(self.device)
+        self.set_image_wh(image_wh)
         self.rt = net.runtime(batch, self.device)
         self.post = ops.PostProcessor(batch, self.P, num_fg, self.device, out_cap)
         self.boxes = torch.empty(batch, self.P, 4, device=self.device)
         self.scores = torch.empty(batch, self.P, num_fg + 1, device=self.device)
 
+    def set_image_wh(self, image_wh):
+        """`scale` of test.py:122-123: one (w, h) for all images or one per image [B,2]."""
+        wh = torch.as_tensor(image_wh, dtype=torch.float32)
+        if wh.dim() == 1:
+            self.scale = torch.stack([wh[0], wh[1], wh[0], wh[1]]).to(self.device)
+        else:
+            if wh.shape[0] != self.batch:
+                raise ValueError('image_wh has %d rows, pipeline batch is %d' % (wh.shape[0], self.batch))
+            self.scale = torch.stack([wh[:, 0], wh[:, 1], wh[:, 0], wh[:, 1]], 1).contiguous().to(self.device)
+
     @torch.no_grad()
-    def run(self, x):
+    def run(self, x, image_wh=None):
         """x [B,3,S,S] (device) -> (out_dets [B,T,cap,5], out_count [B,T]) device tensors."""
+        if image_wh is not None:
+            self.set_image_wh(image_wh)
         loc, conf, obj = self.net.forward_raw(x)
         ops.detect_fused(loc, conf.contiguous(), obj, self.priors, self.variance, True, self.scale,
                          out=(self.boxes, self.scores))

@@ -264,6 +264,14 @@ int ct_maxpool2d_bwd(const float* x, const float* dy, float* dx, long planes, in
 int ct_head_grad_gather(const ct_out_segment* segs, int nseg, int batch, int channels, int hw,
                         float* dz, ct_stream_t stream);
 
+/* Test-time input transform, data/data_augment.py:224-266 (BaseTransform.__call__): bilinear
+ * cv2.resize of uint8 HxWx3 images to size x size, float32, minus `means3`, HWC -> CHW.
+ * src holds `batch` images back to back; image n starts at src + offsets[n] and is
+ * hw[2n] x hw[2n+1] x 3 bytes (offsets, hw: device arrays).  out = float [batch][3][size][size].
+ * Integer arithmetic follows OpenCV's 8-bit INTER_LINEAR path (11-bit coefficients). */
+int ct_preproc_resize(const unsigned char* src, const long long* offsets, const int* hw, int batch,
+                      int size, const float* means3, float* out, ct_stream_t stream);
+
 /* torch.nn.MaxPool2d of models/RFB_Net_vgg.py:328-330,338 (2x2 s2 [ceil], 3x3 s1 p1) on an NCHW
  * buffer: planes = batch*channels; windows are clipped to the input (ceil_mode semantics are
  * encoded in oh/ow by the caller). */

@@ -1,0 +1,106 @@
+"""SURVEY 8f rows 1 and 4 on the MI355X: the device input transform against its oracle and the
+batched do_test harness (ragged last batch, per-image scale, reference all_boxes layout)."""
+import os
+import pickle
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from ctdet import harness, ops, synth
+from oracle import preproc_ref
+
+pytestmark = pytest.mark.gpu
+MEANS = (104, 117, 123)
+
+
+def _images(n, seed):
+    rng = np.random.RandomState(seed)
+    shapes = [(375, 500), (500, 333), (120, 77), (300, 300), (333, 500), (480, 364), (1, 1), (512, 512)]
+    out = []
+    for i in range(n):
+        h, w = shapes[i % len(shapes)]
+        base = rng.randint(0, 256, (max(h // 8, 1), max(w // 8, 1), 3)).astype(np.uint8)
+        img = np.kron(base, np.ones((8, 8, 1), np.uint8))[:h, :w] if h > 8 else rng.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        out.append(np.ascontiguousarray(img + rng.randint(0, 8, img.shape).astype(np.uint8) // 2))
+    return out
+
+
+@pytest.mark.parametrize('size', [300, 512])
+def test_preproc_bit_exact_vs_oracle(size):
+    imgs = _images(8, 5)
+    pre = ops.Preprocessor(size, MEANS, 'cuda:0', max_batch=8)
+    got = pre(imgs).cpu().numpy()
+    for i, img in enumerate(imgs):
+        want = preproc_ref.base_transform(img, size, MEANS)
+        assert np.array_equal(got[i], want), (i, img.shape, np.abs(got[i] - want).max())
+    # second batch through the same staging buffers, different composition
+    got2 = pre(imgs[3:6]).cpu().numpy()
+    assert np.array_equal(got2, got[3:6])
+
+
+def test_preproc_rejects_bad_input():
+    pre = ops.Preprocessor(300, MEANS, 'cuda:0', max_batch=2, max_pixels=64 * 64)
+    with pytest.raises(ValueError):
+        pre([np.zeros((4, 4, 3), np.float32)])
+    with pytest.raises(ValueError):
+        pre([np.zeros((4, 4, 3), np.uint8)] * 3)
+    with pytest.raises(Exception):
+        pre([np.zeros((200, 200, 3), np.uint8)])
+
+
+class _Dataset:
+    def __init__(self, imgs):
+        self.imgs = imgs
+        self.evaluated = None
+
+    def __len__(self):
+        return len(self.imgs)
+
+    def pull_image(self, i):
+        return self.imgs[i]
+
+    def evaluate_detections(self, all_boxes, folder):
+        self.evaluated = (len(all_boxes), len(all_boxes[0]), folder)
+        return 'ok'
+
+
+def test_do_test_harness_ragged_batches(tmp_path):
+    from data import VOC_300, BaseTransform
+    from layers.functions import PriorBox
+    from models.RFB_Net_vgg import build_net
+    net = build_net(types.SimpleNamespace(method='ours', phase=1, setting='transfer'), 300, 20)
+    net.load_state_dict(synth.fill_state_dict(net.state_dict()), strict=True)
+    net = net.eval().cuda()
+    net.device = 'cuda'
+    priors = PriorBox(VOC_300).forward().cuda()
+    imgs = [im for im in _images(6, 9) if im.shape[0] > 1]
+    tf = BaseTransform(300, MEANS, (2, 0, 1), max_batch=4)
+    ds = _Dataset(imgs)
+    all_boxes, ev = harness.do_test(net, priors, ds, tf, 20, str(tmp_path), batch=4)
+    assert ev == 'ok' and ds.evaluated == (21, len(imgs), str(tmp_path))
+    assert len(all_boxes) == 21 and all(len(r) == len(imgs) for r in all_boxes)
+    assert all_boxes[0][0] == []                                    # background row stays empty lists
+    n_det = sum(len(all_boxes[j][i]) for j in range(1, 21) for i in range(len(imgs)))
+    assert n_det > 0
+    for i in range(len(imgs)):
+        assert sum(len(all_boxes[j][i]) for j in range(1, 21)) <= 200
+        for j in range(1, 21):
+            d = all_boxes[j][i]
+            assert d.dtype == np.float32 and d.shape[1] == 5
+            assert np.all(np.diff(d[:, 4]) <= 0)
+    # pickle round trip + retest path
+    back = pickle.load(open(os.path.join(tmp_path, 'detections.pkl'), 'rb'))
+    assert all(np.array_equal(back[j][i], all_boxes[j][i]) for j in range(1, 21) for i in range(len(imgs)))
+    again, _ = harness.do_test(net, priors, ds, tf, 20, str(tmp_path), batch=4, retest=True)
+    assert all(np.array_equal(again[j][i], all_boxes[j][i]) for j in range(1, 21) for i in range(len(imgs)))
+    # image order / batch position must not matter: reversed dataset, same batch size
+    rev = harness.detect_dataset(net, priors, _Dataset(imgs[::-1]), tf, 20, batch=4)
+    n = len(imgs)
+    for j in range(1, 21):
+        for i in range(n):
+            assert np.array_equal(rev[j][n - 1 - i], all_boxes[j][i]), (j, i)
+    # per-image transform callable (reference protocol) gives the same detections as the batched one
+    one = harness.detect_dataset(net, priors, _Dataset(imgs), lambda im: tf(im), 20, batch=4)
+    assert all(np.array_equal(one[j][i], all_boxes[j][i]) for j in range(1, 21) for i in range(n))

@@ -335,8 +335,76 @@ def gen_pipeline():
     save('pipeline.npz', st)
 
 
+# ---------------------------------------------------------------------------
+def gen_voc_eval():
+    """Reference data/voc_eval.py on a synthetic VOC-style tree written to a temp dir (XML
+    annotations, image-set file, results files in the comp4 format).  `np.bool` (removed from
+    numpy >= 1.24, used at data/voc_eval.py:123) is aliased for the duration of the call."""
+    spec = importlib.util.spec_from_file_location('ref_voc_eval', os.path.join(REF, 'data/voc_eval.py'))
+    ve = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ve)
+    if not hasattr(np, 'bool'):
+        np.bool = bool
+    rng = np.random.RandomState(77)
+    classes = ['__background__', 'aeroplane', 'bicycle', 'bird']
+    nimg = 14
+    ids = ['%06d' % (i + 1) for i in range(nimg)]
+    tmp = tempfile.mkdtemp(prefix='ctref_voc_')
+    os.makedirs(os.path.join(tmp, 'Annotations'))
+    st = {'classes': np.array(classes), 'ids': np.array(ids)}
+    gts = {}
+    for i, iid in enumerate(ids):
+        n = rng.randint(0, 5)
+        objs = []
+        for k in range(n):
+            x1, y1 = rng.randint(0, 300), rng.randint(0, 200)
+            w, h = rng.randint(20, 180), rng.randint(20, 150)
+            objs.append((classes[rng.randint(1, 4)], x1, y1, x1 + w, y1 + h, int(rng.rand() < 0.2)))
+        gts[iid] = objs
+        xml = ['<annotation>']
+        for (c, x1, y1, x2, y2, diff) in objs:
+            xml.append('<object><name>%s</name><pose>Unspecified</pose><truncated>0</truncated><difficult>%d</difficult>'
+                       '<bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>'
+                       % (c, diff, x1, y1, x2, y2))
+        xml.append('</annotation>')
+        open(os.path.join(tmp, 'Annotations', iid + '.xml'), 'w').write('\n'.join(xml))
+        st['gt_%s' % iid] = np.array([[classes.index(c), x1, y1, x2, y2, d] for (c, x1, y1, x2, y2, d) in objs],
+                                     dtype=np.int64).reshape(-1, 6)
+    open(os.path.join(tmp, 'test.txt'), 'w').write('\n'.join(ids) + '\n')
+    # detections: jittered copies of the ground truth (some duplicates) + random false positives
+    for ci in range(1, 4):
+        cls = classes[ci]
+        per_img = []
+        for iid in ids:
+            rows = []
+            for (c, x1, y1, x2, y2, d) in gts[iid]:
+                if c == cls:
+                    for rep in range(rng.randint(1, 3)):
+                        j = rng.normal(0, 6, 4)
+                        rows.append([x1 + j[0], y1 + j[1], x2 + j[2], y2 + j[3], rng.uniform(0.3, 1.0)])
+            for _ in range(rng.randint(0, 3)):
+                x1, y1 = rng.uniform(0, 300), rng.uniform(0, 200)
+                rows.append([x1, y1, x1 + rng.uniform(20, 150), y1 + rng.uniform(20, 150), rng.uniform(0.01, 0.6)])
+            per_img.append(np.array(rows, dtype=np.float32).reshape(-1, 5))
+        for i, a in enumerate(per_img):
+            st['det_c%d_i%d' % (ci, i)] = a
+        path = os.path.join(tmp, 'comp4_det_test_%s.txt' % cls)
+        with open(path, 'wt') as f:
+            for iid, dets in zip(ids, per_img):
+                for k in range(dets.shape[0]):
+                    f.write('{:s} {:.3f} {:.1f} {:.1f} {:.1f} {:.1f}\n'.format(
+                        iid, dets[k, -1], dets[k, 0] + 1, dets[k, 1] + 1, dets[k, 2] + 1, dets[k, 3] + 1))
+        st['lines_c%d' % ci] = np.array(open(path).read().splitlines())
+        for m07 in (True, False):
+            rec, prec, ap = ve.voc_eval(os.path.join(tmp, 'comp4_det_test_{:s}.txt'), os.path.join(tmp, 'Annotations', '{:s}.xml'),
+                                        os.path.join(tmp, 'test.txt'), cls, os.path.join(tmp, 'cache'), 0.5, m07)
+            tag = 'c%d_%s' % (ci, '07' if m07 else 'area')
+            st[tag + '_rec'], st[tag + '_prec'], st[tag + '_ap'] = rec, prec, np.float64(ap)
+    save('voc_eval.npz', st)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['box', 'nms', 'model', 'loss', 'pipeline']
+    which = sys.argv[1:] or ['box', 'nms', 'model', 'loss', 'pipeline', 'voc']
     if 'box' in which:
         gen_box_ops()
     if 'nms' in which:
@@ -347,3 +415,5 @@ if __name__ == '__main__':
         gen_loss()
     if 'pipeline' in which:
         gen_pipeline()
+    if 'voc' in which:
+        gen_voc_eval()
