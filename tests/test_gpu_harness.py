@@ -71,7 +71,9 @@ def test_do_test_harness_ragged_batches(tmp_path):
     from layers.functions import PriorBox
     from models.RFB_Net_vgg import build_net
     net = build_net(types.SimpleNamespace(method='ours', phase=1, setting='transfer'), 300, 20)
-    net.load_state_dict(synth.fill_state_dict(net.state_dict()), strict=True)
+    sd = synth.fill_state_dict(net.state_dict())
+    sd['base.0.weight'] = sd['base.0.weight'] / 64      # synthetic weights expect unit-scale inputs, images are +-128
+    net.load_state_dict(sd, strict=True)
     net = net.eval().cuda()
     net.device = 'cuda'
     priors = PriorBox(VOC_300).forward().cuda()
@@ -84,8 +86,12 @@ def test_do_test_harness_ragged_batches(tmp_path):
     assert all_boxes[0][0] == []                                    # background row stays empty lists
     n_det = sum(len(all_boxes[j][i]) for j in range(1, 21) for i in range(len(imgs)))
     assert n_det > 0
+    every = np.concatenate([all_boxes[j][i] for j in range(1, 21) for i in range(len(imgs))])
+    assert np.isfinite(every).all() and len(np.unique(every[:, 4])) > 50      # a non-degenerate case
     for i in range(len(imgs)):
-        assert sum(len(all_boxes[j][i]) for j in range(1, 21)) <= 200
+        sc = np.concatenate([all_boxes[j][i][:, 4] for j in range(1, 21)])
+        if len(sc) > 200:                # test.py:153-158 keeps ties at the 200-th score
+            assert np.sum(sc > sc.min()) < 200
         for j in range(1, 21):
             d = all_boxes[j][i]
             assert d.dtype == np.float32 and d.shape[1] == 5
