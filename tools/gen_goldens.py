@@ -403,8 +403,37 @@ def gen_voc_eval():
     save('voc_eval.npz', st)
 
 
+# ---------------------------------------------------------------------------
+def gen_solver():
+    """Reference utils/solver.py on the reference's own RFBNet: per-tensor LR groups (name order is
+    what optimizer checkpoints depend on) and the warm-up / multi-step schedule."""
+    spec = importlib.util.spec_from_file_location('ref_solver', os.path.join(REF, 'utils/solver.py'))
+    rs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rs)
+    st = {}
+    for tag, (method, phase, setting, C) in {'p2ours': ('ours', 2, 'transfer', 20), 'p1': ('ours', 1, 'transfer', 60),
+                                              'p2ft': ('ft', 2, 'incre', 20)}.items():
+        args = types.SimpleNamespace(method=method, phase=phase, setting=setting, lr=4e-3, weight_decay=5e-4,
+                                     momentum=0.9, steps=[30, 50], warmup_iter=10)
+        net = build_net(args, 300, C)
+        opt = rs.build_optimizer(args, net)
+        names = [k for k, v in net.named_parameters() if v.requires_grad]
+        st[tag + '_names'] = np.array(names)
+        st[tag + '_lr'] = np.array([g['lr'] for g in opt.param_groups])
+        st[tag + '_wd'] = np.array([g['weight_decay'] for g in opt.param_groups])
+        st[tag + '_numel'] = np.array([g['params'][0].numel() for g in opt.param_groups])
+        sched = rs.build_lr_scheduler(args, opt)
+        rows = []
+        for it in range(60):
+            rows.append([opt.param_groups[0]['lr'], opt.param_groups[-1]['lr']])
+            opt.step()
+            sched.step()
+        st[tag + '_sched'] = np.array(rows)
+    save('solver.npz', st)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['box', 'nms', 'model', 'loss', 'pipeline', 'voc']
+    which = sys.argv[1:] or ['box', 'nms', 'model', 'loss', 'pipeline', 'voc', 'solver']
     if 'box' in which:
         gen_box_ops()
     if 'nms' in which:
@@ -417,3 +446,5 @@ if __name__ == '__main__':
         gen_pipeline()
     if 'voc' in which:
         gen_voc_eval()
+    if 'solver' in which:
+        gen_solver()
