@@ -28,6 +28,7 @@ SOURCES = {
     'ct_pool.hip': [],
     'ct_preproc.hip': ['-ffp-contract=off'],
     'ct_attn.hip': [],
+    'ct_attn_bwd.hip': [],
     'ct_train.hip': [],
     'ct_box.hip': ['-ffp-contract=off'],
     'ct_nms.hip': ['-ffp-contract=off'],
@@ -52,7 +53,8 @@ def _newer(a, b):
 def _compile(src, flags, force):
     obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
     path = os.path.join(CSRC, src)
-    deps = [path, os.path.join(REPO, 'include', 'ctdet.h'), os.path.join(CSRC, 'ct_common.h'), __file__]
+    deps = [path, os.path.join(REPO, 'include', 'ctdet.h'), os.path.join(CSRC, 'ct_common.h'),
+            os.path.join(CSRC, 'ct_attn_common.h'), __file__]
     if force or any(_newer(d, obj) for d in deps):
         cmd = [hipcc()] + COMMON + flags + ['-x', 'hip', '-c', path, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -17,59 +17,9 @@
 //                        Epilogue in registers: (conf + O/l * Wz) -> L2 normalise -> cosine
 //                        classifier OBJ_Target * scale, written to out[B,P,(d)+T].
 #include "ct_common.h"
-#include <algorithm>
+#include "ct_attn_common.h"
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int DP = 64;      // padded feature dim
-constexpr int QW = 32;      // queries per wave
-constexpr int QB = 128;     // queries per workgroup
-constexpr int KT = 32;      // keys per tile
-
-__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// mode 0: Qs, 1: Kt, 2: Vs, 3: plain rows into `out` (row stride ostride)
-__global__ __launch_bounds__(256) void ctx_project_kernel(const float* __restrict__ x, int rows_valid,
-                                                          int rows_pad, int d,
-                                                          const float* __restrict__ W,
-                                                          const float* __restrict__ bias, int mode,
-                                                          float* __restrict__ out, int ostride)
-{
-    __shared__ float Wt[DP * DP];      // Wt[i][o]
-    __shared__ float Xs[64 * DP];      // 64 rows
-    const int b = blockIdx.y;
-    const int r0 = blockIdx.x * 64;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < DP * DP; e += 256) {
-        const int i = e / DP, o = e % DP;
-        Wt[e] = (i < d && o < d) ? W[o * d + i] : 0.f;
-    }
-    for (int e = tid; e < 64 * DP; e += 256) {
-        const int r = e / DP, i = e % DP;
-        const int row = r0 + r;
-        Xs[e] = (row < rows_valid && i < d) ? x[((size_t)b * rows_valid + row) * d + i] : 0.f;
-    }
-    __syncthreads();
-    const int o = tid & 63, rg = tid >> 6;
-    const float bo = (o < d) ? bias[o] : 0.f;
-    for (int r = rg; r < 64; r += 4) {
-        const int row = r0 + r;
-        if (row >= rows_pad) break;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int i = 0; i < DP; ++i) acc += Xs[r * DP + i] * Wt[i * DP + o];
-        float y = (row < rows_valid && o < d) ? acc + bo + Xs[r * DP + o] : 0.f;
-        if (mode == 0)
-            out[((size_t)b * rows_pad + row) * DP + (o & 1) * 32 + (o >> 1)] = y;
-        else if (mode == 1)
-            out[((size_t)b * DP + o) * rows_pad + row] = y;
-        else if (mode == 2)
-            out[((size_t)b * rows_pad + row) * DP + o] = y;
-        else if (row < rows_valid && o < d)
-            out[((size_t)b * rows_valid + row) * ostride + o] = y;
-    }
-}
 
 struct AttnArgs {
     const float* Qs;
@@ -79,6 +29,8 @@ struct AttnArgs {
     const float* wz;
     const float* obj_w;
     float* out;
+    float* save_d;      // training: aggregated context rows D = softmax(S) g, [B][P_pad][64]
+    float* save_lse;    // training: log2-domain log-sum-exp of each affinity row, [B][P_pad]
     int P, P_pad, M, M_pad, d, T, ostride, ooff;
     float scale;
 };
@@ -173,7 +125,7 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
         }
 
         // ---- online softmax over this tile's 32 keys (16 in-lane + partner lane^32) ----
-        if (t == nt - 1) {
+        if ((t + 1) * KT > a.M) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (t * KT + acc_row(r, h) >= a.M) s[r] = -INFINITY;
@@ -233,8 +185,29 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
     }
 
     // ---- epilogue: residual, L2 normalise, cosine classifier ----
-    if (q >= a.P) return;
+    if (q >= a.P) {
+        if (a.save_d) {                       // padding rows: exp2(s - inf) = 0 in the backward pass
+            float4* drow = reinterpret_cast<float4*>(a.save_d + ((size_t)b * a.P_pad + q) * DP);
+            for (int g = 0; g < 4; ++g) {
+                drow[2 * g + h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                drow[8 + 2 * g + h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (h == 0) a.save_lse[(size_t)b * a.P_pad + q] = INFINITY;
+        }
+        return;
+    }
     const float inv_l = 1.f / l_run;
+    if (a.save_d) {
+        float4* drow = reinterpret_cast<float4*>(a.save_d + ((size_t)b * a.P_pad + q) * DP);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {         // acc rows 4g..4g+3 are features 8g+4h .. +3 (and +32)
+            drow[2 * g + h] = make_float4(o0[4 * g] * inv_l, o0[4 * g + 1] * inv_l, o0[4 * g + 2] * inv_l,
+                                          o0[4 * g + 3] * inv_l);
+            drow[8 + 2 * g + h] = make_float4(o1[4 * g] * inv_l, o1[4 * g + 1] * inv_l, o1[4 * g + 2] * inv_l,
+                                              o1[4 * g + 3] * inv_l);
+        }
+        if (h == 0) a.save_lse[(size_t)b * a.P_pad + q] = m_run * 1.4426950408889634f + log2f(l_run);
+    }
     const float* crow = a.conf + ((size_t)b * a.P + q) * a.d;
     float x[32];
     float n2 = 0.f;
@@ -288,6 +261,54 @@ Ws carve(char* base, int batch, int P, int M)
     return w;
 }
 
+int check_params(const ct_ctx_params* prm, const char* who)
+{
+    CT_REQUIRE(prm->d >= 1 && prm->d <= DP && prm->t >= 1 && prm->t <= 32, "%s: d=%d (<=64) t=%d (<=32)", who,
+               prm->d, prm->t);
+    CT_REQUIRE(prm->theta_w && prm->theta_b && prm->phi_w && prm->phi_b && prm->g_w && prm->g_b && prm->wz &&
+                   prm->obj_w, "%s: null parameter", who);
+    CT_REQUIRE(!prm->fc_w || prm->fc_b, "%s: fc_b missing", who);
+    return CT_OK;
+}
+
+int forward_impl(const float* conf, const float* pool, int batch, int num_priors, int num_ctx,
+                 const ct_ctx_params* prm, float* out, float* save_d, float* save_lse, void* workspace,
+                 size_t workspace_bytes, hipStream_t st)
+{
+    const size_t need = carve(nullptr, batch, num_priors, num_ctx).total;
+    if (workspace_bytes < need)
+        return ctdet::fail(CT_ERR_WORKSPACE, "ct_ctx_attention_fwd: workspace %zu < %zu", workspace_bytes, need);
+    Ws w = carve((char*)workspace, batch, num_priors, num_ctx);
+    const int d = prm->d;
+    const int ostride = (prm->fc_w ? d : 0) + prm->t;
+    const dim3 blk(256);
+    float* none = nullptr;
+    hipLaunchKernelGGL(ctx_project_kernel, dim3(w.P_pad / 64, batch), blk, 0, st, conf, num_priors,
+                       w.P_pad, d, prm->theta_w, prm->theta_b, w.Qs, none, none, none, 0);
+    CT_LAUNCH_CHECK("ctx_project_kernel(theta)");
+    hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
+                       w.M_pad, d, prm->phi_w, prm->phi_b, none, w.Kt, none, none, 0);
+    CT_LAUNCH_CHECK("ctx_project_kernel(phi)");
+    hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
+                       w.M_pad, d, prm->g_w, prm->g_b, none, none, w.Vs, none, 0);
+    CT_LAUNCH_CHECK("ctx_project_kernel(g)");
+    if (prm->fc_w) {
+        hipLaunchKernelGGL(ctx_project_kernel, dim3((num_priors + 63) / 64, batch), blk, 0, st, conf,
+                           num_priors, num_priors, d, prm->fc_w, prm->fc_b, none, none, none, out, ostride);
+        CT_LAUNCH_CHECK("ctx_project_kernel(fc_base)");
+    }
+    AttnArgs a{};
+    a.Qs = w.Qs; a.Kt = w.Kt; a.Vs = w.Vs;
+    a.conf = conf; a.wz = prm->wz; a.obj_w = prm->obj_w; a.out = out;
+    a.save_d = save_d; a.save_lse = save_lse;
+    a.P = num_priors; a.P_pad = w.P_pad; a.M = num_ctx; a.M_pad = w.M_pad;
+    a.d = d; a.T = prm->t; a.ostride = ostride; a.ooff = prm->fc_w ? d : 0;
+    a.scale = prm->scale;
+    hipLaunchKernelGGL(ctx_attn_kernel, dim3(w.P_pad / QB, batch), blk, 0, st, a);
+    CT_LAUNCH_CHECK("ctx_attn_kernel");
+    return CT_OK;
+}
+
 }  // namespace
 
 extern "C" size_t ct_ctx_attention_workspace_bytes(int batch, int num_priors, int num_ctx, int)
@@ -301,40 +322,31 @@ extern "C" int ct_ctx_attention_fwd(const float* conf, const float* pool, int ba
 {
     CT_REQUIRE(conf && pool && prm && out && workspace, "ct_ctx_attention_fwd: null pointer");
     CT_REQUIRE(batch > 0 && num_priors > 0 && num_ctx > 0, "ct_ctx_attention_fwd: bad sizes");
-    CT_REQUIRE(prm->d >= 1 && prm->d <= DP && prm->t >= 1 && prm->t <= 32,
-               "ct_ctx_attention_fwd: d=%d (<=64) t=%d (<=32)", prm->d, prm->t);
-    CT_REQUIRE(prm->theta_w && prm->theta_b && prm->phi_w && prm->phi_b && prm->g_w && prm->g_b &&
-                   prm->wz && prm->obj_w, "ct_ctx_attention_fwd: null parameter");
-    const size_t need = ct_ctx_attention_workspace_bytes(batch, num_priors, num_ctx, prm->d);
-    if (workspace_bytes < need)
-        return ctdet::fail(CT_ERR_WORKSPACE, "ct_ctx_attention_fwd: workspace %zu < %zu", workspace_bytes, need);
-    Ws w = carve((char*)workspace, batch, num_priors, num_ctx);
-    hipStream_t st = ctdet::as_stream(stream);
-    const int d = prm->d;
-    const int ostride = (prm->fc_w ? d : 0) + prm->t;
-    const dim3 blk(256);
-    hipLaunchKernelGGL(ctx_project_kernel, dim3(w.P_pad / 64, batch), blk, 0, st, conf, num_priors,
-                       w.P_pad, d, prm->theta_w, prm->theta_b, 0, w.Qs, 0);
-    CT_LAUNCH_CHECK("ctx_project_kernel(theta)");
-    hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
-                       w.M_pad, d, prm->phi_w, prm->phi_b, 1, w.Kt, 0);
-    CT_LAUNCH_CHECK("ctx_project_kernel(phi)");
-    hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
-                       w.M_pad, d, prm->g_w, prm->g_b, 2, w.Vs, 0);
-    CT_LAUNCH_CHECK("ctx_project_kernel(g)");
-    if (prm->fc_w) {
-        CT_REQUIRE(prm->fc_b, "ct_ctx_attention_fwd: fc_b missing");
-        hipLaunchKernelGGL(ctx_project_kernel, dim3((num_priors + 63) / 64, batch), blk, 0, st, conf,
-                           num_priors, num_priors, d, prm->fc_w, prm->fc_b, 3, out, ostride);
-        CT_LAUNCH_CHECK("ctx_project_kernel(fc_base)");
-    }
-    AttnArgs a{};
-    a.Qs = w.Qs; a.Kt = w.Kt; a.Vs = w.Vs;
-    a.conf = conf; a.wz = prm->wz; a.obj_w = prm->obj_w; a.out = out;
-    a.P = num_priors; a.P_pad = w.P_pad; a.M = num_ctx; a.M_pad = w.M_pad;
-    a.d = d; a.T = prm->t; a.ostride = ostride; a.ooff = prm->fc_w ? d : 0;
-    a.scale = prm->scale;
-    hipLaunchKernelGGL(ctx_attn_kernel, dim3(w.P_pad / QB, batch), blk, 0, st, a);
-    CT_LAUNCH_CHECK("ctx_attn_kernel");
-    return CT_OK;
+    if (int rc = check_params(prm, "ct_ctx_attention_fwd")) return rc;
+    return forward_impl(conf, pool, batch, num_priors, num_ctx, prm, out, nullptr, nullptr, workspace,
+                        workspace_bytes, ctdet::as_stream(stream));
+}
+
+extern "C" size_t ct_ctx_attention_saved_bytes(int batch, int num_priors)
+{
+    const size_t P_pad = (size_t)(num_priors + QB - 1) / QB * QB;
+    return (size_t)batch * P_pad * (DP + 1) * sizeof(float);
+}
+
+extern "C" int ct_ctx_attention_fwd_train(const float* conf, const float* pool, int batch, int num_priors,
+                                          int num_ctx, const ct_ctx_params* prm, float* out, void* saved,
+                                          size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                                          ct_stream_t stream)
+{
+    CT_REQUIRE(conf && pool && prm && out && workspace && saved, "ct_ctx_attention_fwd_train: null pointer");
+    CT_REQUIRE(batch > 0 && num_priors > 0 && num_ctx > 0, "ct_ctx_attention_fwd_train: bad sizes");
+    if (int rc = check_params(prm, "ct_ctx_attention_fwd_train")) return rc;
+    if (saved_bytes < ct_ctx_attention_saved_bytes(batch, num_priors))
+        return ctdet::fail(CT_ERR_WORKSPACE, "ct_ctx_attention_fwd_train: saved buffer %zu < %zu", saved_bytes,
+                           ct_ctx_attention_saved_bytes(batch, num_priors));
+    const size_t P_pad = (size_t)(num_priors + QB - 1) / QB * QB;
+    float* save_d = (float*)saved;
+    float* save_lse = save_d + (size_t)batch * P_pad * DP;
+    return forward_impl(conf, pool, batch, num_priors, num_ctx, prm, out, save_d, save_lse, workspace,
+                        workspace_bytes, ctdet::as_stream(stream));
 }

@@ -1,0 +1,689 @@
+// libctdet: backward pass of the Context-Transformer block (models/RFB_Net_vgg.py:253-271; the
+// reference gets it from autograd over matmul/softmax/linear).  With
+//     Q = theta(X)+X   K = phi(Pl)+Pl   V = g(Pl)+Pl   A = softmax(Q K^T)   D = A V
+//     Y = X + D*Wz     N = Y/|Y|        out = scale * N OBJ^T              (X = conf, Pl = pooled conf)
+// the gradient of `out` flows back as
+//   ctx_out_bwd_kernel   per query row: dN -> dY -> (dX direct, dD = dY*Wz, delta = dD.D), dWz, dOBJ
+//   ctx_attn_bwd_q       flash-style, one wave = 32 queries, loops over key tiles (fp32 MFMA):
+//                          S^T = K Q^T, dA^T = V dD^T, dS = A*(dA - delta), dQ^T += K^T dS^T
+//   ctx_attn_bwd_kv      one wave = 32 keys, loops over query tiles:
+//                          S = Q K^T, dA = dD V^T, dV^T += dD^T A, dK^T += Q^T dS
+//                        (the [P,M] affinity matrix is recomputed from the saved row log-sum-exp,
+//                         never stored; the query range is split over blockIdx.z, partial sums
+//                         meet in dK/dV through float atomics)
+//   ctx_linear_bwd_kernel  y = Lin(x)+x: dx (+)= dy + dy W, dW += dy^T x, db += sum dy
+//   ctx_pool_bwd_kernel    max-pool backward of the context pooling (first maximum per window)
+#include "ct_common.h"
+#include "ct_attn_common.h"
+#include <mutex>
+
+namespace {
+
+constexpr int RS = 72;            // LDS row stride of [row][feature] tiles: 4*RS % 64 == 32 keeps the
+                                  // two half-waves of an MFMA A-fragment read on disjoint banks
+constexpr float kLog2e = 1.4426950408889634f;
+
+__device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// ------------------------------------------------------------------------------------------------
+// per-row part: everything after the aggregation
+// ------------------------------------------------------------------------------------------------
+struct OutBwdArgs {
+    const float* conf;      // [B][P][d]
+    const float* D;         // saved [B][P_pad][64]
+    const float* dout;      // [B][P][ostride]
+    const float* wz;
+    const float* obj_w;     // [T][d]
+    float* dconf;           // [B][P][d]   (written)
+    float* dDs;             // [B][P_pad][64] swizzled
+    float* dDt;             // [B][64][P_pad]
+    float* delta;           // [B][P_pad]
+    float* dwz;             // [d]    (atomics)
+    float* dobj;            // [T][d] (atomics)
+    int P, P_pad, d, T, ostride, ooff, chunks;
+    float scale;
+};
+
+// 256 threads = 64 rows x 4 feature quarters (16 features each); a block walks `chunks` 64-row chunks.
+__global__ __launch_bounds__(256) void ctx_out_bwd_kernel(const OutBwdArgs a)
+{
+    __shared__ float objw[32 * DP];          // [t][i]
+    __shared__ float Ns[64 * (DP + 1)];      // normalised rows of the chunk
+    __shared__ float dOs[64 * 33];           // dOut rows of the chunk
+    __shared__ float wzs[DP];
+    __shared__ float red[DP];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int rl = tid >> 2, part = tid & 3, f0 = part * 16;
+    for (int e = tid; e < 32 * DP; e += 256) {
+        const int t = e / DP, i = e % DP;
+        objw[e] = (t < a.T && i < a.d) ? a.obj_w[t * a.d + i] : 0.f;
+    }
+    if (tid < DP) { wzs[tid] = tid < a.d ? a.wz[tid] : 0.f; red[tid] = 0.f; }
+    __syncthreads();
+
+    float dwz_acc[16];
+    float dobj_acc[8];                       // outputs e = tid + 256*j of the [32][64] dOBJ tile
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dwz_acc[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dobj_acc[j] = 0.f;
+
+    for (int c = 0; c < a.chunks; ++c) {
+        const int row = (blockIdx.x * a.chunks + c) * 64 + rl;
+        const bool live = row < a.P;
+        float X[16], Dv[16], Y[16];
+        float n2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = f0 + j;
+            const bool ok = live && i < a.d;
+            X[j] = ok ? a.conf[((size_t)b * a.P + row) * a.d + i] : 0.f;
+            Dv[j] = ok ? a.D[((size_t)b * a.P_pad + row) * DP + i] : 0.f;
+            Y[j] = X[j] + Dv[j] * wzs[i];
+            n2 += Y[j] * Y[j];
+        }
+        n2 += __shfl_xor(n2, 1);
+        n2 += __shfl_xor(n2, 2);
+        const float rn = live ? 1.f / sqrtf(n2) : 0.f;
+        // stage dOut row + N row
+        for (int t = part; t < 32; t += 4)
+            dOs[rl * 33 + t] = (live && t < a.T) ? a.dout[((size_t)b * a.P + row) * a.ostride + a.ooff + t] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            Y[j] *= rn;                       // Y now holds N
+            Ns[rl * (DP + 1) + f0 + j] = Y[j];
+        }
+        __syncthreads();
+        // dN = scale * dOut . OBJ ;  c = N . dN
+        float dN[16];
+        float cdot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dN[j] = 0.f;
+        for (int t = 0; t < a.T; ++t) {
+            const float g = dOs[rl * 33 + t] * a.scale;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dN[j] += g * objw[t * DP + f0 + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) cdot += Y[j] * dN[j];
+        cdot += __shfl_xor(cdot, 1);
+        cdot += __shfl_xor(cdot, 2);
+        float dl = 0.f;
+        if (row < a.P_pad) {
+            float* dsw = a.dDs + ((size_t)b * a.P_pad + row) * DP;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int i = f0 + j;
+                const float dY = rn * (dN[j] - Y[j] * cdot);
+                const float dD = dY * wzs[i];
+                if (live && i < a.d) a.dconf[((size_t)b * a.P + row) * a.d + i] = dY;
+                dsw[(i & 1) * 32 + (i >> 1)] = dD;
+                a.dDt[((size_t)b * DP + i) * a.P_pad + row] = dD;
+                dl += dD * Dv[j];
+                dwz_acc[j] += dY * Dv[j];
+            }
+        }
+        dl += __shfl_xor(dl, 1);
+        dl += __shfl_xor(dl, 2);
+        if (part == 0 && row < a.P_pad) a.delta[(size_t)b * a.P_pad + row] = dl;
+        // dOBJ[t][i] += scale * sum_rows dOut[row][t] * N[row][i]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = tid + 256 * j, t = e >> 6, i = e & 63;
+            float acc = 0.f;
+            for (int r = 0; r < 64; ++r) acc += dOs[r * 33 + t] * Ns[r * (DP + 1) + i];
+            dobj_acc[j] += acc;
+        }
+        __syncthreads();
+    }
+    // block totals -> global (atomics)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) atomicAdd(&red[f0 + j], dwz_acc[j]);
+    __syncthreads();
+    if (tid < a.d) atomic_add_f32(&a.dwz[tid], red[tid]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int e = tid + 256 * j, t = e >> 6, i = e & 63;
+        if (t < a.T && i < a.d) atomic_add_f32(&a.dobj[t * a.d + i], dobj_acc[j] * a.scale);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// query side: dQ
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    const float *Qs, *Qt, *Ksw, *Kt, *Vsw, *Vt, *dDs, *dDt, *lse, *delta;
+    float *dQ, *dK, *dV;
+    int P, P_pad, M, M_pad, split;
+};
+
+__global__ __launch_bounds__(256) void ctx_attn_bwd_q(const BwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float kt[2][DP * KT];    // [d][key]
+    __shared__ __attribute__((aligned(16))) float vt[2][DP * KT];    // [d][key]
+    __shared__ __attribute__((aligned(16))) float kr[2][KT * RS];    // [key][d'] (swizzled features)
+
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = blockIdx.x * QB + wave * QW + l31;
+
+    float qreg[32], dreg[32];
+    {
+        const float4* qp = reinterpret_cast<const float4*>(a.Qs + ((size_t)b * a.P_pad + q) * DP + h * 32);
+        const float4* dp = reinterpret_cast<const float4*>(a.dDs + ((size_t)b * a.P_pad + q) * DP + h * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 v = qp[i], w = dp[i];
+            qreg[4 * i + 0] = v.x; qreg[4 * i + 1] = v.y; qreg[4 * i + 2] = v.z; qreg[4 * i + 3] = v.w;
+            dreg[4 * i + 0] = w.x; dreg[4 * i + 1] = w.y; dreg[4 * i + 2] = w.z; dreg[4 * i + 3] = w.w;
+        }
+    }
+    const float lse2 = a.lse[(size_t)b * a.P_pad + q];
+    const float dlt = a.delta[(size_t)b * a.P_pad + q];
+
+    const float* Ktb = a.Kt + (size_t)b * DP * a.M_pad;
+    const float* Vtb = a.Vt + (size_t)b * DP * a.M_pad;
+    const float* Krb = a.Ksw + (size_t)b * a.M_pad * DP;
+    const int nt = a.M_pad / KT;
+
+    float4 pk[2], pv[2], pr[2];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f >> 3, c4 = f & 7;
+            pk[i] = *reinterpret_cast<const float4*>(Ktb + (size_t)row * a.M_pad + t * KT + c4 * 4);
+            pv[i] = *reinterpret_cast<const float4*>(Vtb + (size_t)row * a.M_pad + t * KT + c4 * 4);
+            pr[i] = *reinterpret_cast<const float4*>(Krb + (size_t)t * KT * DP + f * 4);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            *reinterpret_cast<float4*>(&kt[buf][f * 4]) = pk[i];
+            *reinterpret_cast<float4*>(&vt[buf][f * 4]) = pv[i];
+            *reinterpret_cast<float4*>(&kr[buf][(f >> 4) * RS + (f & 15) * 4]) = pr[i];
+        }
+    };
+
+    f32x16 dq0, dq1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < nt;
+        if (more) load_tile(t + 1);
+
+        f32x16 s, da;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; da[r] = 0.f; }
+        const float* kb = &kt[buf][h * KT + l31];
+        const float* vb = &vt[buf][h * KT + l31];
+#pragma unroll
+        for (int g4 = 0; g4 < 8; ++g4) {
+            float ak[4], av[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ak[u] = kb[(2 * (4 * g4 + u)) * KT];
+                av[u] = vb[(2 * (4 * g4 + u)) * KT];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[u], qreg[4 * g4 + u], s, 0, 0, 0);
+                da = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], dreg[4 * g4 + u], da, 0, 0, 0);
+            }
+        }
+        // dS^T = A^T * (dA^T - delta), A from the saved log-sum-exp
+        const bool edge = (t + 1) * KT > a.M;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = __builtin_amdgcn_exp2f(s[r] * kLog2e - lse2);
+            if (edge && t * KT + acc_row(r, h) >= a.M) p = 0.f;
+            s[r] = p * (da[r] - dlt);
+        }
+        // dQ^T += K^T dS^T
+        const float* rb = &kr[buf][l31];
+#pragma unroll
+        for (int g2 = 0; g2 < 8; ++g2) {
+            float a0[2], a1[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                a0[u] = rb[acc_row(2 * g2 + u, h) * RS];
+                a1[u] = rb[acc_row(2 * g2 + u, h) * RS + 32];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], s[2 * g2 + u], dq0, 0, 0, 0);
+                dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], s[2 * g2 + u], dq1, 0, 0, 0);
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    // dq0 row d' = acc_row(r,h) is feature 2d', dq1 is feature 2d'+1
+    float2* orow = reinterpret_cast<float2*>(a.dQ + ((size_t)b * a.P_pad + q) * DP);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) orow[acc_row(r, h)] = make_float2(dq0[r], dq1[r]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// key side: dK, dV
+// ------------------------------------------------------------------------------------------------
+constexpr int KV_TILE_FLOATS = 2 * DP * KT + 2 * KT * RS + 2 * KT;     // Qt, dDt, Qs rows, dDs rows, lse, delta
+constexpr int KV_LDS_BYTES = 2 * KV_TILE_FLOATS * 4;
+
+__global__ __launch_bounds__(256) void ctx_attn_bwd_kv(const BwdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int key = blockIdx.x * QB + wave * QW + l31;           // < M_pad (M_pad % 128 == 0)
+
+    float kreg[32], vreg[32];
+    {
+        const float4* kp = reinterpret_cast<const float4*>(a.Ksw + ((size_t)b * a.M_pad + key) * DP + h * 32);
+        const float4* vp = reinterpret_cast<const float4*>(a.Vsw + ((size_t)b * a.M_pad + key) * DP + h * 32);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 v = kp[i], w = vp[i];
+            kreg[4 * i + 0] = v.x; kreg[4 * i + 1] = v.y; kreg[4 * i + 2] = v.z; kreg[4 * i + 3] = v.w;
+            vreg[4 * i + 0] = w.x; vreg[4 * i + 1] = w.y; vreg[4 * i + 2] = w.z; vreg[4 * i + 3] = w.w;
+        }
+    }
+    const bool key_live = key < a.M;
+
+    const float* Qtb = a.Qt + (size_t)b * DP * a.P_pad;
+    const float* Dtb = a.dDt + (size_t)b * DP * a.P_pad;
+    const float* Qrb = a.Qs + (size_t)b * a.P_pad * DP;
+    const float* Drb = a.dDs + (size_t)b * a.P_pad * DP;
+    const float* lseb = a.lse + (size_t)b * a.P_pad;
+    const float* delb = a.delta + (size_t)b * a.P_pad;
+    const int nt_all = a.P_pad / KT;
+    const int t_begin = (int)((long)nt_all * blockIdx.z / a.split);
+    const int t_end = (int)((long)nt_all * (blockIdx.z + 1) / a.split);
+
+    float4 pq[2], pd[2], prq[2], prd[2];
+    float pl = 0.f;
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            const int row = f >> 3, c4 = f & 7;
+            pq[i] = *reinterpret_cast<const float4*>(Qtb + (size_t)row * a.P_pad + t * KT + c4 * 4);
+            pd[i] = *reinterpret_cast<const float4*>(Dtb + (size_t)row * a.P_pad + t * KT + c4 * 4);
+            prq[i] = *reinterpret_cast<const float4*>(Qrb + (size_t)t * KT * DP + f * 4);
+            prd[i] = *reinterpret_cast<const float4*>(Drb + (size_t)t * KT * DP + f * 4);
+        }
+        if (tid < 32) pl = lseb[t * KT + tid];
+        else if (tid < 64) pl = delb[t * KT + tid - 32];
+    };
+    auto store_tile = [&](int buf) {
+        float* base = lds + buf * KV_TILE_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i;
+            *reinterpret_cast<float4*>(&base[f * 4]) = pq[i];
+            *reinterpret_cast<float4*>(&base[DP * KT + f * 4]) = pd[i];
+            *reinterpret_cast<float4*>(&base[2 * DP * KT + (f >> 4) * RS + (f & 15) * 4]) = prq[i];
+            *reinterpret_cast<float4*>(&base[2 * DP * KT + KT * RS + (f >> 4) * RS + (f & 15) * 4]) = prd[i];
+        }
+        if (tid < 64) base[2 * DP * KT + 2 * KT * RS + tid] = pl;
+    };
+
+    f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+
+    if (t_begin < t_end) {
+        load_tile(t_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int buf = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        if (more) load_tile(t + 1);
+        const float* base = lds + buf * KV_TILE_FLOATS;
+        const float* qt = base + h * KT + l31;
+        const float* dt = base + DP * KT + h * KT + l31;
+        const float* qr = base + 2 * DP * KT + l31;
+        const float* dr = base + 2 * DP * KT + KT * RS + l31;
+        const float* ls = base + 2 * DP * KT + 2 * KT * RS;
+
+        f32x16 s, da;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; da[r] = 0.f; }
+#pragma unroll
+        for (int g4 = 0; g4 < 8; ++g4) {
+            float aq[4], ad[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                aq[u] = qt[(2 * (4 * g4 + u)) * KT];
+                ad[u] = dt[(2 * (4 * g4 + u)) * KT];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u], kreg[4 * g4 + u], s, 0, 0, 0);
+                da = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[u], vreg[4 * g4 + u], da, 0, 0, 0);
+            }
+        }
+        // A[q][key] and dS[q][key] for this lane's key; rows are the tile's queries acc_row(r,h)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qq = acc_row(r, h);
+            float p = __builtin_amdgcn_exp2f(s[r] * kLog2e - ls[qq]);
+            if (!key_live) p = 0.f;
+            s[r] = p;
+            da[r] = p * (da[r] - ls[32 + qq]);
+        }
+#pragma unroll
+        for (int g2 = 0; g2 < 8; ++g2) {
+            float d0[2], d1[2], q0[2], q1[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int ro = acc_row(2 * g2 + u, h) * RS;
+                d0[u] = dr[ro]; d1[u] = dr[ro + 32];
+                q0[u] = qr[ro]; q1[u] = qr[ro + 32];
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0[u], s[2 * g2 + u], dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[u], s[2 * g2 + u], dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0[u], da[2 * g2 + u], dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1[u], da[2 * g2 + u], dk1, 0, 0, 0);
+            }
+        }
+        if (more) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+    float* krow = a.dK + ((size_t)b * a.M_pad + key) * DP;
+    float* vrow = a.dV + ((size_t)b * a.M_pad + key) * DP;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = 2 * acc_row(r, h);
+        atomic_add_f32(&krow[i], dk0[r]);
+        atomic_add_f32(&krow[i + 1], dk1[r]);
+        atomic_add_f32(&vrow[i], dv0[r]);
+        atomic_add_f32(&vrow[i + 1], dv1[r]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// y = Linear(x) + x backward.  dy rows have stride `dy_stride` (64 for the padded gradient rows, the
+// output stride for the fc_base half); x is [B][rows][d].
+// ------------------------------------------------------------------------------------------------
+struct LinBwdArgs {
+    const float* dy;
+    const float* x;
+    const float* W;          // [d][d] (out, in)
+    float* dx;               // [B][rows][d]
+    float* dW;               // [d][d] atomics
+    float* db;               // [d]    atomics
+    long long dy_batch_stride;
+    int rows, d, dy_stride, accumulate, chunks;
+};
+
+__global__ __launch_bounds__(256) void ctx_linear_bwd_kernel(const LinBwdArgs a)
+{
+    __shared__ float Ws[DP * (DP + 1)];      // W[o][i]
+    __shared__ float dYs[64 * (DP + 1)];
+    __shared__ float Xs[64 * (DP + 1)];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int rl = tid >> 2, part = tid & 3, f0 = part * 16;
+    for (int e = tid; e < DP * DP; e += 256) {
+        const int o = e / DP, i = e % DP;
+        Ws[o * (DP + 1) + i] = (o < a.d && i < a.d) ? a.W[o * a.d + i] : 0.f;
+    }
+    float dw_acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dw_acc[j] = 0.f;
+    float db_acc = 0.f;
+    const float* dyb = a.dy + (size_t)b * a.dy_batch_stride;
+
+    for (int c = 0; c < a.chunks; ++c) {
+        const int r0 = (blockIdx.x * a.chunks + c) * 64;
+        if (r0 >= a.rows) break;
+        __syncthreads();
+        for (int e = tid; e < 64 * DP; e += 256) {
+            const int r = e / DP, i = e % DP;
+            const int row = r0 + r;
+            const bool ok = row < a.rows && i < a.d;
+            dYs[r * (DP + 1) + i] = ok ? dyb[(size_t)row * a.dy_stride + i] : 0.f;
+            Xs[r * (DP + 1) + i] = ok ? a.x[((size_t)b * a.rows + row) * a.d + i] : 0.f;
+        }
+        __syncthreads();
+        // dx[row][i] = dy[row][i] + sum_o dy[row][o] W[o][i]
+        {
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = dYs[rl * (DP + 1) + f0 + j];
+            for (int o = 0; o < a.d; ++o) {
+                const float g = dYs[rl * (DP + 1) + o];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc[j] += g * Ws[o * (DP + 1) + f0 + j];
+            }
+            const int row = r0 + rl;
+            if (row < a.rows) {
+                float* out = a.dx + ((size_t)b * a.rows + row) * a.d;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int i = f0 + j;
+                    if (i < a.d) out[i] = a.accumulate ? out[i] + acc[j] : acc[j];
+                }
+            }
+        }
+        // dW[o][i] += sum_r dy[r][o] x[r][i]   (thread: o = tid>>2, i = f0..f0+15)
+        {
+            const int o = rl;
+            for (int r = 0; r < 64; ++r) {
+                const float g = dYs[r * (DP + 1) + o];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) dw_acc[j] += g * Xs[r * (DP + 1) + f0 + j];
+            }
+            if (tid < DP)
+                for (int r = 0; r < 64; ++r) db_acc += dYs[r * (DP + 1) + tid];
+        }
+    }
+    const int o = rl;
+    if (o < a.d) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (f0 + j < a.d) atomic_add_f32(&a.dW[o * a.d + f0 + j], dw_acc[j]);
+    }
+    if (tid < a.d) atomic_add_f32(&a.db[tid], db_acc);
+}
+
+// channels-last max-pool backward, kernel = stride = k, ceil_mode: every input cell belongs to one
+// window; it receives the window's gradient iff it is the first maximum in (h, w) scan order.
+__global__ __launch_bounds__(256) void ctx_pool_bwd_kernel(const float* __restrict__ in, long long in_img,
+                                                           const float* __restrict__ dpool,
+                                                           long long pool_img, float* __restrict__ din,
+                                                           long long din_img, int batch, int H, int W,
+                                                           int OH, int OW, int ch, int k)
+{
+    const long total = (long)batch * H * W * ch;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % ch);
+        long t = idx / ch;
+        const int w = (int)(t % W);
+        t /= W;
+        const int hh = (int)(t % H);
+        const int n = (int)(t / H);
+        const int oh = hh / k, ow = w / k;
+        const float* p = in + (long long)n * in_img;
+        const int h1 = min(oh * k + k, H), w1 = min(ow * k + k, W);
+        float m = -INFINITY;
+        int am = -1;
+        for (int y = oh * k; y < h1; ++y)
+            for (int x = ow * k; x < w1; ++x) {
+                const float v = p[((long)y * W + x) * ch + c];
+                if (v > m || am < 0) { m = v; am = y * W + x; }
+            }
+        if (am == hh * W + w)
+            din[(long long)n * din_img + ((long)hh * W + w) * ch + c] +=
+                dpool[(long long)n * pool_img + ((long)oh * OW + ow) * ch + c];
+    }
+}
+
+struct BwdWs {
+    float *Qs, *Qt, *Ksw, *Kt, *Vsw, *Vt, *dDs, *dDt, *delta, *dQ, *dK, *dV;
+    int P_pad, M_pad;
+    size_t total;
+};
+
+BwdWs carve_bwd(char* base, int batch, int P, int M)
+{
+    BwdWs w{};
+    w.P_pad = (P + QB - 1) / QB * QB;
+    w.M_pad = (M + QB - 1) / QB * QB;
+    size_t off = 0;
+    auto take = [&](size_t floats) {
+        char* p = base ? base + off : nullptr;
+        off += ctdet::align_up(floats * 4, 256);
+        return (float*)p;
+    };
+    const size_t pq = (size_t)batch * w.P_pad * DP, mk = (size_t)batch * w.M_pad * DP;
+    w.Qs = take(pq); w.Qt = take(pq); w.dDs = take(pq); w.dDt = take(pq); w.dQ = take(pq);
+    w.delta = take((size_t)batch * w.P_pad);
+    w.Ksw = take(mk); w.Kt = take(mk); w.Vsw = take(mk); w.Vt = take(mk);
+    w.dK = take(mk); w.dV = take(mk);          // adjacent: zeroed with one memset
+    w.total = off;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t ct_ctx_attention_bwd_workspace_bytes(int batch, int num_priors, int num_ctx)
+{
+    return carve_bwd(nullptr, batch, num_priors, num_ctx).total;
+}
+
+extern "C" int ct_ctx_attention_bwd(const float* conf, const float* pool, int batch, int num_priors,
+                                    int num_ctx, const ct_ctx_params* prm, const void* saved,
+                                    const float* dout, float* dconf, float* dpool, const ct_ctx_grads* grads,
+                                    void* workspace, size_t workspace_bytes, ct_stream_t stream)
+{
+    CT_REQUIRE(conf && pool && prm && saved && dout && dconf && dpool && grads && workspace,
+               "ct_ctx_attention_bwd: null pointer");
+    CT_REQUIRE(batch > 0 && num_priors > 0 && num_ctx > 0, "ct_ctx_attention_bwd: bad sizes");
+    CT_REQUIRE(prm->d >= 1 && prm->d <= DP && prm->t >= 1 && prm->t <= 32, "ct_ctx_attention_bwd: d=%d t=%d",
+               prm->d, prm->t);
+    CT_REQUIRE(grads->theta_w && grads->theta_b && grads->phi_w && grads->phi_b && grads->g_w && grads->g_b &&
+                   grads->wz && grads->obj_w, "ct_ctx_attention_bwd: null gradient buffer");
+    CT_REQUIRE(!prm->fc_w || (grads->fc_w && grads->fc_b && prm->fc_b), "ct_ctx_attention_bwd: fc gradient missing");
+    const size_t need = ct_ctx_attention_bwd_workspace_bytes(batch, num_priors, num_ctx);
+    if (workspace_bytes < need)
+        return ctdet::fail(CT_ERR_WORKSPACE, "ct_ctx_attention_bwd: workspace %zu < %zu", workspace_bytes, need);
+    BwdWs w = carve_bwd((char*)workspace, batch, num_priors, num_ctx);
+    hipStream_t st = ctdet::as_stream(stream);
+    const int d = prm->d, T = prm->t;
+    const int ostride = (prm->fc_w ? d : 0) + T;
+    const dim3 blk(256);
+    float* none = nullptr;
+    const float* save_d = (const float*)saved;
+    const float* save_lse = save_d + (size_t)batch * w.P_pad * DP;
+
+    // zero the accumulated outputs
+    CT_HIP(hipMemsetAsync(grads->theta_w, 0, (size_t)d * d * 4, st));
+    CT_HIP(hipMemsetAsync(grads->phi_w, 0, (size_t)d * d * 4, st));
+    CT_HIP(hipMemsetAsync(grads->g_w, 0, (size_t)d * d * 4, st));
+    CT_HIP(hipMemsetAsync(grads->theta_b, 0, (size_t)d * 4, st));
+    CT_HIP(hipMemsetAsync(grads->phi_b, 0, (size_t)d * 4, st));
+    CT_HIP(hipMemsetAsync(grads->g_b, 0, (size_t)d * 4, st));
+    CT_HIP(hipMemsetAsync(grads->wz, 0, (size_t)d * 4, st));
+    CT_HIP(hipMemsetAsync(grads->obj_w, 0, (size_t)T * d * 4, st));
+    if (prm->fc_w) {
+        CT_HIP(hipMemsetAsync(grads->fc_w, 0, (size_t)d * d * 4, st));
+        CT_HIP(hipMemsetAsync(grads->fc_b, 0, (size_t)d * 4, st));
+    }
+    CT_HIP(hipMemsetAsync(w.dK, 0, ((char*)w.dV - (char*)w.dK) + (size_t)batch * w.M_pad * DP * 4, st));
+
+    // recompute the projections in the operand layouts of the two MFMA kernels
+    hipLaunchKernelGGL(ctx_project_kernel, dim3(w.P_pad / 64, batch), blk, 0, st, conf, num_priors, w.P_pad, d,
+                       prm->theta_w, prm->theta_b, w.Qs, w.Qt, none, none, 0);
+    CT_LAUNCH_CHECK("ctx_project_kernel(theta)");
+    hipLaunchKernelGGL(ctx_project_kernel, dim3(w.M_pad / 64, batch), blk, 0, st, pool, num_ctx, w.M_pad, d,
+                       prm->phi_w, prm->phi_b, w.Ksw, w.Kt, none, none, 0);
+    CT_LAUNCH_CHECK("ctx_project_kernel(phi)");
+    hipLaunchKernelGGL(ctx_project_kernel, dim3(w.M_pad / 64, batch), blk, 0, st, pool, num_ctx, w.M_pad, d,
+                       prm->g_w, prm->g_b, w.Vsw, w.Vt, none, none, 0);
+    CT_LAUNCH_CHECK("ctx_project_kernel(g)");
+
+    OutBwdArgs oa{};
+    oa.conf = conf; oa.D = save_d; oa.dout = dout; oa.wz = prm->wz; oa.obj_w = prm->obj_w;
+    oa.dconf = dconf; oa.dDs = w.dDs; oa.dDt = w.dDt; oa.delta = w.delta;
+    oa.dwz = grads->wz; oa.dobj = grads->obj_w;
+    oa.P = num_priors; oa.P_pad = w.P_pad; oa.d = d; oa.T = T; oa.ostride = ostride;
+    oa.ooff = prm->fc_w ? d : 0; oa.chunks = 4; oa.scale = prm->scale;
+    hipLaunchKernelGGL(ctx_out_bwd_kernel, dim3((w.P_pad / 64 + oa.chunks - 1) / oa.chunks, batch), blk, 0, st, oa);
+    CT_LAUNCH_CHECK("ctx_out_bwd_kernel");
+
+    BwdArgs ba{};
+    ba.Qs = w.Qs; ba.Qt = w.Qt; ba.Ksw = w.Ksw; ba.Kt = w.Kt; ba.Vsw = w.Vsw; ba.Vt = w.Vt;
+    ba.dDs = w.dDs; ba.dDt = w.dDt; ba.lse = save_lse; ba.delta = w.delta;
+    ba.dQ = w.dQ; ba.dK = w.dK; ba.dV = w.dV;
+    ba.P = num_priors; ba.P_pad = w.P_pad; ba.M = num_ctx; ba.M_pad = w.M_pad;
+    // enough workgroups to fill 256 CUs twice over
+    const int kv_blocks = (w.M_pad / QB) * batch;
+    ba.split = std::max(1, std::min(w.P_pad / (8 * KT), (1024 + kv_blocks - 1) / kv_blocks));
+    hipLaunchKernelGGL(ctx_attn_bwd_q, dim3(w.P_pad / QB, batch), blk, 0, st, ba);
+    CT_LAUNCH_CHECK("ctx_attn_bwd_q");
+    {
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute((const void*)ctx_attn_bwd_kv, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           KV_LDS_BYTES);
+        });
+        CT_HIP(attr_err);
+    }
+    hipLaunchKernelGGL(ctx_attn_bwd_kv, dim3(w.M_pad / QB, batch, ba.split), blk, KV_LDS_BYTES, st, ba);
+    CT_LAUNCH_CHECK("ctx_attn_bwd_kv");
+
+    // projections backward
+    auto linear = [&](const float* dy, long long dy_bs, int dy_stride, const float* x, int rows, const float* W,
+                      float* dx, int accumulate, float* dW, float* db, const char* name) -> int {
+        LinBwdArgs la{};
+        la.dy = dy; la.x = x; la.W = W; la.dx = dx; la.dW = dW; la.db = db;
+        la.dy_batch_stride = dy_bs; la.rows = rows; la.d = d; la.dy_stride = dy_stride;
+        la.accumulate = accumulate; la.chunks = 4;
+        hipLaunchKernelGGL(ctx_linear_bwd_kernel, dim3((rows + 64 * la.chunks - 1) / (64 * la.chunks), batch), blk,
+                           0, st, la);
+        CT_LAUNCH_CHECK(name);
+        return CT_OK;
+    };
+    if (int rc = linear(w.dQ, (long long)w.P_pad * DP, DP, conf, num_priors, prm->theta_w, dconf, 1,
+                        grads->theta_w, grads->theta_b, "ctx_linear_bwd_kernel(theta)")) return rc;
+    if (prm->fc_w)
+        if (int rc = linear(dout, (long long)num_priors * ostride, ostride, conf, num_priors, prm->fc_w, dconf, 1,
+                            grads->fc_w, grads->fc_b, "ctx_linear_bwd_kernel(fc_base)")) return rc;
+    if (int rc = linear(w.dK, (long long)w.M_pad * DP, DP, pool, num_ctx, prm->phi_w, dpool, 0, grads->phi_w,
+                        grads->phi_b, "ctx_linear_bwd_kernel(phi)")) return rc;
+    if (int rc = linear(w.dV, (long long)w.M_pad * DP, DP, pool, num_ctx, prm->g_w, dpool, 1, grads->g_w,
+                        grads->g_b, "ctx_linear_bwd_kernel(g)")) return rc;
+    return CT_OK;
+}
+
+extern "C" int ct_ctx_pool_bwd(const float* in, long long in_img_stride, const float* dpool,
+                               long long dpool_img_stride, float* din, long long din_img_stride, int batch,
+                               int h, int w, int ch, int k, ct_stream_t stream)
+{
+    CT_REQUIRE(in && dpool && din && batch > 0 && h > 0 && w > 0 && ch > 0 && k >= 1, "ct_ctx_pool_bwd: bad argument");
+    const int oh = (h + k - 1) / k, ow = (w + k - 1) / k;
+    const long total = (long)batch * h * w * ch;
+    hipLaunchKernelGGL(ctx_pool_bwd_kernel, dim3((int)std::min<long>((total + 255) / 256, 256 * 16)), dim3(256), 0,
+                       ctdet::as_stream(stream), in, in_img_stride, dpool, dpool_img_stride, din, din_img_stride,
+                       batch, h, w, oh, ow, ch, k);
+    CT_LAUNCH_CHECK("ctx_pool_bwd_kernel");
+    return CT_OK;
+}

@@ -47,6 +47,11 @@ class CtxParams(C.Structure):
                 ('scale', C.c_float), ('d', C.c_int), ('t', C.c_int)]
 
 
+class CtxGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('theta_w', 'theta_b', 'phi_w', 'phi_b', 'g_w', 'g_b', 'wz', 'obj_w',
+                                          'fc_w', 'fc_b')]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -95,6 +100,12 @@ SIGNATURES = {
     'ct_ctx_pool_fwd': (_I, [_P, _LL, _P, _LL, _I, _I, _I, _I, _I, _P]),
     'ct_ctx_attention_workspace_bytes': (_Z, [_I, _I, _I, _I]),
     'ct_ctx_attention_fwd': (_I, [_P, _P, _I, _I, _I, C.POINTER(CtxParams), _P, _P, _Z, _P]),
+    'ct_ctx_attention_saved_bytes': (_Z, [_I, _I]),
+    'ct_ctx_attention_fwd_train': (_I, [_P, _P, _I, _I, _I, C.POINTER(CtxParams), _P, _P, _Z, _P, _Z, _P]),
+    'ct_ctx_attention_bwd_workspace_bytes': (_Z, [_I, _I, _I]),
+    'ct_ctx_attention_bwd': (_I, [_P, _P, _I, _I, _I, C.POINTER(CtxParams), _P, _P, _P, _P, C.POINTER(CtxGrads),
+                                  _P, _Z, _P]),
+    'ct_ctx_pool_bwd': (_I, [_P, _LL, _P, _LL, _P, _LL, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

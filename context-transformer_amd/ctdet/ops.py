@@ -265,20 +265,25 @@ def maxpool2d(x, k, stride, pad=0, ceil_mode=False):
     return out
 
 
+def _ctx_prm(params, d, T, incre):
+    prm = _lib.CtxParams()
+    for k in ('theta_w', 'theta_b', 'phi_w', 'phi_b', 'g_w', 'g_b', 'wz', 'obj_w'):
+        setattr(prm, k, _dev(params[k], k).value)
+    if incre:
+        prm.fc_w = _dev(params['fc_w'], 'fc_w').value
+        prm.fc_b = _dev(params['fc_b'], 'fc_b').value
+    prm.scale = float(params['scale'])
+    prm.d, prm.t = d, T
+    return prm
+
+
 def ctx_attention(conf, pool, params, setting_incre=False):
     """models/RFB_Net_vgg.py:253-271.  params: dict of device tensors theta_w, theta_b, phi_w, phi_b,
     g_w, g_b, wz, obj_w[, fc_w, fc_b] and float `scale`."""
     B, P, d = conf.shape
     M = pool.shape[1]
     T = params['obj_w'].shape[0]
-    prm = _lib.CtxParams()
-    for k in ('theta_w', 'theta_b', 'phi_w', 'phi_b', 'g_w', 'g_b', 'wz', 'obj_w'):
-        setattr(prm, k, _dev(params[k], k).value)
-    if setting_incre:
-        prm.fc_w = _dev(params['fc_w'], 'fc_w').value
-        prm.fc_b = _dev(params['fc_b'], 'fc_b').value
-    prm.scale = float(params['scale'])
-    prm.d, prm.t = d, T
+    prm = _ctx_prm(params, d, T, setting_incre)
     out = torch.empty(B, P, (d if setting_incre else 0) + T, device=conf.device, dtype=torch.float32)
     ws_bytes = lib().ct_ctx_attention_workspace_bytes(B, P, M, d)
     ws = torch.empty(ws_bytes, device=conf.device, dtype=torch.uint8)
@@ -286,6 +291,57 @@ def ctx_attention(conf, pool, params, setting_incre=False):
                                      _dev(out, 'out'), _dev(ws, 'ws', torch.uint8), ws_bytes, _stream()),
           'ct_ctx_attention_fwd')
     return out
+
+
+class CtxTrainer:
+    """Forward-with-saved-rows + backward of the Context-Transformer block for one (B, P, M, d, T)
+    (train.py:222-229 differentiates models/RFB_Net_vgg.py:253-271 through autograd).  Owns the
+    workspaces; gradients come back in fresh tensors keyed like `params`."""
+    KEYS = ('theta_w', 'theta_b', 'phi_w', 'phi_b', 'g_w', 'g_b', 'wz', 'obj_w')
+
+    def __init__(self, B, P, M, d, T, incre, device):
+        self.B, self.P, self.M, self.d, self.T, self.incre = B, P, M, d, T, bool(incre)
+        self.device = torch.device(device)
+        L = lib()
+        self.ws_bytes = max(L.ct_ctx_attention_workspace_bytes(B, P, M, d),
+                            L.ct_ctx_attention_bwd_workspace_bytes(B, P, M))
+        self.ws = torch.empty(self.ws_bytes, device=self.device, dtype=torch.uint8)
+        self.saved_bytes = L.ct_ctx_attention_saved_bytes(B, P)
+        self.saved = torch.empty(self.saved_bytes, device=self.device, dtype=torch.uint8)
+        self.keys = self.KEYS + (('fc_w', 'fc_b') if self.incre else ())
+        self.dconf = torch.empty(B, P, d, device=self.device)
+        self.dpool = torch.empty(B, M, d, device=self.device)
+
+    def forward(self, conf, pool, params):
+        prm = _ctx_prm(params, self.d, self.T, self.incre)
+        out = torch.empty(self.B, self.P, (self.d if self.incre else 0) + self.T, device=self.device)
+        check(lib().ct_ctx_attention_fwd_train(_dev(conf, 'conf'), _dev(pool, 'pool'), self.B, self.P, self.M,
+                                               C.byref(prm), _dev(out, 'out'), _dev(self.saved, 'saved', torch.uint8),
+                                               self.saved_bytes, _dev(self.ws, 'ws', torch.uint8), self.ws_bytes,
+                                               _stream()), 'ct_ctx_attention_fwd_train')
+        return out
+
+    def backward(self, conf, pool, params, dout):
+        """-> (dconf [B,P,d] without the pooled path, dpool [B,M,d], {key: grad})."""
+        prm = _ctx_prm(params, self.d, self.T, self.incre)
+        grads = {k: torch.empty_like(params[k]) for k in self.keys}
+        g = _lib.CtxGrads()
+        for k in self.keys:
+            setattr(g, k, _dev(grads[k], 'd' + k).value)
+        check(lib().ct_ctx_attention_bwd(_dev(conf, 'conf'), _dev(pool, 'pool'), self.B, self.P, self.M, C.byref(prm),
+                                         _dev(self.saved, 'saved', torch.uint8), _dev(dout, 'dout'),
+                                         _dev(self.dconf, 'dconf'), _dev(self.dpool, 'dpool'), C.byref(g),
+                                         _dev(self.ws, 'ws', torch.uint8), self.ws_bytes, _stream()),
+              'ct_ctx_attention_bwd')
+        return self.dconf, self.dpool, grads
+
+
+def ctx_pool_bwd(conf_flat, src_base, dpool_flat, dst_base, dconf_flat, B, h, w, ch, k):
+    """Adds the pooled-path gradient of one source into the flat conf gradient (element offsets)."""
+    check(lib().ct_ctx_pool_bwd(C.c_void_p(_dev(conf_flat, 'conf').value + 4 * src_base), conf_flat.shape[1],
+                                C.c_void_p(_dev(dpool_flat, 'dpool').value + 4 * dst_base), dpool_flat.shape[1],
+                                C.c_void_p(_dev(dconf_flat, 'dconf').value + 4 * src_base), dconf_flat.shape[1],
+                                B, h, w, ch, k, _stream()), 'ct_ctx_pool_bwd')
 
 
 def device_info(device=0):

@@ -12,14 +12,17 @@ What the reference gets from autograd + cuDNN in `train.py:222-229` (`model(data
             transposed mode, accumulating into the producer's gradient buffer through the residual
             input), ct_maxpool2d_bwd for the pools, ct_head_grad_gather for the head scatter.
 
+  phase 2   the Context-Transformer block on top of the conf head: ct_ctx_pool_fwd +
+            ct_ctx_attention_fwd_train forward, ct_ctx_attention_bwd + ct_ctx_pool_bwd backward
+            (ops.CtxTrainer), producing the gradient of the raw conf logits the head backward consumes.
+
 Buffers are owned by the runtime and reused every step (call backward before the next forward).
-Not covered yet: the Context-Transformer block's backward (phase-2 'ours' training raises).
 """
 import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, ops
 from .engine import ConvPart, ConvStep, HipBackend, Plan
 
 
@@ -29,9 +32,6 @@ class _StepState:
 
 class TrainRuntime:
     def __init__(self, net, batch, backend):
-        if net.method == 'ours' and net.phase == 2:
-            raise _lib.CtdetError('training the Context-Transformer block (phase 2, method "ours") is not '
-                                  'implemented yet: its backward kernel is missing')
         self.net, self.batch, self.be = net, batch, backend
         self.lib = backend.lib
         self.plan = Plan(net, batch)
@@ -41,6 +41,19 @@ class TrainRuntime:
         self.state = {}
         self.params = []            # ordered parameters that receive gradients
         self._pindex = {}
+        self.ctx = None
+        if self.plan.ctx:
+            C_ = net.num_classes
+            self.P = self.bufs['conf'].shape[1] // C_
+            self.ctx = ops.CtxTrainer(batch, self.P, self.plan.M, C_, net.OBJ_Target.weight.shape[0],
+                                      net.setting == 'incre', backend.device)
+            self.ctx_params = dict(obj_w=net.OBJ_Target.weight, wz=net.Wz, theta_w=net.theta.weight,
+                                   theta_b=net.theta.bias, phi_w=net.phi.weight, phi_b=net.phi.bias,
+                                   g_w=net.g.weight, g_b=net.g.bias)
+            if net.setting == 'incre':
+                self.ctx_params.update(fc_w=net.fc_base.weight, fc_b=net.fc_base.bias)
+            for prm in self.ctx_params.values():
+                self._reg(prm)
         for st in self.plan.steps:
             if st.kind != 'conv':
                 continue
@@ -113,7 +126,7 @@ class TrainRuntime:
 
     def production_order(self):
         """Parameters in the order backward() produces their gradients (heads first)."""
-        order = []
+        order = list(self.ctx_params.values()) if self.ctx is not None else []
         for st in reversed(self.plan.steps):
             if st.kind != 'conv':
                 continue
@@ -138,8 +151,14 @@ class TrainRuntime:
         return C.c_void_p(torch.cuda.current_stream(self.be.device).cuda_stream)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x):
+    def _ctx_tensors(self):
+        p = {k: v.detach() for k, v in self.ctx_params.items()}
+        p['scale'] = float(self.net.scale.item())
+        return p
+
+    def forward(self, x, use_ctx=True):
         lib, B = self.lib, self.batch
+        self.used_ctx = bool(use_ctx and self.ctx is not None)
         if tuple(x.shape) != tuple(self.bufs['x'].shape):
             raise _lib.CtdetError('training plan was built for input %s, got %s'
                                   % (tuple(self.bufs['x'].shape), tuple(x.shape)))
@@ -147,6 +166,10 @@ class TrainRuntime:
         for st in self.plan.steps:
             if st.kind == 'pool':
                 self.be.run_pool(st, self.bufs, B)
+                continue
+            if st.kind == 'ctxpool':
+                if self.used_ctx:
+                    self.be.run_ctxpool(st, self.bufs, B)
                 continue
             if st.kind != 'conv':
                 raise _lib.CtdetError('step %s has no training implementation' % st.name)
@@ -174,12 +197,31 @@ class TrainRuntime:
                     st.res_coff, float(st.res_scale), dst.data_ptr(), dst.shape[1], st.dst_coff + off,
                     z.shape[1], off, B, p.cout, hw, self._s()), st.name + ' bn apply')
                 off += p.cout
+        if self.used_ctx:
+            d = self.net.num_classes
+            out = self.ctx.forward(self.bufs['conf'].view(B, self.P, d), self.bufs['pool'].view(B, self.plan.M, d),
+                                   self._ctx_tensors())
+            return self.bufs['loc'], out, self.bufs['obj']
         return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
 
     # ------------------------------------------------------------------ backward
     def backward(self, dloc, dconf, dobj):
         lib, B = self.lib, self.batch
-        flat = {'loc': dloc.contiguous(), 'conf': dconf.contiguous(), 'obj': dobj.contiguous()}
+        ctx_grads = None
+        if self.used_ctx:
+            # Context-Transformer block: gradient of its output -> gradient of the raw conf logits
+            d = self.net.num_classes
+            conf3 = self.bufs['conf'].view(B, self.P, d)
+            dc, dpool, ctx_grads = self.ctx.backward(conf3, self.bufs['pool'].view(B, self.plan.M, d),
+                                                     self._ctx_tensors(), dconf.contiguous().view(B, self.P, -1))
+            dconf = dc.view(B, -1)
+            dpool = dpool.view(B, -1)
+            for st in self.plan.steps:
+                if st.kind == 'ctxpool':
+                    ops.ctx_pool_bwd(self.bufs['conf'], st.src_base, dpool, st.dst_base, dconf, B, st.h, st.w,
+                                     st.ch, st.k)
+        flat = {'loc': dloc.contiguous().view(B, -1), 'conf': dconf.contiguous().view(B, -1),
+                'obj': dobj.contiguous().view(B, -1)}
         written = {}
 
         def overlaps(name, c0, c1):
@@ -199,7 +241,12 @@ class TrainRuntime:
                 g = v.view(g.shape)
             grads_out[self._pindex[id(prm)]] = g
 
+        if ctx_grads is not None:
+            for k, prm in self.ctx_params.items():
+                put(prm, ctx_grads[k])
         for st in reversed(self.plan.steps):
+            if st.kind == 'ctxpool':
+                continue
             if st.kind == 'pool':
                 acc = overlaps(st.src, 0, st.ch)
                 _lib.check(lib.ct_maxpool2d_bwd(self.bufs[st.src].data_ptr(), self.grads[st.dst].data_ptr(),
@@ -281,12 +328,12 @@ class BackboneFunction(torch.autograd.Function):
     """(x, *params) -> (loc, conf, obj) flattened head outputs, differentiable w.r.t. the parameters."""
 
     @staticmethod
-    def forward(ctx, rt, x, *params):
+    def forward(ctx, rt, x, use_ctx, *params):
         ctx.rt = rt
-        loc, conf, obj = rt.forward(x)
+        loc, conf, obj = rt.forward(x, use_ctx)
         return loc.clone(), conf.clone(), obj.clone()
 
     @staticmethod
     def backward(ctx, dloc, dconf, dobj):
         grads = ctx.rt.backward(dloc, dconf, dobj)
-        return (None, None) + tuple(grads)
+        return (None, None, None) + tuple(grads)

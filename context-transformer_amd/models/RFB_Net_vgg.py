@@ -235,9 +235,12 @@ class RFBNet(nn.Module):
             # batch-statistics BatchNorm + autograd: the whole backbone is one autograd function
             # whose backward is the HIP backward pass (ctdet.train_engine)
             trt = self.train_runtime(num)
-            loc, conf, obj = _train.BackboneFunction.apply(trt, x, *trt.params)
-            conf = conf.view(num, -1, self.num_classes)
-            return (conf if init else (loc.view(num, -1, 4), conf, obj.view(num, -1, 2)))
+            loc, conf, obj = _train.BackboneFunction.apply(trt, x, not init, *trt.params)
+            if init:
+                return conf.view(num, -1, self.num_classes)
+            if not (self.method == 'ours' and self.phase == 2):
+                conf = conf.view(num, -1, self.num_classes)
+            return loc.view(num, -1, 4), conf, obj.view(num, -1, 2)
         rt = self.runtime(x.shape[0])
         loc, conf, obj = rt.run_backbone(x)
         conf = conf.view(num, -1, self.num_classes)

@@ -304,6 +304,36 @@ int ct_ctx_attention_fwd(const float* conf, const float* pool, int batch, int nu
                          int num_ctx, const ct_ctx_params* prm, float* out,
                          void* workspace, size_t workspace_bytes, ct_stream_t stream);
 
+
+/* ---- training of the Context-Transformer block ------------------------------------------------
+ * The reference differentiates models/RFB_Net_vgg.py:253-271 with autograd (train.py:222-229).
+ * Here: a forward that additionally saves, per query row, the aggregated context D = softmax(S) g
+ * and the row log-sum-exp (`saved`, ct_ctx_attention_saved_bytes), and one backward entry point
+ * that recomputes the affinity tiles on the MFMA path instead of storing the [P,M] matrix. */
+size_t ct_ctx_attention_saved_bytes(int batch, int num_priors);
+int ct_ctx_attention_fwd_train(const float* conf, const float* pool, int batch, int num_priors,
+                               int num_ctx, const ct_ctx_params* prm, float* out, void* saved,
+                               size_t saved_bytes, void* workspace, size_t workspace_bytes,
+                               ct_stream_t stream);
+/* Gradient buffers (device), same shapes as the parameters; overwritten by ct_ctx_attention_bwd. */
+typedef struct ct_ctx_grads {
+    float *theta_w, *theta_b, *phi_w, *phi_b, *g_w, *g_b;
+    float *wz, *obj_w;
+    float *fc_w, *fc_b;       /* required iff prm->fc_w */
+} ct_ctx_grads;
+size_t ct_ctx_attention_bwd_workspace_bytes(int batch, int num_priors, int num_ctx);
+/* dout [B,P,(fc?d:0)+T] -> dconf [B,P,d] (direct + theta + fc_base paths; the pooled path is added
+ * by ct_ctx_pool_bwd), dpool [B,M,d], parameter gradients in `grads`. */
+int ct_ctx_attention_bwd(const float* conf, const float* pool, int batch, int num_priors, int num_ctx,
+                         const ct_ctx_params* prm, const void* saved, const float* dout, float* dconf,
+                         float* dpool, const ct_ctx_grads* grads, void* workspace,
+                         size_t workspace_bytes, ct_stream_t stream);
+/* Backward of ct_ctx_pool_fwd (max_pool2d, kernel = stride = k, ceil_mode, channels-last): adds the
+ * window gradient dpool to din at the first maximum of each window (torch's tie rule). */
+int ct_ctx_pool_bwd(const float* in, long long in_img_stride, const float* dpool,
+                    long long dpool_img_stride, float* din, long long din_img_stride, int batch,
+                    int h, int w, int ch, int k, ct_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
