@@ -83,10 +83,11 @@ def cpu_baseline(size, num_fg, images=4, reps=3):
                       % (images, size, size, reps)}
 
 
-def pmc_traffic(event_name):
+def pmc_traffic(event_name, workload):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same
-    workload, 2*FETCH+WRITE per MI355X_MICROARCH.md); None when no pass covers this kernel."""
+    (profiles/*_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, 2*FETCH+WRITE per
+    MI355X_MICROARCH.md).  Only passes recorded for THIS workload (`__workload__` entry of the file)
+    count; None when no pass covers this kernel on this workload."""
     import glob
     import re
     m = re.match(r'conv_igemm_f32<(\d+)x(\d+),(\d+)x(\d+)', event_name)
@@ -99,6 +100,8 @@ def pmc_traffic(event_name):
             table = json.load(open(path))
         except (OSError, ValueError):
             continue
+        if table.get('__workload__', {'size': 300, 'batch': 32, 'phase': 1, 'classes': 20}) != workload:
+            continue
         for k, v in table.items():
             f = [x.strip() for x in k[k.find('<') + 1:k.find('>')].split(',')] if '<' in k else []
             if k.startswith('conv_igemm_f32') and len(f) >= 5 and f[0] == kh and f[1] == kw and f[3] == bm and f[4] == bn:
@@ -106,7 +109,7 @@ def pmc_traffic(event_name):
     return best
 
 
-def conv_roofline(rt, batch):
+def conv_roofline(rt, batch, workload):
     """Per-instantiation totals from the HIP events the engine recorded around every conv launch
     of the timed region; reports the instantiation with the most accumulated time."""
     from ctdet import _lib
@@ -124,7 +127,7 @@ def conv_roofline(rt, batch):
     tot_f = sum(a[1] for a in agg.values())
     name, (t, f, n) = max(agg.items(), key=lambda kv: kv[1][0])
     ach = f / t / 1e12
-    traffic = pmc_traffic(name)
+    traffic = pmc_traffic(name, workload)
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
         'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
@@ -210,7 +213,8 @@ def main():
     log('timed region done: %.2f ms/step' % (dt / a.steps * 1e3))
     roof = None
     if pipe.rt.event_log:
-        roof = conv_roofline(pipe.rt, a.batch)
+        roof = conv_roofline(pipe.rt, a.batch, {'size': a.size, 'batch': a.batch, 'phase': a.phase,
+                                                    'classes': a.classes})
         pipe.rt.event_log = None
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -25,6 +25,7 @@ ARCH = 'gfx950'
 SOURCES = {
     'ct_api.cpp': [],
     'ct_conv.hip': [],
+    'ct_wino.hip': [],
     'ct_pool.hip': [],
     'ct_preproc.hip': ['-ffp-contract=off'],
     'ct_attn.hip': [],

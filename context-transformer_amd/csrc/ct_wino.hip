@@ -1,0 +1,369 @@
+// libctdet: Winograd F(2x2,3x3) convolution on the fp32 MFMA path for the 3x3 / stride 1 /
+// dilation 1 / pad 1 layers of the RFBNet-VGG stack (80 % of its FLOPs: models/RFB_Net_vgg.py:219-227
+// VGG trunk and the 3x3 BasicConv layers).  Same ct_conv_desc contract and fused epilogue as
+// ct_conv2d_fwd; 2.25x fewer multiplications than the direct implicit GEMM:
+//
+//   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A      per 2x2 output tile, 4x4 input patch d
+//
+// One fused kernel, nothing transformed ever touches HBM except the pre-transformed weights U:
+//   workgroup (512 threads, 8 waves) = 64 output tiles x 64 output channels, loops over 8-channel chunks
+//     * every thread loads ONE 4x4 patch (tile, channel) with 16 bounds-checked buffer loads
+//       (zero padding = out-of-range offset), applies B^T d B in registers and writes the 16
+//       transform-domain values V[xi][c][tile] to LDS;
+//     * the chunk's U[xi][c][k] block (32 KB, packed contiguously by ct_conv_pack_weights_wino)
+//       is copied global -> LDS with float4 loads;
+//     * wave w owns transform points xi = 2w, 2w+1 and runs, per xi, the [64 k] x [64 tiles] x [8 c]
+//       GEMM as v_mfma_f32_32x32x2_f32 (A = U, B = V, both [c-pair][row][2] so that a fragment is one
+//       conflict-free ds_read_b32);  accumulators: 2 xi x 2x2 blocks x 16 = 128 registers;
+//     * double-buffered LDS (2 x 64 KB), one barrier per chunk;
+//   after the channel loop the accumulators go through LDS once (two passes of 32 tiles),
+//   each thread applies A^T M A for a (channel, tile) pair and the usual epilogue
+//   (*scale + shift, residual, ReLU / per-channel floor) and stores the 2x2 outputs to NCHW.
+#include "ct_common.h"
+#include <algorithm>
+#include <mutex>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kInvalidOff = 0x7FFFFFF0;
+constexpr long long kMaxBufBytes = 0x7FFFFF00LL;
+constexpr int CC = 8;                       // channels per chunk
+constexpr int TB = 64;                      // tiles per workgroup
+constexpr int KB = 64;                      // output channels per workgroup
+constexpr int XI_STRIDE = (CC / 2) * 64 * 2;          // 512 floats: [s][row 64][h 2]
+constexpr int CHUNK_FLOATS = 16 * XI_STRIDE;          // 8192 floats = 32 KB (U or V of one chunk)
+constexpr int WINO_LDS_BYTES = 2 * 2 * CHUNK_FLOATS * 4;   // 128 KB
+
+struct WinoArgs {
+    const float* in;
+    const float* U;          // [kblocks][chunks][16][4][64][2]
+    const float* scale;
+    const float* shift;
+    const float* res;
+    const float* lo;
+    float* out;
+    unsigned in_bytes;
+    int Cin, H, W, in_ctot, in_coff;
+    int M, chunks;
+    int TY, TX, NT, tile_blocks;
+    int out_ctot, out_coff, res_ctot, res_coff;
+    float res_scale;
+    int relu;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+__global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kb = blockIdx.x / a.tile_blocks;
+    const int tb0 = (blockIdx.x - kb * a.tile_blocks) * TB;
+    const int HW = a.H * a.W;
+
+    // ---- patch-loader role: tile = l31 + 32*(wave&1), channel-in-chunk = 2*(wave>>1) + h
+    const int tile_l = l31 + 32 * (wave & 1);
+    const int s_l = wave >> 1;
+    int voff[16];
+    {
+        const int T = tb0 + tile_l;
+        const bool live = T < a.NT;
+        const int n = T / (a.TY * a.TX);
+        const int rem = T - n * (a.TY * a.TX);
+        const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+        const long base = (((long)n * a.in_ctot + a.in_coff + h) * a.H + y0) * (long)a.W + x0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H && (unsigned)(x0 + j) < (unsigned)a.W;
+                voff[i * 4 + j] = ok ? (int)((base + (long)i * a.W + j) * 4) : kInvalidOff;
+            }
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const float4* Ub = reinterpret_cast<const float4*>(a.U + (size_t)kb * a.chunks * CHUNK_FLOATS);
+
+    typedef __attribute__((address_space(1))) const void gvoid;
+    typedef __attribute__((address_space(3))) void lvoid;
+    // U chunk: global -> LDS directly (wave-uniform LDS base + lane*16 B, linear copy)
+    auto copy_u = [&](int c, int buf) {
+        float* Ul = lds + buf * 2 * CHUNK_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gvoid*)(Ub + (size_t)c * (CHUNK_FLOATS / 4) + tid + 512 * i),
+                                             (lvoid*)(Ul + (wave * 64 + 512 * i) * 4), 16, 0, 0);
+    };
+    auto load_patch = [&](int c, float (&d)[16]) {
+        const int soff = (c * CC + 2 * s_l) * HW * 4;            // wave-uniform channel offset (bytes)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            d[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[e], soff, 0));
+    };
+    // V = B^T d B  ->  V[xi][s][tile][h]
+    auto store_v = [&](int buf, const float (&d)[16]) {
+        float* Vl = lds + buf * 2 * CHUNK_FLOATS + CHUNK_FLOATS;
+        float t[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+            t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+            t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+            t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+        }
+        float* vp = Vl + s_l * 128 + tile_l * 2 + h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            vp[(i * 4 + 0) * XI_STRIDE] = t[i * 4 + 0] - t[i * 4 + 2];
+            vp[(i * 4 + 1) * XI_STRIDE] = t[i * 4 + 1] + t[i * 4 + 2];
+            vp[(i * 4 + 2) * XI_STRIDE] = t[i * 4 + 2] - t[i * 4 + 1];
+            vp[(i * 4 + 3) * XI_STRIDE] = t[i * 4 + 1] - t[i * 4 + 3];
+        }
+    };
+
+    f32x16 acc[2][2][2];       // [xi][k block][tile block]
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[x][i][j][r] = 0.f;
+
+    auto mfma_half = [&](int buf, int x) {
+        const float* Ul = lds + buf * 2 * CHUNK_FLOATS + (2 * wave + x) * XI_STRIDE + l31 * 2 + h;
+        const float* Vl = Ul + CHUNK_FLOATS;
+#pragma unroll
+        for (int s = 0; s < CC / 2; ++s) {
+            const float a0 = Ul[s * 128];
+            const float a1 = Ul[s * 128 + 64];
+            const float b0 = Vl[s * 128];
+            const float b1 = Vl[s * 128 + 64];
+            acc[x][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[x][0][0], 0, 0, 0);
+            acc[x][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[x][0][1], 0, 0, 0);
+            acc[x][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[x][1][0], 0, 0, 0);
+            acc[x][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[x][1][1], 0, 0, 0);
+        }
+    };
+
+    // Software pipeline: during the MFMAs of chunk c, chunk c+1's U block streams global -> LDS, chunk
+    // c+1's patch (loaded one iteration ago) is transformed into the other LDS buffer, and chunk c+2's
+    // patch loads are in flight.  The barrier waits only for the U copy (vmcnt counts in order: the 16
+    // younger patch loads may stay outstanding).
+    // Loads past the last chunk are clamped to it (redundant, never consumed): every iteration then
+    // issues the same 4 + 16 memory operations and the wait counts are static.
+    float dA[16], dB[16];
+    const int last = a.chunks - 1;
+    copy_u(0, 0);
+    load_patch(0, dA);
+    load_patch(min(1, last), dB);
+    store_v(0, dA);
+    __syncthreads();
+
+    auto body = [&](int c, float (&cur)[16], float (&nxt)[16]) {
+        const int buf = c & 1;
+        copy_u(min(c + 1, last), buf ^ 1);
+        load_patch(min(c + 2, last), nxt);
+        mfma_half(buf, 0);
+        store_v(buf ^ 1, cur);
+        mfma_half(buf, 1);
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    for (int c = 0; c < a.chunks; c += 2) {
+        body(c, dB, dA);
+        if (c + 1 < a.chunks) body(c + 1, dA, dB);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- output transform: two passes of 32 tiles through LDS  M[xi][k 64][tile 32]
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? 0x7FFFFF00u : 0u);
+    (void)rres;
+    for (int tbk = 0; tbk < 2; ++tbk) {
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    lds[(2 * wave + x) * 2048 + k * 32 + l31] = tbk == 0 ? acc[x][i][0][r] : acc[x][i][1][r];
+                }
+        __syncthreads();
+        const int tl = tid & 31;
+        const int T = tb0 + tbk * 32 + tl;
+        const bool live = T < a.NT;
+        const int n = T / (a.TY * a.TX);
+        const int rem = T - n * (a.TY * a.TX);
+        const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        const int OH = a.H, OW = a.W;                  // pad 1, stride 1: same spatial size
+        const int oy = 2 * ty, ox = 2 * tx;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int k = (tid >> 5) + 16 * it;
+            const int co = kb * KB + k;
+            float m[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) m[e] = lds[e * 2048 + k * 32 + tl];
+            if (!live || co >= a.M) continue;
+            float u0[4], u1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u0[j] = m[0 * 4 + j] + m[1 * 4 + j] + m[2 * 4 + j];
+                u1[j] = m[1 * 4 + j] - m[2 * 4 + j] - m[3 * 4 + j];
+            }
+            float y[4] = {u0[0] + u0[1] + u0[2], u0[1] - u0[2] - u0[3], u1[0] + u1[1] + u1[2], u1[1] - u1[2] - u1[3]};
+            const float sc = a.scale[co], sh = a.shift[co];
+            const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int yy = oy + (q >> 1), xx = ox + (q & 1);
+                if (yy >= OH || xx >= OW) continue;
+                float v = y[q] * sc + sh;
+                if (a.res) v = v * a.res_scale + a.res[(((size_t)n * a.res_ctot + a.res_coff + co) * OH + yy) * OW + xx];
+                v = fmaxf(v, lo);
+                a.out[(((size_t)n * a.out_ctot + a.out_coff + co) * OH + yy) * OW + xx] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// U[kb][chunk][xi][s][k][h] = (G g G^T)[xi] for co = kb*64+k, ci = chunk*8 + 2s + h (zero padded couts)
+struct WinoPackArgs {
+    const float* w[6];
+    int mbeg[7];
+    int nparts, cin, cout, chunks, kblocks;
+    float* U;
+};
+
+__global__ void wino_pack_kernel(const WinoPackArgs p)
+{
+    const long total = (long)p.kblocks * p.chunks * CHUNK_FLOATS;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int hh = (int)(idx & 1);
+        const int k = (int)((idx >> 1) & 63);
+        const int s = (int)((idx >> 7) & 3);
+        const int xi = (int)((idx >> 9) & 15);
+        const long rest = idx >> 13;
+        const int chunk = (int)(rest % p.chunks);
+        const int kb = (int)(rest / p.chunks);
+        const int co = kb * KB + k, ci = chunk * CC + 2 * s + hh;
+        float val = 0.f;
+        if (co < p.cout) {
+            int part = 0;
+            while (part + 1 < p.nparts && co >= p.mbeg[part + 1]) ++part;
+            const float* g = p.w[part] + ((size_t)(co - p.mbeg[part]) * p.cin + ci) * 9;
+            const int ar = xi >> 2, bc = xi & 3;
+            // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+            float Ga[3], Gb[3];
+            auto grow = [](int r, float* o) {
+                if (r == 0) { o[0] = 1.f; o[1] = 0.f; o[2] = 0.f; }
+                else if (r == 1) { o[0] = .5f; o[1] = .5f; o[2] = .5f; }
+                else if (r == 2) { o[0] = .5f; o[1] = -.5f; o[2] = .5f; }
+                else { o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; }
+            };
+            grow(ar, Ga);
+            grow(bc, Gb);
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) val += Ga[i] * g[i * 3 + j] * Gb[j];
+        }
+        p.U[idx] = val;
+    }
+}
+
+bool wino_ok(const ct_conv_desc* d)
+{
+    return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+           d->cin % CC == 0 && d->nseg == 0 && !d->transposed && d->oh == d->h && d->ow == d->w;
+}
+
+}  // namespace
+
+extern "C" int ct_conv_wino_supported(const ct_conv_desc* d) { return d && wino_ok(d) ? 1 : 0; }
+
+extern "C" size_t ct_conv_wino_packed_floats(int cin, int cout)
+{
+    if (cin <= 0 || cout <= 0 || cin % CC) return 0;
+    return (size_t)((cout + KB - 1) / KB) * (cin / CC) * CHUNK_FLOATS;
+}
+
+extern "C" int ct_conv_pack_weights_wino(const float* const* w, const int* cout, int nparts, int cin,
+                                         float* upacked, ct_stream_t stream)
+{
+    CT_REQUIRE(w && cout && upacked && nparts >= 1 && nparts <= 6, "ct_conv_pack_weights_wino: bad argument");
+    CT_REQUIRE(cin > 0 && cin % CC == 0, "ct_conv_pack_weights_wino: cin=%d must be a multiple of %d", cin, CC);
+    WinoPackArgs p{};
+    int tot = 0;
+    for (int i = 0; i < nparts; ++i) {
+        CT_REQUIRE(w[i] && cout[i] > 0, "ct_conv_pack_weights_wino: part %d", i);
+        p.w[i] = w[i];
+        p.mbeg[i] = tot;
+        tot += cout[i];
+    }
+    p.mbeg[nparts] = tot;
+    p.nparts = nparts; p.cin = cin; p.cout = tot; p.chunks = cin / CC; p.kblocks = (tot + KB - 1) / KB;
+    p.U = upacked;
+    const long total = (long)p.kblocks * p.chunks * CHUNK_FLOATS;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       ctdet::as_stream(stream), p);
+    CT_LAUNCH_CHECK("wino_pack_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_conv2d_wino_fwd(const ct_conv_desc* d, const float* upacked, ct_stream_t stream)
+{
+    CT_REQUIRE(d && upacked, "ct_conv2d_wino_fwd: null pointer");
+    CT_REQUIRE(d->in && d->out && d->scale && d->shift, "ct_conv2d_wino_fwd: null tensor");
+    if (!wino_ok(d))
+        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wino_fwd: needs 3x3 stride 1 dilation 1 pad 1, cin %% 8 == 0, "
+                           "NCHW output (got %dx%d s%d d%d p%d cin=%d nseg=%d)", d->kh, d->kw, d->stride, d->dil,
+                           d->pad_h, d->cin, d->nseg);
+    CT_REQUIRE(d->batch > 0 && d->cout > 0, "ct_conv2d_wino_fwd: bad shape");
+    CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "ct_conv2d_wino_fwd: input slice");
+    CT_REQUIRE(d->out_coff >= 0 && d->out_coff + d->cout <= d->out_ctot, "ct_conv2d_wino_fwd: output slice");
+    CT_REQUIRE(!d->res || (d->res_coff >= 0 && d->res_coff + d->cout <= d->res_ctot), "ct_conv2d_wino_fwd: residual slice");
+    const long long img_in_bytes = (long long)d->in_ctot * d->h * d->w * 4;
+    CT_REQUIRE(img_in_bytes < kMaxBufBytes, "ct_conv2d_wino_fwd: one image exceeds 2 GiB");
+    const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / img_in_bytes);
+    hipStream_t st = ctdet::as_stream(stream);
+    {
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute((const void*)wino_f2x2_3x3_f32, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           WINO_LDS_BYTES);
+        });
+        CT_HIP(attr_err);
+    }
+    const int OHW = d->oh * d->ow;
+    for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
+        const int nb = std::min(max_chunk, d->batch - b0);
+        WinoArgs a{};
+        a.in = d->in + (size_t)b0 * d->in_ctot * d->h * d->w;
+        a.U = upacked;
+        a.scale = d->scale; a.shift = d->shift; a.lo = d->lo;
+        a.res = d->res ? d->res + (size_t)b0 * d->res_ctot * OHW : nullptr;
+        a.out = d->out + (size_t)b0 * d->out_ctot * OHW;
+        a.in_bytes = (unsigned)(img_in_bytes * nb);
+        a.Cin = d->cin; a.H = d->h; a.W = d->w; a.in_ctot = d->in_ctot; a.in_coff = d->in_coff;
+        a.M = d->cout; a.chunks = d->cin / CC;
+        a.TY = (d->oh + 1) / 2; a.TX = (d->ow + 1) / 2;
+        a.NT = nb * a.TY * a.TX;
+        a.tile_blocks = (a.NT + TB - 1) / TB;
+        a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
+        a.res_ctot = d->res_ctot; a.res_coff = d->res_coff; a.res_scale = d->res_scale;
+        a.relu = d->relu;
+        const int kblocks = (d->cout + KB - 1) / KB;
+        hipLaunchKernelGGL(wino_f2x2_3x3_f32, dim3(a.tile_blocks * kblocks), dim3(512), WINO_LDS_BYTES, st, a);
+        CT_LAUNCH_CHECK("wino_f2x2_3x3_f32");
+    }
+    return CT_OK;
+}

@@ -343,6 +343,9 @@ class Plan:
 
 
 # ======================================================================================
+WINO = -1          # ConvStep.rt['config'] value selecting the Winograd F(2x2,3x3) kernel
+
+
 class HipBackend:
     """Executes plan steps through libctdet (the only backend the product ships)."""
 
@@ -408,8 +411,31 @@ class HipBackend:
             d.res, d.res_ctot, d.res_coff, d.res_scale = r.data_ptr(), r.shape[1], st.res_coff, st.res_scale
         d.relu = int(all(relus))
         d.lo = rt['lo'].data_ptr() if rt['lo'] is not None else None
-        d.config = rt.get('config', 0)
+        d.config = max(rt.get('config', 0), 0)
         rt['desc'] = d
+        rt['wino_ok'] = bool(lib.ct_conv_wino_supported(C.byref(d)))
+        if rt.get('config', 0) == WINO:
+            self.enable_wino(st)
+
+    def enable_wino(self, st, on=True):
+        """Route this conv through the Winograd F(2x2,3x3) kernel (3x3 s1 d1 p1 layers only)."""
+        rt = st.rt
+        if not on:
+            rt['wino'] = False
+            return
+        if not rt.get('wino_ok'):
+            raise _lib.CtdetError('%s: geometry has no Winograd path' % st.name)
+        if 'U' not in rt:
+            rt['U'] = self.alloc((self.lib.ct_conv_wino_packed_floats(st.cin, st.cout),))
+        rt['wino'] = True
+        self._pack_wino(st)
+
+    def _pack_wino(self, st):
+        n = len(st.parts)
+        ptrs = (C.c_void_p * n)(*[p.weight.detach().data_ptr() for p in st.parts])
+        couts = (C.c_int * n)(*[p.cout for p in st.parts])
+        _lib.check(self.lib.ct_conv_pack_weights_wino(ptrs, couts, n, st.cin, st.rt['U'].data_ptr(), self._stream()),
+                   'ct_conv_pack_weights_wino')
 
     def pack_conv(self, st):
         """(Re)pack weights and fold the epilogue from the CURRENT parameter values."""
@@ -423,6 +449,8 @@ class HipBackend:
         couts = (C.c_int * n)(*[p.cout for p in st.parts])
         _lib.check(lib.ct_conv_pack_weights(ptrs, couts, n, st.cin, st.kh, st.kw, rt['wpk'].data_ptr(),
                                             rt['mpad'], rt['kpad'], self._stream()), 'ct_conv_pack_weights')
+        if rt.get('wino'):
+            self._pack_wino(st)
         rt['scale'].fill_(1.0)
         rt['shift'].zero_()
         off = 0
@@ -451,6 +479,10 @@ class HipBackend:
         return v
 
     def run_conv(self, st):
+        if st.rt.get('wino'):
+            _lib.check(self.lib.ct_conv2d_wino_fwd(C.byref(st.rt['desc']), st.rt['U'].data_ptr(), self._stream()),
+                       st.name)
+            return
         _lib.check(self.lib.ct_conv2d_fwd(C.byref(st.rt['desc']), self._stream()), st.name)
 
     def run_pool(self, st, bufs, batch):
@@ -469,6 +501,7 @@ class HipBackend:
         ncfg = self.lib.ct_conv_num_configs()
         best, best_t = 0, float('inf')
         times = []
+        self.enable_wino(st, False)
         for cfg in range(ncfg):
             st.rt['desc'].config = cfg + 1
             try:
@@ -489,6 +522,20 @@ class HipBackend:
                 best, best_t = cfg, t
         st.rt['desc'].config = best + 1
         st.rt['config'] = best + 1
+        if st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
+            self.enable_wino(st)
+            self.run_conv(st)
+            torch.cuda.synchronize(self.device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                self.run_conv(st)
+            e1.record()
+            torch.cuda.synchronize(self.device)
+            t = e0.elapsed_time(e1) / iters
+            times.append(t)
+            if t >= best_t:
+                self.enable_wino(st, False)
         st.rt['tune_ms'] = times
         return best, times
 
@@ -519,7 +566,9 @@ class Runtime:
             missing = []
             for st in self.conv_steps():
                 cfg = table.get(st.tune_key(batch))
-                if cfg in names:
+                if cfg == 'wino' and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
+                    backend.enable_wino(st)
+                elif cfg in names:
                     st.rt['config'] = names.index(cfg) + 1
                     st.rt['desc'].config = st.rt['config']
                 else:
@@ -537,8 +586,9 @@ class Runtime:
 
     def tuned_configs(self):
         lib = self.backend.lib
-        return {st.tune_key(self.batch): lib.ct_conv_config_name(st.rt['desc'].config - 1).decode()
-                for st in self.conv_steps() if st.rt['desc'].config > 0}
+        return {st.tune_key(self.batch): ('wino' if st.rt.get('wino') else
+                                          lib.ct_conv_config_name(st.rt['desc'].config - 1).decode())
+                for st in self.conv_steps() if st.rt['desc'].config > 0 or st.rt.get('wino')}
 
     def refresh_weights(self):
         """Re-pack any fused conv whose parameters changed since the last pack."""

@@ -221,6 +221,16 @@ int ct_conv_fold_epilogue(const float* gamma, const float* beta, const float* me
                           float* scale, float* shift, ct_stream_t stream);
 int ct_conv2d_fwd(const ct_conv_desc* desc, ct_stream_t stream);
 
+/* Winograd F(2x2,3x3) variant of ct_conv2d_fwd for 3x3 / stride 1 / dilation 1 / pad 1 convolutions with
+ * cin % 8 == 0 and an NCHW output (the VGG trunk and the 3x3 BasicConv layers, models/RFB_Net_vgg.py:7-22,
+ * 219-227): same descriptor, same fused epilogue, 2.25x fewer multiplications.  `desc->wpacked/k_pad/m_pad`
+ * are ignored; the weights come pre-transformed (U = G g G^T) from ct_conv_pack_weights_wino. */
+int ct_conv_wino_supported(const ct_conv_desc* desc);
+size_t ct_conv_wino_packed_floats(int cin, int cout);
+int ct_conv_pack_weights_wino(const float* const* w, const int* cout, int nparts, int cin, float* upacked,
+                              ct_stream_t stream);
+int ct_conv2d_wino_fwd(const ct_conv_desc* desc, const float* upacked, ct_stream_t stream);
+
 /* ------------------------------------------------------------ training side ---- */
 /* What `losses.backward()` (train.py:228) makes autograd/cuDNN do for the layers above.  The data
  * gradient of a convolution is ct_conv2d_fwd with desc.transposed = 1. */

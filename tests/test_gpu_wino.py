@@ -1,0 +1,68 @@
+"""Winograd F(2x2,3x3) convolution (ct_conv2d_wino_fwd) against torch-CPU conv2d and against the direct
+implicit-GEMM kernel: same descriptor, same fused epilogues, 1e-4 relative."""
+import zlib
+
+import pytest
+import torch
+
+from conftest import rel_err
+from ctdet import _lib, engine
+from test_gpu_kernels import _bn, _ref_conv, _run_conv
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+W = engine.WINO
+
+CASES = [  # name, B, Cin, H, W, Cout
+    ('vgg', 2, 64, 38, 38, 128), ('odd_hw', 3, 16, 19, 17, 70), ('one_pixel', 2, 8, 1, 1, 5), ('tiny', 2, 24, 5, 5, 64),
+    ('wide', 1, 128, 75, 75, 64), ('cout_156', 2, 32, 10, 10, 156), ('many_tiles', 4, 8, 150, 150, 8),
+    ('deep', 1, 512, 19, 19, 96), ('row', 2, 16, 1, 9, 33), ('col', 2, 16, 7, 1, 33),
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_wino_matches_reference(case):
+    name, B, Cin, H, Wd, Cout = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    x = torch.randn(B, Cin, H, Wd, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.rand(Cout, generator=g) - 0.5
+    want = _ref_conv(x, [(w, b, None, True)], 1, 1, 1)
+    got = _run_conv(x, [(w, b, None, True)], 1, 1, 1, config=W)
+    assert got.shape == want.shape and rel_err(got, want) < TOL
+    direct = _run_conv(x, [(w, b, None, True)], 1, 1, 1, config=0)
+    assert rel_err(got, direct) < TOL
+
+
+def test_wino_fused_epilogues():
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 96, 19, 19, generator=g)
+    # BN + ReLU, mixed ReLU parts in one launch (per-channel floor)
+    w1 = torch.randn(40, 96, 3, 3, generator=g) * 0.05
+    w2 = torch.randn(72, 96, 3, 3, generator=g) * 0.05
+    parts = [(w1, None, _bn(40, g), True), (w2, None, _bn(72, g), False)]
+    assert rel_err(_run_conv(x, parts, 1, 1, 1, config=W), _ref_conv(x, parts, 1, 1, 1)) < TOL
+    # residual * scale + ReLU
+    w3 = torch.randn(64, 96, 3, 3, generator=g) * 0.05
+    bn3 = _bn(64, g)
+    res = torch.randn(2, 64, 19, 19, generator=g)
+    got = _run_conv(x, [(w3, None, bn3, True)], 1, 1, 1, config=W, res=res, res_scale=0.5)
+    assert rel_err(got, _ref_conv(x, [(w3, None, bn3, True)], 1, 1, 1, res=res, res_scale=0.5)) < TOL
+    # input channel slice [32:80), output at channel offset 8 of a 100-channel buffer, no ReLU
+    w4 = torch.randn(64, 48, 3, 3, generator=g) * 0.05
+    got = _run_conv(x, [(w4, None, bn3, False)], 1, 1, 1, config=W, cin_off=32, cin=48, out_ctot=100, out_coff=8)
+    want = _ref_conv(x[:, 32:80], [(w4, None, bn3, False)], 1, 1, 1)
+    assert rel_err(got[:, 8:72], want) < TOL
+    assert torch.isnan(got[:, :8]).all() and torch.isnan(got[:, 72:]).all()
+
+
+def test_wino_rejects_other_geometries():
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 16, 9, 9, generator=g)
+    for (k, stride, pad, dil, cin) in ((3, 2, 1, 1, 16), (3, 1, 2, 2, 16), (1, 1, 0, 1, 16), (3, 1, 0, 1, 16)):
+        w = torch.randn(8, cin, k, k, generator=g)
+        with pytest.raises(_lib.CtdetError):
+            _run_conv(x, [(w, None, None, False)], stride, pad, dil, config=W)
+    with pytest.raises(_lib.CtdetError):                     # cin not a multiple of 8
+        _run_conv(torch.randn(1, 3, 9, 9, generator=g), [(torch.randn(8, 3, 3, 3, generator=g), None, None, False)],
+                  1, 1, 1, config=W)

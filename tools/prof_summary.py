@@ -14,6 +14,7 @@ ap.add_argument('--fetch')
 ap.add_argument('--write')
 ap.add_argument('--tag', default='r01')
 ap.add_argument('--cmd', default='python bench.py --steps 20 --warmup 5 --no-cpu-baseline')
+ap.add_argument('--workload', default='300,32,1,20', help='size,batch,phase,classes of the profiled bench run')
 a = ap.parse_args()
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out_dir = os.path.join(REPO, 'profiles')
@@ -63,6 +64,7 @@ for r in rows:
         '%.0f' % f if f is not None else '-', '%.0f' % w if w is not None else '-',
         '%.1f' % hbm if hbm is not None else '-'))
 open(os.path.join(out_dir, '%s_kernel_stats.md' % a.tag), 'w').write('\n'.join(lines) + '\n')
+traffic['__workload__'] = dict(zip(('size', 'batch', 'phase', 'classes'), map(int, a.workload.split(','))))
 json.dump(traffic, open(os.path.join(out_dir, '%s_pmc_traffic.json' % a.tag), 'w'), indent=1, sort_keys=True)
 open(os.path.join(out_dir, '%s_kernel_stats.csv' % a.tag), 'w').write(open(a.stats).read())
 print('\n'.join(lines[:22]))

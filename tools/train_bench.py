@@ -9,6 +9,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--size', type=int, default=300); ap.add_argument('--batch', type=int, default=32)
 ap.add_argument('--classes', type=int, default=20); ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--sync', type=int, default=0)
+ap.add_argument('--phase', type=int, default=1); ap.add_argument('--setting', default='transfer')
 a = ap.parse_args()
 from ctdet import synth, dist as cdist
 from models.RFB_Net_vgg import build_net
@@ -17,15 +18,16 @@ from layers.modules.multibox_loss_combined import MultiBoxLoss_combined
 import data as cfgs
 rank, local, world = cdist.init('nccl')
 torch.cuda.set_device(local)
-net = build_net(types.SimpleNamespace(method='ours', phase=1, setting='transfer'), a.size, a.classes)
+net = build_net(types.SimpleNamespace(method='ours', phase=a.phase, setting=a.setting), a.size, a.classes)
 net.load_state_dict(synth.fill_state_dict(net.state_dict()))
 net = net.cuda().train(); net.device = 'cuda'
 priors = PriorBox(getattr(cfgs, 'VOC_%d' % a.size)).forward().cuda()
-crit = MultiBoxLoss_combined(a.classes + 1, 0.5, True, 0, True, 3, 0.5, False)
+nout = a.classes if a.phase == 1 else net.OBJ_Target.weight.shape[0] + (a.classes if a.setting == 'incre' else 0)
+crit = MultiBoxLoss_combined(nout + 1, 0.5, True, 0, True, 3, 0.5, False)
 crit.sync_normalizer = world > 1
 opt = torch.optim.SGD(net.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
 x = synth.images(a.batch, a.size, 'randn', 1234 + rank).cuda()
-tg = [t.cuda() for t in synth.targets(a.batch, a.classes + 1, 99 + rank)]
+tg = [t.cuda() for t in synth.targets(a.batch, nout + 1, 99 + rank)]
 trt = net.train_runtime(a.batch)
 if a.sync or world > 1:
     trt.enable_grad_sync()
@@ -56,5 +58,5 @@ cdist.barrier('cuda')
 dt = cdist.max_over_ranks((time.perf_counter() - t0) / a.steps, 'cuda')
 if rank == 0:
     n = a.steps
-    print('RFBNet-%d bs=%d x %d GPU(s): %.1f ms/step = %.1f img/s | fwd %.1f  loss %.1f  bwd %.1f ms | loss %.4f'
-          % (a.size, a.batch, world, dt * 1e3, a.batch * world / dt, tf / n, tl / n, tb / n, float(loss)))
+    print('RFBNet-%d phase %d bs=%d x %d GPU(s): %.1f ms/step = %.1f img/s | fwd %.1f  loss %.1f  bwd %.1f ms | loss %.4f'
+          % (a.size, a.phase, a.batch, world, dt * 1e3, a.batch * world / dt, tf / n, tl / n, tb / n, float(loss)))
