@@ -57,7 +57,7 @@ def _compile(src, flags, force):
     deps = [path, os.path.join(REPO, 'include', 'ctdet.h'), os.path.join(CSRC, 'ct_common.h'),
             os.path.join(CSRC, 'ct_attn_common.h'), __file__]
     if force or any(_newer(d, obj) for d in deps):
-        cmd = [hipcc()] + COMMON + flags + ['-x', 'hip', '-c', path, '-o', obj]
+        cmd = [hipcc()] + COMMON + flags + os.environ.get('CTDET_EXTRA_FLAGS', '').split() + ['-x', 'hip', '-c', path, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError('hipcc failed on %s:\n%s\n%s' % (src, ' '.join(cmd), r.stderr[-8000:]))

@@ -22,6 +22,7 @@
 #include "ct_common.h"
 #include <algorithm>
 #include <mutex>
+#pragma clang diagnostic ignored "-Winline-asm"
 
 namespace {
 
@@ -33,7 +34,7 @@ constexpr int TB = 64;                      // tiles per workgroup
 constexpr int KB = 64;                      // output channels per workgroup
 constexpr int XI_STRIDE = (CC / 2) * 64 * 2;          // 512 floats: [s][row 64][h 2]
 constexpr int CHUNK_FLOATS = 16 * XI_STRIDE;          // 8192 floats = 32 KB (U or V of one chunk)
-constexpr int WINO_LDS_BYTES = 2 * 2 * CHUNK_FLOATS * 4;   // 128 KB
+constexpr int WINO_LDS_BYTES = 5 * CHUNK_FLOATS * 4;       // 160 KB: U x3 (ring) + V x2
 
 struct WinoArgs {
     const float* in;
@@ -43,7 +44,7 @@ struct WinoArgs {
     const float* res;
     const float* lo;
     float* out;
-    unsigned in_bytes;
+    unsigned in_bytes, out_bytes, res_bytes;
     int Cin, H, W, in_ctot, in_coff;
     int M, chunks;
     int TY, TX, NT, tile_blocks;
@@ -89,15 +90,21 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
     const float4* Ub = reinterpret_cast<const float4*>(a.U + (size_t)kb * a.chunks * CHUNK_FLOATS);
 
-    typedef __attribute__((address_space(1))) const void gvoid;
     typedef __attribute__((address_space(3))) void lvoid;
-    // U chunk: global -> LDS directly (wave-uniform LDS base + lane*16 B, linear copy)
-    auto copy_u = [&](int c, int buf) {
-        float* Ul = lds + buf * 2 * CHUNK_FLOATS;
+    // LDS: U ring of 3 chunk blocks at [0, 3*CHUNK), V double buffer at [3*CHUNK, 5*CHUNK)
+    float* const Ulds = lds;
+    float* const Vlds = lds + 3 * CHUNK_FLOATS;
+    // U chunk: global -> LDS directly (wave-uniform LDS base in M0 + lane*16 B, linear copy).  Issued
+    // through inline asm: the compiler would otherwise order every later LDS access behind the copy with a
+    // vmcnt(0); here the ring-slot protocol below guarantees there is no overlap and the waits are explicit.
+    const unsigned lds_u0 = (unsigned)(size_t)(lvoid*)Ulds;
+    auto copy_u = [&](int c, int slot) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gvoid*)(Ub + (size_t)c * (CHUNK_FLOATS / 4) + tid + 512 * i),
-                                             (lvoid*)(Ul + (wave * 64 + 512 * i) * 4), 16, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            const float4* src = Ub + (size_t)c * (CHUNK_FLOATS / 4) + tid + 512 * i;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_u0 + (slot * CHUNK_FLOATS + (wave * 64 + 512 * i) * 4) * 4);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
+        }
     };
     auto load_patch = [&](int c, float (&d)[16]) {
         const int soff = (c * CC + 2 * s_l) * HW * 4;            // wave-uniform channel offset (bytes)
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
     };
     // V = B^T d B  ->  V[xi][s][tile][h]
     auto store_v = [&](int buf, const float (&d)[16]) {
-        float* Vl = lds + buf * 2 * CHUNK_FLOATS + CHUNK_FLOATS;
+        float* Vl = Vlds + buf * CHUNK_FLOATS;
         float t[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -136,56 +143,160 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][i][j][r] = 0.f;
 
-    auto mfma_half = [&](int buf, int x) {
-        const float* Ul = lds + buf * 2 * CHUNK_FLOATS + (2 * wave + x) * XI_STRIDE + l31 * 2 + h;
-        const float* Vl = Ul + CHUNK_FLOATS;
+    struct Frag { float a0[4], a1[4], b0[4], b1[4]; };
+    auto read_frag = [&](int slot, int buf, int x, Frag& f) {
+        const float* Ul = Ulds + slot * CHUNK_FLOATS + (2 * wave + x) * XI_STRIDE + l31 * 2 + h;
+        const float* Vl = Vlds + buf * CHUNK_FLOATS + (2 * wave + x) * XI_STRIDE + l31 * 2 + h;
 #pragma unroll
-        for (int s = 0; s < CC / 2; ++s) {
-            const float a0 = Ul[s * 128];
-            const float a1 = Ul[s * 128 + 64];
-            const float b0 = Vl[s * 128];
-            const float b1 = Vl[s * 128 + 64];
-            acc[x][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[x][0][0], 0, 0, 0);
-            acc[x][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[x][0][1], 0, 0, 0);
-            acc[x][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[x][1][0], 0, 0, 0);
-            acc[x][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[x][1][1], 0, 0, 0);
+        for (int s = 0; s < 4; ++s) {
+            f.a0[s] = Ul[s * 128]; f.a1[s] = Ul[s * 128 + 64];
+            f.b0[s] = Vl[s * 128]; f.b1[s] = Vl[s * 128 + 64];
+        }
+    };
+    auto mfma_frag = [&](int x, const Frag& f, int s0, int s1) {
+#pragma unroll
+        for (int s = s0; s < s1; ++s) {
+            acc[x][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[s], f.b0[s], acc[x][0][0], 0, 0, 0);
+            acc[x][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[s], f.b1[s], acc[x][0][1], 0, 0, 0);
+            acc[x][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[s], f.b0[s], acc[x][1][0], 0, 0, 0);
+            acc[x][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[s], f.b1[s], acc[x][1][1], 0, 0, 0);
         }
     };
 
-    // Software pipeline: during the MFMAs of chunk c, chunk c+1's U block streams global -> LDS, chunk
-    // c+1's patch (loaded one iteration ago) is transformed into the other LDS buffer, and chunk c+2's
-    // patch loads are in flight.  The barrier waits only for the U copy (vmcnt counts in order: the 16
-    // younger patch loads may stay outstanding).
-    // Loads past the last chunk are clamped to it (redundant, never consumed): every iteration then
-    // issues the same 4 + 16 memory operations and the wait counts are static.
+    // Software pipeline (3 chunks deep for U, 2 for the patches).  Iteration c:
+    //   MFMAs of chunk c (first quarter)            <- fragments read from U slot c%3, V buffer c&1
+    //   transform patch(c+1) -> V buffer (c+1)&1     <- its loads were issued one iteration ago; the
+    //                                                   compiler's wait here also retires U(c+1)
+    //   issue U(c+2) -> ring slot (c+2)%3, patch(c+2) -> registers
+    //   remaining MFMAs of chunk c, then lgkmcnt(0) + barrier: no memory latency on the critical path.
+    // Loads past the last chunk are clamped to it (redundant, never consumed).
     float dA[16], dB[16];
     const int last = a.chunks - 1;
     copy_u(0, 0);
     load_patch(0, dA);
+    copy_u(min(1, last), 1);
     load_patch(min(1, last), dB);
+    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");          // U(0), patch(0) landed
     store_v(0, dA);
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    load_patch(min(2, last), dA);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 
-    auto body = [&](int c, float (&cur)[16], float (&nxt)[16]) {
+    // Iteration c: `d` holds patch(c+1) and is refilled with patch(c+3) right after its transform.  Memory
+    // operations complete in issue order; at the wait the youngest 20 are [patch(c+2) x16 | U(c+2) x4], so
+    // vmcnt(20) retires exactly patch(c+1) and U(c+1) and leaves a full iteration of loads in flight.
+    // Vector-memory instructions are spread one per MFMA: eight waves pushing 20 loads back to back would
+    // fill the address-unit queue and stall the (in-order) waves in front of their MFMAs.
+#define WINO_MFMA(x, i, j, av, bv) acc[x][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x][i][j], 0, 0, 0)
+#define WINO_PIN() __builtin_amdgcn_sched_barrier(0)
+    auto body = [&](int c, int slot, float (&d)[16]) {
         const int buf = c & 1;
-        copy_u(min(c + 1, last), buf ^ 1);
-        load_patch(min(c + 2, last), nxt);
-        mfma_half(buf, 0);
-        store_v(buf ^ 1, cur);
-        mfma_half(buf, 1);
-        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        const int slot2 = slot >= 1 ? slot - 1 : 2;             // (c+2) % 3
+        const int cu = min(c + 2, last), cp = min(c + 3, last);
+        const int soff = (cp * CC + 2 * s_l) * HW * 4;
+        Frag f0, f1;
+        read_frag(slot, buf, 0, f0);
+        // s = 0: one U-copy instruction behind each MFMA
+        {
+            const float4* src = Ub + (size_t)cu * (CHUNK_FLOATS / 4) + tid;
+            const unsigned dst0 = lds_u0 + (slot2 * CHUNK_FLOATS + wave * 256) * 4;
+#define WINO_GLDS(i)                                                                                          \
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + 512 * (i)),   \
+                 "s"(__builtin_amdgcn_readfirstlane(dst0 + 512 * 16 * (i))) : "memory", "m0")
+            WINO_MFMA(0, 0, 0, f0.a0[0], f0.b0[0]); WINO_GLDS(0); WINO_PIN();
+            WINO_MFMA(0, 0, 1, f0.a0[0], f0.b1[0]); WINO_GLDS(1); WINO_PIN();
+            WINO_MFMA(0, 1, 0, f0.a1[0], f0.b0[0]); WINO_GLDS(2); WINO_PIN();
+            WINO_MFMA(0, 1, 1, f0.a1[0], f0.b1[0]); WINO_GLDS(3); WINO_PIN();
+#undef WINO_GLDS
+        }
+        WINO_PIN();
+        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        // x = 0, s = 1: the transform of patch(c+1) in four slices behind the MFMAs
+        float t[16], v[16];
+        WINO_MFMA(0, 0, 0, f0.a0[1], f0.b0[1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+            t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+            t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+            t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+        }
+        WINO_PIN();
+        WINO_MFMA(0, 0, 1, f0.a0[1], f0.b1[1]);
+#pragma unroll
+        for (int j = 2; j < 4; ++j) {
+            t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
+            t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
+            t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
+            t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
+        }
+        WINO_PIN();
+        WINO_MFMA(0, 1, 0, f0.a1[1], f0.b0[1]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            v[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
+            v[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
+            v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
+            v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
+        }
+        WINO_PIN();
+        WINO_MFMA(0, 1, 1, f0.a1[1], f0.b1[1]);
+#pragma unroll
+        for (int i = 2; i < 4; ++i) {
+            v[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
+            v[i * 4 + 1] = t[i * 4 + 1] + t[i * 4 + 2];
+            v[i * 4 + 2] = t[i * 4 + 2] - t[i * 4 + 1];
+            v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
+        }
+        WINO_PIN();
+        read_frag(slot, buf, 1, f1);
+        float* vp = Vlds + (buf ^ 1) * CHUNK_FLOATS + s_l * 128 + tile_l * 2 + h;
+#define WINO_VST(e) vp[(e) * XI_STRIDE] = v[e]
+#define WINO_LD(e) d[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[e], soff, 0))
+        // x = 0, s = 2, 3: LDS stores of V, then the first patch loads
+        WINO_MFMA(0, 0, 0, f0.a0[2], f0.b0[2]); WINO_VST(0); WINO_VST(1); WINO_VST(2); WINO_VST(3); WINO_PIN();
+        WINO_MFMA(0, 0, 1, f0.a0[2], f0.b1[2]); WINO_VST(4); WINO_VST(5); WINO_VST(6); WINO_VST(7); WINO_PIN();
+        WINO_MFMA(0, 1, 0, f0.a1[2], f0.b0[2]); WINO_VST(8); WINO_VST(9); WINO_VST(10); WINO_VST(11); WINO_PIN();
+        WINO_MFMA(0, 1, 1, f0.a1[2], f0.b1[2]); WINO_VST(12); WINO_VST(13); WINO_VST(14); WINO_VST(15); WINO_PIN();
+        WINO_MFMA(0, 0, 0, f0.a0[3], f0.b0[3]); WINO_LD(0); WINO_PIN();
+        WINO_MFMA(0, 0, 1, f0.a0[3], f0.b1[3]); WINO_LD(1); WINO_PIN();
+        WINO_MFMA(0, 1, 0, f0.a1[3], f0.b0[3]); WINO_LD(2); WINO_PIN();
+        WINO_MFMA(0, 1, 1, f0.a1[3], f0.b1[3]); WINO_LD(3); WINO_PIN();
+        // x = 1: one patch load behind each of the first twelve MFMAs
+#define WINO_X1(s, e0)                                                                     \
+        WINO_MFMA(1, 0, 0, f1.a0[s], f1.b0[s]); WINO_LD(e0); WINO_PIN();                   \
+        WINO_MFMA(1, 0, 1, f1.a0[s], f1.b1[s]); WINO_LD(e0 + 1); WINO_PIN();               \
+        WINO_MFMA(1, 1, 0, f1.a1[s], f1.b0[s]); WINO_LD(e0 + 2); WINO_PIN();               \
+        WINO_MFMA(1, 1, 1, f1.a1[s], f1.b1[s]); WINO_LD(e0 + 3); WINO_PIN();
+        WINO_X1(0, 4)
+        WINO_X1(1, 8)
+        WINO_X1(2, 12)
+#undef WINO_X1
+        mfma_frag(1, f1, 3, 4);
+#undef WINO_VST
+#undef WINO_LD
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
-    for (int c = 0; c < a.chunks; c += 2) {
-        body(c, dB, dA);
-        if (c + 1 < a.chunks) body(c + 1, dA, dB);
+    int slot = 0;
+    int c = 0;
+    for (; c + 1 < a.chunks; c += 2) {          // straight-line pair of iterations: static wait counts
+        body(c, slot, dB);
+        slot = slot == 2 ? 0 : slot + 1;
+        body(c + 1, slot, dA);
+        slot = slot == 2 ? 0 : slot + 1;
     }
+    if (c < a.chunks) body(c, slot, dB);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // ---- output transform: two passes of 32 tiles through LDS  M[xi][k 64][tile 32]
-    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? 0x7FFFFF00u : 0u);
-    (void)rres;
+    // ---- output transform: two passes of 32 tiles through LDS  M[xi][k 64][tile 32], row stride 40 floats:
+    // the two half-waves of an accumulator store (k and k+4) and of a transform read land on disjoint banks
+    constexpr int MS = 40, MXI = 64 * MS;
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
     for (int tbk = 0; tbk < 2; ++tbk) {
 #pragma unroll
         for (int x = 0; x < 2; ++x)
@@ -194,7 +305,7 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int k = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    lds[(2 * wave + x) * 2048 + k * 32 + l31] = tbk == 0 ? acc[x][i][0][r] : acc[x][i][1][r];
+                    lds[(2 * wave + x) * MXI + k * MS + l31] = tbk == 0 ? acc[x][i][0][r] : acc[x][i][1][r];
                 }
         __syncthreads();
         const int tl = tid & 31;
@@ -205,13 +316,14 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
         const int ty = rem / a.TX, tx = rem - ty * a.TX;
         const int OH = a.H, OW = a.W;                  // pad 1, stride 1: same spatial size
         const int oy = 2 * ty, ox = 2 * tx;
+        const bool two = ox + 1 < OW;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int k = (tid >> 5) + 16 * it;
+            const int k = 8 * wave + it + 4 * ((tid >> 5) & 1);
             const int co = kb * KB + k;
             float m[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) m[e] = lds[e * 2048 + k * 32 + tl];
+            for (int e = 0; e < 16; ++e) m[e] = lds[e * MXI + k * MS + tl];
             if (!live || co >= a.M) continue;
             float u0[4], u1[4];
 #pragma unroll
@@ -223,13 +335,29 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
             const float sc = a.scale[co], sh = a.shift[co];
             const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int yy = oy + (q >> 1), xx = ox + (q & 1);
-                if (yy >= OH || xx >= OW) continue;
-                float v = y[q] * sc + sh;
-                if (a.res) v = v * a.res_scale + a.res[(((size_t)n * a.res_ctot + a.res_coff + co) * OH + yy) * OW + xx];
-                v = fmaxf(v, lo);
-                a.out[(((size_t)n * a.out_ctot + a.out_coff + co) * OH + yy) * OW + xx] = v;
+            for (int q = 0; q < 2; ++q) {              // output row oy + q: two adjacent pixels, one 8-byte access
+                const int yy = oy + q;
+                if (yy >= OH) continue;
+                float v0 = y[2 * q] * sc + sh, v1 = y[2 * q + 1] * sc + sh;
+                if (a.res) {
+                    const unsigned ro = (unsigned)(((((size_t)n * a.res_ctot + a.res_coff + co) * OH + yy) * OW + ox) * 4);
+                    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rres, ro, 0, 0));
+                    const float r1 = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(rres, two ? ro + 4 : (unsigned)kInvalidOff, 0, 0));
+                    v0 = v0 * a.res_scale + r0;
+                    v1 = v1 * a.res_scale + r1;
+                }
+                v0 = fmaxf(v0, lo);
+                v1 = fmaxf(v1, lo);
+                const unsigned oo = (unsigned)(((((size_t)n * a.out_ctot + a.out_coff + co) * OH + yy) * OW + ox) * 4);
+                if (two) {
+                    i32x2 pk;
+                    pk.x = __builtin_bit_cast(int, v0);
+                    pk.y = __builtin_bit_cast(int, v1);
+                    __builtin_amdgcn_raw_buffer_store_b64(pk, rout, oo, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v0), rout, oo, 0, 0);
+                }
             }
         }
         __syncthreads();
@@ -332,7 +460,10 @@ extern "C" int ct_conv2d_wino_fwd(const ct_conv_desc* d, const float* upacked, c
     CT_REQUIRE(!d->res || (d->res_coff >= 0 && d->res_coff + d->cout <= d->res_ctot), "ct_conv2d_wino_fwd: residual slice");
     const long long img_in_bytes = (long long)d->in_ctot * d->h * d->w * 4;
     CT_REQUIRE(img_in_bytes < kMaxBufBytes, "ct_conv2d_wino_fwd: one image exceeds 2 GiB");
-    const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / img_in_bytes);
+    const long long img_out_bytes = (long long)d->out_ctot * d->oh * d->ow * 4;
+    const long long img_res_bytes = d->res ? (long long)d->res_ctot * d->oh * d->ow * 4 : 0;
+    CT_REQUIRE(img_out_bytes < kMaxBufBytes && img_res_bytes < kMaxBufBytes, "ct_conv2d_wino_fwd: one image exceeds 2 GiB");
+    const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / std::max(img_in_bytes, std::max(img_out_bytes, img_res_bytes)));
     hipStream_t st = ctdet::as_stream(stream);
     {
         static std::once_flag once;
@@ -353,6 +484,8 @@ extern "C" int ct_conv2d_wino_fwd(const ct_conv_desc* d, const float* upacked, c
         a.res = d->res ? d->res + (size_t)b0 * d->res_ctot * OHW : nullptr;
         a.out = d->out + (size_t)b0 * d->out_ctot * OHW;
         a.in_bytes = (unsigned)(img_in_bytes * nb);
+        a.out_bytes = (unsigned)(img_out_bytes * nb);
+        a.res_bytes = (unsigned)(img_res_bytes * nb);
         a.Cin = d->cin; a.H = d->h; a.W = d->w; a.in_ctot = d->in_ctot; a.in_coff = d->in_coff;
         a.M = d->cout; a.chunks = d->cin / CC;
         a.TY = (d->oh + 1) / 2; a.TX = (d->ow + 1) / 2;
