@@ -91,9 +91,9 @@ def pmc_traffic(event_name, workload):
     import glob
     import re
     m = re.match(r'conv_igemm_f32<(\d+)x(\d+),(\d+)x(\d+)', event_name)
-    if not m:
+    if not m and not event_name.startswith('wino_'):
         return None
-    kh, kw, bm, bn = m.groups()
+    kh, kw, bm, bn = m.groups() if m else (None,) * 4
     best = None
     for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_pmc_traffic.json'))):
         try:
@@ -103,6 +103,10 @@ def pmc_traffic(event_name, workload):
         if table.get('__workload__', {'size': 300, 'batch': 32, 'phase': 1, 'classes': 20}) != workload:
             continue
         for k, v in table.items():
+            if not m:
+                if k.startswith(event_name):
+                    best = v['hbm_bytes']
+                continue
             f = [x.strip() for x in k[k.find('<') + 1:k.find('>')].split(',')] if '<' in k else []
             if k.startswith('conv_igemm_f32') and len(f) >= 5 and f[0] == kh and f[1] == kw and f[3] == bm and f[4] == bn:
                 best = v['hbm_bytes']
@@ -117,15 +121,18 @@ def conv_roofline(rt, batch, workload):
     agg = {}
     for st, e0, e1 in rt.event_log:
         cfg = st.rt['desc'].config
-        name = 'conv_igemm_f32<%dx%d,%s>' % (st.kh, st.kw, lib.ct_conv_config_name(cfg - 1).decode()
-                                            if cfg > 0 else 'auto')
-        a = agg.setdefault(name, [0.0, 0.0, 0])
+        wino = bool(st.rt.get('wino'))
+        name = 'wino_f2x2_3x3_f32' if wino else 'conv_igemm_f32<%dx%d,%s>' % (
+            st.kh, st.kw, lib.ct_conv_config_name(cfg - 1).decode() if cfg > 0 else 'auto')
+        a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
         a[0] += e0.elapsed_time(e1) * 1e-3
-        a[1] += st.flops(batch)
+        a[1] += st.flops(batch)                # ALGORITHMIC flops (direct convolution)
         a[2] += 1
+        a[3] += st.flops(batch) * (16.0 / 36.0 if wino else 1.0)      # multiply-adds actually sent to the MFMA pipe
     tot_t = sum(a[0] for a in agg.values())
     tot_f = sum(a[1] for a in agg.values())
-    name, (t, f, n) = max(agg.items(), key=lambda kv: kv[1][0])
+    tot_x = sum(a[3] for a in agg.values())
+    name, (t, f, n, fx) = max(agg.items(), key=lambda kv: kv[1][0])
     ach = f / t / 1e12
     traffic = pmc_traffic(name, workload)
     return {
@@ -133,8 +140,12 @@ def conv_roofline(rt, batch, workload):
         'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
         'kernel': name, 'launches': n, 'avg_launch_us': round(t / n * 1e6, 2),
         'flops_per_launch': round(f / n),
+        # Winograd F(2x2,3x3) executes 16/36 of the algorithmic multiply-adds: `frac` above is algorithmic
+        # flops / peak (can exceed 1), `mfma_pipe_frac` is what the matrix pipe really sustained
+        'mfma_pipe_frac': round(fx / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
         'all_conv': {'achieved': round(tot_f / tot_t / 1e12, 2),
                      'frac': round(tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                     'mfma_pipe_frac': round(tot_x / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                      'time_share_of_dominant': round(t / tot_t, 3),
                      'conv_ms_per_step': round(tot_t / max(1, len(rt.event_log)) * len(rt.conv_steps()) * 1e3, 3),
                      'launches_per_step': len(rt.conv_steps())},
