@@ -576,6 +576,43 @@ class Runtime:
             if missing and mode != '0':
                 self.autotune(missing)
             self.tuned = not missing or mode != '0'
+        self._build_schedule()
+
+    # ---- two-stream schedule: the Norm branch and the multibox heads are independent of the trunk that
+    # follows their source (base.23.., extras..), and the small 19x19 .. 1x1 kernels of that trunk cannot fill
+    # 256 CUs on their own; running the side work on a second HIP stream lets it soak up the idle CUs.
+    def _build_schedule(self):
+        self.side = None
+        steps = self.plan.steps
+        if os.environ.get('CTDET_STREAMS', '2') == '1' or self.backend.device.type != 'cuda':
+            return
+        sid = [1 if (st.name.startswith(('Norm.', 'head.')) or st.kind == 'ctxpool') else 0 for st in steps]
+        if not any(sid):
+            return
+
+        def reads(st):
+            r = [st.src]
+            if getattr(st, 'res', None) is not None:
+                r.append(st.res)
+            return r
+
+        def writes(st):
+            if st.kind == 'conv' and st.segs:
+                return [sg.dst for sg in st.segs]
+            return [st.dst]
+        writers = {}
+        self.xdeps, self.signal = [[] for _ in steps], set()
+        for i, st in enumerate(steps):
+            for b in reads(st):
+                for j in writers.get(b, []):
+                    if sid[j] != sid[i]:
+                        self.xdeps[i].append(j)
+                        self.signal.add(j)
+            for b in writes(st):
+                writers.setdefault(b, []).append(i)
+        self.sid = sid
+        self.side = torch.cuda.Stream(self.backend.device)
+        self.ev = {j: torch.cuda.Event() for j in self.signal}
 
     def autotune(self, steps=None):
         self.bufs['x'].normal_()
@@ -619,8 +656,26 @@ class Runtime:
             raise _lib.CtdetError('plan was built for input %s, got %s' % (tuple(self.bufs['x'].shape), tuple(x.shape)))
         self.refresh_weights()
         self.bufs['x'].copy_(x)
-        for st in self.plan.steps:
-            self._run_step(st)
+        if self.side is None:
+            for st in self.plan.steps:
+                self._run_step(st)
+            return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
+        main = torch.cuda.current_stream(self.backend.device)
+        self.side.wait_stream(main)
+        streams = (main, self.side)
+        steps = self.plan.steps
+        i, n = 0, len(steps)
+        while i < n:
+            k = self.sid[i]
+            with torch.cuda.stream(streams[k]):
+                while i < n and self.sid[i] == k:
+                    for j in self.xdeps[i]:
+                        streams[k].wait_event(self.ev[j])
+                    self._run_step(steps[i])
+                    if i in self.signal:
+                        self.ev[i].record(streams[k])
+                    i += 1
+        main.wait_stream(self.side)
         return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
 
     def conv_steps(self):
