@@ -369,6 +369,8 @@ struct WinoPackArgs {
     const float* w[6];
     int mbeg[7];
     int nparts, cin, cout, chunks, kblocks;
+    int dgrad;               // 1: weights of the data-gradient convolution (channels swapped, taps flipped)
+    int cin_fwd;
     float* U;
 };
 
@@ -386,9 +388,11 @@ __global__ void wino_pack_kernel(const WinoPackArgs p)
         const int co = kb * KB + k, ci = chunk * CC + 2 * s + hh;
         float val = 0.f;
         if (co < p.cout) {
+            // forward: g = w[co][ci];  data gradient: this conv's (co, ci) = forward (ci, co), taps rotated 180 deg
+            const int fco = p.dgrad ? ci : co, fci = p.dgrad ? co : ci;
             int part = 0;
-            while (part + 1 < p.nparts && co >= p.mbeg[part + 1]) ++part;
-            const float* g = p.w[part] + ((size_t)(co - p.mbeg[part]) * p.cin + ci) * 9;
+            while (part + 1 < p.nparts && fco >= p.mbeg[part + 1]) ++part;
+            const float* g = p.w[part] + ((size_t)(fco - p.mbeg[part]) * p.cin_fwd + fci) * 9;
             const int ar = xi >> 2, bc = xi & 3;
             // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
             float Ga[3], Gb[3];
@@ -401,7 +405,8 @@ __global__ void wino_pack_kernel(const WinoPackArgs p)
             grow(ar, Ga);
             grow(bc, Gb);
             for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j) val += Ga[i] * g[i * 3 + j] * Gb[j];
+                for (int j = 0; j < 3; ++j)
+                    val += Ga[i] * (p.dgrad ? g[(2 - i) * 3 + (2 - j)] : g[i * 3 + j]) * Gb[j];
         }
         p.U[idx] = val;
     }
@@ -423,27 +428,47 @@ extern "C" size_t ct_conv_wino_packed_floats(int cin, int cout)
     return (size_t)((cout + KB - 1) / KB) * (cin / CC) * CHUNK_FLOATS;
 }
 
-extern "C" int ct_conv_pack_weights_wino(const float* const* w, const int* cout, int nparts, int cin,
-                                         float* upacked, ct_stream_t stream)
+namespace {
+int pack_wino(const float* const* w, const int* cout, int nparts, int cin, int dgrad, float* upacked,
+              ct_stream_t stream, const char* who)
 {
-    CT_REQUIRE(w && cout && upacked && nparts >= 1 && nparts <= 6, "ct_conv_pack_weights_wino: bad argument");
-    CT_REQUIRE(cin > 0 && cin % CC == 0, "ct_conv_pack_weights_wino: cin=%d must be a multiple of %d", cin, CC);
+    CT_REQUIRE(w && cout && upacked && nparts >= 1 && nparts <= 6, "%s: bad argument", who);
     WinoPackArgs p{};
     int tot = 0;
     for (int i = 0; i < nparts; ++i) {
-        CT_REQUIRE(w[i] && cout[i] > 0, "ct_conv_pack_weights_wino: part %d", i);
+        CT_REQUIRE(w[i] && cout[i] > 0, "%s: part %d", who, i);
         p.w[i] = w[i];
         p.mbeg[i] = tot;
         tot += cout[i];
     }
     p.mbeg[nparts] = tot;
-    p.nparts = nparts; p.cin = cin; p.cout = tot; p.chunks = cin / CC; p.kblocks = (tot + KB - 1) / KB;
+    p.nparts = nparts;
+    p.dgrad = dgrad;
+    p.cin_fwd = cin;
+    p.cin = dgrad ? tot : cin;          // input channels of THIS convolution
+    p.cout = dgrad ? cin : tot;
+    CT_REQUIRE(p.cin > 0 && p.cin % CC == 0, "%s: %d input channels, must be a multiple of %d", who, p.cin, CC);
+    p.chunks = p.cin / CC;
+    p.kblocks = (p.cout + KB - 1) / KB;
     p.U = upacked;
     const long total = (long)p.kblocks * p.chunks * CHUNK_FLOATS;
     hipLaunchKernelGGL(wino_pack_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
                        ctdet::as_stream(stream), p);
     CT_LAUNCH_CHECK("wino_pack_kernel");
     return CT_OK;
+}
+}  // namespace
+
+extern "C" int ct_conv_pack_weights_wino(const float* const* w, const int* cout, int nparts, int cin,
+                                         float* upacked, ct_stream_t stream)
+{
+    return pack_wino(w, cout, nparts, cin, 0, upacked, stream, "ct_conv_pack_weights_wino");
+}
+
+extern "C" int ct_conv_pack_weights_wino_dgrad(const float* const* w, const int* cout, int nparts, int cin,
+                                               float* upacked, ct_stream_t stream)
+{
+    return pack_wino(w, cout, nparts, cin, 1, upacked, stream, "ct_conv_pack_weights_wino_dgrad");
 }
 
 extern "C" int ct_conv2d_wino_fwd(const ct_conv_desc* d, const float* upacked, ct_stream_t stream)

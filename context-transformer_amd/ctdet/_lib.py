@@ -97,6 +97,7 @@ SIGNATURES = {
     'ct_conv_wino_supported': (_I, [C.POINTER(ConvDesc)]),
     'ct_conv_wino_packed_floats': (_Z, [_I, _I]),
     'ct_conv_pack_weights_wino': (_I, [_P, _P, _I, _I, _P, _P]),
+    'ct_conv_pack_weights_wino_dgrad': (_I, [_P, _P, _I, _I, _P, _P]),
     'ct_conv2d_wino_fwd': (_I, [C.POINTER(ConvDesc), _P, _P]),
     'ct_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P]),
     'ct_maxpool2d_fwd': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),

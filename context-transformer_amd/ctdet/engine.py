@@ -540,6 +540,20 @@ class HipBackend:
         return best, times
 
 
+def apply_tuned(backend, st, batch):
+    """Give a prepared conv step the committed tile choice for its shape; False if the table has none."""
+    cfg = tune_table().get(st.tune_key(batch))
+    names = [backend.lib.ct_conv_config_name(i).decode() for i in range(backend.lib.ct_conv_num_configs())]
+    if cfg == 'wino' and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
+        backend.enable_wino(st)
+        return True
+    if cfg in names:
+        st.rt['config'] = names.index(cfg) + 1
+        st.rt['desc'].config = st.rt['config']
+        return True
+    return False
+
+
 class Runtime:
     """A Plan bound to a backend: buffers, packed weights, and the forward entry points."""
 
@@ -561,18 +575,7 @@ class Runtime:
         self.tuned = False
         self.event_log = None        # set to a list to collect (step, start_event, end_event) per conv
         if hasattr(backend, 'tune_conv'):
-            names = [backend.lib.ct_conv_config_name(i).decode() for i in range(backend.lib.ct_conv_num_configs())]
-            table = tune_table() if mode != '2' else {}
-            missing = []
-            for st in self.conv_steps():
-                cfg = table.get(st.tune_key(batch))
-                if cfg == 'wino' and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
-                    backend.enable_wino(st)
-                elif cfg in names:
-                    st.rt['config'] = names.index(cfg) + 1
-                    st.rt['desc'].config = st.rt['config']
-                else:
-                    missing.append(st)
+            missing = [st for st in self.conv_steps() if mode == '2' or not apply_tuned(backend, st, batch)]
             if missing and mode != '0':
                 self.autotune(missing)
             self.tuned = not missing or mode != '0'

@@ -23,7 +23,7 @@ import ctypes as C
 import torch
 
 from . import _lib, ops
-from .engine import ConvPart, ConvStep, HipBackend, Plan
+from .engine import ConvPart, ConvStep, HipBackend, Plan, apply_tuned
 
 
 class _StepState:
@@ -72,6 +72,7 @@ class TrainRuntime:
                                    st.kh, st.kw, st.stride, st.ph, st.pw, st.dil, st.src, st.src_coff, st.h,
                                    st.w, zname, 0)
                 backend.prepare_conv(s.zstep, self.bufs, batch)
+                apply_tuned(backend, s.zstep, batch)
                 s.fwd = s.zstep
                 s.mean = [al((p.cout,)) for p in st.parts]
                 s.var = [al((p.cout,)) for p in st.parts]
@@ -79,6 +80,7 @@ class TrainRuntime:
                 s.dbeta = [al((p.cout,)) for p in st.parts]
             else:
                 backend.prepare_conv(st, self.bufs, batch)
+                apply_tuned(backend, st, batch)
                 s.fwd = st
                 s.dbias = [al((p.cout,)) for p in st.parts]
             # data-gradient launch (not needed for the image itself)
@@ -102,6 +104,18 @@ class TrainRuntime:
                 d.transposed = 1
                 s.dgrad = d
                 s.kpad_d, s.mpad_d = kpad, mpad
+                # 3x3 / stride 1 / pad 1 layers: the data gradient is itself such a convolution (channels
+                # swapped, taps rotated) -> Winograd kernel on dY with ct_conv_pack_weights_wino_dgrad
+                s.dgrad_wino = None
+                if (st.kh, st.kw, st.stride, st.dil, st.ph, st.pw) == (3, 3, 1, 1, 1, 1) and ctot % 8 == 0 \
+                        and st.oh * st.ow >= 19 * 19:
+                    w2 = _lib.ConvDesc()
+                    C.memmove(C.byref(w2), C.byref(d), C.sizeof(d))
+                    w2.transposed = 0
+                    w2.kh = w2.kw = 3
+                    if self.lib.ct_conv_wino_supported(C.byref(w2)):
+                        s.dgrad_wino = w2
+                        s.U_d = al((self.lib.ct_conv_wino_packed_floats(ctot, st.cin),))
             # weight-gradient descriptor = forward geometry on the forward input
             w = _lib.ConvDesc()
             src = self.bufs[st.src]
@@ -312,11 +326,19 @@ class TrainRuntime:
                 n = len(st.parts)
                 ptrs = (C.c_void_p * n)(*[p.weight.data_ptr() for p in st.parts])
                 couts = (C.c_int * n)(*[p.cout for p in st.parts])
-                _lib.check(lib.ct_conv_pack_weights_dgrad(ptrs, couts, n, st.cin, st.kh, st.kw, s.wpk_d.data_ptr(),
-                                                          s.mpad_d, s.kpad_d, self._s()), st.name + ' pack dgrad')
                 acc = overlaps(st.src, st.src_coff, st.src_coff + st.cin)
-                s.dgrad.res = self.grads[st.src].data_ptr() if acc else None
-                _lib.check(lib.ct_conv2d_fwd(C.byref(s.dgrad), self._s()), st.name + ' dgrad')
+                if s.dgrad_wino is not None:
+                    _lib.check(lib.ct_conv_pack_weights_wino_dgrad(ptrs, couts, n, st.cin, s.U_d.data_ptr(), self._s()),
+                               st.name + ' pack dgrad (winograd)')
+                    s.dgrad_wino.res = self.grads[st.src].data_ptr() if acc else None
+                    _lib.check(lib.ct_conv2d_wino_fwd(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self._s()),
+                               st.name + ' dgrad (winograd)')
+                else:
+                    _lib.check(lib.ct_conv_pack_weights_dgrad(ptrs, couts, n, st.cin, st.kh, st.kw,
+                                                              s.wpk_d.data_ptr(), s.mpad_d, s.kpad_d, self._s()),
+                               st.name + ' pack dgrad')
+                    s.dgrad.res = self.grads[st.src].data_ptr() if acc else None
+                    _lib.check(lib.ct_conv2d_fwd(C.byref(s.dgrad), self._s()), st.name + ' dgrad')
                 written.setdefault(st.src, []).append((st.src_coff, st.src_coff + st.cin))
         if bk is not None:
             bk.finish()

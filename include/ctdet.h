@@ -230,6 +230,11 @@ size_t ct_conv_wino_packed_floats(int cin, int cout);
 int ct_conv_pack_weights_wino(const float* const* w, const int* cout, int nparts, int cin, float* upacked,
                               ct_stream_t stream);
 int ct_conv2d_wino_fwd(const ct_conv_desc* desc, const float* upacked, ct_stream_t stream);
+/* Weights of the DATA-GRADIENT convolution of a 3x3 / stride 1 / pad 1 layer (input channels = sum cout,
+ * output channels = cin, taps rotated by 180 degrees), for ct_conv2d_wino_fwd on dY:
+ * upacked holds ct_conv_wino_packed_floats(sum cout, cin) floats. */
+int ct_conv_pack_weights_wino_dgrad(const float* const* w, const int* cout, int nparts, int cin,
+                                    float* upacked, ct_stream_t stream);
 
 /* ------------------------------------------------------------ training side ---- */
 /* What `losses.backward()` (train.py:228) makes autograd/cuDNN do for the layers above.  The data
