@@ -51,6 +51,8 @@ struct WinoArgs {
     int out_ctot, out_coff, res_ctot, res_coff;
     float res_scale;
     int relu;
+    float* pool_out;         // optional fused 2x2 / stride 2 max-pool of the activation (NCHW), else null
+    int pool_ctot, pool_coff, pool_oh, pool_ow, write_full;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -334,6 +336,7 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
             float y[4] = {u0[0] + u0[1] + u0[2], u0[1] - u0[2] - u0[3], u1[0] + u1[1] + u1[2], u1[1] - u1[2] - u1[3]};
             const float sc = a.scale[co], sh = a.shift[co];
             const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
+            float pooled = -INFINITY;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {              // output row oy + q: two adjacent pixels, one 8-byte access
                 const int yy = oy + q;
@@ -349,6 +352,8 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
                 }
                 v0 = fmaxf(v0, lo);
                 v1 = fmaxf(v1, lo);
+                pooled = fmaxf(pooled, two ? fmaxf(v0, v1) : v0);
+                if (!a.write_full) continue;
                 const unsigned oo = (unsigned)(((((size_t)n * a.out_ctot + a.out_coff + co) * OH + yy) * OW + ox) * 4);
                 if (two) {
                     i32x2 pk;
@@ -359,6 +364,9 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v0), rout, oo, 0, 0);
                 }
             }
+            // the 2x2 output tile IS the pooling window of MaxPool2d(2, 2[, ceil_mode]) (models/RFB_Net_vgg.py:328-330)
+            if (a.pool_out && ty < a.pool_oh && tx < a.pool_ow)
+                a.pool_out[(((size_t)n * a.pool_ctot + a.pool_coff + co) * a.pool_oh + ty) * a.pool_ow + tx] = pooled;
         }
         __syncthreads();
     }
@@ -471,7 +479,16 @@ extern "C" int ct_conv_pack_weights_wino_dgrad(const float* const* w, const int*
     return pack_wino(w, cout, nparts, cin, 1, upacked, stream, "ct_conv_pack_weights_wino_dgrad");
 }
 
+extern "C" int ct_conv2d_wino_pool_fwd(const ct_conv_desc* d, const float* upacked, float* pool_out, int pool_ctot,
+                                       int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
+
 extern "C" int ct_conv2d_wino_fwd(const ct_conv_desc* d, const float* upacked, ct_stream_t stream)
+{
+    return ct_conv2d_wino_pool_fwd(d, upacked, nullptr, 0, 0, 0, 0, 1, stream);
+}
+
+extern "C" int ct_conv2d_wino_pool_fwd(const ct_conv_desc* d, const float* upacked, float* pool_out, int pool_ctot,
+                                       int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream)
 {
     CT_REQUIRE(d && upacked, "ct_conv2d_wino_fwd: null pointer");
     CT_REQUIRE(d->in && d->out && d->scale && d->shift, "ct_conv2d_wino_fwd: null tensor");
@@ -480,6 +497,12 @@ extern "C" int ct_conv2d_wino_fwd(const ct_conv_desc* d, const float* upacked, c
                            "NCHW output (got %dx%d s%d d%d p%d cin=%d nseg=%d)", d->kh, d->kw, d->stride, d->dil,
                            d->pad_h, d->cin, d->nseg);
     CT_REQUIRE(d->batch > 0 && d->cout > 0, "ct_conv2d_wino_fwd: bad shape");
+    CT_REQUIRE(write_full || pool_out, "ct_conv2d_wino_pool_fwd: nothing to write");
+    if (pool_out) {
+        CT_REQUIRE(pool_coff >= 0 && pool_coff + d->cout <= pool_ctot, "ct_conv2d_wino_pool_fwd: pooled output slice");
+        CT_REQUIRE((pool_oh == d->oh / 2 || pool_oh == (d->oh + 1) / 2) && (pool_ow == d->ow / 2 || pool_ow == (d->ow + 1) / 2),
+                   "ct_conv2d_wino_pool_fwd: pooled size %dx%d for a %dx%d map", pool_oh, pool_ow, d->oh, d->ow);
+    }
     CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "ct_conv2d_wino_fwd: input slice");
     CT_REQUIRE(d->out_coff >= 0 && d->out_coff + d->cout <= d->out_ctot, "ct_conv2d_wino_fwd: output slice");
     CT_REQUIRE(!d->res || (d->res_coff >= 0 && d->res_coff + d->cout <= d->res_ctot), "ct_conv2d_wino_fwd: residual slice");
@@ -519,6 +542,9 @@ extern "C" int ct_conv2d_wino_fwd(const ct_conv_desc* d, const float* upacked, c
         a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
         a.res_ctot = d->res_ctot; a.res_coff = d->res_coff; a.res_scale = d->res_scale;
         a.relu = d->relu;
+        a.pool_out = pool_out ? pool_out + (size_t)b0 * pool_ctot * pool_oh * pool_ow : nullptr;
+        a.pool_ctot = pool_ctot; a.pool_coff = pool_coff; a.pool_oh = pool_oh; a.pool_ow = pool_ow;
+        a.write_full = write_full;
         const int kblocks = (d->cout + KB - 1) / KB;
         hipLaunchKernelGGL(wino_f2x2_3x3_f32, dim3(a.tile_blocks * kblocks), dim3(512), WINO_LDS_BYTES, st, a);
         CT_LAUNCH_CHECK("wino_f2x2_3x3_f32");

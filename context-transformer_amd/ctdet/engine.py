@@ -480,6 +480,12 @@ class HipBackend:
 
     def run_conv(self, st):
         if st.rt.get('wino'):
+            pool = st.rt.get('pool')
+            if pool is not None:        # fused MaxPool2d(2, 2): (pooled buffer, oh, ow, write_full)
+                t, poh, pow_, full = pool
+                _lib.check(self.lib.ct_conv2d_wino_pool_fwd(C.byref(st.rt['desc']), st.rt['U'].data_ptr(), t.data_ptr(),
+                                                            t.shape[1], 0, poh, pow_, int(full), self._stream()), st.name)
+                return
             _lib.check(self.lib.ct_conv2d_wino_fwd(C.byref(st.rt['desc']), st.rt['U'].data_ptr(), self._stream()),
                        st.name)
             return
@@ -579,7 +585,26 @@ class Runtime:
             if missing and mode != '0':
                 self.autotune(missing)
             self.tuned = not missing or mode != '0'
+        self._fuse_pools()
         self._build_schedule()
+
+    def _fuse_pools(self):
+        """MaxPool2d(2, 2) directly behind a Winograd conv: the 2x2 output tile is the pooling window, so
+        the conv writes the pooled map itself (and skips its full-resolution output if nothing else reads it)."""
+        steps = self.plan.steps
+        if os.environ.get('CTDET_FUSE_POOL', '1') == '0':
+            return
+        for pi, ps in enumerate(steps):
+            if ps.kind != 'pool' or (ps.k, ps.stride, ps.pad) != (2, 2, 0):
+                continue
+            prod = [st for st in steps if st.kind == 'conv' and not st.segs and st.dst == ps.src]
+            if len(prod) != 1 or not prod[0].rt.get('wino') or prod[0].dst_coff != 0 or prod[0].cout != ps.ch \
+                    or prod[0].res is not None:
+                continue
+            others = [st for st in steps if st is not ps and (getattr(st, 'src', None) == ps.src or
+                                                              getattr(st, 'res', None) == ps.src)]
+            prod[0].rt['pool'] = (self.bufs[ps.dst], ps.oh, ps.ow, bool(others))
+            ps.fused_into = prod[0].name
 
     # ---- two-stream schedule: the Norm branch and the multibox heads are independent of the trunk that
     # follows their source (base.23.., extras..), and the small 19x19 .. 1x1 kernels of that trunk cannot fill
@@ -602,6 +627,8 @@ class Runtime:
         def writes(st):
             if st.kind == 'conv' and st.segs:
                 return [sg.dst for sg in st.segs]
+            if st.kind == 'conv' and st.rt.get('pool') is not None:
+                return [st.dst] + [p.dst for p in steps if getattr(p, 'fused_into', None) == st.name]
             return [st.dst]
         writers = {}
         self.xdeps, self.signal = [[] for _ in steps], set()
@@ -647,7 +674,8 @@ class Runtime:
                 return
             self.backend.run_conv(st)
         elif st.kind == 'pool':
-            self.backend.run_pool(st, self.bufs, self.batch)
+            if getattr(st, 'fused_into', None) is None:
+                self.backend.run_pool(st, self.bufs, self.batch)
         elif st.kind == 'ctxpool':
             self.backend.run_ctxpool(st, self.bufs, self.batch)
         else:

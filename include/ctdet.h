@@ -230,6 +230,12 @@ size_t ct_conv_wino_packed_floats(int cin, int cout);
 int ct_conv_pack_weights_wino(const float* const* w, const int* cout, int nparts, int cin, float* upacked,
                               ct_stream_t stream);
 int ct_conv2d_wino_fwd(const ct_conv_desc* desc, const float* upacked, ct_stream_t stream);
+/* Same with the following MaxPool2d(2, 2[, ceil_mode]) (models/RFB_Net_vgg.py:328-330) fused: the 2x2 Winograd
+ * output tile is the pooling window, so the pooled activation [B, pool_ctot, pool_oh, pool_ow] (channels at
+ * pool_coff) is written from registers; write_full = 0 skips the full-resolution output when nothing else reads it.
+ * pool_oh/ow = floor or ceil of oh/2, ow/2 (ceil_mode windows are clipped to the map). */
+int ct_conv2d_wino_pool_fwd(const ct_conv_desc* desc, const float* upacked, float* pool_out, int pool_ctot,
+                            int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
 /* Weights of the DATA-GRADIENT convolution of a 3x3 / stride 1 / pad 1 layer (input channels = sum cout,
  * output channels = cin, taps rotated by 180 degrees), for ct_conv2d_wino_fwd on dY:
  * upacked holds ct_conv_wino_packed_floats(sum cout, cin) floats. */

@@ -66,3 +66,38 @@ def test_wino_rejects_other_geometries():
     with pytest.raises(_lib.CtdetError):                     # cin not a multiple of 8
         _run_conv(torch.randn(1, 3, 9, 9, generator=g), [(torch.randn(8, 3, 3, 3, generator=g), None, None, False)],
                   1, 1, 1, config=W)
+
+
+@pytest.mark.parametrize('case', [(2, 16, 20, 20, 24, False, 1), (2, 16, 75, 75, 40, True, 0), (1, 8, 19, 17, 70, False, 0),
+                                  (2, 8, 19, 17, 9, True, 1), (1, 8, 1, 1, 5, True, 0)])
+def test_wino_fused_maxpool(case):
+    """MaxPool2d(2, 2[, ceil_mode]) behind the conv (models/RFB_Net_vgg.py:328-330) from the Winograd epilogue."""
+    import torch.nn.functional as F
+    B, Cin, H, Wd, Cout, ceil, full = case
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cout)
+    x = torch.randn(B, Cin, H, Wd, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.rand(Cout, generator=g) - 0.5
+    be = engine.HipBackend('cuda:0')
+    wp = torch.nn.Parameter(w.cuda(), requires_grad=False)
+    bp = torch.nn.Parameter(b.cuda(), requires_grad=False)
+    st = engine.ConvStep('t', [engine.ConvPart(wp, bp, None, True)], Cin, 3, 3, 1, 1, 1, 1, 'x', 0, H, Wd, 'y', 0)
+    poh = -(-H // 2) if ceil else H // 2
+    pow_ = -(-Wd // 2) if ceil else Wd // 2
+    bufs = {'x': x.cuda(), 'y': torch.full((B, Cout, H, Wd), float('nan'), device='cuda')}
+    pooled = torch.full((B, Cout, max(poh, 1), max(pow_, 1)), float('nan'), device='cuda')
+    st.rt['config'] = W
+    be.prepare_conv(st, bufs, B)
+    if poh == 0 or pow_ == 0:
+        return
+    st.rt['pool'] = (pooled, poh, pow_, bool(full))
+    be.run_conv(st)
+    torch.cuda.synchronize()
+    y = F.relu(F.conv2d(x, w, b, 1, 1))
+    want = F.max_pool2d(y, 2, 2, 0, ceil_mode=ceil)
+    assert rel_err(pooled.cpu(), want) < TOL
+    if full:
+        assert rel_err(bufs['y'].cpu(), y) < TOL
+        assert torch.equal(F.max_pool2d(bufs['y'], 2, 2, 0, ceil_mode=ceil), pooled)     # same values, exactly
+    else:
+        assert torch.isnan(bufs['y']).all()                                             # full-resolution map skipped
