@@ -53,6 +53,8 @@ struct WinoArgs {
     int relu;
     float* pool_out;         // optional fused 2x2 / stride 2 max-pool of the activation (NCHW), else null
     int pool_ctot, pool_coff, pool_oh, pool_ow, write_full;
+    int nseg;                // > 0: channels-last scatter into the flattened head buffers (ct_out_segment)
+    ct_out_segment seg[3];
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -354,6 +356,17 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
                 v1 = fmaxf(v1, lo);
                 pooled = fmaxf(pooled, two ? fmaxf(v0, v1) : v0);
                 if (!a.write_full) continue;
+                if (a.nseg > 0) {          // heads: permute(0,2,3,1) + view + cat of models/RFB_Net_vgg.py:239-248
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end) {
+                            float* dst = a.seg[g].ptr + (size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                         (size_t)(yy * OW + ox) * a.seg[g].pix_stride + (co - a.seg[g].co_begin);
+                            dst[0] = v0;
+                            if (two) dst[a.seg[g].pix_stride] = v1;
+                        }
+                    continue;
+                }
                 const unsigned oo = (unsigned)(((((size_t)n * a.out_ctot + a.out_coff + co) * OH + yy) * OW + ox) * 4);
                 if (two) {
                     i32x2 pk;
@@ -423,7 +436,8 @@ __global__ void wino_pack_kernel(const WinoPackArgs p)
 bool wino_ok(const ct_conv_desc* d)
 {
     return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
-           d->cin % CC == 0 && d->nseg == 0 && !d->transposed && d->oh == d->h && d->ow == d->w;
+           d->cin % CC == 0 && d->nseg >= 0 && d->nseg <= 3 && (d->nseg == 0 || !d->res) && !d->transposed &&
+           d->oh == d->h && d->ow == d->w;
 }
 
 }  // namespace
@@ -491,10 +505,10 @@ extern "C" int ct_conv2d_wino_pool_fwd(const ct_conv_desc* d, const float* upack
                                        int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream)
 {
     CT_REQUIRE(d && upacked, "ct_conv2d_wino_fwd: null pointer");
-    CT_REQUIRE(d->in && d->out && d->scale && d->shift, "ct_conv2d_wino_fwd: null tensor");
+    CT_REQUIRE(d->in && (d->out || d->nseg > 0) && d->scale && d->shift, "ct_conv2d_wino_fwd: null tensor");
     if (!wino_ok(d))
-        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wino_fwd: needs 3x3 stride 1 dilation 1 pad 1, cin %% 8 == 0, "
-                           "NCHW output (got %dx%d s%d d%d p%d cin=%d nseg=%d)", d->kh, d->kw, d->stride, d->dil,
+        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wino_fwd: needs 3x3 stride 1 dilation 1 pad 1, cin %% 8 == 0 "
+                           "(got %dx%d s%d d%d p%d cin=%d nseg=%d)", d->kh, d->kw, d->stride, d->dil,
                            d->pad_h, d->cin, d->nseg);
     CT_REQUIRE(d->batch > 0 && d->cout > 0, "ct_conv2d_wino_fwd: bad shape");
     CT_REQUIRE(write_full || pool_out, "ct_conv2d_wino_pool_fwd: nothing to write");
@@ -504,11 +518,16 @@ extern "C" int ct_conv2d_wino_pool_fwd(const ct_conv_desc* d, const float* upack
                    "ct_conv2d_wino_pool_fwd: pooled size %dx%d for a %dx%d map", pool_oh, pool_ow, d->oh, d->ow);
     }
     CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "ct_conv2d_wino_fwd: input slice");
-    CT_REQUIRE(d->out_coff >= 0 && d->out_coff + d->cout <= d->out_ctot, "ct_conv2d_wino_fwd: output slice");
+    if (d->nseg == 0)
+        CT_REQUIRE(d->out_coff >= 0 && d->out_coff + d->cout <= d->out_ctot, "ct_conv2d_wino_fwd: output slice");
+    else {
+        CT_REQUIRE(!pool_out && write_full, "ct_conv2d_wino_fwd: pooling with segmented output");
+        for (int g = 0; g < d->nseg; ++g) CT_REQUIRE(d->seg[g].ptr, "ct_conv2d_wino_fwd: null segment");
+    }
     CT_REQUIRE(!d->res || (d->res_coff >= 0 && d->res_coff + d->cout <= d->res_ctot), "ct_conv2d_wino_fwd: residual slice");
     const long long img_in_bytes = (long long)d->in_ctot * d->h * d->w * 4;
     CT_REQUIRE(img_in_bytes < kMaxBufBytes, "ct_conv2d_wino_fwd: one image exceeds 2 GiB");
-    const long long img_out_bytes = (long long)d->out_ctot * d->oh * d->ow * 4;
+    const long long img_out_bytes = d->nseg ? 4 : (long long)d->out_ctot * d->oh * d->ow * 4;
     const long long img_res_bytes = d->res ? (long long)d->res_ctot * d->oh * d->ow * 4 : 0;
     CT_REQUIRE(img_out_bytes < kMaxBufBytes && img_res_bytes < kMaxBufBytes, "ct_conv2d_wino_fwd: one image exceeds 2 GiB");
     const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / std::max(img_in_bytes, std::max(img_out_bytes, img_res_bytes)));
@@ -530,7 +549,12 @@ extern "C" int ct_conv2d_wino_pool_fwd(const ct_conv_desc* d, const float* upack
         a.U = upacked;
         a.scale = d->scale; a.shift = d->shift; a.lo = d->lo;
         a.res = d->res ? d->res + (size_t)b0 * d->res_ctot * OHW : nullptr;
-        a.out = d->out + (size_t)b0 * d->out_ctot * OHW;
+        a.out = d->nseg ? nullptr : d->out + (size_t)b0 * d->out_ctot * OHW;
+        a.nseg = d->nseg;
+        for (int g = 0; g < d->nseg; ++g) {
+            a.seg[g] = d->seg[g];
+            a.seg[g].ptr += (size_t)b0 * d->seg[g].img_stride;
+        }
         a.in_bytes = (unsigned)(img_in_bytes * nb);
         a.out_bytes = (unsigned)(img_out_bytes * nb);
         a.res_bytes = (unsigned)(img_res_bytes * nb);

@@ -101,3 +101,35 @@ def test_wino_fused_maxpool(case):
         assert torch.equal(F.max_pool2d(bufs['y'], 2, 2, 0, ceil_mode=ceil), pooled)     # same values, exactly
     else:
         assert torch.isnan(bufs['y']).all()                                             # full-resolution map skipped
+
+
+@pytest.mark.parametrize('use_wino', [True, False])
+def test_head_scatter_output(use_wino):
+    """Multibox head (models/RFB_Net_vgg.py:239-248): one fused loc|conf|obj conv writing channels-last into
+    three flattened buffers at a prior offset -- Winograd and direct kernels against permute/view/cat."""
+    g = torch.Generator().manual_seed(21)
+    B, Cin, H, Wd, A, Cc = 2, 32, 10, 9, 6, 7
+    x = torch.randn(B, Cin, H, Wd, generator=g)
+    ws = [torch.randn(A * n, Cin, 3, 3, generator=g) * 0.06 for n in (4, Cc, 2)]
+    bs = [torch.rand(A * n, generator=g) - 0.5 for n in (4, Cc, 2)]
+    be = engine.HipBackend('cuda:0')
+    parts = [engine.ConvPart(torch.nn.Parameter(w.cuda(), requires_grad=False),
+                             torch.nn.Parameter(b.cuda(), requires_grad=False), None, False) for w, b in zip(ws, bs)]
+    st = engine.ConvStep('h', parts, Cin, 3, 3, 1, 1, 1, 1, 'x', 0, H, Wd, None, 0)
+    pbase, P = 11, 11 + H * Wd * A + 5                       # priors before / after this source
+    st.segs = [engine.Segment('loc', 0, A * 4, A * 4, pbase * 4), engine.Segment('conf', A * 4, A * (4 + Cc), A * Cc, pbase * Cc),
+               engine.Segment('obj', A * (4 + Cc), A * (6 + Cc), A * 2, pbase * 2)]
+    bufs = {'x': x.cuda(), 'loc': torch.full((B, P * 4), float('nan'), device='cuda'),
+            'conf': torch.full((B, P * Cc), float('nan'), device='cuda'), 'obj': torch.full((B, P * 2), float('nan'), device='cuda')}
+    st.rt['config'] = W if use_wino else 0
+    be.prepare_conv(st, bufs, B)
+    assert bool(st.rt.get('wino')) == use_wino
+    be.run_conv(st)
+    torch.cuda.synchronize()
+    import torch.nn.functional as F
+    for name, w, b, n in zip(('loc', 'conf', 'obj'), ws, bs, (4, Cc, 2)):
+        want = F.conv2d(x, w, b, 1, 1).permute(0, 2, 3, 1).reshape(B, -1)
+        got = bufs[name].cpu()
+        lo, hi = pbase * n, pbase * n + H * Wd * A * n
+        assert rel_err(got[:, lo:hi], want) < TOL, name
+        assert torch.isnan(got[:, :lo]).all() and torch.isnan(got[:, hi:]).all(), name
