@@ -4,6 +4,8 @@
 // of a convolution is the `transposed` mode of ct_conv2d_fwd (ct_conv.hip).
 #include "ct_common.h"
 #include <algorithm>
+#include <mutex>
+#include <unordered_set>
 
 namespace {
 
@@ -18,7 +20,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 
 // ------------------------------------------------------------------------------------------
 // weight gradient:  dW[co][ci][kh][kw] = sum_{n,oh,ow} dZ[n][co][oh][ow] * X[n][ci][ih][iw]
-// GEMM  M = cout, N = cin*kh*kw, K = batch*oh*ow (pixels), fp32 MFMA 32x32x2, 64x64 tile,
+// GEMM  M = cout, N = cin*kh*kw, K = batch*oh*ow (pixels), fp32 MFMA 32x32x2, 128x128 (or 64x64) tile,
 // split over pixel ranges across workgroups (fp32 atomicAdd into a zeroed dW).
 // Lanes run along pixels (coalesced rows of dZ and of the shifted X), tiles are staged to LDS
 // transposed ([pixel][row], stride 65) so the MFMA fragments read conflict-free.
@@ -35,17 +37,19 @@ struct WgradArgs {
     int tiles_m, tiles_n, pix_per_split;
 };
 
-template <int KH, int KW>
+template <int KH, int KW, int TB>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
 {
+    // workgroup tile (64*TB couts) x (64*TB columns), each wave TB x TB accumulator blocks of 32x32
     constexpr int KHW = KH * KW;
-    constexpr int BM = 64, BN = 64, BKP = 64, LD = 65;
-    __shared__ float As[BKP * LD];
-    __shared__ float Bs[BKP * LD];
+    constexpr int BM = 64 * TB, BN = 64 * TB, BKP = 64, LD = BM + 1, ROWS = 16 * TB;
+    extern __shared__ float wg_lds[];
+    float* As = wg_lds;
+    float* Bs = wg_lds + BKP * LD;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave & 1) * 32, wn0 = (wave >> 1) * 32;
+    const int wm0 = (wave & 1) * 32 * TB, wn0 = (wave >> 1) * 32 * TB;
     const int tile = blockIdx.x;
     const int m0 = (tile % a.tiles_m) * BM;
     const int c0 = (tile / a.tiles_m) * BN;
@@ -58,9 +62,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
     const int HW = a.H * a.W;
 
     // wave-uniform row descriptors: A rows = cout m0 + wave + 4j, B rows = column c0 + wave + 4j
-    int a_soff[16], b_soff[16], b_dh[16], b_dw[16];
+    int a_soff[ROWS], b_soff[ROWS], b_dh[ROWS], b_dw[ROWS];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < ROWS; ++j) {
         const int m = m0 + wave + 4 * j;
         a_soff[j] = m < a.Cout ? m * a.OHW * 4 : -1;
         const int col = c0 + wave + 4 * j;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
         b_dw[j] = kw * a.dil - a.pad_w;
     }
 
-    float areg[16], breg[16];
+    float areg[ROWS], breg[ROWS];
     auto load_chunk = [&](int p0) {
         const int P = p0 + lane;
         const bool pv = P < p_end;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
         const int xbase = (n * a.x_ctot + a.x_coff) * HW;
         const int ih0 = oh * a.stride, iw0 = ow * a.stride;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < ROWS; ++j) {
             areg[j] = a_soff[j] >= 0
                           ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff, a_soff[j], 0))
                           : 0.f;
@@ -96,14 +100,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
         }
     };
 
-    f32x16 acc;
+    f32x16 acc[TB][TB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int i = 0; i < TB; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     load_chunk(p_begin);
     for (int p0 = p_begin; p0 < p_end; p0 += BKP) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
+        for (int j = 0; j < ROWS; ++j) {
             As[lane * LD + wave + 4 * j] = areg[j];
             Bs[lane * LD + wave + 4 * j] = breg[j];
         }
@@ -111,19 +119,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
         if (p0 + BKP < p_end) load_chunk(p0 + BKP);
         const float* Ab = As + hsel * LD + wm0 + l31;
         const float* Bb = Bs + hsel * LD + wn0 + l31;
+#pragma unroll 8
+        for (int s = 0; s < BKP / 2; ++s) {
+            float af[TB], bf[TB];
 #pragma unroll
-        for (int s = 0; s < BKP / 2; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[(2 * s) * LD], Bb[(2 * s) * LD], acc, 0, 0, 0);
+            for (int i = 0; i < TB; ++i) {
+                af[i] = Ab[(2 * s) * LD + 32 * i];
+                bf[i] = Bb[(2 * s) * LD + 32 * i];
+            }
+#pragma unroll
+            for (int i = 0; i < TB; ++i)
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
         __syncthreads();
     }
 
-    const int col = c0 + wn0 + l31;
-    if (col < a.Ncols) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-            if (m < a.Cout) atomicAdd(a.dw + (size_t)m * a.Ncols + col, acc[r]);
-        }
+    for (int j = 0; j < TB; ++j) {
+        const int col = c0 + wn0 + 32 * j + l31;
+        if (col >= a.Ncols) continue;
+#pragma unroll
+        for (int i = 0; i < TB; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                if (m < a.Cout) unsafeAtomicAdd(a.dw + (size_t)m * a.Ncols + col, acc[i][j][r]);
+            }
     }
 }
 
@@ -394,8 +417,13 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
     a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.dil = d->dil;
     a.Npix = d->batch * a.OHW;
     a.Ncols = d->cin * d->kh * d->kw;
-    a.tiles_m = (d->cout + 63) / 64;
-    a.tiles_n = (a.Ncols + 63) / 64;
+    // the 128x128 variant (TB = 2) measured slower on the RFBNet shapes (fewer pixel splits in flight, the
+    // 64 gathers per thread arrive in one burst); kept for experiments behind CTDET_WGRAD_TB=2
+    static const int tb_env = getenv("CTDET_WGRAD_TB") ? atoi(getenv("CTDET_WGRAD_TB")) : 1;
+    const int tb = (tb_env == 2 && d->cout >= 96 && a.Ncols >= 96) ? 2 : 1;
+    const int bt = 64 * tb;
+    a.tiles_m = (d->cout + bt - 1) / bt;
+    a.tiles_n = (a.Ncols + bt - 1) / bt;
     const int tiles = a.tiles_m * a.tiles_n;
     int splits = std::max(1, std::min((a.Npix + 255) / 256, (2048 + tiles - 1) / tiles));
     a.pix_per_split = ((a.Npix + splits - 1) / splits + 63) / 64 * 64;
@@ -403,12 +431,33 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
     hipStream_t st = ctdet::as_stream(stream);
     CT_HIP(hipMemsetAsync(dw, 0, (size_t)d->cout * a.Ncols * 4, st));
     const dim3 grid(tiles, splits), block(256);
-    if (d->kh == 3 && d->kw == 3) hipLaunchKernelGGL((conv_wgrad_f32<3, 3>), grid, block, 0, st, a);
-    else if (d->kh == 1 && d->kw == 1) hipLaunchKernelGGL((conv_wgrad_f32<1, 1>), grid, block, 0, st, a);
-    else if (d->kh == 1 && d->kw == 3) hipLaunchKernelGGL((conv_wgrad_f32<1, 3>), grid, block, 0, st, a);
-    else if (d->kh == 3 && d->kw == 1) hipLaunchKernelGGL((conv_wgrad_f32<3, 1>), grid, block, 0, st, a);
-    else if (d->kh == 4 && d->kw == 4) hipLaunchKernelGGL((conv_wgrad_f32<4, 4>), grid, block, 0, st, a);
+    const size_t smem = 2 * 64 * (size_t)(bt + 1) * 4;
+    hipError_t le = hipSuccess;
+    auto go = [&](auto kernel) {
+        if (smem > 64 * 1024) {
+            static std::mutex mu;
+            static std::unordered_set<const void*> done;
+            std::lock_guard<std::mutex> lk(mu);
+            if (!done.count((const void*)kernel)) {
+                le = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                done.insert((const void*)kernel);
+            }
+        }
+        if (le == hipSuccess) hipLaunchKernelGGL(kernel, grid, block, smem, st, a);
+    };
+#define CT_WGRAD_GO(KH, KW)                                   \
+    do {                                                      \
+        if (tb == 2) go(conv_wgrad_f32<KH, KW, 2>);           \
+        else go(conv_wgrad_f32<KH, KW, 1>);                   \
+    } while (0)
+    if (d->kh == 3 && d->kw == 3) CT_WGRAD_GO(3, 3);
+    else if (d->kh == 1 && d->kw == 1) CT_WGRAD_GO(1, 1);
+    else if (d->kh == 1 && d->kw == 3) CT_WGRAD_GO(1, 3);
+    else if (d->kh == 3 && d->kw == 1) CT_WGRAD_GO(3, 1);
+    else if (d->kh == 4 && d->kw == 4) CT_WGRAD_GO(4, 4);
     else return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wgrad: %dx%d filters not built", d->kh, d->kw);
+#undef CT_WGRAD_GO
+    CT_HIP(le);
     CT_LAUNCH_CHECK("conv_wgrad_f32");
     return CT_OK;
 }
