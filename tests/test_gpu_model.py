@@ -196,3 +196,36 @@ def test_large_batch_512_matches_small_batches():
                 assert rel_err(a[i0:i0 + 4].cpu(), b.cpu()) < 1e-5
     del net
     torch.cuda.empty_cache()
+
+
+def test_schedule_variants_agree(monkeypatch):
+    """The execution variants of the engine are pure scheduling / algebra choices: one stream vs the two-stream
+    schedule and fused vs separate MaxPool2d(2,2) give bit-identical outputs, Winograd vs direct convolution
+    agrees to the parity tolerance."""
+    x = synth.images(4, 300, 'randn', 77).cuda()
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        net = _net(300, 20)
+        out = [t.clone() for t in net.forward_raw(x)]
+        rt = net.runtime(4)
+        for k in env:
+            monkeypatch.delenv(k)
+        return out, rt
+
+    base, rt = run()
+    assert rt.side is not None and any(st.rt.get('wino') for st in rt.conv_steps())
+    assert any(getattr(st, 'fused_into', None) for st in rt.plan.steps)
+    one, rt1 = run(CTDET_STREAMS='1')
+    assert rt1.side is None
+    for a, b in zip(base, one):
+        assert torch.equal(a, b)
+    sep, rt2 = run(CTDET_FUSE_POOL='0')
+    assert not any(getattr(st, 'fused_into', None) for st in rt2.plan.steps)
+    for a, b in zip(base, sep):
+        assert torch.equal(a, b)
+    direct, rt3 = run(CTDET_WINO='0', CTDET_TUNE='0')
+    assert not any(st.rt.get('wino') for st in rt3.conv_steps())
+    for a, b in zip(base, direct):
+        assert rel_err(a.cpu(), b.cpu()) < TOL
