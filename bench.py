@@ -147,8 +147,11 @@ def conv_roofline(rt, batch, workload):
                      'frac': round(tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                      'mfma_pipe_frac': round(tot_x / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                      'time_share_of_dominant': round(t / tot_t, 3),
-                     'conv_ms_per_step': round(tot_t / max(1, len(rt.event_log)) * len(rt.conv_steps()) * 1e3, 3),
-                     'launches_per_step': len(rt.conv_steps())},
+                     # sum of the launch durations; with the two-stream schedule launches overlap, so this
+                     # can exceed the wall time of a step (and every duration includes the contention)
+                     'sum_launch_ms_per_step': round(tot_t / max(1, len(rt.event_log)) * len(rt.conv_steps()) * 1e3, 3),
+                     'launches_per_step': len(rt.conv_steps()),
+                     'streams': 2 if getattr(rt, 'side', None) is not None else 1},
     }
 
 
