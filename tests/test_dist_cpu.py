@@ -102,3 +102,61 @@ def test_grad_bucketer_two_ranks():
         assert res[rank][3] == 12                                # (10 + 14) / 2
         for a, b in zip(res[rank][1], want):
             assert np.allclose(a, b.numpy(), atol=1e-6)
+
+
+class _FakeNet:
+    """Stands in for RFBNet in the 2-rank init_reweight test: returns prepared conf tensors for init=True."""
+
+    def __init__(self, confs, C, T):
+        self.confs, self.i = confs, 0
+        self.OBJ_Target = torch.nn.Linear(C, T, bias=False)
+
+    def _device(self):
+        return torch.device('cpu')
+
+    def __call__(self, x, init=False):
+        assert init
+        self.i += 1
+        return self.confs[self.i - 1]
+
+
+def _reweight_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    cdist.init('gloo')
+    from ctdet import ops, reweight
+    g = torch.Generator().manual_seed(5)
+    P, C, ncls = 50, 12, 7
+    confs = [torch.randn(2, P, C, generator=g) for _ in range(4)]
+    labels = [torch.randint(0, ncls, (2, P), generator=g).float() for _ in range(4)]
+    mine = list(range(rank, 4, world))                     # each rank sees its own batches
+    it = iter([labels[i] for i in mine])
+    real = ops.match_batched
+    ops.match_batched = lambda *a, **k: (None, torch.stack([next(it), torch.ones(2, P)], 2), None)   # no HIP here
+    try:
+        net = _FakeNet([confs[i] for i in mine], C, ncls - 1)
+        batches = [(torch.zeros(2, 3, 4, 4), [torch.zeros(1, 6)] * 2) for _ in mine]
+        w = reweight.init_reweight(net, torch.zeros(P, 4), batches, ncls)
+    finally:
+        ops.match_batched = real
+    s = c = 0
+    for cf, lb in zip(confs, labels):                      # single-process answer over ALL batches
+        a, b = reweight.class_feature_sums(cf, lb, ncls)
+        s, c = s + a, c + b
+    want = reweight.weights_from_sums(s, c)
+    q.put((rank, float((w - want).abs().max())))
+    torch.distributed.destroy_process_group()
+
+
+def test_init_reweight_reduces_over_ranks():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_reweight_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(err < 1e-6 for _, err in res), res

@@ -199,3 +199,31 @@ def test_phase2_training_step_vs_oracle_autograd(setting):
         if cos < 0.99 or abs(na / nb - 1) > 0.08:
             bad[name] = (cos, na / nb)
     assert not bad, sorted(bad.items())[:12]
+
+
+def test_init_reweight_on_device_vs_oracle():
+    """train.py:252-286 through the product: model(x, init=True) + ct_match_batched + class means."""
+    from layers.functions import PriorBox
+    from data import VOC_300
+    from ctdet import reweight
+    from oracle import reweight_ref
+    net = _net(300, 60, 'transfer').eval()
+    priors = PriorBox(VOC_300).forward()
+    batches = []
+    for it in range(2):
+        x = synth.images(2, 300, 'randn', 50 + it)
+        tg = []
+        for b in range(2):
+            t = synth.targets(1, 21, 400 + 10 * it + b)[0]
+            t[:, 4] = (torch.arange(t.shape[0]) + 5 * (2 * it + b)) % 20 + 1
+            tg.append(t)
+        batches.append((x, tg))
+    with torch.no_grad():
+        confs = [net(x.cuda(), init=True).cpu() for x, _ in batches]
+    want = reweight_ref.init_reweight(confs, [t for _, t in batches], priors, 21, 0.5, 'transfer')
+    got = reweight.init_reweight(net, priors, batches, 21, 0.5, 'transfer').cpu()
+    assert got.shape == want.shape == (20, 60)
+    seen = ~torch.isnan(want[:, 0])
+    assert seen.sum() >= 10 and torch.equal(torch.isnan(got[:, 0]), ~seen)       # unseen classes: NaN like the reference
+    assert rel_err(got[seen], want[seen]) < 1e-5
+    assert torch.equal(net.OBJ_Target.weight.data.cpu()[seen], got[seen])

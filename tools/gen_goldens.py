@@ -432,8 +432,42 @@ def gen_solver():
     save('solver.npz', st)
 
 
+# ---------------------------------------------------------------------------
+def gen_reweight():
+    """train.py:252-286 (`init_reweight`) cannot be imported (argparse + cv2 at module import); its body is
+    torch glue around the reference's `match`, replayed here line by line on the reference's own functions."""
+    st = {}
+    priors = PriorBox(refcfg.VOC_300).forward()
+    P = priors.shape[0]
+    for tag, (ncls, C, setting) in {'transfer': (21, 60, 'transfer'), 'incre': (21, 15, 'incre')}.items():
+        g = torch.Generator().manual_seed(31 if setting == 'transfer' else 32)
+        cls_list = [torch.empty(0) for _ in range(ncls - 1)]
+        for it in range(2):
+            num = 3
+            conf_data = torch.randn(num, P, C, generator=g)
+            targets = []
+            for b in range(num):
+                G = 7
+                xy = torch.rand(G, 2, generator=g) * 0.5
+                wh = torch.rand(G, 2, generator=g) * 0.4 + 0.1
+                lab = ((torch.arange(G) + 7 * (it * num + b)) % (ncls - 1) + 1).float()[:, None]
+                targets.append(torch.cat([xy, xy + wh, lab, torch.ones(G, 1)], 1))
+            st['%s_targets_%d' % (tag, it)] = torch.stack(targets).numpy()
+            loc_t = torch.Tensor(num, P, 4); conf_t = torch.Tensor(num, P, 2); obj_t = torch.BoolTensor(num, P)
+            for idx in range(num):
+                rbu.match(0.5, targets[idx][:, :-2], priors, [0.1, 0.2], targets[idx][:, -2:], loc_t, conf_t, obj_t, idx)
+            lists = [conf_data[conf_t[:, :, 0] == i] for i in range(1, ncls)]
+            cls_list = [torch.cat((cls_list[i], lists[i]), 0) for i in range(ncls - 1)]
+        st[tag + '_counts'] = np.array([len(c) for c in cls_list])
+        cls_list = [(item / item.norm(dim=1, keepdim=True)).mean(0) for item in cls_list]
+        if setting == 'incre':
+            cls_list = cls_list[15:]
+        st[tag + '_weight'] = torch.stack([item / item.norm() for item in cls_list], 0).numpy()
+    save('reweight.npz', st)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['box', 'nms', 'model', 'loss', 'pipeline', 'voc', 'solver']
+    which = sys.argv[1:] or ['box', 'nms', 'model', 'loss', 'pipeline', 'voc', 'solver', 'reweight']
     if 'box' in which:
         gen_box_ops()
     if 'nms' in which:
@@ -448,3 +482,5 @@ if __name__ == '__main__':
         gen_voc_eval()
     if 'solver' in which:
         gen_solver()
+    if 'reweight' in which:
+        gen_reweight()
