@@ -38,3 +38,27 @@ pipe.post.run(pipe.boxes, pipe.scores, max_per_image=0)
 print('kept per (img,cls) before top-k: mean %.0f max %d' % (pipe.post.out_count.float().mean().item(), int(pipe.post.out_count.max().item())))
 loc, conf, obj = net.forward_raw(x)
 print('detect_fused: %.3f ms' % t(lambda: ops.detect_fused(loc, conf.contiguous(), obj, pipe.priors, (0.1, 0.2), True, pipe.scale, out=(pipe.boxes, pipe.scores))))
+
+# ---- SURVEY 8(d) regimes on synthetic detections (no model): R1 "all-pass" = every prior of every class is a
+# candidate (640 problems of N = P); R2 "trained-like" = 50..400 clustered boxes per (image, class), tie-free scores
+P, T = pipe.P, 20
+g = torch.Generator().manual_seed(4321)
+pri = pipe.priors.cpu()
+boxes = torch.cat([pri[:, :2] - pri[:, 2:] / 2, pri[:, :2] + pri[:, 2:] / 2], 1).clamp(0, 1)
+boxes = (boxes[None].repeat(B, 1, 1) * torch.tensor([500., 375., 500., 375.])).contiguous().cuda()
+scores = torch.zeros(B, P, T + 1)
+scores[:, :, 1:] = 0.011 + 0.97 * torch.rand(B, P, T, generator=g)
+scores = scores.cuda()
+for topk in (200, 0):
+    ms = t(lambda: pipe.post.run(boxes, scores, max_per_image=topk), 5)
+    print('R1 all-pass (N = P = %d per class, %d problems), max_per_image=%d: %.2f ms' % (P, B * T, topk, ms))
+scores2 = torch.zeros(B, P, T + 1)
+for b in range(B):
+    for c in range(T):
+        n = int(torch.randint(50, 401, (1,), generator=g))
+        idx = torch.randperm(P, generator=g)[:n]
+        scores2[b, idx, 1 + c] = torch.linspace(0.011, 0.99, n)[torch.randperm(n, generator=g)]
+scores2 = scores2.cuda()
+for topk in (200, 0):
+    ms = t(lambda: pipe.post.run(boxes, scores2, max_per_image=topk), 10)
+    print('R2 trained-like (50..400 per class), max_per_image=%d: %.3f ms' % (topk, ms))
