@@ -125,6 +125,11 @@ def lib():
             raise CtdetError(
                 'libctdet.so not found at %s -- build it with `python context-transformer_amd/build.py` '
                 '(the HIP library is the product; there is no fallback path)' % LIB_PATH)
+        # The host glue hands torch's device pointers and streams to the library, so both must sit on ONE HIP
+        # runtime: PyTorch-ROCm ships its own libamdhip64; importing torch first makes the dynamic loader resolve
+        # libctdet's dependency to that copy instead of a second runtime from /opt/rocm (which would know no device
+        # context of torch's allocations: "no ROCm-capable device is detected" on the first launch).
+        import torch  # noqa: F401
         try:
             handle = C.CDLL(LIB_PATH)
         except OSError as e:
