@@ -614,7 +614,17 @@ class Runtime:
         steps = self.plan.steps
         if os.environ.get('CTDET_STREAMS', '2') == '1' or self.backend.device.type != 'cuda':
             return
-        sid = [1 if (st.name.startswith(('Norm.', 'head.')) or st.kind == 'ctxpool') else 0 for st in steps]
+        nstreams = int(os.environ.get('CTDET_STREAMS', '2'))
+
+        def stream_of(st):
+            side = st.name.startswith(('Norm.', 'head.')) or st.kind == 'ctxpool'
+            sid = 1 if side else 0
+            if nstreams > 2:                     # the independent branches of an RFB block on their own streams
+                for b, tag in enumerate(('.b1.', '.b2.', '.b3.')):
+                    if tag in st.name:
+                        sid = 2 + (3 if side else 0) + b
+            return sid
+        sid = [stream_of(st) for st in steps]
         if not any(sid):
             return
 
@@ -641,7 +651,8 @@ class Runtime:
             for b in writes(st):
                 writers.setdefault(b, []).append(i)
         self.sid = sid
-        self.side = torch.cuda.Stream(self.backend.device)
+        self.sides = [torch.cuda.Stream(self.backend.device) for _ in range(max(sid))]
+        self.side = self.sides[0]
         self.ev = {j: torch.cuda.Event() for j in self.signal}
 
     def autotune(self, steps=None):
@@ -692,8 +703,9 @@ class Runtime:
                 self._run_step(st)
             return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
         main = torch.cuda.current_stream(self.backend.device)
-        self.side.wait_stream(main)
-        streams = (main, self.side)
+        for sd in self.sides:
+            sd.wait_stream(main)
+        streams = [main] + self.sides
         steps = self.plan.steps
         i, n = 0, len(steps)
         while i < n:
@@ -706,7 +718,8 @@ class Runtime:
                     if i in self.signal:
                         self.ev[i].record(streams[k])
                     i += 1
-        main.wait_stream(self.side)
+        for sd in self.sides:
+            main.wait_stream(sd)
         return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
 
     def conv_steps(self):
