@@ -229,3 +229,36 @@ def test_schedule_variants_agree(monkeypatch):
     assert not any(st.rt.get('wino') for st in rt3.conv_steps())
     for a, b in zip(base, direct):
         assert rel_err(a.cpu(), b.cpu()) < TOL
+
+
+def test_full_size_pipeline_properties():
+    """BASELINE configs[1] at full size (RFBNet-300, bs 32, 20 classes): properties that do not need the oracle
+    at that size -- batch-position invariance (exact), descending scores, the top-200 rule, NMS idempotence."""
+    from layers.functions import PriorBox
+    from data import VOC_300
+    from utils.nms_wrapper import nms
+    net = _net(300, 20)
+    priors = PriorBox(VOC_300).forward()
+    pipe = DetectionPipeline(net, priors, 32, 20)
+    x = synth.images(32, 300, 'randn', 2024).cuda()
+    pipe.run(x)
+    base = pipe.results()
+    perm = torch.randperm(32, generator=torch.Generator().manual_seed(3))
+    pipe.run(x[perm.cuda()].contiguous())
+    shuffled = pipe.results()
+    for new_pos, old_pos in enumerate(perm.tolist()):
+        for j in range(1, 21):
+            assert np.array_equal(shuffled[new_pos][j], base[old_pos][j]), (new_pos, old_pos, j)
+    total = 0
+    for i in range(32):
+        sc = np.concatenate([base[i][j][:, 4] for j in range(1, 21)])
+        total += len(sc)
+        assert len(sc) > 0 and np.isfinite(np.concatenate([base[i][j] for j in range(1, 21)])).all()
+        if len(sc) > 200:
+            assert np.sum(sc > sc.min()) < 200                 # only ties at the 200-th score may exceed it
+        for j in range(1, 21):
+            d = base[i][j]
+            assert np.all(np.diff(d[:, 4]) <= 0)
+            if len(d) > 1 and i % 8 == 0:                        # kept boxes do not suppress each other
+                assert list(nms(d, 0.45)) == list(range(len(d)))
+    assert total >= 32 * 150
