@@ -74,7 +74,12 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
     // ---- patch-loader role: tile = l31 + 32*(wave&1), channel-in-chunk = 2*(wave>>1) + h
     const int tile_l = l31 + 32 * (wave & 1);
     const int s_l = wave >> 1;
-    int voff[16];
+    // One 16-byte buffer load per patch row (4 consecutive pixels from x0 = 2tx-1; dword aligned).  Rows outside
+    // the image use the out-of-range offset (-> zeros).  The left padding column (tx == 0, x0 = -1) is handled by
+    // loading from x = 0 and shifting the unpack by one; the columns right of the image are masked after the load.
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    int voffr[4];
+    bool lp, m2, m3;
     {
         const int T = tb0 + tile_l;
         const bool live = T < a.NT;
@@ -82,14 +87,15 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
         const int rem = T - n * (a.TY * a.TX);
         const int ty = rem / a.TX, tx = rem - ty * a.TX;
         const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-        const long base = (((long)n * a.in_ctot + a.in_coff + h) * a.H + y0) * (long)a.W + x0;
+        lp = tx == 0;
+        m2 = x0 + 2 < a.W;
+        m3 = x0 + 3 < a.W;
+        const long base = (((long)n * a.in_ctot + a.in_coff + h) * a.H + y0) * (long)a.W + x0 + (lp ? 1 : 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H && (unsigned)(x0 + j) < (unsigned)a.W;
-                voff[i * 4 + j] = ok ? (int)((base + (long)i * a.W + j) * 4) : kInvalidOff;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
+            voffr[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
+        }
     }
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
     const float4* Ub = reinterpret_cast<const float4*>(a.U + (size_t)kb * a.chunks * CHUNK_FLOATS);
@@ -110,16 +116,30 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
         }
     };
-    auto load_patch = [&](int c, float (&d)[16]) {
+    auto load_patch = [&](int c, i32x4 (&r)[4]) {
         const int soff = (c * CC + 2 * s_l) * HW * 4;            // wave-uniform channel offset (bytes)
 #pragma unroll
-        for (int e = 0; e < 16; ++e)
-            d[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[e], soff, 0));
+        for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[i], soff, 0);
+    };
+    auto unpack = [&](const i32x4 (&r)[4], float (&d)[16]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            // Reinterpret the WHOLE vector before taking components: on this toolchain
+            // bit_cast<float>(int_vector.y) compiles to component 0 for every lane of the vector.
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const f32x4 q = __builtin_bit_cast(f32x4, r[i]);
+            const float vx = q.x, vy = q.y, vz = q.z, vw = q.w;
+            d[i * 4 + 0] = lp ? 0.f : vx;
+            d[i * 4 + 1] = lp ? vx : vy;
+            d[i * 4 + 2] = m2 ? (lp ? vy : vz) : 0.f;
+            d[i * 4 + 3] = m3 ? (lp ? vz : vw) : 0.f;
+        }
     };
     // V = B^T d B  ->  V[xi][s][tile][h]
-    auto store_v = [&](int buf, const float (&d)[16]) {
+    auto store_v = [&](int buf, const i32x4 (&r)[4]) {
         float* Vl = Vlds + buf * CHUNK_FLOATS;
-        float t[16];
+        float d[16], t[16];
+        unpack(r, d);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
@@ -174,27 +194,27 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
     //   issue U(c+2) -> ring slot (c+2)%3, patch(c+2) -> registers
     //   remaining MFMAs of chunk c, then lgkmcnt(0) + barrier: no memory latency on the critical path.
     // Loads past the last chunk are clamped to it (redundant, never consumed).
-    float dA[16], dB[16];
+    i32x4 dA[4], dB[4];
     const int last = a.chunks - 1;
     copy_u(0, 0);
     load_patch(0, dA);
     copy_u(min(1, last), 1);
     load_patch(min(1, last), dB);
-    asm volatile("s_waitcnt vmcnt(20)" ::: "memory");          // U(0), patch(0) landed
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // U(0), patch(0) landed
     store_v(0, dA);
     __builtin_amdgcn_sched_barrier(0);
     load_patch(min(2, last), dA);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // Iteration c: `d` holds patch(c+1) and is refilled with patch(c+3) right after its transform.  Memory
-    // operations complete in issue order; at the wait the youngest 20 are [patch(c+2) x16 | U(c+2) x4], so
-    // vmcnt(20) retires exactly patch(c+1) and U(c+1) and leaves a full iteration of loads in flight.
+    // Iteration c: `rw` holds patch(c+1) and is refilled with patch(c+3) right after its transform.  Memory
+    // operations complete in issue order; at the wait the youngest 8 are [patch(c+2) x4 | U(c+2) x4], so
+    // vmcnt(8) retires exactly patch(c+1) and U(c+1) and leaves a full iteration of loads in flight.
     // Vector-memory instructions are spread one per MFMA: eight waves pushing 20 loads back to back would
     // fill the address-unit queue and stall the (in-order) waves in front of their MFMAs.
 #define WINO_MFMA(x, i, j, av, bv) acc[x][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x][i][j], 0, 0, 0)
 #define WINO_PIN() __builtin_amdgcn_sched_barrier(0)
-    auto body = [&](int c, int slot, float (&d)[16]) {
+    auto body = [&](int c, int slot, i32x4 (&rw)[4]) {
         const int buf = c & 1;
         const int slot2 = slot >= 1 ? slot - 1 : 2;             // (c+2) % 3
         const int cu = min(c + 2, last), cp = min(c + 3, last);
@@ -215,9 +235,10 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
 #undef WINO_GLDS
         }
         WINO_PIN();
-        asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         // x = 0, s = 1: the transform of patch(c+1) in four slices behind the MFMAs
-        float t[16], v[16];
+        float d[16], t[16], v[16];
+        unpack(rw, d);
         WINO_MFMA(0, 0, 0, f0.a0[1], f0.b0[1]);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -257,27 +278,22 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
         read_frag(slot, buf, 1, f1);
         float* vp = Vlds + (buf ^ 1) * CHUNK_FLOATS + s_l * 128 + tile_l * 2 + h;
 #define WINO_VST(e) vp[(e) * XI_STRIDE] = v[e]
-#define WINO_LD(e) d[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, voff[e], soff, 0))
+#define WINO_LD(i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[i], soff, 0)
         // x = 0, s = 2, 3: LDS stores of V, then the first patch loads
         WINO_MFMA(0, 0, 0, f0.a0[2], f0.b0[2]); WINO_VST(0); WINO_VST(1); WINO_VST(2); WINO_VST(3); WINO_PIN();
         WINO_MFMA(0, 0, 1, f0.a0[2], f0.b1[2]); WINO_VST(4); WINO_VST(5); WINO_VST(6); WINO_VST(7); WINO_PIN();
         WINO_MFMA(0, 1, 0, f0.a1[2], f0.b0[2]); WINO_VST(8); WINO_VST(9); WINO_VST(10); WINO_VST(11); WINO_PIN();
         WINO_MFMA(0, 1, 1, f0.a1[2], f0.b1[2]); WINO_VST(12); WINO_VST(13); WINO_VST(14); WINO_VST(15); WINO_PIN();
         WINO_MFMA(0, 0, 0, f0.a0[3], f0.b0[3]); WINO_LD(0); WINO_PIN();
-        WINO_MFMA(0, 0, 1, f0.a0[3], f0.b1[3]); WINO_LD(1); WINO_PIN();
-        WINO_MFMA(0, 1, 0, f0.a1[3], f0.b0[3]); WINO_LD(2); WINO_PIN();
-        WINO_MFMA(0, 1, 1, f0.a1[3], f0.b1[3]); WINO_LD(3); WINO_PIN();
-        // x = 1: one patch load behind each of the first twelve MFMAs
-#define WINO_X1(s, e0)                                                                     \
-        WINO_MFMA(1, 0, 0, f1.a0[s], f1.b0[s]); WINO_LD(e0); WINO_PIN();                   \
-        WINO_MFMA(1, 0, 1, f1.a0[s], f1.b1[s]); WINO_LD(e0 + 1); WINO_PIN();               \
-        WINO_MFMA(1, 1, 0, f1.a1[s], f1.b0[s]); WINO_LD(e0 + 2); WINO_PIN();               \
-        WINO_MFMA(1, 1, 1, f1.a1[s], f1.b1[s]); WINO_LD(e0 + 3); WINO_PIN();
-        WINO_X1(0, 4)
-        WINO_X1(1, 8)
-        WINO_X1(2, 12)
-#undef WINO_X1
-        mfma_frag(1, f1, 3, 4);
+        WINO_MFMA(0, 0, 1, f0.a0[3], f0.b1[3]); WINO_PIN();
+        WINO_MFMA(0, 1, 0, f0.a1[3], f0.b0[3]); WINO_LD(1); WINO_PIN();
+        WINO_MFMA(0, 1, 1, f0.a1[3], f0.b1[3]); WINO_PIN();
+        // x = 1: the last two row loads behind the first MFMAs
+        WINO_MFMA(1, 0, 0, f1.a0[0], f1.b0[0]); WINO_LD(2); WINO_PIN();
+        WINO_MFMA(1, 0, 1, f1.a0[0], f1.b1[0]); WINO_PIN();
+        WINO_MFMA(1, 1, 0, f1.a1[0], f1.b0[0]); WINO_LD(3); WINO_PIN();
+        WINO_MFMA(1, 1, 1, f1.a1[0], f1.b1[0]); WINO_PIN();
+        mfma_frag(1, f1, 1, 4);
 #undef WINO_VST
 #undef WINO_LD
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
