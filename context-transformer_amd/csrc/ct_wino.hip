@@ -7,22 +7,22 @@
 //
 // One fused kernel, nothing transformed ever touches HBM except the pre-transformed weights U:
 //   workgroup (512 threads, 8 waves) = 64 output tiles x 64 output channels, loops over 8-channel chunks
-//     * every thread loads ONE 4x4 patch (tile, channel) with 16 bounds-checked buffer loads
-//       (zero padding = out-of-range offset), applies B^T d B in registers and writes the 16
+//     * every thread loads ONE 4x4 patch (tile, channel) with four 16-byte buffer loads (one per row; rows
+//       outside the image = out-of-range offset -> zeros), applies B^T d B in registers and writes the 16
 //       transform-domain values V[xi][c][tile] to LDS;
-//     * the chunk's U[xi][c][k] block (32 KB, packed contiguously by ct_conv_pack_weights_wino)
-//       is copied global -> LDS with float4 loads;
 //     * wave w owns transform points xi = 2w, 2w+1 and runs, per xi, the [64 k] x [64 tiles] x [8 c]
-//       GEMM as v_mfma_f32_32x32x2_f32 (A = U, B = V, both [c-pair][row][2] so that a fragment is one
-//       conflict-free ds_read_b32);  accumulators: 2 xi x 2x2 blocks x 16 = 128 registers;
-//     * double-buffered LDS (2 x 64 KB), one barrier per chunk;
+//       GEMM as v_mfma_f32_32x32x2_f32.  Its A fragments (U) never pass through LDS: ct_conv_pack_weights_wino
+//       stores, per (cout block, chunk, wave, lane), exactly the 16 floats that lane feeds to its MFMAs, so a
+//       chunk is four coalesced 16-byte loads per lane into registers (double buffered).  B fragments (V) are
+//       [c-pair][tile][2] in LDS: one conflict-free ds_read_b32 each.  Accumulators: 2 xi x 2x2 blocks x 16 = 128;
+//     * V double-buffered in LDS (2 x 32 KB), ONE barrier per chunk, every vector-memory instruction issued
+//       behind an MFMA (never back to back);
 //   after the channel loop the accumulators go through LDS once (two passes of 32 tiles),
 //   each thread applies A^T M A for a (channel, tile) pair and the usual epilogue
-//   (*scale + shift, residual, ReLU / per-channel floor) and stores the 2x2 outputs to NCHW.
+//   (*scale + shift, residual, ReLU / per-channel floor, optional fused 2x2 max-pool, NCHW or head scatter).
 #include "ct_common.h"
 #include <algorithm>
 #include <mutex>
-#pragma clang diagnostic ignored "-Winline-asm"
 
 namespace {
 
@@ -34,11 +34,11 @@ constexpr int TB = 64;                      // tiles per workgroup
 constexpr int KB = 64;                      // output channels per workgroup
 constexpr int XI_STRIDE = (CC / 2) * 64 * 2;          // 512 floats: [s][row 64][h 2]
 constexpr int CHUNK_FLOATS = 16 * XI_STRIDE;          // 8192 floats = 32 KB (U or V of one chunk)
-constexpr int WINO_LDS_BYTES = 5 * CHUNK_FLOATS * 4;       // 160 KB: U x3 (ring) + V x2
+constexpr int WINO_LDS_BYTES = 16 * 64 * 40 * 4;           // 160 KB: output staging M[16][64][40] (the main loop uses 64 KB)
 
 struct WinoArgs {
     const float* in;
-    const float* U;          // [kblocks][chunks][16][4][64][2]
+    const float* U;          // [kblocks][chunks][wave 8][piece 4][lane 64][4]
     const float* scale;
     const float* shift;
     const float* res;
@@ -98,24 +98,8 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
         }
     }
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
-    const float4* Ub = reinterpret_cast<const float4*>(a.U + (size_t)kb * a.chunks * CHUNK_FLOATS);
 
-    typedef __attribute__((address_space(3))) void lvoid;
-    // LDS: U ring of 3 chunk blocks at [0, 3*CHUNK), V double buffer at [3*CHUNK, 5*CHUNK)
-    float* const Ulds = lds;
-    float* const Vlds = lds + 3 * CHUNK_FLOATS;
-    // U chunk: global -> LDS directly (wave-uniform LDS base in M0 + lane*16 B, linear copy).  Issued
-    // through inline asm: the compiler would otherwise order every later LDS access behind the copy with a
-    // vmcnt(0); here the ring-slot protocol below guarantees there is no overlap and the waits are explicit.
-    const unsigned lds_u0 = (unsigned)(size_t)(lvoid*)Ulds;
-    auto copy_u = [&](int c, int slot) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float4* src = Ub + (size_t)c * (CHUNK_FLOATS / 4) + tid + 512 * i;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(lds_u0 + (slot * CHUNK_FLOATS + (wave * 64 + 512 * i) * 4) * 4);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(dst) : "memory", "m0");
-        }
-    };
+    float* const Vlds = lds;                 // V double buffer only: the weights stay in registers
     auto load_patch = [&](int c, i32x4 (&r)[4]) {
         const int soff = (c * CC + 2 * s_l) * HW * 4;            // wave-uniform channel offset (bytes)
 #pragma unroll
@@ -167,79 +151,57 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][i][j][r] = 0.f;
 
-    struct Frag { float a0[4], a1[4], b0[4], b1[4]; };
-    auto read_frag = [&](int slot, int buf, int x, Frag& f) {
-        const float* Ul = Ulds + slot * CHUNK_FLOATS + (2 * wave + x) * XI_STRIDE + l31 * 2 + h;
+#define WINO_MFMA(XI, II, JJ, av, bv) acc[XI][II][JJ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[XI][II][JJ], 0, 0, 0)
+#define WINO_PIN() __builtin_amdgcn_sched_barrier(0)
+    // ---- weights in registers.  The A fragments a wave needs for a chunk are 16 floats per lane, stored by
+    // ct_conv_pack_weights_wino in exactly that order: four coalesced 16-byte loads per lane and chunk, no LDS
+    // copy, no LDS reads for A.  Per iteration c:   MFMAs of chunk c  |  U(c+1) -> the other register set  |
+    // transform patch(c+1) -> V buffer (c+1)&1  |  patch(c+2) -> registers  |  barrier
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const f32x4* Ug = reinterpret_cast<const f32x4*>(a.U + (size_t)kb * a.chunks * CHUNK_FLOATS) + wave * 256 + lane;
+    auto load_u = [&](int c, f32x4 (&u)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) u[i] = Ug[(size_t)c * (CHUNK_FLOATS / 4) + 64 * i];
+    };
+    struct FragB { float b0[4], b1[4]; };
+    auto read_b = [&](int buf, int x, FragB& f) {
         const float* Vl = Vlds + buf * CHUNK_FLOATS + (2 * wave + x) * XI_STRIDE + l31 * 2 + h;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            f.a0[s] = Ul[s * 128]; f.a1[s] = Ul[s * 128 + 64];
-            f.b0[s] = Vl[s * 128]; f.b1[s] = Vl[s * 128 + 64];
-        }
+        for (int s = 0; s < 4; ++s) { f.b0[s] = Vl[s * 128]; f.b1[s] = Vl[s * 128 + 64]; }
     };
-    auto mfma_frag = [&](int x, const Frag& f, int s0, int s1) {
-#pragma unroll
-        for (int s = s0; s < s1; ++s) {
-            acc[x][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[s], f.b0[s], acc[x][0][0], 0, 0, 0);
-            acc[x][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a0[s], f.b1[s], acc[x][0][1], 0, 0, 0);
-            acc[x][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[s], f.b0[s], acc[x][1][0], 0, 0, 0);
-            acc[x][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a1[s], f.b1[s], acc[x][1][1], 0, 0, 0);
-        }
-    };
-
-    // Software pipeline (3 chunks deep for U, 2 for the patches).  Iteration c:
-    //   MFMAs of chunk c (first quarter)            <- fragments read from U slot c%3, V buffer c&1
-    //   transform patch(c+1) -> V buffer (c+1)&1     <- its loads were issued one iteration ago; the
-    //                                                   compiler's wait here also retires U(c+1)
-    //   issue U(c+2) -> ring slot (c+2)%3, patch(c+2) -> registers
-    //   remaining MFMAs of chunk c, then lgkmcnt(0) + barrier: no memory latency on the critical path.
-    // Loads past the last chunk are clamped to it (redundant, never consumed).
-    i32x4 dA[4], dB[4];
+    // A fragments of (x, s): u[2x + (s>>1)] components ((s&1)*2, (s&1)*2 + 1)
+#define WINO_A0(UU, XX, SS) ((SS) & 1 ? UU[2 * (XX) + ((SS) >> 1)].z : UU[2 * (XX) + ((SS) >> 1)].x)
+#define WINO_A1(UU, XX, SS) ((SS) & 1 ? UU[2 * (XX) + ((SS) >> 1)].w : UU[2 * (XX) + ((SS) >> 1)].y)
+#define WINO_4(UU, FF, XX, SS)                                        \
+    WINO_MFMA(XX, 0, 0, WINO_A0(UU, XX, SS), FF.b0[SS]);              \
+    WINO_MFMA(XX, 0, 1, WINO_A0(UU, XX, SS), FF.b1[SS]);              \
+    WINO_MFMA(XX, 1, 0, WINO_A1(UU, XX, SS), FF.b0[SS]);              \
+    WINO_MFMA(XX, 1, 1, WINO_A1(UU, XX, SS), FF.b1[SS])
+    i32x4 rw[4];
+    f32x4 uA[4], uB[4];
     const int last = a.chunks - 1;
-    copy_u(0, 0);
-    load_patch(0, dA);
-    copy_u(min(1, last), 1);
-    load_patch(min(1, last), dB);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");           // U(0), patch(0) landed
-    store_v(0, dA);
-    __builtin_amdgcn_sched_barrier(0);
-    load_patch(min(2, last), dA);
+    load_u(0, uA);
+    load_patch(0, rw);
+    store_v(0, rw);
+    load_patch(min(1, last), rw);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    // Iteration c: `rw` holds patch(c+1) and is refilled with patch(c+3) right after its transform.  Memory
-    // operations complete in issue order; at the wait the youngest 8 are [patch(c+2) x4 | U(c+2) x4], so
-    // vmcnt(8) retires exactly patch(c+1) and U(c+1) and leaves a full iteration of loads in flight.
-    // Vector-memory instructions are spread one per MFMA: eight waves pushing 20 loads back to back would
-    // fill the address-unit queue and stall the (in-order) waves in front of their MFMAs.
-#define WINO_MFMA(x, i, j, av, bv) acc[x][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[x][i][j], 0, 0, 0)
-#define WINO_PIN() __builtin_amdgcn_sched_barrier(0)
-    auto body = [&](int c, int slot, i32x4 (&rw)[4]) {
+    auto body = [&](int c, const f32x4 (&ucur)[4], f32x4 (&unxt)[4]) {
         const int buf = c & 1;
-        const int slot2 = slot >= 1 ? slot - 1 : 2;             // (c+2) % 3
-        const int cu = min(c + 2, last), cp = min(c + 3, last);
+        const int cn = min(c + 1, last), cp = min(c + 2, last);
         const int soff = (cp * CC + 2 * s_l) * HW * 4;
-        Frag f0, f1;
-        read_frag(slot, buf, 0, f0);
-        // s = 0: one U-copy instruction behind each MFMA
-        {
-            const float4* src = Ub + (size_t)cu * (CHUNK_FLOATS / 4) + tid;
-            const unsigned dst0 = lds_u0 + (slot2 * CHUNK_FLOATS + wave * 256) * 4;
-#define WINO_GLDS(i)                                                                                          \
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src + 512 * (i)),   \
-                 "s"(__builtin_amdgcn_readfirstlane(dst0 + 512 * 16 * (i))) : "memory", "m0")
-            WINO_MFMA(0, 0, 0, f0.a0[0], f0.b0[0]); WINO_GLDS(0); WINO_PIN();
-            WINO_MFMA(0, 0, 1, f0.a0[0], f0.b1[0]); WINO_GLDS(1); WINO_PIN();
-            WINO_MFMA(0, 1, 0, f0.a1[0], f0.b0[0]); WINO_GLDS(2); WINO_PIN();
-            WINO_MFMA(0, 1, 1, f0.a1[0], f0.b1[0]); WINO_GLDS(3); WINO_PIN();
-#undef WINO_GLDS
-        }
-        WINO_PIN();
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        FragB f0, f1;
+        read_b(buf, 0, f0);
+        const f32x4* up = Ug + (size_t)cn * (CHUNK_FLOATS / 4);
+        WINO_MFMA(0, 0, 0, WINO_A0(ucur, 0, 0), f0.b0[0]); unxt[0] = up[0]; WINO_PIN();
+        WINO_MFMA(0, 0, 1, WINO_A0(ucur, 0, 0), f0.b1[0]); unxt[1] = up[64]; WINO_PIN();
+        WINO_MFMA(0, 1, 0, WINO_A1(ucur, 0, 0), f0.b0[0]); unxt[2] = up[128]; WINO_PIN();
+        WINO_MFMA(0, 1, 1, WINO_A1(ucur, 0, 0), f0.b1[0]); unxt[3] = up[192]; WINO_PIN();
         // x = 0, s = 1: the transform of patch(c+1) in four slices behind the MFMAs
         float d[16], t[16], v[16];
         unpack(rw, d);
-        WINO_MFMA(0, 0, 0, f0.a0[1], f0.b0[1]);
+        WINO_MFMA(0, 0, 0, WINO_A0(ucur, 0, 1), f0.b0[1]);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
@@ -248,7 +210,7 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
             t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
         }
         WINO_PIN();
-        WINO_MFMA(0, 0, 1, f0.a0[1], f0.b1[1]);
+        WINO_MFMA(0, 0, 1, WINO_A0(ucur, 0, 1), f0.b1[1]);
 #pragma unroll
         for (int j = 2; j < 4; ++j) {
             t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
@@ -257,7 +219,7 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
             t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
         }
         WINO_PIN();
-        WINO_MFMA(0, 1, 0, f0.a1[1], f0.b0[1]);
+        WINO_MFMA(0, 1, 0, WINO_A1(ucur, 0, 1), f0.b0[1]);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             v[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
@@ -266,7 +228,7 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
             v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
         }
         WINO_PIN();
-        WINO_MFMA(0, 1, 1, f0.a1[1], f0.b1[1]);
+        WINO_MFMA(0, 1, 1, WINO_A1(ucur, 0, 1), f0.b1[1]);
 #pragma unroll
         for (int i = 2; i < 4; ++i) {
             v[i * 4 + 0] = t[i * 4 + 0] - t[i * 4 + 2];
@@ -275,39 +237,36 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
             v[i * 4 + 3] = t[i * 4 + 1] - t[i * 4 + 3];
         }
         WINO_PIN();
-        read_frag(slot, buf, 1, f1);
+        read_b(buf, 1, f1);
         float* vp = Vlds + (buf ^ 1) * CHUNK_FLOATS + s_l * 128 + tile_l * 2 + h;
 #define WINO_VST(e) vp[(e) * XI_STRIDE] = v[e]
 #define WINO_LD(i) rw[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[i], soff, 0)
-        // x = 0, s = 2, 3: LDS stores of V, then the first patch loads
-        WINO_MFMA(0, 0, 0, f0.a0[2], f0.b0[2]); WINO_VST(0); WINO_VST(1); WINO_VST(2); WINO_VST(3); WINO_PIN();
-        WINO_MFMA(0, 0, 1, f0.a0[2], f0.b1[2]); WINO_VST(4); WINO_VST(5); WINO_VST(6); WINO_VST(7); WINO_PIN();
-        WINO_MFMA(0, 1, 0, f0.a1[2], f0.b0[2]); WINO_VST(8); WINO_VST(9); WINO_VST(10); WINO_VST(11); WINO_PIN();
-        WINO_MFMA(0, 1, 1, f0.a1[2], f0.b1[2]); WINO_VST(12); WINO_VST(13); WINO_VST(14); WINO_VST(15); WINO_PIN();
-        WINO_MFMA(0, 0, 0, f0.a0[3], f0.b0[3]); WINO_LD(0); WINO_PIN();
-        WINO_MFMA(0, 0, 1, f0.a0[3], f0.b1[3]); WINO_PIN();
-        WINO_MFMA(0, 1, 0, f0.a1[3], f0.b0[3]); WINO_LD(1); WINO_PIN();
-        WINO_MFMA(0, 1, 1, f0.a1[3], f0.b1[3]); WINO_PIN();
-        // x = 1: the last two row loads behind the first MFMAs
-        WINO_MFMA(1, 0, 0, f1.a0[0], f1.b0[0]); WINO_LD(2); WINO_PIN();
-        WINO_MFMA(1, 0, 1, f1.a0[0], f1.b1[0]); WINO_PIN();
-        WINO_MFMA(1, 1, 0, f1.a1[0], f1.b0[0]); WINO_LD(3); WINO_PIN();
-        WINO_MFMA(1, 1, 1, f1.a1[0], f1.b1[0]); WINO_PIN();
-        mfma_frag(1, f1, 1, 4);
+        WINO_MFMA(0, 0, 0, WINO_A0(ucur, 0, 2), f0.b0[2]); WINO_VST(0); WINO_VST(1); WINO_VST(2); WINO_VST(3); WINO_PIN();
+        WINO_MFMA(0, 0, 1, WINO_A0(ucur, 0, 2), f0.b1[2]); WINO_VST(4); WINO_VST(5); WINO_VST(6); WINO_VST(7); WINO_PIN();
+        WINO_MFMA(0, 1, 0, WINO_A1(ucur, 0, 2), f0.b0[2]); WINO_VST(8); WINO_VST(9); WINO_VST(10); WINO_VST(11); WINO_PIN();
+        WINO_MFMA(0, 1, 1, WINO_A1(ucur, 0, 2), f0.b1[2]); WINO_VST(12); WINO_VST(13); WINO_VST(14); WINO_VST(15); WINO_PIN();
+        WINO_MFMA(0, 0, 0, WINO_A0(ucur, 0, 3), f0.b0[3]); WINO_LD(0); WINO_PIN();
+        WINO_MFMA(0, 0, 1, WINO_A0(ucur, 0, 3), f0.b1[3]); WINO_PIN();
+        WINO_MFMA(0, 1, 0, WINO_A1(ucur, 0, 3), f0.b0[3]); WINO_LD(1); WINO_PIN();
+        WINO_MFMA(0, 1, 1, WINO_A1(ucur, 0, 3), f0.b1[3]); WINO_PIN();
+        WINO_MFMA(1, 0, 0, WINO_A0(ucur, 1, 0), f1.b0[0]); WINO_LD(2); WINO_PIN();
+        WINO_MFMA(1, 0, 1, WINO_A0(ucur, 1, 0), f1.b1[0]); WINO_PIN();
+        WINO_MFMA(1, 1, 0, WINO_A1(ucur, 1, 0), f1.b0[0]); WINO_LD(3); WINO_PIN();
+        WINO_MFMA(1, 1, 1, WINO_A1(ucur, 1, 0), f1.b1[0]); WINO_PIN();
+        WINO_4(ucur, f1, 1, 1);
+        WINO_4(ucur, f1, 1, 2);
+        WINO_4(ucur, f1, 1, 3);
 #undef WINO_VST
 #undef WINO_LD
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
-    int slot = 0;
     int c = 0;
     for (; c + 1 < a.chunks; c += 2) {          // straight-line pair of iterations: static wait counts
-        body(c, slot, dB);
-        slot = slot == 2 ? 0 : slot + 1;
-        body(c + 1, slot, dA);
-        slot = slot == 2 ? 0 : slot + 1;
+        body(c, uA, uB);
+        body(c + 1, uB, uA);
     }
-    if (c < a.chunks) body(c, slot, dB);
+    if (c < a.chunks) body(c, uA, uB);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -401,7 +360,7 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
     }
 }
 
-// U[kb][chunk][xi][s][k][h] = (G g G^T)[xi] for co = kb*64+k, ci = chunk*8 + 2s + h (zero padded couts)
+// U[kb][chunk][wave][piece][lane][4]: (G g G^T)[xi] values in MFMA A-fragment order (zero padded couts)
 struct WinoPackArgs {
     const float* w[6];
     int mbeg[7];
@@ -415,10 +374,13 @@ __global__ void wino_pack_kernel(const WinoPackArgs p)
 {
     const long total = (long)p.kblocks * p.chunks * CHUNK_FLOATS;
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int hh = (int)(idx & 1);
-        const int k = (int)((idx >> 1) & 63);
-        const int s = (int)((idx >> 7) & 3);
-        const int xi = (int)((idx >> 9) & 15);
+        // register layout: [wave 8][piece 4][lane 64][4]: piece = (x, s-pair), element = (s parity, cout half);
+        // wave w / lane (l31, hh) gets exactly the A fragments it feeds to its MFMAs, as four float4
+        const int e = (int)(idx & 3), ln = (int)((idx >> 2) & 63), pc = (int)((idx >> 8) & 3), wv = (int)((idx >> 10) & 7);
+        const int hh = ln >> 5;
+        const int k = (ln & 31) + 32 * (e & 1);
+        const int s = 2 * (pc & 1) + (e >> 1);
+        const int xi = 2 * wv + (pc >> 1);
         const long rest = idx >> 13;
         const int chunk = (int)(rest % p.chunks);
         const int kb = (int)(rest / p.chunks);
