@@ -74,47 +74,47 @@ def voc_eval_lines(lines, gt, ovthresh=0.5, use_07_metric=False):
 
     gt: {image_id: {'bbox': int array [k,4], 'difficult': bool array [k]}} for THIS class
     (images without objects of the class may be missing).  Returns (rec, prec, ap)."""
-    class_recs, npos = {}, 0
+    per_image, num_pos = {}, 0
     for img, r in gt.items():
         bbox = np.asarray(r['bbox']).reshape(-1, 4) if len(r['bbox']) else np.zeros((0, 4))
         difficult = np.asarray(r['difficult'], dtype=bool).reshape(-1)
-        class_recs[img] = {'bbox': bbox, 'difficult': difficult, 'det': [False] * len(difficult)}
-        npos += int(np.sum(~difficult))
+        per_image[img] = {'bbox': bbox, 'difficult': difficult, 'det': [False] * len(difficult)}
+        num_pos += int(np.sum(~difficult))
     split = [x.strip().split(' ') for x in lines]
     image_ids = [x[0] for x in split]
-    confidence = np.array([float(x[1]) for x in split])
+    scores = np.array([float(x[1]) for x in split])
     BB = np.array([[float(z) for z in x[2:]] for x in split])
-    sorted_ind = np.argsort(-confidence)
-    BB = BB[sorted_ind, :] if BB.size != 0 else BB
-    image_ids = [image_ids[x] for x in sorted_ind]
+    order = np.argsort(-scores)
+    BB = BB[order, :] if BB.size != 0 else BB
+    image_ids = [image_ids[x] for x in order]
     nd = len(image_ids)
     tp, fp = np.zeros(nd), np.zeros(nd)
     empty = {'bbox': np.zeros((0, 4)), 'difficult': np.zeros(0, bool), 'det': []}
     for d in range(nd):
-        R = class_recs.get(image_ids[d], empty)
+        rec_i = per_image.get(image_ids[d], empty)
         bb = BB[d, :].astype(float)
-        ovmax = -np.inf
-        BBGT = R['bbox'].astype(float)
-        if BBGT.size > 0:
-            iw = np.maximum(np.minimum(BBGT[:, 2], bb[2]) - np.maximum(BBGT[:, 0], bb[0]) + 1., 0.)
-            ih = np.maximum(np.minimum(BBGT[:, 3], bb[3]) - np.maximum(BBGT[:, 1], bb[1]) + 1., 0.)
-            inters = iw * ih
-            uni = ((bb[2] - bb[0] + 1.) * (bb[3] - bb[1] + 1.) +
-                   (BBGT[:, 2] - BBGT[:, 0] + 1.) * (BBGT[:, 3] - BBGT[:, 1] + 1.) - inters)
-            overlaps = inters / uni
-            ovmax = np.max(overlaps)
-            jmax = np.argmax(overlaps)
-        if ovmax > ovthresh:
-            if not R['difficult'][jmax]:
-                if not R['det'][jmax]:
+        best_iou = -np.inf
+        gt_boxes = rec_i['bbox'].astype(float)
+        if gt_boxes.size > 0:
+            iw = np.maximum(np.minimum(gt_boxes[:, 2], bb[2]) - np.maximum(gt_boxes[:, 0], bb[0]) + 1., 0.)
+            ih = np.maximum(np.minimum(gt_boxes[:, 3], bb[3]) - np.maximum(gt_boxes[:, 1], bb[1]) + 1., 0.)
+            inter_area = iw * ih
+            union_area = ((bb[2] - bb[0] + 1.) * (bb[3] - bb[1] + 1.) +
+                   (gt_boxes[:, 2] - gt_boxes[:, 0] + 1.) * (gt_boxes[:, 3] - gt_boxes[:, 1] + 1.) - inter_area)
+            ious = inter_area / union_area
+            best_iou = np.max(ious)
+            best_j = np.argmax(ious)
+        if best_iou > ovthresh:
+            if not rec_i['difficult'][best_j]:
+                if not rec_i['det'][best_j]:
                     tp[d] = 1.
-                    R['det'][jmax] = 1
+                    rec_i['det'][best_j] = 1
                 else:
                     fp[d] = 1.
         else:
             fp[d] = 1.
     fp, tp = np.cumsum(fp), np.cumsum(tp)
-    rec = tp / float(npos)
+    rec = tp / float(num_pos)
     prec = tp / np.maximum(tp + fp, np.finfo(np.float64).eps)
     return rec, prec, voc_ap(rec, prec, use_07_metric)
 
