@@ -4,7 +4,6 @@
 // of a convolution is the `transposed` mode of ct_conv2d_fwd (ct_conv.hip).
 #include "ct_common.h"
 #include <algorithm>
-#include <cstring>
 #include <mutex>
 #include <unordered_set>
 
@@ -38,23 +37,19 @@ struct WgradArgs {
     int tiles_m, tiles_n, pix_per_split;
 };
 
-template <int KH, int KW, int TBM, int TBN>
+template <int KH, int KW, int TB>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
 {
-    // workgroup tile (64*TBM couts) x (64*TBN columns), each wave TBM x TBN accumulator blocks of 32x32
+    // workgroup tile (64*TB couts) x (64*TB columns), each wave TB x TB accumulator blocks of 32x32
     constexpr int KHW = KH * KW;
-    // LDS tiles hold pixel PAIRS interleaved: [pixel pair][row][2], pair stride 2*BM+2 floats -- the fragment
-    // read (lanes = 32 rows x 2 pixels of the pair) and the transposed store (lanes = 64 pixels of one row)
-    // are both bank-conflict free
-    constexpr int BM = 64 * TBM, BN = 64 * TBN, BKP = 64, PSA = 2 * BM + 2, PSB = 2 * BN + 2;
-    constexpr int RA = 16 * TBM, RB = 16 * TBN;
+    constexpr int BM = 64 * TB, BN = 64 * TB, BKP = 64, LD = BM + 1, ROWS = 16 * TB;
     extern __shared__ float wg_lds[];
     float* As = wg_lds;
-    float* Bs = wg_lds + (BKP / 2) * PSA;
+    float* Bs = wg_lds + BKP * LD;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave & 1) * 32 * TBM, wn0 = (wave >> 1) * 32 * TBN;
+    const int wm0 = (wave & 1) * 32 * TB, wn0 = (wave >> 1) * 32 * TB;
     const int tile = blockIdx.x;
     const int m0 = (tile % a.tiles_m) * BM;
     const int c0 = (tile / a.tiles_m) * BN;
@@ -67,14 +62,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
     const int HW = a.H * a.W;
 
     // wave-uniform row descriptors: A rows = cout m0 + wave + 4j, B rows = column c0 + wave + 4j
-    int a_soff[RA], b_soff[RB], b_dh[RB], b_dw[RB];
+    int a_soff[ROWS], b_soff[ROWS], b_dh[ROWS], b_dw[ROWS];
 #pragma unroll
-    for (int j = 0; j < RA; ++j) {
+    for (int j = 0; j < ROWS; ++j) {
         const int m = m0 + wave + 4 * j;
         a_soff[j] = m < a.Cout ? m * a.OHW * 4 : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
         const int col = c0 + wave + 4 * j;
         const int ci = col / KHW, tap = col - ci * KHW;
         const int kh = tap / KW, kw = tap - kh * KW;
@@ -83,88 +75,73 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
         b_dw[j] = kw * a.dil - a.pad_w;
     }
 
-    float areg[RA], breg[RB];
-    // per-chunk lane state (this lane's pixel of the chunk being loaded) + one row load at a time, so that the
-    // 2*ROWS gathers of the NEXT chunk can be issued one behind each MFMA instead of in a burst
-    int zoff, xbase, ih0, iw0;
-    bool pv;
-    auto chunk_setup = [&](int p0) {
+    float areg[ROWS], breg[ROWS];
+    auto load_chunk = [&](int p0) {
         const int P = p0 + lane;
-        pv = P < p_end;
+        const bool pv = P < p_end;
         const int Pc = pv ? P : 0;
         const int n = Pc / a.OHW;
-        const int sp = Pc - n * a.OHW;
-        const int oh = sp / a.OW, ow = sp - oh * a.OW;
-        zoff = pv ? ((n * a.dz_ctot + a.dz_coff) * a.OHW + sp) * 4 : kInvalidOff;
-        xbase = (n * a.x_ctot + a.x_coff) * HW;
-        ih0 = oh * a.stride;
-        iw0 = ow * a.stride;
-    };
-    auto load_a = [&](int j) {
-        areg[j] = a_soff[j] >= 0 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff, a_soff[j], 0)) : 0.f;
-    };
-    auto load_b = [&](int j) {
-        const int ih = ih0 + b_dh[j], iw = iw0 + b_dw[j];
-        const bool ok = pv && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-        const int xoff = ok ? (xbase + ih * a.W + iw) * 4 : kInvalidOff;
-        breg[j] = b_soff[j] >= 0 ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff, b_soff[j], 0)) : 0.f;
+        const int s = Pc - n * a.OHW;
+        const int oh = s / a.OW, ow = s - oh * a.OW;
+        const int zoff = pv ? ((n * a.dz_ctot + a.dz_coff) * a.OHW + s) * 4 : kInvalidOff;
+        const int xbase = (n * a.x_ctot + a.x_coff) * HW;
+        const int ih0 = oh * a.stride, iw0 = ow * a.stride;
+#pragma unroll
+        for (int j = 0; j < ROWS; ++j) {
+            areg[j] = a_soff[j] >= 0
+                          ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff, a_soff[j], 0))
+                          : 0.f;
+            const int ih = ih0 + b_dh[j], iw = iw0 + b_dw[j];
+            const bool ok = pv && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const int xoff = ok ? (xbase + ih * a.W + iw) * 4 : kInvalidOff;
+            breg[j] = b_soff[j] >= 0
+                          ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff, b_soff[j], 0))
+                          : 0.f;
+        }
     };
 
-    f32x16 acc[TBM][TBN];
+    f32x16 acc[TB][TB];
 #pragma unroll
-    for (int i = 0; i < TBM; ++i)
+    for (int i = 0; i < TB; ++i)
 #pragma unroll
-        for (int j = 0; j < TBN; ++j)
+        for (int j = 0; j < TB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    chunk_setup(p_begin);
-#pragma unroll
-    for (int j = 0; j < RA; ++j) load_a(j);
-#pragma unroll
-    for (int j = 0; j < RB; ++j) load_b(j);
+    load_chunk(p_begin);
     for (int p0 = p_begin; p0 < p_end; p0 += BKP) {
 #pragma unroll
-        for (int j = 0; j < RA; ++j) As[(lane >> 1) * PSA + (wave + 4 * j) * 2 + (lane & 1)] = areg[j];
-#pragma unroll
-        for (int j = 0; j < RB; ++j) Bs[(lane >> 1) * PSB + (wave + 4 * j) * 2 + (lane & 1)] = breg[j];
+        for (int j = 0; j < ROWS; ++j) {
+            As[lane * LD + wave + 4 * j] = areg[j];
+            Bs[lane * LD + wave + 4 * j] = breg[j];
+        }
         __syncthreads();
-        const bool more = p0 + BKP < p_end;
-        if (more) chunk_setup(p0 + BKP);
-        const float* Ab = As + (wm0 + l31) * 2 + hsel;
-        const float* Bb = Bs + (wn0 + l31) * 2 + hsel;
-        constexpr int LPS = (RA + RB + BKP / 2 - 1) / (BKP / 2);      // row loads per k-pair slot
-#pragma unroll
+        if (p0 + BKP < p_end) load_chunk(p0 + BKP);
+        const float* Ab = As + hsel * LD + wm0 + l31;
+        const float* Bb = Bs + hsel * LD + wn0 + l31;
+#pragma unroll 8
         for (int s = 0; s < BKP / 2; ++s) {
-            float af[TBM], bf[TBN];
+            float af[TB], bf[TB];
 #pragma unroll
-            for (int i = 0; i < TBM; ++i) af[i] = Ab[s * PSA + 64 * i];
-#pragma unroll
-            for (int j = 0; j < TBN; ++j) bf[j] = Bb[s * PSB + 64 * j];
-#pragma unroll
-            for (int i = 0; i < TBM; ++i)
-#pragma unroll
-                for (int j = 0; j < TBN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-            if (more) {
-#pragma unroll
-                for (int q = 0; q < LPS; ++q) {
-                    const int e = s * LPS + q;
-                    if (e < RA) load_a(e);
-                    else if (e < RA + RB) load_b(e - RA);
-                }
+            for (int i = 0; i < TB; ++i) {
+                af[i] = Ab[(2 * s) * LD + 32 * i];
+                bf[i] = Bb[(2 * s) * LD + 32 * i];
             }
-            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < TB; ++i)
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
 
 #pragma unroll
-    for (int j = 0; j < TBN; ++j) {
+    for (int j = 0; j < TB; ++j) {
         const int col = c0 + wn0 + 32 * j + l31;
         if (col >= a.Ncols) continue;
 #pragma unroll
-        for (int i = 0; i < TBM; ++i)
+        for (int i = 0; i < TB; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hsel;
@@ -440,17 +417,13 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
     a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.dil = d->dil;
     a.Npix = d->batch * a.OHW;
     a.Ncols = d->cin * d->kh * d->kw;
-    // tile shape (64*tbm couts) x (64*tbn columns).  Measured on the RFBNet shapes, 64x64 / 128x64 / 64x128 /
-    // 128x128 all land within 3 % of each other (~78 TFLOP/s on the 512-channel layers), 64x256 is slower;
-    // CTDET_WGRAD_TILE=MxN (in units of 64) overrides the default for experiments
-    static const char* tile_env = getenv("CTDET_WGRAD_TILE");
-    int tbm = 1, tbn = 1;
-    if (tile_env && strlen(tile_env) == 3) { tbm = tile_env[0] - '0'; tbn = tile_env[2] - '0'; }
-    if (d->cout < 96) tbm = 1;
-    if (!((tbm == 1 || tbm == 2) && (tbn == 1 || tbn == 2 || tbn == 4)) || (tbm == 2 && tbn == 4)) { tbm = 1; tbn = 1; }
-    const int bt = 64 * tbm, btn = 64 * tbn;
+    // the 128x128 variant (TB = 2) measured slower on the RFBNet shapes (fewer pixel splits in flight, the
+    // 64 gathers per thread arrive in one burst); kept for experiments behind CTDET_WGRAD_TB=2
+    static const int tb_env = getenv("CTDET_WGRAD_TB") ? atoi(getenv("CTDET_WGRAD_TB")) : 1;
+    const int tb = (tb_env == 2 && d->cout >= 96 && a.Ncols >= 96) ? 2 : 1;
+    const int bt = 64 * tb;
     a.tiles_m = (d->cout + bt - 1) / bt;
-    a.tiles_n = (a.Ncols + btn - 1) / btn;
+    a.tiles_n = (a.Ncols + bt - 1) / bt;
     const int tiles = a.tiles_m * a.tiles_n;
     int splits = std::max(1, std::min((a.Npix + 255) / 256, (2048 + tiles - 1) / tiles));
     a.pix_per_split = ((a.Npix + splits - 1) / splits + 63) / 64 * 64;
@@ -458,7 +431,7 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
     hipStream_t st = ctdet::as_stream(stream);
     CT_HIP(hipMemsetAsync(dw, 0, (size_t)d->cout * a.Ncols * 4, st));
     const dim3 grid(tiles, splits), block(256);
-    const size_t smem = 32 * (size_t)(2 * bt + 2 + 2 * btn + 2) * 4;
+    const size_t smem = 2 * 64 * (size_t)(bt + 1) * 4;
     hipError_t le = hipSuccess;
     auto go = [&](auto kernel) {
         if (smem > 64 * 1024) {
@@ -472,13 +445,10 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
         }
         if (le == hipSuccess) hipLaunchKernelGGL(kernel, grid, block, smem, st, a);
     };
-#define CT_WGRAD_GO(KH, KW)                                                  \
-    do {                                                                     \
-        if (tbm == 2 && tbn == 2) go(conv_wgrad_f32<KH, KW, 2, 2>);          \
-        else if (tbm == 2) go(conv_wgrad_f32<KH, KW, 2, 1>);                 \
-        else if (tbn == 4) go(conv_wgrad_f32<KH, KW, 1, 4>);                 \
-        else if (tbn == 2) go(conv_wgrad_f32<KH, KW, 1, 2>);                 \
-        else go(conv_wgrad_f32<KH, KW, 1, 1>);                               \
+#define CT_WGRAD_GO(KH, KW)                                   \
+    do {                                                      \
+        if (tb == 2) go(conv_wgrad_f32<KH, KW, 2>);           \
+        else go(conv_wgrad_f32<KH, KW, 1>);                   \
     } while (0)
     if (d->kh == 3 && d->kw == 3) CT_WGRAD_GO(3, 3);
     else if (d->kh == 1 && d->kw == 1) CT_WGRAD_GO(1, 1);

@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libctdet.so')
+LIB_PATH = os.environ.get('CTDET_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libctdet.so')
 
 CT_OK = 0
 
