@@ -5,23 +5,26 @@
 
 namespace {
 
+// IDX = int when planes*OH*OW < 2^31 (always, for this network): 64-bit div/mod per element made the kernel
+// instruction-bound at ~0.5 TB/s
+template <typename IDX>
 __global__ __launch_bounds__(256) void maxpool2d_nchw(const float* __restrict__ in,
                                                       float* __restrict__ out, long planes, int H,
                                                       int W, int OH, int OW, int k, int stride, int pad)
 {
-    const long total = planes * OH * OW;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+    const IDX total = (IDX)(planes * OH * OW);
+    for (IDX idx = (IDX)blockIdx.x * (IDX)blockDim.x + threadIdx.x; idx < total;
+         idx += (IDX)gridDim.x * (IDX)blockDim.x) {
         const int ow = (int)(idx % OW);
-        const long t = idx / OW;
+        const IDX t = idx / OW;
         const int oh = (int)(t % OH);
-        const long pl = t / OH;
+        const IDX pl = t / OH;
         const int h0 = oh * stride - pad, w0 = ow * stride - pad;
         const int h1 = min(h0 + k, H), w1 = min(w0 + k, W);
-        const float* p = in + pl * (long)H * W;
+        const float* p = in + (long)pl * H * W;
         float m = -INFINITY;
         for (int h = max(h0, 0); h < h1; ++h)
-            for (int w = max(w0, 0); w < w1; ++w) m = fmaxf(m, p[(long)h * W + w]);
+            for (int w = max(w0, 0); w < w1; ++w) m = fmaxf(m, p[h * W + w]);
         out[idx] = m;
     }
 }
@@ -60,8 +63,12 @@ extern "C" int ct_maxpool2d_fwd(const float* in, float* out, long planes, int h,
     CT_REQUIRE(k >= 1 && stride >= 1 && pad >= 0 && pad < k, "ct_maxpool2d_fwd: k=%d stride=%d pad=%d", k, stride, pad);
     CT_REQUIRE((oh - 1) * stride - pad < h && (ow - 1) * stride - pad < w,
                "ct_maxpool2d_fwd: last window starts outside the input");
-    hipLaunchKernelGGL(maxpool2d_nchw, dim3(grid_for(planes * oh * ow)), dim3(256), 0,
-                       ctdet::as_stream(stream), in, out, planes, h, w, oh, ow, k, stride, pad);
+    if (planes * oh * ow < 0x7FFFFFFFL)
+        hipLaunchKernelGGL(maxpool2d_nchw<int>, dim3(grid_for(planes * oh * ow)), dim3(256), 0,
+                           ctdet::as_stream(stream), in, out, planes, h, w, oh, ow, k, stride, pad);
+    else
+        hipLaunchKernelGGL(maxpool2d_nchw<long>, dim3(grid_for(planes * oh * ow)), dim3(256), 0,
+                           ctdet::as_stream(stream), in, out, planes, h, w, oh, ow, k, stride, pad);
     CT_LAUNCH_CHECK("maxpool2d_nchw");
     return CT_OK;
 }

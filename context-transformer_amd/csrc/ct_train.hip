@@ -218,10 +218,9 @@ struct BnApplyArgs {
 __global__ __launch_bounds__(256) void bn_apply_kernel(const BnApplyArgs a)
 {
     const long total = (long)a.batch * a.C * a.HW;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {
         const int i = (int)(idx % a.HW);
-        const long t = idx / a.HW;
+        const unsigned t = idx / a.HW;
         const int c = (int)(t % a.C);
         const int n = (int)(t / a.C);
         const float inv = 1.f / sqrtf(a.var[c] + a.eps);
@@ -284,10 +283,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a)
 {
     const long total = (long)a.batch * a.C * a.HW;
     const float cnt = (float)a.batch * a.HW;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {
         const int i = (int)(idx % a.HW);
-        const long t = idx / a.HW;
+        const unsigned t = idx / a.HW;
         const int c = (int)(t % a.C);
         const int n = (int)(t / a.C);
         const float inv = 1.f / sqrtf(a.var[c] + a.eps);
@@ -304,29 +302,54 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a)
 }
 
 // y = act(conv + bias):  dz = dy * (y > 0 if relu),  dbias = sum dz   (VGG convs, heads)
+// grid (channel, slice): a slice is a contiguous range of the channel's batch*HW elements, so a 64-channel
+// 300x300 layer still fills the chip; per-slice sums meet in dbias through one float atomic per block.
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restrict__ dy, int dy_ctot,
                                                            int dy_coff, const float* __restrict__ y,
                                                            int y_ctot, int y_coff, int relu, int batch,
                                                            int C, int HW, float* __restrict__ dz,
                                                            int dz_ctot, int dz_coff,
-                                                           float* __restrict__ dbias)
+                                                           float* __restrict__ dbias, int per_slice)
 {
     __shared__ double red[4];
     const int c = blockIdx.x;
+    const long e0 = (long)blockIdx.y * per_slice, e1 = min(e0 + per_slice, (long)batch * HW);
     double sb = 0.0;
-    for (int n = 0; n < batch; ++n) {
-        const float* g = dy + ((size_t)n * dy_ctot + dy_coff + c) * HW;
-        const float* yy = y ? y + ((size_t)n * y_ctot + y_coff + c) * HW : nullptr;
-        float* o = dz + ((size_t)n * dz_ctot + dz_coff + c) * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            float v = g[i];
-            if (relu && yy[i] <= 0.f) v = 0.f;
-            o[i] = v;
-            sb += v;
+    const bool vec = (HW & 3) == 0 && (per_slice & 3) == 0;
+    int n = (int)(e0 / HW);
+    int i0 = (int)(e0 - (long)n * HW);
+    for (long e = e0; e < e1;) {
+        const int len = (int)min((long)(HW - i0), e1 - e);
+        const float* g = dy + ((size_t)n * dy_ctot + dy_coff + c) * HW + i0;
+        const float* yy = y ? y + ((size_t)n * y_ctot + y_coff + c) * HW + i0 : nullptr;
+        float* o = dz + ((size_t)n * dz_ctot + dz_coff + c) * HW + i0;
+        if (vec) {
+            for (int i = threadIdx.x * 4; i < len; i += 1024) {
+                float4 v = *reinterpret_cast<const float4*>(g + i);
+                if (relu) {
+                    const float4 t = *reinterpret_cast<const float4*>(yy + i);
+                    v.x = t.x <= 0.f ? 0.f : v.x;
+                    v.y = t.y <= 0.f ? 0.f : v.y;
+                    v.z = t.z <= 0.f ? 0.f : v.z;
+                    v.w = t.w <= 0.f ? 0.f : v.w;
+                }
+                *reinterpret_cast<float4*>(o + i) = v;
+                sb += (double)((v.x + v.y) + (v.z + v.w));
+            }
+        } else {
+            for (int i = threadIdx.x; i < len; i += 256) {
+                float v = g[i];
+                if (relu && yy[i] <= 0.f) v = 0.f;
+                o[i] = v;
+                sb += v;
+            }
         }
+        e += len;
+        i0 = 0;
+        ++n;
     }
     sb = block_sum(sb, red);
-    if (threadIdx.x == 0 && dbias) dbias[c] = (float)sb;
+    if (threadIdx.x == 0 && dbias) unsafeAtomicAdd(&dbias[c], (float)sb);
 }
 
 // max-pool backward (gather form): every input element collects dy of the windows whose FIRST
@@ -338,10 +361,9 @@ __global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const float* __restr
                                                             int pad, int accumulate)
 {
     const long total = planes * H * W;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {
         const int w = (int)(idx % W);
-        const long t = idx / W;
+        const unsigned t = idx / W;
         const int h = (int)(t % H);
         const long pl = t / H;
         const float* xp = x + pl * (long)H * W;
@@ -376,10 +398,9 @@ struct HeadGatherArgs {
 __global__ __launch_bounds__(256) void head_grad_gather_kernel(const HeadGatherArgs a)
 {
     const long total = (long)a.batch * a.C * a.HW;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+    for (unsigned idx = blockIdx.x * blockDim.x + threadIdx.x; idx < (unsigned)total; idx += gridDim.x * blockDim.x) {
         const int i = (int)(idx % a.HW);
-        const long t = idx / a.HW;
+        const unsigned t = idx / a.HW;
         const int c = (int)(t % a.C);
         const int n = (int)(t / a.C);
         float v = 0.f;
@@ -491,6 +512,7 @@ extern "C" int ct_bn_train_apply(const float* z, const float* mean, const float*
     a.batch = batch; a.C = channels; a.HW = hw; a.y_ctot = y_ctot; a.y_coff = y_coff;
     a.res_ctot = res_ctot; a.res_coff = res_coff; a.eps = eps; a.rscale = res_scale; a.relu = relu;
     a.z_ctot = z_ctot; a.z_coff = z_coff;
+    CT_REQUIRE((long)batch * channels * hw < 0xFFFFFFFFL, "ct_bn_train_apply: more than 2^32 elements");
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for((long)batch * channels * hw)), dim3(256), 0,
                        ctdet::as_stream(stream), a);
     CT_LAUNCH_CHECK("bn_apply_kernel");
@@ -527,8 +549,17 @@ extern "C" int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, c
                                     int dz_ctot, int dz_coff, float* dbias, ct_stream_t stream)
 {
     CT_REQUIRE(dy && dz && (!relu || y), "ct_bias_act_backward: null pointer");
-    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(channels), dim3(256), 0, ctdet::as_stream(stream), dy,
-                       dy_ctot, dy_coff, y, y_ctot, y_coff, relu, batch, channels, hw, dz, dz_ctot, dz_coff, dbias);
+    CT_REQUIRE(batch > 0 && channels > 0 && hw > 0, "ct_bias_act_backward: bad shape");
+    hipStream_t st = ctdet::as_stream(stream);
+    const long per_channel = (long)batch * hw;
+    int slices = (int)std::max<long>(1, std::min<long>((2048 + channels - 1) / channels, (per_channel + 4095) / 4096));
+    slices = std::min(slices, 65535);
+    int per_slice = (int)((per_channel + slices - 1) / slices);
+    per_slice = (per_slice + 3) / 4 * 4;
+    slices = (int)((per_channel + per_slice - 1) / per_slice);
+    if (dbias) CT_HIP(hipMemsetAsync(dbias, 0, (size_t)channels * 4, st));
+    hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(channels, slices), dim3(256), 0, st, dy, dy_ctot, dy_coff, y,
+                       y_ctot, y_coff, relu, batch, channels, hw, dz, dz_ctot, dz_coff, dbias, per_slice);
     CT_LAUNCH_CHECK("bias_act_bwd_kernel");
     return CT_OK;
 }
@@ -538,6 +569,7 @@ extern "C" int ct_maxpool2d_bwd(const float* x, const float* dy, float* dx, long
                                 ct_stream_t stream)
 {
     CT_REQUIRE(x && dy && dx && planes > 0, "ct_maxpool2d_bwd: bad arguments");
+    CT_REQUIRE(planes * h * w < 0xFFFFFFFFL, "ct_maxpool2d_bwd: more than 2^32 elements");
     hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0,
                        ctdet::as_stream(stream), x, dy, dx, planes, h, w, oh, ow, k, stride, pad, accumulate);
     CT_LAUNCH_CHECK("maxpool2d_bwd_kernel");
