@@ -37,7 +37,11 @@ struct WgradArgs {
     int tiles_m, tiles_n, pix_per_split;
 };
 
-template <int KH, int KW, int TB>
+// TAPMAJOR (needs cin % (64*TB) == 0): the GEMM columns are ordered tap-major (col = tap*cin + ci), so all rows of
+// a column tile share ONE filter tap: the shifted-pixel offset and its bounds test are computed once per chunk and
+// lane instead of once per gathered row -- the generic path spends ~12 VALU instructions per MFMA on that and starves
+// the matrix pipe (measured 78 TFLOP/s, half of peak, independent of tile shape).
+template <int KH, int KW, int TB, bool TAPMAJOR>
 __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
 {
     // workgroup tile (64*TB couts) x (64*TB columns), each wave TB x TB accumulator blocks of 32x32
@@ -63,16 +67,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
 
     // wave-uniform row descriptors: A rows = cout m0 + wave + 4j, B rows = column c0 + wave + 4j
     int a_soff[ROWS], b_soff[ROWS], b_dh[ROWS], b_dw[ROWS];
+    const int tm_tap = TAPMAJOR ? c0 / a.Cin : 0, tm_ci0 = TAPMAJOR ? c0 - tm_tap * a.Cin : 0;
+    const int tm_dh = (tm_tap / KW) * a.dil - a.pad_h, tm_dw = (tm_tap % KW) * a.dil - a.pad_w;
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         const int m = m0 + wave + 4 * j;
         a_soff[j] = m < a.Cout ? m * a.OHW * 4 : -1;
-        const int col = c0 + wave + 4 * j;
-        const int ci = col / KHW, tap = col - ci * KHW;
-        const int kh = tap / KW, kw = tap - kh * KW;
-        b_soff[j] = col < a.Ncols ? ci * HW * 4 : -1;
-        b_dh[j] = kh * a.dil - a.pad_h;
-        b_dw[j] = kw * a.dil - a.pad_w;
+        if (TAPMAJOR) {
+            b_soff[j] = (tm_ci0 + wave + 4 * j) * HW * 4;
+            b_dh[j] = tm_dh;
+            b_dw[j] = tm_dw;
+        } else {
+            const int col = c0 + wave + 4 * j;
+            const int ci = col / KHW, tap = col - ci * KHW;
+            const int kh = tap / KW, kw = tap - kh * KW;
+            b_soff[j] = col < a.Ncols ? ci * HW * 4 : -1;
+            b_dh[j] = kh * a.dil - a.pad_h;
+            b_dw[j] = kw * a.dil - a.pad_w;
+        }
     }
 
     float areg[ROWS], breg[ROWS];
@@ -86,6 +98,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
         const int zoff = pv ? ((n * a.dz_ctot + a.dz_coff) * a.OHW + s) * 4 : kInvalidOff;
         const int xbase = (n * a.x_ctot + a.x_coff) * HW;
         const int ih0 = oh * a.stride, iw0 = ow * a.stride;
+        if (TAPMAJOR) {
+            const int ih = ih0 + tm_dh, iw = iw0 + tm_dw;
+            const bool ok = pv && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const int xoff = ok ? (xbase + ih * a.W + iw) * 4 : kInvalidOff;
+#pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                areg[j] = a_soff[j] >= 0
+                              ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff, a_soff[j], 0))
+                              : 0.f;
+                breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff, b_soff[j], 0));
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
             areg[j] = a_soff[j] >= 0
@@ -138,8 +163,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
 
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
-        const int col = c0 + wn0 + 32 * j + l31;
+        int col = c0 + wn0 + 32 * j + l31;
         if (col >= a.Ncols) continue;
+        if (TAPMAJOR) col = (tm_ci0 + wn0 + 32 * j + l31) * KHW + tm_tap;      // back to dW's [ci][tap] order
 #pragma unroll
         for (int i = 0; i < TB; ++i)
 #pragma unroll
@@ -466,10 +492,13 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
         }
         if (le == hipSuccess) hipLaunchKernelGGL(kernel, grid, block, smem, st, a);
     };
-#define CT_WGRAD_GO(KH, KW)                                   \
-    do {                                                      \
-        if (tb == 2) go(conv_wgrad_f32<KH, KW, 2>);           \
-        else go(conv_wgrad_f32<KH, KW, 1>);                   \
+    const bool tapmajor = d->cin % bt == 0 && !(getenv("CTDET_WGRAD_GENERIC"));
+#define CT_WGRAD_GO(KH, KW)                                                    \
+    do {                                                                       \
+        if (tb == 2 && tapmajor) go(conv_wgrad_f32<KH, KW, 2, true>);          \
+        else if (tb == 2) go(conv_wgrad_f32<KH, KW, 2, false>);                \
+        else if (tapmajor) go(conv_wgrad_f32<KH, KW, 1, true>);                \
+        else go(conv_wgrad_f32<KH, KW, 1, false>);                             \
     } while (0)
     if (d->kh == 3 && d->kw == 3) CT_WGRAD_GO(3, 3);
     else if (d->kh == 1 && d->kw == 1) CT_WGRAD_GO(1, 1);
