@@ -133,3 +133,20 @@ def test_head_scatter_output(use_wino):
         lo, hi = pbase * n, pbase * n + H * Wd * A * n
         assert rel_err(got[:, lo:hi], want) < TOL, name
         assert torch.isnan(got[:, :lo]).all() and torch.isnan(got[:, hi:]).all(), name
+
+
+@pytest.mark.parametrize('use_wino', [True, False])
+def test_conv_input_above_2gib_is_chunked(use_wino):
+    """BASELINE configs[4] shapes put more than 2 GiB into one activation (32x64x512x512 fp32): the buffer
+    descriptors are 32-bit, so both kernels split the batch -- the images on both sides of the split must be right."""
+    import torch.nn.functional as F
+    B, Cin, H, Cout = 33, 64, 512, 8
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, Cin, H, H, generator=g)
+    assert x.numel() * 4 > 2 ** 31
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    b = torch.rand(Cout, generator=g) - 0.5
+    got = _run_conv(x, [(w, b, None, True)], 1, 1, 1, config=W if use_wino else 0)
+    for n in (0, 30, 31, 32):                 # first image, both sides of the 2 GiB boundary, last image
+        want = F.relu(F.conv2d(x[n:n + 1], w, b, 1, 1))
+        assert rel_err(got[n:n + 1], want) < TOL, n
