@@ -370,3 +370,32 @@ def test_ctx_attention_vs_oracle(setting, d, T):
     got = ops.ctx_attention(_cuda(conf), _cuda(pool), prm, setting == 'incre').cpu()
     assert got.shape == want.shape
     assert rel_err(got, want) < TOL, rel_err(got, want)
+
+
+def test_degenerate_inputs():
+    """Edge cases of the reference's own loops: an image whose scores never pass the threshold
+    (test.py:141-143 writes empty [0,5] arrays), images without ground truth in `match`, a single box in NMS."""
+    priors = box_ref.prior_box(box_ref.ANCHOR_CFGS['VOC_300'])
+    P = priors.shape[0]
+    B, T = 2, 20
+    boxes = torch.rand(B, P, 4)
+    scores = torch.full((B, P, T + 1), 0.001)               # everything below conf_thresh = 0.01
+    scores[1, 5, 3] = 0.9                                     # ... except one prior of image 1, class 3
+    post = ops.PostProcessor(B, P, T, DEV)
+    post.run(_cuda(boxes), _cuda(scores), 0.01, 0.45, False, 200)
+    res = post.to_all_boxes()
+    assert all(res[0][j].shape == (0, 5) and res[0][j].dtype == np.float32 for j in range(T + 1))
+    assert res[1][3].shape == (1, 5) and abs(float(res[1][3][0, 4]) - 0.9) < 1e-7
+    assert np.array_equal(res[1][3][0, :4], boxes[1, 5].numpy())
+    assert sum(len(res[1][j]) for j in range(T + 1)) == 1
+    # match: an image without objects gives all-background targets (labels 0, weights 1, loc finite)
+    t0 = torch.zeros(0, 6)
+    t1 = torch.tensor([[0.1, 0.1, 0.5, 0.6, 3.0, 1.0]])
+    loc_t, conf_t, obj_t = ops.match_batched([_cuda(t0), _cuda(t1)], _cuda(priors), 0.5, (0.1, 0.2))
+    assert not obj_t[0].any() and (conf_t[0, :, 0] == 0).all() and (conf_t[0, :, 1] == 1).all()
+    assert obj_t[1].any() and torch.isfinite(loc_t[1]).all()
+    want = box_ref.match(0.5, t1[:, :4], priors, [0.1, 0.2], t1[:, 4:])
+    assert torch.equal(conf_t[1].cpu(), want[1]) and torch.equal(obj_t[1].cpu(), want[2])
+    # one box: kept
+    one = np.array([[10, 10, 50, 60, 0.7]], np.float32)
+    assert ops.nms_sorted_host(one, 0.45).tolist() == [0]
