@@ -216,6 +216,40 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
+// sliced variants (grid = channels x slices): block sums in double meet in `scratch` ([2][C] doubles, zeroed by the
+// host entry) through f64 atomics; a one-block-per-channel reduction leaves most of the chip idle on the RFB maps
+__global__ __launch_bounds__(256) void bn_stats_part_kernel(const float* __restrict__ z, int batch, int ctot,
+                                                            int coff, int C, int HW, int per_slice,
+                                                            double* __restrict__ scratch)
+{
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const long e0 = (long)blockIdx.y * per_slice, e1 = min(e0 + per_slice, (long)batch * HW);
+    double s = 0.0, ss = 0.0;
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int n = (int)(e / HW), i = (int)(e - (long)n * HW);
+        const double v = z[((size_t)n * ctot + coff + c) * HW + i];
+        s += v;
+        ss += v * v;
+    }
+    s = block_sum(s, red);
+    ss = block_sum(ss, red);
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(&scratch[c], s);
+        unsafeAtomicAdd(&scratch[C + c], ss);
+    }
+}
+
+__global__ void bn_stats_final_kernel(const double* __restrict__ scratch, int C, double cnt,
+                                      float* __restrict__ mean, float* __restrict__ var)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double m = scratch[c] / cnt;
+    mean[c] = (float)m;
+    var[c] = (float)fmax(scratch[C + c] / cnt - m * m, 0.0);
+}
+
 // running_mean/var update of nn.BatchNorm2d (momentum m, unbiased variance), count = batch*HW
 __global__ void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var, int C,
                                   float momentum, float unbias, float* __restrict__ rmean,
@@ -303,6 +337,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdArgs a)
         a.dbeta[c] = (float)sb;
         a.dgamma[c] = (float)sg;
     }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_part_kernel(const BnBwdArgs a, int per_slice,
+                                                                 double* __restrict__ scratch)
+{
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    const float inv = 1.f / sqrtf(a.var[c] + a.eps), mu = a.mean[c];
+    const long e0 = (long)blockIdx.y * per_slice, e1 = min(e0 + per_slice, (long)a.batch * a.HW);
+    double sb = 0.0, sg = 0.0;
+    for (long e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int n = (int)(e / a.HW), i = (int)(e - (long)n * a.HW);
+        const float g = masked_dy(a, n, c, i) * a.rscale;
+        sb += g;
+        sg += (double)g * ((a.z[((size_t)n * a.z_ctot + a.z_coff + c) * a.HW + i] - mu) * inv);
+    }
+    sb = block_sum(sb, red);
+    sg = block_sum(sg, red);
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(&scratch[c], sb);
+        unsafeAtomicAdd(&scratch[a.C + c], sg);
+    }
+}
+
+__global__ void bn_bwd_reduce_final_kernel(const double* __restrict__ scratch, int C, float* __restrict__ dbeta,
+                                           float* __restrict__ dgamma)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)scratch[c];
+    dgamma[c] = (float)scratch[C + c];
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a)
@@ -514,12 +579,25 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
 
 extern "C" int ct_bn_train_stats(const float* z, int batch, int ctot, int coff, int channels, int hw,
                                  float* mean, float* var, float momentum, float* running_mean,
-                                 float* running_var, ct_stream_t stream)
+                                 float* running_var, void* scratch, ct_stream_t stream)
 {
     CT_REQUIRE(z && mean && var && batch > 0 && channels > 0 && hw > 0, "ct_bn_train_stats: bad arguments");
     hipStream_t st = ctdet::as_stream(stream);
-    hipLaunchKernelGGL(bn_stats_kernel, dim3(channels), dim3(256), 0, st, z, batch, ctot, coff, hw, mean, var);
-    CT_LAUNCH_CHECK("bn_stats_kernel");
+    const long per_channel = (long)batch * hw;
+    const int slices = (int)std::max<long>(1, std::min<long>((1024 + channels - 1) / channels, per_channel / 2048));
+    if (scratch && slices > 1) {
+        const int per_slice = (int)((per_channel + slices - 1) / slices);
+        CT_HIP(hipMemsetAsync(scratch, 0, (size_t)2 * channels * sizeof(double), st));
+        hipLaunchKernelGGL(bn_stats_part_kernel, dim3(channels, slices), dim3(256), 0, st, z, batch, ctot, coff,
+                           channels, hw, per_slice, (double*)scratch);
+        CT_LAUNCH_CHECK("bn_stats_part_kernel");
+        hipLaunchKernelGGL(bn_stats_final_kernel, dim3((channels + 255) / 256), dim3(256), 0, st,
+                           (const double*)scratch, channels, (double)per_channel, mean, var);
+        CT_LAUNCH_CHECK("bn_stats_final_kernel");
+    } else {
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(channels), dim3(256), 0, st, z, batch, ctot, coff, hw, mean, var);
+        CT_LAUNCH_CHECK("bn_stats_kernel");
+    }
     if (running_mean && running_var) {
         const float cnt = (float)batch * hw;
         hipLaunchKernelGGL(bn_running_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, mean, var,
@@ -554,7 +632,7 @@ extern "C" int ct_bn_train_backward(const float* dy, int dy_ctot, int dy_coff, c
                                     float res_scale, float* dres, int dres_ctot, int dres_coff,
                                     int dres_accumulate, float* dz, float* dgamma, float* dbeta,
                                     int z_ctot, int z_coff, int batch, int channels, int hw,
-                                    ct_stream_t stream)
+                                    void* scratch, ct_stream_t stream)
 {
     CT_REQUIRE(dy && z && mean && var && gamma && dz && dgamma && dbeta, "ct_bn_train_backward: null pointer");
     CT_REQUIRE(!(relu || lo) || y, "ct_bn_train_backward: ReLU mask needs the forward output");
@@ -566,8 +644,21 @@ extern "C" int ct_bn_train_backward(const float* dy, int dy_ctot, int dy_coff, c
     a.dres_accumulate = dres_accumulate; a.eps = eps; a.rscale = res_scale; a.relu = relu;
     a.z_ctot = z_ctot; a.z_coff = z_coff;
     hipStream_t st = ctdet::as_stream(stream);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(channels), dim3(256), 0, st, a);
-    CT_LAUNCH_CHECK("bn_bwd_reduce_kernel");
+    const long per_channel = (long)batch * hw;
+    const int slices = (int)std::max<long>(1, std::min<long>((1024 + channels - 1) / channels, per_channel / 2048));
+    if (scratch && slices > 1) {
+        const int per_slice = (int)((per_channel + slices - 1) / slices);
+        CT_HIP(hipMemsetAsync(scratch, 0, (size_t)2 * channels * sizeof(double), st));
+        hipLaunchKernelGGL(bn_bwd_reduce_part_kernel, dim3(channels, slices), dim3(256), 0, st, a, per_slice,
+                           (double*)scratch);
+        CT_LAUNCH_CHECK("bn_bwd_reduce_part_kernel");
+        hipLaunchKernelGGL(bn_bwd_reduce_final_kernel, dim3((channels + 255) / 256), dim3(256), 0, st,
+                           (const double*)scratch, channels, dbeta, dgamma);
+        CT_LAUNCH_CHECK("bn_bwd_reduce_final_kernel");
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(channels), dim3(256), 0, st, a);
+        CT_LAUNCH_CHECK("bn_bwd_reduce_kernel");
+    }
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long)batch * channels * hw)), dim3(256), 0, st, a);
     CT_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return CT_OK;

@@ -86,10 +86,10 @@ SIGNATURES = {
     'ct_conv_pack_weights': (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
     'ct_conv_pack_weights_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
     'ct_conv2d_wgrad': (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P]),
-    'ct_bn_train_stats': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P]),
+    'ct_bn_train_stats': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     'ct_bn_train_apply': (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _I, _I, _F, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'ct_bn_train_backward': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _F, _I, _P, _F, _P, _I, _I, _I,
-                                  _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+                                  _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'ct_bias_act_backward': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
     'ct_maxpool2d_bwd': (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'ct_head_grad_gather': (_I, [C.POINTER(OutSegment), _I, _I, _I, _I, _P, _P]),

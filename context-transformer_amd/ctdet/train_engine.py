@@ -78,6 +78,7 @@ class TrainRuntime:
                 s.var = [al((p.cout,)) for p in st.parts]
                 s.dgamma = [al((p.cout,)) for p in st.parts]
                 s.dbeta = [al((p.cout,)) for p in st.parts]
+                s.scratch = [al((2 * p.cout,), torch.float64) for p in st.parts]     # sliced BN reductions
             else:
                 backend.prepare_conv(st, self.bufs, batch)
                 apply_tuned(backend, st, batch)
@@ -200,7 +201,8 @@ class TrainRuntime:
                 bn = p.bn
                 _lib.check(lib.ct_bn_train_stats(z.data_ptr(), B, z.shape[1], off, p.cout, hw,
                                                  s.mean[i].data_ptr(), s.var[i].data_ptr(), float(bn.momentum),
-                                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), self._s()),
+                                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                                 s.scratch[i].data_ptr(), self._s()),
                            st.name + ' bn stats')
                 bn.num_batches_tracked += 1
                 res = self.bufs[st.res] if st.res is not None else None
@@ -303,7 +305,7 @@ class TrainRuntime:
                             z.data_ptr(), s.mean[i].data_ptr(), s.var[i].data_ptr(), p.bn.weight.data_ptr(),
                             float(p.bn.eps), int(p.relu), None, float(st.res_scale), dres, dres_ctot, st.res_coff,
                             dres_acc, s.dz.data_ptr(), s.dgamma[i].data_ptr(), s.dbeta[i].data_ptr(), ctot, off,
-                            B, p.cout, hw, self._s()), st.name + ' bn bwd')
+                            B, p.cout, hw, s.scratch[i].data_ptr(), self._s()), st.name + ' bn bwd')
                         put(p.bn.weight, s.dgamma[i].clone())
                         put(p.bn.bias, s.dbeta[i].clone())
                     else:

@@ -260,9 +260,11 @@ int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ctot, int dz_
  *            variance when running_mean/var are given)
  *   apply    y = act( ((z-mean)/sqrt(var+eps)*gamma + beta) [* res_scale + res] ) into a channel slice
  *   backward dz, dgamma, dbeta (and the residual branch's gradient) from dy */
+/* `scratch` (both BatchNorm entry points): optional device buffer of 2*channels doubles; with it the per-channel
+ * reductions are split over several workgroups per channel (f64 atomics), without it one workgroup per channel. */
 int ct_bn_train_stats(const float* z, int batch, int ctot, int coff, int channels, int hw,
                       float* mean, float* var, float momentum, float* running_mean, float* running_var,
-                      ct_stream_t stream);
+                      void* scratch, ct_stream_t stream);
 int ct_bn_train_apply(const float* z, const float* mean, const float* var, const float* gamma,
                       const float* beta, float eps, int relu, const float* lo, const float* res,
                       int res_ctot, int res_coff, float res_scale, float* y, int y_ctot, int y_coff,
@@ -272,7 +274,7 @@ int ct_bn_train_backward(const float* dy, int dy_ctot, int dy_coff, const float*
                          float eps, int relu, const float* lo, float res_scale,
                          float* dres, int dres_ctot, int dres_coff, int dres_accumulate,
                          float* dz, float* dgamma, float* dbeta, int z_ctot, int z_coff,
-                         int batch, int channels, int hw, ct_stream_t stream);
+                         int batch, int channels, int hw, void* scratch, ct_stream_t stream);
 /* y = act(conv + bias): dz = dy * (y > 0 if relu) into a channel slice, dbias[c] = sum dz (may be NULL). */
 int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot, int y_coff,
                          int relu, int batch, int channels, int hw, float* dz, int dz_ctot, int dz_coff,

@@ -78,10 +78,11 @@ def test_conv_dgrad_wgrad_vs_autograd(g):
     assert rel_err(dx[:, 2:2 + Cin].cpu(), 2 * x.grad) < 1e-4
 
 
-def test_batchnorm_train_forward_backward():
+@pytest.mark.parametrize('sliced', [False, True])
+def test_batchnorm_train_forward_backward(sliced):
     lib = _lib.lib()
     gen = torch.Generator().manual_seed(3)
-    B, Cc, H, W = 3, 10, 7, 5
+    B, Cc, H, W = (4, 10, 40, 30) if sliced else (3, 10, 7, 5)      # 4800 elements per channel -> 2 slices
     z = (torch.randn(B, Cc + 3, H, W, generator=gen) * 2 + 0.5)
     zs = z[:, 2:2 + Cc].clone().requires_grad_(True)
     gamma = (torch.rand(Cc, generator=gen) + 0.5).requires_grad_(True)
@@ -94,9 +95,10 @@ def test_batchnorm_train_forward_backward():
     y.backward(dy)
     zd = _cuda(z)
     mean, var = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
+    scratch = torch.empty(2 * Cc, device=DEV, dtype=torch.float64)       # enables the sliced reductions
     rmd, rvd = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
     _lib.check(lib.ct_bn_train_stats(zd.data_ptr(), B, Cc + 3, 2, Cc, H * W, mean.data_ptr(), var.data_ptr(), 0.01,
-                                     rmd.data_ptr(), rvd.data_ptr(), _s()), 'stats')
+                                     rmd.data_ptr(), rvd.data_ptr(), scratch.data_ptr() if sliced else None, _s()), 'stats')
     assert rel_err(rmd.cpu(), rm) < 1e-5 and rel_err(rvd.cpu(), rv) < 1e-5
     yd = torch.full((B, Cc + 2, H, W), 9.0, device=DEV)
     gd, bd, resd = _cuda(gamma.detach()), _cuda(beta.detach()), _cuda(res.detach())
@@ -110,8 +112,8 @@ def test_batchnorm_train_forward_backward():
     dg, db = torch.empty(Cc, device=DEV), torch.empty(Cc, device=DEV)
     _lib.check(lib.ct_bn_train_backward(dyd.data_ptr(), Cc, 0, yd.data_ptr(), Cc + 2, 1, zd.data_ptr(), mean.data_ptr(),
                                         var.data_ptr(), gd.data_ptr(), 1e-5, 1, None, 0.7, dres.data_ptr(), Cc, 0, 0,
-                                        dz.data_ptr(), dg.data_ptr(), db.data_ptr(), Cc + 3, 2, B, Cc, H * W, _s()),
-               'bn bwd')
+                                        dz.data_ptr(), dg.data_ptr(), db.data_ptr(), Cc + 3, 2, B, Cc, H * W,
+                                        scratch.data_ptr() if sliced else None, _s()), 'bn bwd')
     assert rel_err(dz[:, 2:2 + Cc].cpu(), zs.grad) < 1e-4
     assert rel_err(dg.cpu(), gamma.grad) < 1e-4 and rel_err(db.cpu(), beta.grad) < 1e-4
     assert rel_err(dres.cpu(), res.grad) < 1e-5
