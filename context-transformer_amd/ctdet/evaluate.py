@@ -130,3 +130,46 @@ def evaluate_detections(all_boxes, image_ids, gt_by_class, classes, use_07_metri
         lines = results_lines(all_boxes[cls_ind], image_ids)
         aps[cls] = float(voc_eval_lines(lines, gt_by_class.get(cls, {}), ovthresh, use_07_metric)[2])
     return aps, float(np.mean(list(aps.values()))) if aps else float('nan')
+
+
+def coco_results(all_boxes, image_ids, category_ids):
+    """data/coco.py:242-270: all_boxes[cls][img] -> the list of COCO result dicts
+    {image_id, category_id, bbox [x, y, w, h] with the +1 width/height convention, score}.
+    category_ids[cls] is the COCO id of class index cls (index 0 = background is skipped)."""
+    out = []
+    for cls_ind, cat_id in enumerate(category_ids):
+        if cls_ind == 0:
+            continue
+        for im_ind, image_id in enumerate(image_ids):
+            dets = all_boxes[cls_ind][im_ind]
+            if len(dets) == 0:
+                continue
+            dets = np.asarray(dets, dtype=np.float64)
+            xs, ys = dets[:, 0], dets[:, 1]
+            ws, hs = dets[:, 2] - xs + 1, dets[:, 3] - ys + 1
+            out.extend({'image_id': image_id, 'category_id': cat_id,
+                        'bbox': [float(xs[k]), float(ys[k]), float(ws[k]), float(hs[k])],
+                        'score': float(dets[k, -1])} for k in range(dets.shape[0]))
+    return out
+
+
+def write_coco_results(all_boxes, image_ids, category_ids, res_file):
+    """data/coco.py:260-274: JSON file for pycocotools' loadRes."""
+    import json
+    with open(res_file, 'w') as f:
+        json.dump(coco_results(all_boxes, image_ids, category_ids), f)
+    return res_file
+
+
+def detection_collate(batch):
+    """data/voc0712.py:429-451: (image tensor, [G,6] annotation array) samples -> (stacked images, list of
+    float target tensors [x1,y1,x2,y2,label,weight]) -- the layout MultiBoxLoss_combined and init_reweight take."""
+    import torch
+    imgs, targets = [], []
+    for sample in batch:
+        for item in sample:
+            if torch.is_tensor(item):
+                imgs.append(item)
+            elif isinstance(item, np.ndarray):
+                targets.append(torch.from_numpy(item).float())
+    return torch.stack(imgs, 0), targets

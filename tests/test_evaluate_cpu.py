@@ -97,3 +97,22 @@ def test_file_based_voc_eval_entry_point(tmp_path):
                                         str(tmp_path / 'test.txt'), CLASSES[ci], str(tmp_path / 'cache'), 0.5, True)
             assert np.array_equal(rec, G['c%d_07_rec' % ci]) and ap == float(G['c%d_07_ap' % ci])
     assert os.path.isfile(tmp_path / 'cache' / 'annots.pkl')
+
+
+def test_coco_results_and_collate(tmp_path):
+    """data/coco.py:242-274 result dicts (x, y, w+1, h+1) and data/voc0712.py:429-451 collate layout."""
+    import json
+    import torch
+    ab = [[[], []], [np.array([[10., 20., 29., 59., 0.5]], np.float32), np.empty((0, 5), np.float32)],
+          [[], np.array([[1., 2., 3., 4., 0.25], [0., 0., 9., 9., 0.75]], np.float32)]]
+    res = evaluate.coco_results(ab, [42, 43], [0, 18, 7])
+    assert res == [{'image_id': 42, 'category_id': 18, 'bbox': [10.0, 20.0, 20.0, 40.0], 'score': 0.5},
+                   {'image_id': 43, 'category_id': 7, 'bbox': [1.0, 2.0, 3.0, 3.0], 'score': 0.25},
+                   {'image_id': 43, 'category_id': 7, 'bbox': [0.0, 0.0, 10.0, 10.0], 'score': 0.75}]
+    path = evaluate.write_coco_results(ab, [42, 43], [0, 18, 7], str(tmp_path / 'r.json'))
+    assert json.load(open(path)) == res
+    batch = [(torch.zeros(3, 4, 4), np.array([[0.1, 0.1, 0.5, 0.5, 3, 1]])),
+             (torch.ones(3, 4, 4), np.zeros((0, 6)))]
+    imgs, targets = evaluate.detection_collate(batch)
+    assert imgs.shape == (2, 3, 4, 4) and [t.shape for t in targets] == [(1, 6), (0, 6)]
+    assert targets[0].dtype == torch.float32
