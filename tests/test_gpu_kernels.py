@@ -399,3 +399,20 @@ def test_degenerate_inputs():
     # one box: kept
     one = np.array([[10, 10, 50, 60, 0.7]], np.float32)
     assert ops.nms_sorted_host(one, 0.45).tolist() == [0]
+
+
+def test_c_caller_runs_the_nms_contract_on_the_device(tmp_path):
+    """examples/c_caller.c (plain C, no Python) through ct_nms_sorted_host: the drop-in for the reference's `_nms`."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('gcc not available')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(repo, 'context-transformer_amd', 'lib')
+    exe = str(tmp_path / 'c_caller')
+    subprocess.check_call(['gcc', '-std=c99', '-I' + os.path.join(repo, 'include'), os.path.join(repo, 'examples', 'c_caller.c'),
+                           '-L' + libdir, '-lctdet', '-Wl,-rpath,' + libdir, '-o', exe])
+    r = subprocess.run([exe, 'gpu'], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert '_nms contract keeps 2: 0 2' in r.stdout
