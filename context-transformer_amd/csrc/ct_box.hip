@@ -5,6 +5,7 @@
 // reference's rounding sequence (no FMA contraction), so integer results derived from these
 // values (arg-max indices, match labels) are reproducible against the CPU path.
 #include "ct_common.h"
+#include <mutex>
 #include <algorithm>
 
 #pragma clang fp contract(off)
@@ -67,6 +68,10 @@ __global__ __launch_bounds__(256) void encode_kernel(const float4* __restrict__ 
 }
 
 // layers/functions/detection.py:44-53 (+ models/RFB_Net_vgg.py:282-284 when SOFTMAX)
+// One workgroup = 256 consecutive (image, prior) rows.  The class rows (C floats in, C+1 out) are contiguous
+// in memory, so the block copies them through LDS with fully coalesced loads / stores (odd row stride in LDS ->
+// conflict-free per-row access); each thread then does its row's arithmetic
+// in exactly the reference's order (max, sum of exp, exp / sum, * obj1).
 template <bool SOFTMAX>
 __global__ __launch_bounds__(256) void detect_kernel(const float4* __restrict__ loc,
                                                      const float* __restrict__ conf,
@@ -76,9 +81,20 @@ __global__ __launch_bounds__(256) void detect_kernel(const float4* __restrict__ 
                                                      const float* __restrict__ scale4, int per_image,
                                                      float4* __restrict__ boxes, float* __restrict__ scores)
 {
+    extern __shared__ float tile[];                    // [256][LDC], row = [obj0, class 0 .. C-1]
+    const int LDC = (C + 1) | 1;                       // odd row stride: conflict-free per-row access
     const long total = (long)batch * P;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+    const long row0 = (long)blockIdx.x * 256;
+    const int rows = (int)min((long)256, total - row0);
+    const float* cin = conf + row0 * C;
+    for (int e = threadIdx.x; e < rows * C; e += 256) {
+        const int r = e / C, k = e - r * C;
+        tile[r * LDC + 1 + k] = cin[e];
+    }
+    __syncthreads();
+    const int r = threadIdx.x;
+    if (r < rows) {
+        const long idx = row0 + r;
         const int p = (int)(idx % P);
         float4 bx = decode_one(loc[idx], priors[p], v0, v1);
         if (scale4) {
@@ -87,8 +103,7 @@ __global__ __launch_bounds__(256) void detect_kernel(const float4* __restrict__ 
         }
         boxes[idx] = bx;
         float2 o = obj[idx];
-        const float* c = conf + idx * C;
-        float* s = scores + idx * (C + 1);
+        float* c = tile + r * LDC + 1;
         if (SOFTMAX) {
             const float om = fmaxf(o.x, o.y);
             const float e0 = expf(o.x - om), e1 = expf(o.y - om);
@@ -98,13 +113,22 @@ __global__ __launch_bounds__(256) void detect_kernel(const float4* __restrict__ 
             float m = -INFINITY;
             for (int k = 0; k < C; ++k) m = fmaxf(m, c[k]);
             float sum = 0.f;
-            for (int k = 0; k < C; ++k) sum += expf(c[k] - m);
-            s[0] = o.x;
-            for (int k = 0; k < C; ++k) s[1 + k] = o.y * (expf(c[k] - m) / sum);
+            for (int k = 0; k < C; ++k) {
+                const float ex = expf(c[k] - m);
+                c[k] = ex;
+                sum += ex;
+            }
+            for (int k = 0; k < C; ++k) c[k] = o.y * (c[k] / sum);
         } else {
-            s[0] = o.x;
-            for (int k = 0; k < C; ++k) s[1 + k] = o.y * c[k];
+            for (int k = 0; k < C; ++k) c[k] = o.y * c[k];
         }
+        c[-1] = o.x;
+    }
+    __syncthreads();
+    float* sout = scores + row0 * (C + 1);
+    for (int e = threadIdx.x; e < rows * (C + 1); e += 256) {
+        const int rr = e / (C + 1), k = e - rr * (C + 1);
+        sout[e] = tile[rr * LDC + k];
     }
 }
 
@@ -269,14 +293,29 @@ extern "C" int ct_detect_fused(const float* loc, const float* conf, const float*
 {
     CT_REQUIRE(loc && conf && obj && priors && boxes && scores, "ct_detect_fused: null tensor");
     CT_REQUIRE(batch > 0 && num_priors > 0 && num_fg > 0, "ct_detect_fused: bad shape");
-    const dim3 grid(grid_for((long)batch * num_priors)), block(256);
+    CT_REQUIRE(num_fg <= 1024, "ct_detect_fused: num_fg=%d (<= 1024)", num_fg);
+    const long nblk = ((long)batch * num_priors + 255) / 256;
+    CT_REQUIRE(nblk < 0x7FFFFFFFL, "ct_detect_fused: too many rows");
+    const dim3 grid((unsigned)nblk), block(256);
+    const size_t smem = (size_t)256 * (num_fg + 2) * sizeof(float);
     hipStream_t st = ctdet::as_stream(stream);
+    if (smem > 64 * 1024) {
+        static std::once_flag once;
+        static hipError_t e1 = hipSuccess, e2 = hipSuccess;
+        std::call_once(once, [] {
+            e1 = hipFuncSetAttribute((const void*)detect_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            e2 = hipFuncSetAttribute((const void*)detect_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        });
+        CT_HIP(e1);
+        CT_HIP(e2);
+        CT_REQUIRE(smem <= 160 * 1024, "ct_detect_fused: num_fg=%d needs %zu bytes of LDS", num_fg, smem);
+    }
     if (apply_softmax)
-        hipLaunchKernelGGL(detect_kernel<true>, grid, block, 0, st, (const float4*)loc, conf,
+        hipLaunchKernelGGL(detect_kernel<true>, grid, block, smem, st, (const float4*)loc, conf,
                            (const float2*)obj, (const float4*)priors, batch, num_priors, num_fg, var0,
                            var1, scale4, scale_per_image, (float4*)boxes, scores);
     else
-        hipLaunchKernelGGL(detect_kernel<false>, grid, block, 0, st, (const float4*)loc, conf,
+        hipLaunchKernelGGL(detect_kernel<false>, grid, block, smem, st, (const float4*)loc, conf,
                            (const float2*)obj, (const float4*)priors, batch, num_priors, num_fg, var0,
                            var1, scale4, scale_per_image, (float4*)boxes, scores);
     CT_LAUNCH_CHECK("detect_kernel");
