@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
 #pragma unroll
     for (int j = 0; j < ROWS; ++j) {
         const int m = m0 + wave + 4 * j;
-        a_soff[j] = m < a.Cout ? m * a.OHW * 4 : -1;
+        a_soff[j] = min(m, a.Cout - 1) * a.OHW * 4;      // rows past Cout repeat the last one: their results are never stored
         if (TAPMAJOR) {
             b_soff[j] = (tm_ci0 + wave + 4 * j) * HW * 4;
             b_dh[j] = tm_dh;
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
             const int col = c0 + wave + 4 * j;
             const int ci = col / KHW, tap = col - ci * KHW;
             const int kh = tap / KW, kw = tap - kh * KW;
-            b_soff[j] = col < a.Ncols ? ci * HW * 4 : -1;
+            b_soff[j] = min(ci, a.Cin - 1) * HW * 4;    // columns past Ncols: clamped, never stored
             b_dh[j] = kh * a.dil - a.pad_h;
             b_dw[j] = kw * a.dil - a.pad_w;
         }
@@ -104,24 +104,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
             const int xoff = ok ? (xbase + ih * a.W + iw) * 4 : kInvalidOff;
 #pragma unroll
             for (int j = 0; j < ROWS; ++j) {
-                areg[j] = a_soff[j] >= 0
-                              ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff, a_soff[j], 0))
-                              : 0.f;
+                areg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff, a_soff[j], 0));
                 breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff, b_soff[j], 0));
             }
             return;
         }
 #pragma unroll
         for (int j = 0; j < ROWS; ++j) {
-            areg[j] = a_soff[j] >= 0
-                          ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff, a_soff[j], 0))
-                          : 0.f;
+            areg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff, a_soff[j], 0));
             const int ih = ih0 + b_dh[j], iw = iw0 + b_dw[j];
             const bool ok = pv && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
             const int xoff = ok ? (xbase + ih * a.W + iw) * 4 : kInvalidOff;
-            breg[j] = b_soff[j] >= 0
-                          ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff, b_soff[j], 0))
-                          : 0.f;
+            breg[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff, b_soff[j], 0));
         }
     };
 
