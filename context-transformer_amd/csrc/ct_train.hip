@@ -119,13 +119,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
         }
     };
 
-    f32x16 acc[TB][TB];
+    f32x16 acc[TB][TB], acc2[TB][TB];
 #pragma unroll
     for (int i = 0; i < TB; ++i)
 #pragma unroll
         for (int j = 0; j < TB; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
 
     load_chunk(p_begin);
     for (int p0 = p_begin; p0 < p_end; p0 += BKP) {
@@ -149,8 +149,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
 #pragma unroll
             for (int i = 0; i < TB; ++i)
 #pragma unroll
-                for (int j = 0; j < TB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TB; ++j) {
+                    if (s & 1) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc2[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
         }
         __syncthreads();
     }
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-                if (m < a.Cout) unsafeAtomicAdd(a.dw + (size_t)m * a.Ncols + col, acc[i][j][r]);
+                if (m < a.Cout) unsafeAtomicAdd(a.dw + (size_t)m * a.Ncols + col, acc[i][j][r] + acc2[i][j][r]);
             }
     }
 }
