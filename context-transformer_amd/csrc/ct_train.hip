@@ -127,34 +127,100 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(const WgradArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acc2[i][j][r] = 0.f; }
 
-    load_chunk(p_begin);
-    for (int p0 = p_begin; p0 < p_end; p0 += BKP) {
+    if (TAPMAJOR && TB == 1) {
+        // Pipelined variant (same structure as the forward implicit-GEMM kernel): two LDS buffers, ONE barrier
+        // per chunk; in k-pair slot e the wave stores element e of chunk c+1 (loaded during chunk c-1) into
+        // the other buffer and re-issues the load of element e for chunk c+2, then runs the slot's MFMA.
+        float* As2 = wg_lds + 2 * BKP * LD;
+        float* Bs2 = As2 + BKP * LD;
+        int zoff, xoff;
+        auto setup = [&](int p0) {
+            const int P = p0 + lane;
+            const bool pv = P < p_end;
+            const int Pc = pv ? P : 0;
+            const int n = Pc / a.OHW;
+            const int sp = Pc - n * a.OHW;
+            const int oh = sp / a.OW, ow = sp - oh * a.OW;
+            zoff = pv ? ((n * a.dz_ctot + a.dz_coff) * a.OHW + sp) * 4 : kInvalidOff;
+            const int ih = oh * a.stride + tm_dh, iw = ow * a.stride + tm_dw;
+            const bool ok = pv && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            xoff = ok ? ((n * a.x_ctot + a.x_coff) * HW + ih * a.W + iw) * 4 : kInvalidOff;
+        };
+        auto load_e = [&](int e) {
+            if (e < ROWS) areg[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rz, zoff, a_soff[e], 0));
+            else breg[e - ROWS] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, xoff, b_soff[e - ROWS], 0));
+        };
+        auto store_e = [&](int e, float* Ad, float* Bd) {
+            if (e < ROWS) Ad[lane * LD + wave + 4 * e] = areg[e];
+            else Bd[lane * LD + wave + 4 * (e - ROWS)] = breg[e - ROWS];
+        };
+        setup(p_begin);
 #pragma unroll
-        for (int j = 0; j < ROWS; ++j) {
-            As[lane * LD + wave + 4 * j] = areg[j];
-            Bs[lane * LD + wave + 4 * j] = breg[j];
-        }
+        for (int e = 0; e < 2 * ROWS; ++e) load_e(e);
+#pragma unroll
+        for (int e = 0; e < 2 * ROWS; ++e) store_e(e, As, Bs);
+        setup(p_begin + BKP);                    // past the end: every offset invalid -> zeros
+#pragma unroll
+        for (int e = 0; e < 2 * ROWS; ++e) load_e(e);
         __syncthreads();
-        if (p0 + BKP < p_end) load_chunk(p0 + BKP);
-        const float* Ab = As + hsel * LD + wm0 + l31;
-        const float* Bb = Bs + hsel * LD + wn0 + l31;
-#pragma unroll 8
-        for (int s = 0; s < BKP / 2; ++s) {
-            float af[TB], bf[TB];
+        int cidx = 0;
+        for (int p0 = p_begin; p0 < p_end; p0 += BKP, ++cidx) {
+            const float* Ac = (cidx & 1) ? As2 : As;
+            const float* Bc = (cidx & 1) ? Bs2 : Bs;
+            float* An = (cidx & 1) ? As : As2;
+            float* Bn = (cidx & 1) ? Bs : Bs2;
+            const float* Ab = Ac + hsel * LD + wm0 + l31;
+            const float* Bb = Bc + hsel * LD + wn0 + l31;
+            // registers hold chunk c+1; the loads issued below fetch chunk c+2
+            setup(p0 + 2 * BKP);
+            float af[2], bf[2];
+            af[0] = Ab[0];
+            bf[0] = Bb[0];
 #pragma unroll
-            for (int i = 0; i < TB; ++i) {
-                af[i] = Ab[(2 * s) * LD + 32 * i];
-                bf[i] = Bb[(2 * s) * LD + 32 * i];
-            }
-#pragma unroll
-            for (int i = 0; i < TB; ++i)
-#pragma unroll
-                for (int j = 0; j < TB; ++j) {
-                    if (s & 1) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc2[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int sidx = 0; sidx < BKP / 2; ++sidx) {
+                const int cur = sidx & 1;
+                if (sidx + 1 < BKP / 2) {
+                    af[cur ^ 1] = Ab[(2 * sidx + 2) * LD];
+                    bf[cur ^ 1] = Bb[(2 * sidx + 2) * LD];
                 }
+                store_e(sidx, An, Bn);
+                load_e(sidx);
+                if (sidx & 1) acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur], acc2[0][0], 0, 0, 0);
+                else acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur], bf[cur], acc[0][0], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    } else {
+    load_chunk(p_begin);
+        for (int p0 = p_begin; p0 < p_end; p0 += BKP) {
+    #pragma unroll
+            for (int j = 0; j < ROWS; ++j) {
+                As[lane * LD + wave + 4 * j] = areg[j];
+                Bs[lane * LD + wave + 4 * j] = breg[j];
+            }
+            __syncthreads();
+            if (p0 + BKP < p_end) load_chunk(p0 + BKP);
+            const float* Ab = As + hsel * LD + wm0 + l31;
+            const float* Bb = Bs + hsel * LD + wn0 + l31;
+    #pragma unroll 8
+            for (int s = 0; s < BKP / 2; ++s) {
+                float af[TB], bf[TB];
+    #pragma unroll
+                for (int i = 0; i < TB; ++i) {
+                    af[i] = Ab[(2 * s) * LD + 32 * i];
+                    bf[i] = Bb[(2 * s) * LD + 32 * i];
+                }
+    #pragma unroll
+                for (int i = 0; i < TB; ++i)
+    #pragma unroll
+                    for (int j = 0; j < TB; ++j) {
+                        if (s & 1) acc2[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc2[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+            __syncthreads();
+        }
     }
 
 #pragma unroll
@@ -538,8 +604,11 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
     splits = (a.Npix + a.pix_per_split - 1) / a.pix_per_split;
     hipStream_t st = ctdet::as_stream(stream);
     CT_HIP(hipMemsetAsync(dw, 0, (size_t)d->cout * a.Ncols * 4, st));
+    const bool tapmajor = d->cin % bt == 0 && !(getenv("CTDET_WGRAD_GENERIC"));
+    const bool tapmajor_for_smem = tapmajor;
     const dim3 grid(tiles, splits), block(256);
-    const size_t smem = 2 * 64 * (size_t)(bt + 1) * 4;
+    const bool pipelined = tapmajor_for_smem && tb == 1;
+    const size_t smem = (pipelined ? 4 : 2) * 64 * (size_t)(bt + 1) * 4;
     hipError_t le = hipSuccess;
     auto go = [&](auto kernel) {
         if (smem > 64 * 1024) {
@@ -553,7 +622,6 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
         }
         if (le == hipSuccess) hipLaunchKernelGGL(kernel, grid, block, smem, st, a);
     };
-    const bool tapmajor = d->cin % bt == 0 && !(getenv("CTDET_WGRAD_GENERIC"));
 #define CT_WGRAD_GO(KH, KW)                                                    \
     do {                                                                       \
         if (tb == 2 && tapmajor) go(conv_wgrad_f32<KH, KW, 2, true>);          \
