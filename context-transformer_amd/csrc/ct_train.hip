@@ -540,6 +540,49 @@ __global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const float* __restr
     }
 }
 
+// MaxPool2d(2, 2) (floor or ceil mode): the windows do not overlap, so one thread owns one window -- reads its
+// (up to) 2x2 inputs, finds the first maximum in row-major order (strict >, as the gather kernel above) and
+// writes all four gradients; input rows/columns no window covers (floor mode, odd extent) get zeros.
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ dy,
+                                                             float* __restrict__ dx, int H, int W, int OH, int OW,
+                                                             int accumulate)
+{
+    const int WH = (H + 1) >> 1, WW = (W + 1) >> 1;
+    const float* xp = x + (size_t)blockIdx.x * H * W;
+    float* dp = dx + (size_t)blockIdx.x * H * W;
+    const float* gp = dy + (size_t)blockIdx.x * OH * OW;
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(WH * WW); idx += 256) {
+        const int wh = idx / (unsigned)WW, ww = idx - wh * WW;
+        const int h0 = 2 * wh, w0 = 2 * ww;
+        const bool h1 = h0 + 1 < H, w1 = w0 + 1 < W;
+        const float g = (wh < OH && ww < OW) ? gp[wh * OW + ww] : 0.f;
+        const int o = h0 * W + w0;
+        const float v00 = xp[o];
+        const float v01 = w1 ? xp[o + 1] : -INFINITY;
+        const float v10 = h1 ? xp[o + W] : -INFINITY;
+        const float v11 = (h1 && w1) ? xp[o + W + 1] : -INFINITY;
+        int sel = -1;
+        float m = -INFINITY;
+        if (v00 > m) { m = v00; sel = 0; }
+        if (v01 > m) { m = v01; sel = 1; }
+        if (v10 > m) { m = v10; sel = 2; }
+        if (v11 > m) { m = v11; sel = 3; }
+        const float g0 = sel == 0 ? g : 0.f, g1 = sel == 1 ? g : 0.f, g2 = sel == 2 ? g : 0.f, g3 = sel == 3 ? g : 0.f;
+        if (accumulate) {
+            dp[o] += g0;
+            if (w1) dp[o + 1] += g1;
+            if (h1) dp[o + W] += g2;
+            if (h1 && w1) dp[o + W + 1] += g3;
+        } else {
+            dp[o] = g0;
+            if (w1) dp[o + 1] = g1;
+            if (h1) dp[o + W] = g2;
+            if (h1 && w1) dp[o + W + 1] = g3;
+        }
+    }
+}
+
 // gradient of the channels-last head scatter: dz[n][co][pix] = dflat[n*img_stride + base + pix*ps + (co-co0)]
 struct HeadGatherArgs {
     ct_out_segment seg[3];
@@ -754,6 +797,12 @@ extern "C" int ct_maxpool2d_bwd(const float* x, const float* dy, float* dx, long
 {
     CT_REQUIRE(x && dy && dx && planes > 0, "ct_maxpool2d_bwd: bad arguments");
     CT_REQUIRE(planes * h * w < 0xFFFFFFFFL, "ct_maxpool2d_bwd: more than 2^32 elements");
+    if (k == 2 && stride == 2 && pad == 0 && oh <= (h + 1) / 2 && ow <= (w + 1) / 2 && planes <= 0x7FFFFFFFL) {
+        hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3((unsigned)planes), dim3(256), 0, ctdet::as_stream(stream), x,
+                           dy, dx, h, w, oh, ow, accumulate);
+        CT_LAUNCH_CHECK("maxpool2x2_bwd_kernel");
+        return CT_OK;
+    }
     hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0,
                        ctdet::as_stream(stream), x, dy, dx, planes, h, w, oh, ow, k, stride, pad, accumulate);
     CT_LAUNCH_CHECK("maxpool2d_bwd_kernel");

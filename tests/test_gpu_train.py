@@ -122,7 +122,8 @@ def test_batchnorm_train_forward_backward(sliced):
 def test_pool_and_bias_backward():
     lib = _lib.lib()
     gen = torch.Generator().manual_seed(5)
-    for (H, W, k, s, p, ceil) in [(30, 30, 2, 2, 0, False), (15, 15, 2, 2, 0, True), (9, 9, 3, 1, 1, False)]:
+    for (H, W, k, s, p, ceil) in [(30, 30, 2, 2, 0, False), (15, 15, 2, 2, 0, True), (15, 13, 2, 2, 0, False),
+                                  (75, 75, 2, 2, 0, True), (9, 9, 3, 1, 1, False)]:
         x = torch.randn(2, 3, H, W, generator=gen)
         x[0, 0, :4, :4] = 1.5                       # ties inside windows
         x = x.requires_grad_(True)
@@ -135,6 +136,10 @@ def test_pool_and_bias_backward():
                                         y.shape[2], y.shape[3], k, s, p, 0, _s()), 'pool bwd')
         torch.cuda.synchronize()
         assert rel_err(dx.cpu(), x.grad) < 1e-6, (H, k, s)
+        _lib.check(lib.ct_maxpool2d_bwd(xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), 6, H, W,
+                                        y.shape[2], y.shape[3], k, s, p, 1, _s()), 'pool bwd accumulate')
+        torch.cuda.synchronize()
+        assert rel_err(dx.cpu(), 2 * x.grad) < 1e-6, (H, k, s, 'accumulate')
     y = torch.randn(2, 6, 5, 5, generator=gen)
     dy = torch.randn(2, 6, 5, 5, generator=gen)
     dz, dbias = torch.empty(2, 6, 5, 5, device=DEV), torch.empty(6, device=DEV)
