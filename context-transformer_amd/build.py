@@ -26,6 +26,7 @@ SOURCES = {
     'ct_api.cpp': [],
     'ct_conv.hip': [],
     'ct_wino.hip': [],
+    'ct_wino_wgrad.hip': [],
     'ct_pool.hip': [],
     'ct_preproc.hip': ['-ffp-contract=off'],
     'ct_attn.hip': [],

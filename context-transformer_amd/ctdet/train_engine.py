@@ -19,6 +19,7 @@ What the reference gets from autograd + cuDNN in `train.py:222-229` (`model(data
 Buffers are owned by the runtime and reused every step (call backward before the next forward).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -54,6 +55,7 @@ class TrainRuntime:
                 self.ctx_params.update(fc_w=net.fc_base.weight, fc_b=net.fc_base.bias)
             for prm in self.ctx_params.values():
                 self._reg(prm)
+        wino_ws = 0
         for st in self.plan.steps:
             if st.kind != 'conv':
                 continue
@@ -126,6 +128,12 @@ class TrainRuntime:
             w.kh, w.kw, w.stride, w.pad_h, w.pad_w, w.dil = st.kh, st.kw, st.stride, st.ph, st.pw, st.dil
             w.oh, w.ow = st.oh, st.ow
             s.wgrad = w
+            # 3x3 / stride 1 / pad 1: Winograd F(3x3, 2x2) weight gradient; one workspace shared by all layers
+            # (stream ordered).  CTDET_WGRAD_WINO=0 keeps the direct kernel.
+            s.wgrad_wino = bool(int(os.environ.get('CTDET_WGRAD_WINO', '1'))) and \
+                bool(self.lib.ct_conv_wgrad_wino_supported(C.byref(w)))
+            if s.wgrad_wino:
+                wino_ws = max(wino_ws, int(self.lib.ct_conv_wgrad_wino_workspace_bytes(C.byref(w))))
             for p in st.parts:
                 self._reg(p.weight)
                 if p.bn is not None:
@@ -133,6 +141,7 @@ class TrainRuntime:
                     self._reg(p.bn.bias)
                 elif p.bias is not None:
                     self._reg(p.bias)
+        self.wgrad_ws = al((max(wino_ws // 4, 1),))
 
     def _reg(self, prm):
         if id(prm) not in self._pindex:
@@ -317,8 +326,12 @@ class TrainRuntime:
                             put(p.bias, s.dbias[i].clone())
                     off += p.cout
             # weight gradient of the fused conv, split back to its parts
-            _lib.check(lib.ct_conv2d_wgrad(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(), self._s()),
-                       st.name + ' wgrad')
+            if s.wgrad_wino:
+                _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
+                                                    self.wgrad_ws.data_ptr(), self._s()), st.name + ' wgrad (winograd)')
+            else:
+                _lib.check(lib.ct_conv2d_wgrad(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
+                                               self._s()), st.name + ' wgrad')
             off = 0
             for p in st.parts:
                 put(p.weight, s.dw[off:off + p.cout].clone())

@@ -1,0 +1,82 @@
+"""Winograd F(3x3, 2x2) weight gradient (ct_conv2d_wgrad_wino) against autograd in float64 and against the direct
+weight-gradient kernel, through the C ABI.  What train.py:228 `losses.backward()` computes for the 3x3 / stride 1
+weights of models/RFB_Net_vgg.py."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from ctdet import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _desc(xd, B, Cin, H, W, ctot, coff, Cout, k=3, stride=1, pad=1, dil=1):
+    d = _lib.ConvDesc()
+    d.in_ = xd.data_ptr()
+    d.batch, d.cin, d.h, d.w, d.in_ctot, d.in_coff = B, Cin, H, W, ctot, coff
+    d.cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil = Cout, k, k, stride, pad, pad, dil
+    d.oh = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    d.ow = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    return d
+
+
+GEOMS = [  # B, Cin, H, W, Cout, x slice (ctot, coff), dz slice (ctot, coff)
+    (2, 64, 19, 19, 64, None, None),
+    (3, 16, 10, 10, 40, None, None),            # partial channel blocks
+    (2, 72, 19, 17, 130, None, None),           # odd sizes, ragged blocks both ways
+    (1, 3, 30, 30, 16, None, None),             # first layer: 3 input channels
+    (5, 8, 5, 5, 8, None, None),                # tiles straddle images inside a chunk
+    (2, 24, 3, 3, 24, None, None), (4, 8, 1, 1, 8, None, None), (3, 8, 2, 2, 8, None, None),
+    (2, 32, 38, 38, 64, (48, 9), (80, 7)),      # channel slices of wider buffers
+    (2, 128, 75, 75, 64, None, None),           # many chunks per split, odd width
+]
+
+
+@pytest.mark.parametrize('g', GEOMS, ids=[str(i) for i in range(len(GEOMS))])
+def test_wino_wgrad_vs_autograd(g):
+    B, Cin, H, W, Cout, xs, zs = g
+    gen = torch.Generator().manual_seed(11 + Cin + H)
+    xctot, xcoff = xs or (Cin, 0)
+    zctot, zcoff = zs or (Cout, 0)
+    xfull = torch.randn(B, xctot, H, W, generator=gen)
+    dzfull = torch.randn(B, zctot, H, W, generator=gen)
+    x = xfull[:, xcoff:xcoff + Cin].double().requires_grad_(True)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, None, 1, 1).backward(dzfull[:, zcoff:zcoff + Cout].double())
+    lib = _lib.lib()
+    xd, dzd = xfull.to(DEV), dzfull.to(DEV)
+    d = _desc(xd, B, Cin, H, W, xctot, xcoff, Cout)
+    assert lib.ct_conv_wgrad_wino_supported(C.byref(d)) == 1
+    ws = torch.empty(lib.ct_conv_wgrad_wino_workspace_bytes(C.byref(d)) // 4, device=DEV)
+    dw = torch.full((Cout, Cin, 3, 3), float('nan'), device=DEV)
+    _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(d), dzd.data_ptr(), zctot, zcoff, dw.data_ptr(), ws.data_ptr(),
+                                        _s()), 'wgrad wino')
+    dw2 = torch.empty_like(dw)
+    _lib.check(lib.ct_conv2d_wgrad(C.byref(d), dzd.data_ptr(), zctot, zcoff, dw2.data_ptr(), _s()), 'wgrad')
+    torch.cuda.synchronize()
+    e_w, e_d = rel_err(dw.cpu().double(), w.grad), rel_err(dw2.cpu().double(), w.grad)
+    assert e_w < 1e-5, (g, e_w, e_d)
+    # a second call reuses the workspace (zeroed inside) and overwrites dw
+    _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(d), dzd.data_ptr(), zctot, zcoff, dw2.data_ptr(), ws.data_ptr(),
+                                        _s()), 'wgrad wino again')
+    torch.cuda.synchronize()
+    assert rel_err(dw2.cpu().double(), w.grad) < 1e-5
+
+
+def test_wino_wgrad_rejects_other_geometries():
+    lib = _lib.lib()
+    x = torch.zeros(1, 8, 10, 10, device=DEV)
+    for kw in (dict(stride=2), dict(dil=2, pad=2), dict(k=1, pad=0), dict(pad=0)):
+        d = _desc(x, 1, 8, 10, 10, 8, 0, 8, **kw)
+        assert lib.ct_conv_wgrad_wino_supported(C.byref(d)) == 0
+        dw = torch.zeros(8 * 8 * 9, device=DEV)
+        rc = lib.ct_conv2d_wgrad_wino(C.byref(d), x.data_ptr(), 8, 0, dw.data_ptr(), dw.data_ptr(), _s())
+        assert rc != 0

@@ -1,0 +1,58 @@
+"""Time the direct and the Winograd weight-gradient kernels on the RFBNet 3x3 layer shapes (batch 32)."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'context-transformer_amd'))
+from ctdet import _lib  # noqa: E402
+
+SHAPES = [(64, 64, 300), (64, 128, 150), (128, 128, 150), (128, 256, 75), (256, 256, 75), (256, 512, 38),
+          (512, 512, 38), (512, 512, 19), (1024, 256, 19), (128, 192, 38), (256, 256, 10)]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--iters', type=int, default=10)
+    a = ap.parse_args()
+    lib = _lib.lib()
+    dev = 'cuda:0'
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for cin, cout, hw in SHAPES:
+        x = torch.randn(a.batch, cin, hw, hw, device=dev)
+        dz = torch.randn(a.batch, cout, hw, hw, device=dev)
+        d = _lib.ConvDesc()
+        d.in_ = x.data_ptr()
+        d.batch, d.cin, d.h, d.w, d.in_ctot, d.in_coff = a.batch, cin, hw, hw, cin, 0
+        d.cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil, d.oh, d.ow = cout, 3, 3, 1, 1, 1, 1, hw, hw
+        dw = torch.empty(cout, cin, 3, 3, device=dev)
+        dw2 = torch.empty_like(dw)
+        ws = torch.empty(lib.ct_conv_wgrad_wino_workspace_bytes(C.byref(d)) // 4, device=dev)
+        res = []
+        for fn in ('direct', 'wino'):
+            def run():
+                if fn == 'direct':
+                    _lib.check(lib.ct_conv2d_wgrad(C.byref(d), dz.data_ptr(), cout, 0, dw.data_ptr(), st), fn)
+                else:
+                    _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(d), dz.data_ptr(), cout, 0, dw2.data_ptr(),
+                                                        ws.data_ptr(), st), fn)
+            run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            res.append(e0.elapsed_time(e1) / a.iters)
+        flops = 2.0 * a.batch * hw * hw * cin * cout * 9
+        err = ((dw - dw2).abs().max() / dw.abs().max()).item()
+        print('%4d -> %4d @ %3d^2  direct %8.1f us (%5.1f TF)   wino %8.1f us (%5.1f TF alg)   max diff %.2e'
+              % (cin, cout, hw, res[0] * 1e3, flops / res[0] / 1e9, res[1] * 1e3, flops / res[1] / 1e9, err))
+
+
+if __name__ == '__main__':
+    main()
