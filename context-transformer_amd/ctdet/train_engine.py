@@ -129,8 +129,9 @@ class TrainRuntime:
             w.oh, w.ow = st.oh, st.ow
             s.wgrad = w
             # 3x3 / stride 1 / pad 1: Winograd F(3x3, 2x2) weight gradient; one workspace shared by all layers
-            # (stream ordered).  CTDET_WGRAD_WINO=0 keeps the direct kernel.
-            s.wgrad_wino = bool(int(os.environ.get('CTDET_WGRAD_WINO', '1'))) and \
+            # (stream ordered).  Maps below 10x10 stay on the direct kernel (tile padding costs more than the
+            # transform saves there); CTDET_WGRAD_WINO=0 keeps the direct kernel everywhere.
+            s.wgrad_wino = bool(int(os.environ.get('CTDET_WGRAD_WINO', '1'))) and st.oh * st.ow >= 100 and \
                 bool(self.lib.ct_conv_wgrad_wino_supported(C.byref(w)))
             if s.wgrad_wino:
                 wino_ws = max(wino_ws, int(self.lib.ct_conv_wgrad_wino_workspace_bytes(C.byref(w))))

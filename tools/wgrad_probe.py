@@ -10,7 +10,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 from ctdet import _lib  # noqa: E402
 
 SHAPES = [(64, 64, 300), (64, 128, 150), (128, 128, 150), (128, 256, 75), (256, 256, 75), (256, 512, 38),
-          (512, 512, 38), (512, 512, 19), (1024, 256, 19), (128, 192, 38), (256, 256, 10)]
+          (512, 512, 38), (512, 512, 19), (1024, 256, 19), (128, 192, 38), (256, 256, 10),
+          (64, 96, 5), (128, 256, 3), (256, 24, 3), (256, 126, 1), (1024, 126, 19), (512, 126, 38), (512, 24, 38)]
 
 
 def main():
