@@ -642,7 +642,8 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
     a.tiles_m = (d->cout + bt - 1) / bt;
     a.tiles_n = (a.Ncols + bt - 1) / bt;
     const int tiles = a.tiles_m * a.tiles_n;
-    int splits = std::max(1, std::min((a.Npix + 255) / 256, (2048 + tiles - 1) / tiles));
+    static const int wg_target = getenv("CTDET_WGRAD_WGS") ? atoi(getenv("CTDET_WGRAD_WGS")) : 512;
+    int splits = std::max(1, std::min((a.Npix + 255) / 256, (wg_target + tiles - 1) / tiles));
     a.pix_per_split = ((a.Npix + splits - 1) / splits + 63) / 64 * 64;
     splits = (a.Npix + a.pix_per_split - 1) / a.pix_per_split;
     hipStream_t st = ctdet::as_stream(stream);
