@@ -81,13 +81,15 @@ class GradBucketer:
     big ring steps per link instead of hundreds of small ones.
     """
 
-    def __init__(self, numels, device, bucket_bytes=32 << 20, group=None):
+    def __init__(self, numels, device, bucket_bytes=32 << 20, group=None, flat=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.offsets = [0]
         for n in numels:
             self.offsets.append(self.offsets[-1] + int(n))
-        self.flat = torch.zeros(self.offsets[-1], dtype=torch.float32, device=device)
+        # `flat`: the caller's own gradient buffer (the training engine's arena) instead of a private staging one
+        self.flat = flat if flat is not None else torch.zeros(self.offsets[-1], dtype=torch.float32, device=device)
+        assert self.flat.numel() >= self.offsets[-1] and self.flat.dtype == torch.float32
         per = max(1, bucket_bytes // 4)
         self.bucket_of = []              # production index -> bucket id
         self.bucket_span = []            # bucket id -> (first elem, last elem)

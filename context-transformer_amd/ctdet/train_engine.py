@@ -143,6 +143,33 @@ class TrainRuntime:
                 elif p.bias is not None:
                     self._reg(p.bias)
         self.wgrad_ws = al((max(wino_ws // 4, 1),))
+        # Gradient arena: ONE flat fp32 buffer in production order.  The weight / bias / BatchNorm gradient kernels
+        # write straight into their slice (no per-parameter copies), the bucketed all-reduce runs on slices of it,
+        # and backward() hands autograd views of a single snapshot.
+        order = self.production_order()
+        assert len({id(q) for q in order}) == len(order) == len(self.params), 'parameter used by two plan steps'
+        self._prod_index = {id(q): i for i, q in enumerate(order)}
+        self._arena_off = [0]
+        for q in order:
+            self._arena_off.append(self._arena_off[-1] + q.numel())
+        self.arena = al((max(self._arena_off[-1], 1),))
+        for st in self.plan.steps:
+            if st.kind != 'conv':
+                continue
+            s = self.state[st.name]
+            for i, p in enumerate(st.parts):
+                if s.is_bn:
+                    s.dgamma[i], s.dbeta[i] = self._arena_view(p.bn.weight), self._arena_view(p.bn.bias)
+                elif p.bias is not None:
+                    s.dbias[i] = self._arena_view(p.bias)
+            i0 = self._prod_index[id(st.parts[0].weight)]
+            assert all(self._prod_index[id(p.weight)] == i0 + k for k, p in enumerate(st.parts))
+            a0 = self._arena_off[i0]
+            s.dw = self.arena[a0:a0 + s.dw.numel()].view(s.dw.shape)
+
+    def _arena_view(self, prm, flat=None):
+        i = self._prod_index[id(prm)]
+        return (self.arena if flat is None else flat)[self._arena_off[i]:self._arena_off[i + 1]].view(prm.shape)
 
     def _reg(self, prm):
         if id(prm) not in self._pindex:
@@ -168,8 +195,8 @@ class TrainRuntime:
         large buckets, overlapped with the rest of the backward pass (ctdet.dist.GradBucketer)."""
         from .dist import GradBucketer
         order = self.production_order()
-        self._prod_index = {id(p): i for i, p in enumerate(order)}
-        self.bucketer = GradBucketer([p.numel() for p in order], self.be.device, bucket_bytes, group)
+        self.bucketer = GradBucketer([p.numel() for p in order], self.be.device, bucket_bytes, group,
+                                     flat=self.arena)
         return self.bucketer
 
     def _s(self):
@@ -259,13 +286,12 @@ class TrainRuntime:
             bk.begin()
 
         def put(prm, g):
-            if bk is not None:                      # stage in the flat buffer, all-reduce per bucket
-                i = self._prod_index[id(prm)]
-                v = bk.view(i)
-                v.copy_(g.reshape(-1))
+            i = self._prod_index[id(prm)]
+            v = self._arena_view(prm)
+            if g.data_ptr() != v.data_ptr():        # produced elsewhere (Context-Transformer block): stage it
+                v.copy_(g.reshape(v.shape))
+            if bk is not None:                      # all-reduce per bucket as soon as its last gradient exists
                 bk.ready(i)
-                g = v.view(g.shape)
-            grads_out[self._pindex[id(prm)]] = g
 
         if ctx_grads is not None:
             for k, prm in self.ctx_params.items():
@@ -296,7 +322,7 @@ class TrainRuntime:
                     _lib.check(lib.ct_bias_act_backward(s.dz.data_ptr(), ctot, off, None, 0, 0, 0, B, p.cout, hw,
                                                         s.dz.data_ptr(), ctot, off, s.dbias[i].data_ptr(),
                                                         self._s()), st.name + ' bias bwd')
-                    put(p.bias, s.dbias[i].clone())
+                    put(p.bias, s.dbias[i])
                     off += p.cout
             else:
                 gy, y = self.grads[st.dst], self.bufs[st.dst]
@@ -316,15 +342,15 @@ class TrainRuntime:
                             float(p.bn.eps), int(p.relu), None, float(st.res_scale), dres, dres_ctot, st.res_coff,
                             dres_acc, s.dz.data_ptr(), s.dgamma[i].data_ptr(), s.dbeta[i].data_ptr(), ctot, off,
                             B, p.cout, hw, s.scratch[i].data_ptr(), self._s()), st.name + ' bn bwd')
-                        put(p.bn.weight, s.dgamma[i].clone())
-                        put(p.bn.bias, s.dbeta[i].clone())
+                        put(p.bn.weight, s.dgamma[i])
+                        put(p.bn.bias, s.dbeta[i])
                     else:
                         _lib.check(lib.ct_bias_act_backward(
                             gy.data_ptr(), gy.shape[1], st.dst_coff + off, y.data_ptr(), y.shape[1], st.dst_coff + off,
                             int(p.relu), B, p.cout, hw, s.dz.data_ptr(), ctot, off,
                             s.dbias[i].data_ptr() if p.bias is not None else None, self._s()), st.name + ' bias bwd')
                         if p.bias is not None:
-                            put(p.bias, s.dbias[i].clone())
+                            put(p.bias, s.dbias[i])
                     off += p.cout
             # weight gradient of the fused conv, split back to its parts
             if s.wgrad_wino:
@@ -335,7 +361,7 @@ class TrainRuntime:
                                                self._s()), st.name + ' wgrad')
             off = 0
             for p in st.parts:
-                put(p.weight, s.dw[off:off + p.cout].clone())
+                put(p.weight, s.dw[off:off + p.cout])
                 off += p.cout
             # data gradient into the producer's gradient buffer (accumulate if already written)
             if s.dgrad is not None:
@@ -358,7 +384,9 @@ class TrainRuntime:
                 written.setdefault(st.src, []).append((st.src_coff, st.src_coff + st.cin))
         if bk is not None:
             bk.finish()
-            grads_out = [g.clone() if g is not None else None for g in grads_out]
+        snap = self.arena.clone()                   # the arena is rewritten by the next backward
+        for prm in self.params:
+            grads_out[self._pindex[id(prm)]] = self._arena_view(prm, snap)
         return grads_out
 
 
