@@ -642,8 +642,19 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
     a.tiles_m = (d->cout + bt - 1) / bt;
     a.tiles_n = (a.Ncols + bt - 1) / bt;
     const int tiles = a.tiles_m * a.tiles_n;
-    static const int wg_target = getenv("CTDET_WGRAD_WGS") ? atoi(getenv("CTDET_WGRAD_WGS")) : 512;
-    int splits = std::max(1, std::min((a.Npix + 255) / 256, (wg_target + tiles - 1) / tiles));
+    // Pixel splits: the chip holds `slots` workgroups at a time (2 per CU with the double-buffered LDS); take the
+    // smallest split count whose last round is at least 92 % full -- one workgroup too many costs a whole round,
+    // and every extra split pays the atomic epilogue again.
+    static const int slots = getenv("CTDET_WGRAD_WGS") ? atoi(getenv("CTDET_WGRAD_WGS")) : 512;
+    const int smax = std::max(1, std::min((a.Npix + 255) / 256, (4 * slots) / tiles));
+    int splits = 1;
+    double best = 0.0;
+    for (int sp = 1; sp <= smax; ++sp) {
+        const int wg = tiles * sp, rounds = (wg + slots - 1) / slots;
+        const double eff = (double)wg / ((double)rounds * slots);
+        if (eff > best + 1e-9) { best = eff; splits = sp; }
+        if (eff >= 0.92) break;
+    }
     a.pix_per_split = ((a.Npix + splits - 1) / splits + 63) / 64 * 64;
     splits = (a.Npix + a.pix_per_split - 1) / a.pix_per_split;
     hipStream_t st = ctdet::as_stream(stream);
