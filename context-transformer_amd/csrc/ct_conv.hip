@@ -58,6 +58,8 @@ struct ConvArgs {
     ct_out_segment seg[3];
     int tiles_m, tiles_n;
     int transposed;
+    int ksplit, steps_per_split;    // > 1: blockIdx.y owns k-steps [y*sps, (y+1)*sps) and writes its raw sums to ws
+    float* ws;                      // [ksplit][M][Npix] partial sums, reduced in fixed order by conv_splitk_epilogue
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -222,9 +224,11 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
     //   ds_read the NEXT pair's operand fragments, ds_write a slice of tile step+1 into the other
     //   LDS buffer, re-issue the gather of the same slice for tile step+2 (a whole k-step to land),
     //   then this pair's MFMAs.  sched_barrier(0) keeps the compiler from regrouping the slots.
+    const int s0 = blockIdx.y * a.steps_per_split;
+    const int s1 = min(a.nsteps, s0 + a.steps_per_split);
     auto k_step = [&](int step, auto store_c, auto load_c) {
         constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
-        const int buf = step & 1;
+        const int buf = (step - s0) & 1;
         const float* Ab = As + buf * (BK * BM) + hsel * BM + wm0 + l31;
         const float* Bb = Bs + buf * (BK * BN) + hsel * BN + wn0 + l31;
         float av[2][TM], bv[2][TN];
@@ -261,15 +265,34 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
     using T_ = std::true_type;
     using F_ = std::false_type;
 
-    const int nsteps = a.nsteps;
-    load_tile(0);
+    load_tile(s0);
     store_tile(0);
-    if (nsteps > 1) load_tile(1);
+    if (s1 - s0 > 1) load_tile(s0 + 1);
     __syncthreads();
-    int step = 0;
-    for (; step + 2 < nsteps; ++step) k_step(step, T_{}, T_{});
-    if (step + 1 < nsteps) { k_step(step, T_{}, F_{}); ++step; }
+    int step = s0;
+    for (; step + 2 < s1; ++step) k_step(step, T_{}, T_{});
+    if (step + 1 < s1) { k_step(step, T_{}, F_{}); ++step; }
     k_step(step, F_{}, F_{});
+
+    if (a.ksplit > 1) {
+        // split-K (small maps: too few tiles to fill the chip, k loop latency bound): every split stores its raw
+        // partial sums in its own slab ws[split][co][pixel] (no atomics: the result does not depend on timing);
+        // conv_splitk_epilogue adds the slabs in order and applies the epilogue
+        float* const slab = a.ws + (size_t)blockIdx.y * a.M * a.Npix;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int P = n0 + wn0 + j * 32 + l31;
+            if (P >= a.Npix) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                    if (co < a.M) slab[(size_t)co * a.Npix + P] = acc[i][j][r];
+                }
+        }
+        return;
+    }
 
     // ---- epilogue ----
 #pragma unroll
@@ -300,6 +323,31 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
                                          (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
                 }
             }
+        }
+    }
+}
+
+// epilogue of a split-K convolution: sum of the slabs in split order, then the same arithmetic as the fused one
+__global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvArgs a)
+{
+    const int total = a.M * a.Npix;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int co = idx / a.Npix, P = idx - co * a.Npix;
+        const int n = P / a.OHW, s = P - n * a.OHW;
+        float sum = a.ws[idx];
+        for (int k = 1; k < a.ksplit; ++k) sum += a.ws[(size_t)k * total + idx];
+        float v = sum * a.scale[co] + a.shift[co];
+        if (a.res) v = v * a.res_scale + a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
+        if (a.lo) v = fmaxf(v, a.lo[co]);
+        else if (a.relu) v = fmaxf(v, 0.f);
+        if (a.nseg == 0) {
+            a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
+                    a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                 (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
         }
     }
 }
@@ -390,7 +438,7 @@ hipError_t launch_one(K kernel, size_t smem, const ConvArgs& a, hipStream_t st)
             raised.insert(fn);
         }
     }
-    hipLaunchKernelGGL(kernel, dim3(a.tiles_m * a.tiles_n), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(kernel, dim3(a.tiles_m * a.tiles_n, a.ksplit > 1 ? a.ksplit : 1), dim3(256), smem, st, a);
     return hipGetLastError();
 }
 
@@ -605,6 +653,22 @@ extern "C" int ct_conv2d_fwd(const ct_conv_desc* d, ct_stream_t stream)
         }
         a.tiles_m = (d->cout + bm - 1) / bm;
         a.tiles_n = (a.Npix + bn - 1) / bn;
+        a.ksplit = 1;
+        a.steps_per_split = a.nsteps;
+        int want = d->ksplit;
+        if (want < 0) {     // auto: aim at ~3 workgroups per CU, at least two k-steps per split
+            static const int target = getenv("CTDET_KSPLIT_TARGET") ? atoi(getenv("CTDET_KSPLIT_TARGET")) : 768;
+            const int tiles = a.tiles_m * a.tiles_n;
+            want = tiles * 2 > target ? 1 : std::min(a.nsteps / 2, target / tiles);
+        }
+        const long long slab = (long long)d->cout * a.Npix;
+        if (d->ksplit_ws && slab > 0) want = (int)std::min<long long>(want, d->ksplit_ws_floats / slab);
+        if (want > 1 && d->ksplit_ws && nb == d->batch && a.nsteps >= 2 && slab < 0x7FFFFFFFLL) {
+            const int ks = std::min(want, a.nsteps);
+            a.steps_per_split = (a.nsteps + ks - 1) / ks;
+            a.ksplit = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;
+            a.ws = d->ksplit_ws;
+        }
         hipError_t e;
         hipStream_t st = ctdet::as_stream(stream);
         if (d->kh == 3 && d->kw == 3) e = launch_geo<3, 3>(cfg, a, st);
@@ -615,6 +679,11 @@ extern "C" int ct_conv2d_fwd(const ct_conv_desc* d, ct_stream_t stream)
         else return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_fwd: %dx%d filters not built", d->kh, d->kw);
         if (e != hipSuccess)
             return ctdet::fail(CT_ERR_HIP, "conv_igemm_f32 launch failed: %s", hipGetErrorString(e));
+        if (a.ksplit > 1) {
+            const int total = a.M * a.Npix;
+            hipLaunchKernelGGL(conv_splitk_epilogue, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, a);
+            CT_LAUNCH_CHECK("conv_splitk_epilogue");
+        }
     }
     return CT_OK;
 }

@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ('nseg', C.c_int), ('seg', OutSegment * 3),
         ('config', C.c_int),
         ('transposed', C.c_int),
+        ('ksplit', C.c_int), ('ksplit_ws', C.c_void_p), ('ksplit_ws_floats', C.c_longlong),
     ]
 
 

@@ -412,6 +412,11 @@ class HipBackend:
         d.relu = int(all(relus))
         d.lo = rt['lo'].data_ptr() if rt['lo'] is not None else None
         d.config = max(rt.get('config', 0), 0)
+        # split-K workspace for maps that cannot fill the chip (the library decides per launch whether to use it)
+        npix = batch * st.oh * st.ow
+        if int(os.environ.get('CTDET_KSPLIT', '1')) and st.cout * npix <= (2 << 20):
+            rt['ksws'] = torch.empty(16 * st.cout * npix, device=self.device)
+            d.ksplit, d.ksplit_ws, d.ksplit_ws_floats = -1, rt['ksws'].data_ptr(), rt['ksws'].numel()
         rt['desc'] = d
         rt['wino_ok'] = bool(lib.ct_conv_wino_supported(C.byref(d)))
         if rt.get('config', 0) == WINO:

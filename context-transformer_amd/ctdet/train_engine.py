@@ -105,6 +105,9 @@ class TrainRuntime:
                 d.out, d.out_ctot, d.out_coff = g.data_ptr(), g.shape[1], st.src_coff
                 d.res_ctot, d.res_coff, d.res_scale = g.shape[1], st.src_coff, 1.0
                 d.transposed = 1
+                if int(os.environ.get('CTDET_KSPLIT', '1')) and st.cin * batch * st.h * st.w <= (2 << 20):
+                    s.ksws_d = al((16 * st.cin * batch * st.h * st.w,))      # split-K slabs (small maps)
+                    d.ksplit, d.ksplit_ws, d.ksplit_ws_floats = -1, s.ksws_d.data_ptr(), s.ksws_d.numel()
                 s.dgrad = d
                 s.kpad_d, s.mpad_d = kpad, mpad
                 # 3x3 / stride 1 / pad 1 layers: the data gradient is itself such a convolution (channels

@@ -197,6 +197,15 @@ typedef struct ct_conv_desc {
      * ct_conv_pack_weights_dgrad; stride/pad/dil are the forward convolution's.  What autograd's
      * conv backward-data does for every Conv2d of models/RFB_Net_vgg.py in train.py:228. */
     int transposed;
+    /* split-K for maps too small to fill the chip (ct_conv2d_fwd only): ksplit > 1 divides the reduction
+     * (cin * kh * kw) over that many workgroups per output tile; each writes its partial sums to its own slab
+     * of ksplit_ws ([ksplit][cout][batch*oh*ow] floats, no atomics) and a finishing kernel adds the slabs in
+     * order and applies the epilogue, so results do not depend on scheduling.  ksplit_ws_floats = capacity of
+     * the workspace (the factor is clamped to what fits).  0 / 1 or a null workspace = off; -1 = let the
+     * library choose from the number of output tiles. */
+    int ksplit;
+    float* ksplit_ws;
+    long long ksplit_ws_floats;
 } ct_conv_desc;
 
 /* Rows of the packed weight matrix for a (cin, kh, kw) filter: k_pad. */

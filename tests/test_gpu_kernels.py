@@ -36,7 +36,7 @@ class _Holder:
 
 
 def _run_conv(x, parts, stride, pad, dil, config=0, res=None, res_scale=1.0, cin_off=0, cin=None,
-              out_ctot=None, out_coff=0):
+              out_ctot=None, out_coff=0, ksplit=None):
     """parts: list of (weight, bias|None, bn_tuple|None, relu).  Returns the NCHW output tensor."""
     be = engine.HipBackend(DEV)
     cps = []
@@ -61,6 +61,9 @@ def _run_conv(x, parts, stride, pad, dil, config=0, res=None, res_scale=1.0, cin
         st.res, st.res_coff, st.res_scale = 'r', 0, res_scale
     st.rt['config'] = config
     be.prepare_conv(st, bufs, B)
+    if ksplit is not None:                      # explicit split-K factor (0 = off) instead of the library's choice
+        st.rt['desc'].ksplit = ksplit
+        st.rt['ksws'].fill_(float('nan'))       # the workspace needs no initialisation
     be.run_conv(st)
     torch.cuda.synchronize()
     return bufs['y'].cpu()
@@ -139,6 +142,32 @@ def test_conv_fused_epilogues():
     want = _ref_conv(x[:, 32:80], [(w4, None, bn3, False)], 1, 1, 1)
     assert rel_err(got[:, 8:72], want) < TOL
     assert torch.isnan(got[:, :8]).all() and torch.isnan(got[:, 72:]).all()     # untouched slices
+
+
+def test_conv_split_k():
+    """Split-K (ct_conv_desc.ksplit) against the single-pass kernel and the reference, all epilogue kinds."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 200, 5, 5, generator=g)
+    w = torch.randn(72, 200, 3, 3, generator=g) * 0.03
+    bn = _bn(72, g)
+    res = torch.randn(2, 72, 5, 5, generator=g)
+    want = _ref_conv(x, [(w, None, bn, True)], 1, 1, 1, res=res, res_scale=0.7)
+    base = _run_conv(x, [(w, None, bn, True)], 1, 1, 1, res=res, res_scale=0.7, ksplit=0)
+    assert rel_err(base, want) < TOL
+    for ks in (2, 3, 7, 1000, -1):              # 1000 > number of k-steps: clamped; -1: library's choice
+        for cfg in (0, 4, 5):
+            got = _run_conv(x, [(w, None, bn, True)], 1, 1, 1, res=res, res_scale=0.7, ksplit=ks, config=cfg)
+            assert rel_err(got, want) < TOL, (ks, cfg)
+            again = _run_conv(x, [(w, None, bn, True)], 1, 1, 1, res=res, res_scale=0.7, ksplit=ks, config=cfg)
+            assert torch.equal(got, again), 'split-K must be run-to-run deterministic'  
+    # 1x1 stride 2, mixed ReLU parts, output slice of a wider buffer
+    x2 = torch.randn(3, 512, 10, 10, generator=g)
+    w1 = torch.randn(40, 512, 1, 1, generator=g) * 0.05
+    w2 = torch.randn(24, 512, 1, 1, generator=g) * 0.05
+    parts = [(w1, None, _bn(40, g), True), (w2, None, _bn(24, g), False)]
+    got = _run_conv(x2, parts, 2, 0, 1, out_ctot=80, out_coff=5, ksplit=4)
+    assert rel_err(got[:, 5:69], _ref_conv(x2, parts, 2, 0, 1)) < TOL
+    assert torch.isnan(got[:, :5]).all() and torch.isnan(got[:, 69:]).all()
 
 
 def test_maxpool_variants():
