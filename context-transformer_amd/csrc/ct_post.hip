@@ -210,19 +210,25 @@ __global__ __launch_bounds__(256) void prefix_cut_kernel(const float* __restrict
 {
     __shared__ int hist[256];
     __shared__ int s_scalars[4];
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, c = blockIdx.y;
     const unsigned thr = kth_largest_kept(dets_sorted, keep, keep_count, P, T, b, max_per_image, hist, s_scalars);
-    for (int c = threadIdx.x; c < T; c += 256) {
-        const int seg = b * T + c, n = seg_count[seg];
-        const float* d = dets_sorted + (size_t)seg * P * 5;
-        int lo = 0, hi = n;                // first candidate with score < thr (descending order)
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (__float_as_uint(d[(size_t)mid * 5 + 4]) >= thr) lo = mid + 1;
-            else hi = mid;
-        }
-        seg_len_out[seg] = lo;
+    // first candidate of class c with score < thr (descending order): 256-ary search by the whole block, two or
+    // three dependent loads instead of the 14 of a per-thread bisection over 11 620 candidates
+    const int seg = b * T + c;
+    const float* d = dets_sorted + (size_t)seg * P * 5;
+    int lo = 0, hi = seg_count[seg];
+    while (hi - lo > 256) {
+        const int step = (hi - lo + 255) / 256;
+        const int p = lo + (int)threadIdx.x * step;
+        const int cnt = __syncthreads_count(p < hi && __float_as_uint(d[(size_t)p * 5 + 4]) >= thr);
+        if (cnt == 0) { hi = lo; break; }
+        const int nlo = lo + (cnt - 1) * step + 1;
+        hi = min(hi, lo + cnt * step);
+        lo = nlo;
     }
+    const int p = lo + (int)threadIdx.x;
+    const int cnt = __syncthreads_count(p < hi && __float_as_uint(d[(size_t)p * 5 + 4]) >= thr);
+    if (threadIdx.x == 0) seg_len_out[seg] = lo + cnt;
 }
 
 __global__ void clamp_len_kernel(const int* __restrict__ in, int n, int cap, int* __restrict__ out)
@@ -357,7 +363,7 @@ extern "C" int ct_postprocess_batched(const float* boxes, const float* scores, i
         CT_LAUNCH_CHECK("clamp_len_kernel");
         rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_len, num_priors, S, nms_thresh, ge, w.keep, w.keep_count, st);
         if (rc != CT_OK) return rc;
-        hipLaunchKernelGGL(prefix_cut_kernel, dim3(batch), dim3(256), 0, st, w.dets_sorted, w.keep, w.keep_count,
+        hipLaunchKernelGGL(prefix_cut_kernel, dim3(batch, num_fg), dim3(256), 0, st, w.dets_sorted, w.keep, w.keep_count,
                            w.seg_count, num_priors, num_fg, max_per_image, w.seg_len);
         CT_LAUNCH_CHECK("prefix_cut_kernel");
         rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_len, num_priors, S, nms_thresh, ge, w.keep, w.keep_count, st);
