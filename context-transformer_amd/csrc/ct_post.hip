@@ -150,32 +150,65 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
 
 // k-th largest kept score of image b (as uint bits; all scores are positive floats), or 0 when
 // at most k boxes are kept.  256 threads; hist/s_* are workgroup scratch.
+constexpr int kStageCap = 8192;      // kept scores of one image staged in LDS for the radix select (32 KB)
+constexpr int kStageMaxT = 128;
+
 __device__ unsigned kth_largest_kept(const float* __restrict__ dets_sorted, const int* __restrict__ keep,
                                      const int* __restrict__ keep_count, int P, int T, int b, int k,
                                      int* hist, int* s_scalars)
 {
+    __shared__ unsigned s_scores[kStageCap];
+    __shared__ int s_off[kStageMaxT + 1];
     const int tid = threadIdx.x;
     if (tid == 0) {
         int t = 0;
-        for (int c = 0; c < T; ++c) t += keep_count[b * T + c];
+        for (int c = 0; c < T; ++c) {
+            if (c <= kStageMaxT) s_off[c] = t;
+            t += keep_count[b * T + c];
+        }
+        if (T <= kStageMaxT) s_off[T] = t;
         s_scalars[0] = t;
     }
     __syncthreads();
     const int total = s_scalars[0];
     __syncthreads();
     if (k <= 0 || total <= k) return 0u;
+    // The four radix passes each walk every kept score through two dependent global loads (index, then score);
+    // when the image's kept scores fit in LDS they are fetched once, all classes in parallel, and the passes
+    // run out of LDS.
+    const bool staged = total <= kStageCap && T <= kStageMaxT;
+    if (staged) {
+        for (int e = tid; e < total; e += 256) {
+            int lo = 0, hi = T;                       // class of element e: last c with s_off[c] <= e
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_off[mid] <= e) lo = mid; else hi = mid;
+            }
+            const int seg = b * T + lo;
+            const int idx = keep[(size_t)seg * P + (e - s_off[lo])];
+            s_scores[e] = __float_as_uint(dets_sorted[((size_t)seg * P + idx) * 5 + 4]);
+        }
+        __syncthreads();
+    }
     unsigned prefix = 0, pmask = 0;
     int krem = k;
     for (int shift = 24; shift >= 0; shift -= 8) {
         hist[tid] = 0;
         __syncthreads();
-        for (int c = 0; c < T; ++c) {
-            const int seg = b * T + c, kc = keep_count[seg];
-            const float* d = dets_sorted + (size_t)seg * P * 5;
-            const int* kp = keep + (size_t)seg * P;
-            for (int i = tid; i < kc; i += 256) {
-                const unsigned u = __float_as_uint(d[(size_t)kp[i] * 5 + 4]);
+        if (staged) {
+            for (int e = tid; e < total; e += 256) {
+                const unsigned u = s_scores[e];
                 if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+            }
+        } else {
+            for (int c = 0; c < T; ++c) {
+                const int seg = b * T + c, kc = keep_count[seg];
+                const float* d = dets_sorted + (size_t)seg * P * 5;
+                const int* kp = keep + (size_t)seg * P;
+                for (int i = tid; i < kc; i += 256) {
+                    const unsigned u = __float_as_uint(d[(size_t)kp[i] * 5 + 4]);
+                    if ((u & pmask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+                }
             }
         }
         __syncthreads();
