@@ -80,3 +80,24 @@ def test_wino_wgrad_rejects_other_geometries():
         dw = torch.zeros(8 * 8 * 9, device=DEV)
         rc = lib.ct_conv2d_wgrad_wino(C.byref(d), x.data_ptr(), 8, 0, dw.data_ptr(), dw.data_ptr(), _s())
         assert rc != 0
+
+
+def test_wino_wgrad_above_2gib():
+    """An input buffer above 2 GiB (RFBNet-512 bs 32: conv1_1's output is exactly 2 GiB) goes through in batch
+    chunks that accumulate into the same transform-domain workspace."""
+    B, ctot, coff, Cin, Cout, S = 3, 704, 301, 8, 8, 512          # 3 x 704 x 512 x 512 x 4 B = 2.2 GB
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    xfull = torch.randn(B, ctot, S, S, device=DEV, generator=gen)
+    dz = torch.randn(B, Cout, S, S, device=DEV, generator=gen)
+    x = xfull[:, coff:coff + Cin].cpu().double().requires_grad_(True)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, None, 1, 1).backward(dz.cpu().double())
+    lib = _lib.lib()
+    d = _desc(xfull, B, Cin, S, S, ctot, coff, Cout)
+    assert lib.ct_conv_wgrad_wino_supported(C.byref(d)) == 1
+    ws = torch.empty(lib.ct_conv_wgrad_wino_workspace_bytes(C.byref(d)) // 4, device=DEV)
+    dw = torch.empty(Cout, Cin, 3, 3, device=DEV)
+    _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(d), dz.data_ptr(), Cout, 0, dw.data_ptr(), ws.data_ptr(), _s()),
+               'wgrad wino > 2 GiB')
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu().double(), w.grad) < 1e-5
