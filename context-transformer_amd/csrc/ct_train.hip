@@ -613,8 +613,31 @@ inline int grid_for(long total) { return (int)std::min<long>((total + 255) / 256
 
 }  // namespace
 
+static int wgrad_impl(const ct_conv_desc* d, const float* dz, int dz_ctot, int dz_coff, float* dw, bool zero,
+                      ct_stream_t stream);
+
 extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ctot, int dz_coff,
                                float* dw, ct_stream_t stream)
+{
+    CT_REQUIRE(d && d->in && dz && dw, "ct_conv2d_wgrad: null pointer");
+    CT_REQUIRE(d->batch > 0 && d->cin > 0 && d->cout > 0, "ct_conv2d_wgrad: bad shape");
+    // buffers above 2 GiB (32-bit buffer offsets): batch chunks accumulate into the same dw
+    const long long img_x = (long long)d->in_ctot * d->h * d->w * 4, img_z = (long long)dz_ctot * d->oh * d->ow * 4;
+    CT_REQUIRE(img_x < kMaxBufBytes && img_z < kMaxBufBytes, "ct_conv2d_wgrad: one image exceeds 2 GiB");
+    const int max_chunk = (int)std::max<long long>(1, (kMaxBufBytes - 1) / std::max(img_x, img_z));
+    if (d->batch <= max_chunk) return wgrad_impl(d, dz, dz_ctot, dz_coff, dw, true, stream);
+    for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
+        ct_conv_desc sub = *d;
+        sub.batch = std::min(max_chunk, d->batch - b0);
+        sub.in = d->in + (size_t)b0 * (img_x / 4);
+        const int rc = wgrad_impl(&sub, dz + (size_t)b0 * (img_z / 4), dz_ctot, dz_coff, dw, b0 == 0, stream);
+        if (rc != CT_OK) return rc;
+    }
+    return CT_OK;
+}
+
+static int wgrad_impl(const ct_conv_desc* d, const float* dz, int dz_ctot, int dz_coff, float* dw, bool zero,
+                      ct_stream_t stream)
 {
     CT_REQUIRE(d && d->in && dz && dw, "ct_conv2d_wgrad: null pointer");
     CT_REQUIRE(d->batch > 0 && d->cin > 0 && d->cout > 0, "ct_conv2d_wgrad: bad shape");
@@ -658,7 +681,7 @@ extern "C" int ct_conv2d_wgrad(const ct_conv_desc* d, const float* dz, int dz_ct
     a.pix_per_split = ((a.Npix + splits - 1) / splits + 63) / 64 * 64;
     splits = (a.Npix + a.pix_per_split - 1) / a.pix_per_split;
     hipStream_t st = ctdet::as_stream(stream);
-    CT_HIP(hipMemsetAsync(dw, 0, (size_t)d->cout * a.Ncols * 4, st));
+    if (zero) CT_HIP(hipMemsetAsync(dw, 0, (size_t)d->cout * a.Ncols * 4, st));
     const bool tapmajor = d->cin % bt == 0 && !(getenv("CTDET_WGRAD_GENERIC"));
     const bool tapmajor_for_smem = tapmajor;
     const dim3 grid(tiles, splits), block(256);

@@ -214,3 +214,23 @@ def test_train_forward_and_backward_vs_oracle_autograd(golden):
     bn = net.Norm.branch0[0].bn
     assert int(bn.num_batches_tracked) == 1
     assert not torch.equal(bn.running_mean.cpu(), sd['Norm.branch0.0.bn.running_mean'])
+
+
+def test_direct_wgrad_above_2gib():
+    """ct_conv2d_wgrad on an input buffer above 2 GiB: batch chunks accumulate into the same dw."""
+    B, ctot, coff, Cin, Cout, S = 3, 704, 100, 8, 16, 512         # 3 x 704 x 512 x 512 x 4 B = 2.2 GB
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    xfull = torch.randn(B, ctot, S, S, device=DEV, generator=gen)
+    dz = torch.randn(B, Cout, S, S, device=DEV, generator=gen)
+    x = xfull[:, coff:coff + Cin].cpu().double().requires_grad_(True)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, None, 1, 2, 2).backward(dz.cpu().double())
+    lib = _lib.lib()
+    d = _lib.ConvDesc()
+    d.in_ = xfull.data_ptr()
+    d.batch, d.cin, d.h, d.w, d.in_ctot, d.in_coff = B, Cin, S, S, ctot, coff
+    d.cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil, d.oh, d.ow = Cout, 3, 3, 1, 2, 2, 2, S, S
+    dw = torch.full((Cout, Cin, 3, 3), float('nan'), device=DEV)
+    _lib.check(lib.ct_conv2d_wgrad(C.byref(d), dz.data_ptr(), Cout, 0, dw.data_ptr(), _s()), 'wgrad > 2 GiB')
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu().double(), w.grad) < 1e-5
