@@ -187,7 +187,7 @@ def test_train_forward_and_backward_vs_oracle_autograd(golden):
     sum(lo.values()).backward()
     for k in ld:
         assert abs(ld[k].item() - lo[k].item()) < 2e-4 * max(1.0, abs(lo[k].item())), k
-    # How exact can this be?  (measured, tools/train_debug.py)  The heads' gradients do not pass a ReLU
+    # How exact can this be?  (measured, tests/train_debug.py)  The heads' gradients do not pass a ReLU
     # or BatchNorm backward and agree to 1e-5.  Everything upstream is a discontinuous function of the
     # forward activations (ReLU kinks: the two fp32 forwards differ by ~1e-5, which flips a few masks)
     # and, at batch 2 with 1x1/3x3/5x5 maps, passes BatchNorm backward over 2..50 samples, where

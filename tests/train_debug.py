@@ -1,6 +1,6 @@
 import os, sys, types
 import torch
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # tests/ -> repo root
 sys.path.insert(0, os.path.join(REPO, 'context-transformer_amd')); sys.path.insert(0, REPO)
 from ctdet import synth
 from oracle import rfbnet_ref
