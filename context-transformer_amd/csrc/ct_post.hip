@@ -159,6 +159,7 @@ __device__ unsigned kth_largest_kept(const float* __restrict__ dets_sorted, cons
 {
     __shared__ unsigned s_scores[kStageCap];
     __shared__ int s_off[kStageMaxT + 1];
+    __shared__ int s_suf[256];
     const int tid = threadIdx.x;
     if (tid == 0) {
         int t = 0;
@@ -178,15 +179,28 @@ __device__ unsigned kth_largest_kept(const float* __restrict__ dets_sorted, cons
     // run out of LDS.
     const bool staged = total <= kStageCap && T <= kStageMaxT;
     if (staged) {
-        for (int e = tid; e < total; e += 256) {
-            int lo = 0, hi = T;                       // class of element e: last c with s_off[c] <= e
-            while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                if (s_off[mid] <= e) lo = mid; else hi = mid;
+        // four elements per thread and trip: the two dependent loads (kept index, then its score) of all four are
+        // in flight together
+        for (int e0 = tid; e0 < total; e0 += 4 * 256) {
+            int idx[4];
+            size_t row[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = min(e0 + 256 * u, total - 1);
+                int lo = 0, hi = T;                   // class of element e: last c with s_off[c] <= e
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_off[mid] <= e) lo = mid; else hi = mid;
+                }
+                row[u] = (size_t)(b * T + lo) * P;
+                idx[u] = keep[row[u] + (e - s_off[lo])];
             }
-            const int seg = b * T + lo;
-            const int idx = keep[(size_t)seg * P + (e - s_off[lo])];
-            s_scores[e] = __float_as_uint(dets_sorted[((size_t)seg * P + idx) * 5 + 4]);
+            unsigned sc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sc[u] = __float_as_uint(dets_sorted[(row[u] + idx[u]) * 5 + 4]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + 256 * u < total) s_scores[e0 + 256 * u] = sc[u];
         }
         __syncthreads();
     }
@@ -212,14 +226,23 @@ __device__ unsigned kth_largest_kept(const float* __restrict__ dets_sorted, cons
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            int cum = 0, x = 255;
-            for (; x > 0; --x) {
-                if (cum + hist[x] >= krem) break;
-                cum += hist[x];
+        // bin of the krem-th largest: the highest x whose suffix count sum_{i >= x} hist[i] reaches krem.  A parallel
+        // suffix scan -- one thread walking 256 LDS bins serially cost ~10 us per radix pass.
+        {
+            const int v = hist[tid];
+            s_suf[tid] = v;
+            __syncthreads();
+            for (int off = 1; off < 256; off <<= 1) {
+                const int add = (tid + off < 256) ? s_suf[tid + off] : 0;
+                __syncthreads();
+                s_suf[tid] += add;
+                __syncthreads();
             }
-            s_scalars[1] = x;
-            s_scalars[2] = krem - cum;
+            const int incl = s_suf[tid], excl = incl - v;
+            if (excl < krem && incl >= krem) {
+                s_scalars[1] = tid;
+                s_scalars[2] = krem - excl;
+            }
         }
         __syncthreads();
         prefix |= (unsigned)s_scalars[1] << shift;
