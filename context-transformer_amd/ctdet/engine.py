@@ -370,8 +370,8 @@ class HipBackend:
         mpad = lib.ct_conv_mpad(st.cout)
         rt = st.rt
         rt['wpk'] = self.alloc((kpad, mpad))
-        rt['scale'] = self.alloc((mpad,))
-        rt['shift'] = self.alloc((mpad,))
+        rt['scale'] = torch.ones(mpad, device=self.device)       # entries past cout stay (1, 0)
+        rt['shift'] = torch.zeros(mpad, device=self.device)
         relus = [p.relu for p in st.parts]
         rt['lo'] = None
         if any(relus) and not all(relus):
@@ -427,6 +427,8 @@ class HipBackend:
         rt = st.rt
         if not on:
             rt['wino'] = False
+            if rt.get('wpk_stale'):
+                self.pack_conv(st)
             return
         if not rt.get('wino_ok'):
             raise _lib.CtdetError('%s: geometry has no Winograd path' % st.name)
@@ -452,14 +454,20 @@ class HipBackend:
                 raise _lib.CtdetError('%s: parameters must be contiguous fp32 on the HIP device' % st.name)
         ptrs = (C.c_void_p * n)(*[wt.data_ptr() for wt in ws])
         couts = (C.c_int * n)(*[p.cout for p in st.parts])
-        _lib.check(lib.ct_conv_pack_weights(ptrs, couts, n, st.cin, st.kh, st.kw, rt['wpk'].data_ptr(),
-                                            rt['mpad'], rt['kpad'], self._stream()), 'ct_conv_pack_weights')
-        if rt.get('wino'):
+        if rt.get('wino'):                      # only the layout the launch reads; the other one is packed on demand
             self._pack_wino(st)
-        rt['scale'].fill_(1.0)
-        rt['shift'].zero_()
+            rt['wpk_stale'] = True
+        else:
+            _lib.check(lib.ct_conv_pack_weights(ptrs, couts, n, st.cin, st.kh, st.kw, rt['wpk'].data_ptr(),
+                                                rt['mpad'], rt['kpad'], self._stream()), 'ct_conv_pack_weights')
+            rt['wpk_stale'] = False
+        first = not rt.get('folded')
+        rt['folded'] = True
         off = 0
         for p in st.parts:
+            if not first and p.bn is None and p.bias is None:
+                off += p.cout                   # identity epilogue: constant, written by the first call
+                continue
             if p.bn is not None:
                 bn = p.bn
                 args = (bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),

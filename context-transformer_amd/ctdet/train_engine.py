@@ -146,6 +146,8 @@ class TrainRuntime:
                 elif p.bias is not None:
                     self._reg(p.bias)
         self.wgrad_ws = al((max(wino_ws // 4, 1),))
+        self._nbt = [p.bn.num_batches_tracked for st in self.plan.steps if st.kind == 'conv' for p in st.parts
+                     if p.bn is not None]
         # Gradient arena: ONE flat fp32 buffer in production order.  The weight / bias / BatchNorm gradient kernels
         # write straight into their slice (no per-parameter copies), the bucketed all-reduce runs on slices of it,
         # and backward() hands autograd views of a single snapshot.
@@ -244,7 +246,6 @@ class TrainRuntime:
                                                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                                                  s.scratch[i].data_ptr(), self._s()),
                            st.name + ' bn stats')
-                bn.num_batches_tracked += 1
                 res = self.bufs[st.res] if st.res is not None else None
                 _lib.check(lib.ct_bn_train_apply(
                     z.data_ptr(), s.mean[i].data_ptr(), s.var[i].data_ptr(), bn.weight.data_ptr(),
@@ -253,6 +254,8 @@ class TrainRuntime:
                     st.res_coff, float(st.res_scale), dst.data_ptr(), dst.shape[1], st.dst_coff + off,
                     z.shape[1], off, B, p.cout, hw, self._s()), st.name + ' bn apply')
                 off += p.cout
+        if self._nbt:
+            torch._foreach_add_(self._nbt, 1)       # nn.BatchNorm2d's num_batches_tracked, one launch for all layers
         if self.used_ctx:
             d = self.net.num_classes
             out = self.ctx.forward(self.bufs['conf'].view(B, self.P, d), self.bufs['pool'].view(B, self.plan.M, d),
