@@ -255,7 +255,8 @@ __device__ __forceinline__ double block_sum(double v, double* red)
 
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ z, int batch, int ctot,
                                                        int coff, int HW, float* __restrict__ mean,
-                                                       float* __restrict__ var)
+                                                       float* __restrict__ var, float momentum, float unbias,
+                                                       float* __restrict__ rmean, float* __restrict__ rvar)
 {
     __shared__ double red[4];
     const int c = blockIdx.x;
@@ -273,8 +274,13 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     if (threadIdx.x == 0) {
         const double cnt = (double)batch * HW;
         const double m = s / cnt;
-        mean[c] = (float)m;
-        var[c] = (float)fmax(ss / cnt - m * m, 0.0);       // biased variance (normalisation)
+        const float mf = (float)m, vf = (float)fmax(ss / cnt - m * m, 0.0);   // biased variance (normalisation)
+        mean[c] = mf;
+        var[c] = vf;
+        if (rmean) {
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mf;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * (vf * unbias);
+        }
     }
 }
 
@@ -303,24 +309,19 @@ __global__ __launch_bounds__(256) void bn_stats_part_kernel(const float* __restr
 }
 
 __global__ void bn_stats_final_kernel(const double* __restrict__ scratch, int C, double cnt,
-                                      float* __restrict__ mean, float* __restrict__ var)
+                                      float* __restrict__ mean, float* __restrict__ var, float momentum,
+                                      float unbias, float* __restrict__ rmean, float* __restrict__ rvar)
 {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const double m = scratch[c] / cnt;
-    mean[c] = (float)m;
-    var[c] = (float)fmax(scratch[C + c] / cnt - m * m, 0.0);
-}
-
-// running_mean/var update of nn.BatchNorm2d (momentum m, unbiased variance), count = batch*HW
-__global__ void bn_running_kernel(const float* __restrict__ mean, const float* __restrict__ var, int C,
-                                  float momentum, float unbias, float* __restrict__ rmean,
-                                  float* __restrict__ rvar)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
-    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (var[c] * unbias);
+    const float mf = (float)m, vf = (float)fmax(scratch[C + c] / cnt - m * m, 0.0);
+    mean[c] = mf;
+    var[c] = vf;
+    if (rmean) {        // running statistics of nn.BatchNorm2d (momentum, unbiased variance), same launch
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mf;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (vf * unbias);
+    }
 }
 
 struct BnApplyArgs {
@@ -727,6 +728,11 @@ extern "C" int ct_bn_train_stats(const float* z, int batch, int ctot, int coff, 
     hipStream_t st = ctdet::as_stream(stream);
     const long per_channel = (long)batch * hw;
     const int slices = (int)std::max<long>(1, std::min<long>((1024 + channels - 1) / channels, per_channel / 2048));
+    const bool run = running_mean && running_var;
+    float* const rm = run ? running_mean : nullptr;
+    float* const rv = run ? running_var : nullptr;
+    const float cntf = (float)batch * hw;
+    const float unbias = cntf > 1.f ? cntf / (cntf - 1.f) : 1.f;
     if (scratch && slices > 1) {
         const int per_slice = (int)((per_channel + slices - 1) / slices);
         CT_HIP(hipMemsetAsync(scratch, 0, (size_t)2 * channels * sizeof(double), st));
@@ -734,17 +740,12 @@ extern "C" int ct_bn_train_stats(const float* z, int batch, int ctot, int coff, 
                            channels, hw, per_slice, (double*)scratch);
         CT_LAUNCH_CHECK("bn_stats_part_kernel");
         hipLaunchKernelGGL(bn_stats_final_kernel, dim3((channels + 255) / 256), dim3(256), 0, st,
-                           (const double*)scratch, channels, (double)per_channel, mean, var);
+                           (const double*)scratch, channels, (double)per_channel, mean, var, momentum, unbias, rm, rv);
         CT_LAUNCH_CHECK("bn_stats_final_kernel");
     } else {
-        hipLaunchKernelGGL(bn_stats_kernel, dim3(channels), dim3(256), 0, st, z, batch, ctot, coff, hw, mean, var);
+        hipLaunchKernelGGL(bn_stats_kernel, dim3(channels), dim3(256), 0, st, z, batch, ctot, coff, hw, mean, var,
+                           momentum, unbias, rm, rv);
         CT_LAUNCH_CHECK("bn_stats_kernel");
-    }
-    if (running_mean && running_var) {
-        const float cnt = (float)batch * hw;
-        hipLaunchKernelGGL(bn_running_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, mean, var,
-                           channels, momentum, cnt > 1.f ? cnt / (cnt - 1.f) : 1.f, running_mean, running_var);
-        CT_LAUNCH_CHECK("bn_running_kernel");
     }
     return CT_OK;
 }
