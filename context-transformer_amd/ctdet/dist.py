@@ -110,9 +110,12 @@ class GradBucketer:
     def begin(self):
         self.handles = []
 
-    def ready(self, i):
-        """Gradient i (in production order) has been written to view(i)."""
+    def ready(self, i, before_launch=None):
+        """Gradient i (in production order) has been written to view(i).  `before_launch()` runs right before a
+        bucket's all-reduce is issued (the training engine joins its weight-gradient stream there)."""
         bid = self.bucket_of[i]
+        if self.last_in_bucket[bid] == i and before_launch is not None:
+            before_launch()
         if self.world > 1 and self.last_in_bucket[bid] == i:
             a, b = self.bucket_span[bid]
             self.handles.append(dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group,

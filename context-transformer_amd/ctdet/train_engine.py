@@ -146,6 +146,11 @@ class TrainRuntime:
                 elif p.bias is not None:
                     self._reg(p.bias)
         self.wgrad_ws = al((max(wino_ws // 4, 1),))
+        # weight gradients on their own stream (CTDET_TRAIN_STREAMS=1 keeps everything on the caller's stream)
+        self.wg_stream = torch.cuda.Stream(backend.device) if int(os.environ.get('CTDET_TRAIN_STREAMS', '2')) > 1 \
+            else None
+        for s_ in self.state.values():
+            s_.ev_dz = torch.cuda.Event()
         self._nbt = [p.bn.num_batches_tracked for st in self.plan.steps if st.kind == 'conv' for p in st.parts
                      if p.bn is not None]
         # Gradient arena: ONE flat fp32 buffer in production order.  The weight / bias / BatchNorm gradient kernels
@@ -287,6 +292,11 @@ class TrainRuntime:
             return any(a < c1 and c0 < b for a, b in written.get(name, []))
 
         grads_out = [None] * len(self.params)
+        main = torch.cuda.current_stream(self.be.device)
+        side = self.wg_stream
+        if side is not None:
+            side.wait_stream(main)
+        join = (lambda: main.wait_stream(side)) if side is not None else None
         bk = getattr(self, 'bucketer', None)
         if bk is not None:
             bk.begin()
@@ -296,8 +306,8 @@ class TrainRuntime:
             v = self._arena_view(prm)
             if g.data_ptr() != v.data_ptr():        # produced elsewhere (Context-Transformer block): stage it
                 v.copy_(g.reshape(v.shape))
-            if bk is not None:                      # all-reduce per bucket as soon as its last gradient exists
-                bk.ready(i)
+            if bk is not None:                      # all-reduce per bucket as soon as its last gradient exists;
+                bk.ready(i, join)                   # the collective is ordered after BOTH streams
 
         if ctx_grads is not None:
             for k, prm in self.ctx_params.items():
@@ -358,13 +368,19 @@ class TrainRuntime:
                         if p.bias is not None:
                             put(p.bias, s.dbias[i])
                     off += p.cout
-            # weight gradient of the fused conv, split back to its parts
-            if s.wgrad_wino:
-                _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
-                                                    self.wgrad_ws.data_ptr(), self._s()), st.name + ' wgrad (winograd)')
-            else:
-                _lib.check(lib.ct_conv2d_wgrad(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
-                                               self._s()), st.name + ' wgrad')
+            # weight gradient of the fused conv, split back to its parts.  Nothing downstream in this backward pass
+            # reads it, so it runs on the side stream next to the data-gradient chain (dz ready -> side stream).
+            if side is not None:
+                s.ev_dz.record(main)
+                side.wait_event(s.ev_dz)
+            with torch.cuda.stream(side if side is not None else main):
+                if s.wgrad_wino:
+                    _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
+                                                        self.wgrad_ws.data_ptr(), self._s()),
+                               st.name + ' wgrad (winograd)')
+                else:
+                    _lib.check(lib.ct_conv2d_wgrad(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
+                                                   self._s()), st.name + ' wgrad')
             off = 0
             for p in st.parts:
                 put(p.weight, s.dw[off:off + p.cout])
@@ -388,6 +404,8 @@ class TrainRuntime:
                     s.dgrad.res = self.grads[st.src].data_ptr() if acc else None
                     _lib.check(lib.ct_conv2d_fwd(C.byref(s.dgrad), self._s()), st.name + ' dgrad')
                 written.setdefault(st.src, []).append((st.src_coff, st.src_coff + st.cin))
+        if side is not None:
+            main.wait_stream(side)
         if bk is not None:
             bk.finish()
         snap = self.arena.clone()                   # the arena is rewritten by the next backward
