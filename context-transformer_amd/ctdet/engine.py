@@ -573,6 +573,33 @@ def apply_tuned(backend, st, batch):
     return False
 
 
+def run_on_streams(rt, run_step):
+    """Walk rt.plan.steps in order, each step on the stream Runtime._build_schedule gave it (rt.sid), cross-stream
+    producer -> consumer edges as events (rt.xdeps / rt.signal / rt.ev); everything joins the caller's stream."""
+    steps = rt.plan.steps
+    if rt.side is None:
+        for st in steps:
+            run_step(st)
+        return
+    main = torch.cuda.current_stream(rt.backend.device)
+    for sd in rt.sides:
+        sd.wait_stream(main)
+    streams = [main] + rt.sides
+    i, n = 0, len(steps)
+    while i < n:
+        k = rt.sid[i]
+        with torch.cuda.stream(streams[k]):
+            while i < n and rt.sid[i] == k:
+                for j in rt.xdeps[i]:
+                    streams[k].wait_event(rt.ev[j])
+                run_step(steps[i])
+                if i in rt.signal:
+                    rt.ev[i].record(streams[k])
+                i += 1
+    for sd in rt.sides:
+        main.wait_stream(sd)
+
+
 class Runtime:
     """A Plan bound to a backend: buffers, packed weights, and the forward entry points."""
 
@@ -711,28 +738,7 @@ class Runtime:
             raise _lib.CtdetError('plan was built for input %s, got %s' % (tuple(self.bufs['x'].shape), tuple(x.shape)))
         self.refresh_weights()
         self.bufs['x'].copy_(x)
-        if self.side is None:
-            for st in self.plan.steps:
-                self._run_step(st)
-            return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
-        main = torch.cuda.current_stream(self.backend.device)
-        for sd in self.sides:
-            sd.wait_stream(main)
-        streams = [main] + self.sides
-        steps = self.plan.steps
-        i, n = 0, len(steps)
-        while i < n:
-            k = self.sid[i]
-            with torch.cuda.stream(streams[k]):
-                while i < n and self.sid[i] == k:
-                    for j in self.xdeps[i]:
-                        streams[k].wait_event(self.ev[j])
-                    self._run_step(steps[i])
-                    if i in self.signal:
-                        self.ev[i].record(streams[k])
-                    i += 1
-        for sd in self.sides:
-            main.wait_stream(sd)
+        run_on_streams(self, self._run_step)
         return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
 
     def conv_steps(self):

@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib, ops
-from .engine import ConvPart, ConvStep, HipBackend, Plan, apply_tuned
+from .engine import ConvPart, ConvStep, HipBackend, Plan, Runtime, apply_tuned, run_on_streams
 
 
 class _StepState:
@@ -146,6 +146,8 @@ class TrainRuntime:
                 elif p.bias is not None:
                     self._reg(p.bias)
         self.wgrad_ws = al((max(wino_ws // 4, 1),))
+        self.backend = backend
+        Runtime._build_schedule(self)           # forward: Norm branch / heads on a side stream (CTDET_STREAMS)
         # weight gradients on their own stream (CTDET_TRAIN_STREAMS=1 keeps everything on the caller's stream)
         self.wg_stream = torch.cuda.Stream(backend.device) if int(os.environ.get('CTDET_TRAIN_STREAMS', '2')) > 1 \
             else None
@@ -225,21 +227,22 @@ class TrainRuntime:
             raise _lib.CtdetError('training plan was built for input %s, got %s'
                                   % (tuple(self.bufs['x'].shape), tuple(x.shape)))
         self.bufs['x'].copy_(x)
-        for st in self.plan.steps:
+
+        def fwd_step(st):
             if st.kind == 'pool':
                 self.be.run_pool(st, self.bufs, B)
-                continue
+                return
             if st.kind == 'ctxpool':
                 if self.used_ctx:
                     self.be.run_ctxpool(st, self.bufs, B)
-                continue
+                return
             if st.kind != 'conv':
                 raise _lib.CtdetError('step %s has no training implementation' % st.name)
             s = self.state[st.name]
             self.be.pack_conv(s.fwd)
             self.be.run_conv(s.fwd)
             if not s.is_bn:
-                continue
+                return
             z = self.bufs[s.zstep.dst]
             hw = st.oh * st.ow
             dst = self.bufs[st.dst]
@@ -259,6 +262,8 @@ class TrainRuntime:
                     st.res_coff, float(st.res_scale), dst.data_ptr(), dst.shape[1], st.dst_coff + off,
                     z.shape[1], off, B, p.cout, hw, self._s()), st.name + ' bn apply')
                 off += p.cout
+        # Norm branch and heads on the side stream, like the inference runtime (same schedule builder)
+        run_on_streams(self, fwd_step)
         if self._nbt:
             torch._foreach_add_(self._nbt, 1)       # nn.BatchNorm2d's num_batches_tracked, one launch for all layers
         if self.used_ctx:
