@@ -65,14 +65,20 @@ def _bucket_worker(rank, world, port, q):
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     cdist.init('gloo')
     numels = [5, 1000, 3, 70000, 12, 40000, 7]
-    bk = cdist.GradBucketer(numels, 'cpu', bucket_bytes=200000)       # 50k floats per bucket -> several buckets
+    # the training engine's mode: the bucketer reduces slices of the caller's own flat buffer (gradient arena) and
+    # calls before_launch() exactly once per bucket, right before its all-reduce (stream join point)
+    arena = torch.full((sum(numels) + 9,), float('nan'))
+    bk = cdist.GradBucketer(numels, 'cpu', bucket_bytes=200000, flat=arena)   # 50k floats per bucket -> several buckets
     g = torch.Generator().manual_seed(100 + rank)
     grads = [torch.randn(n, generator=g) for n in numels]
+    joins = []
     bk.begin()
     for i, t in enumerate(grads):
         bk.view(i).copy_(t)
-        bk.ready(i)
+        bk.ready(i, lambda i=i: joins.append(i))
     bk.finish()
+    assert bk.flat.data_ptr() == arena.data_ptr() and torch.isnan(arena[sum(numels):]).all()
+    assert joins == sorted(bk.last_in_bucket.values()), (joins, bk.last_in_bucket)
     n = cdist.global_normalizer(torch.tensor(10 + 4 * rank), 'cpu')
     q.put((rank, [bk.view(i).numpy().copy() for i in range(len(numels))], len(bk.bucket_span), int(n)))
     torch.distributed.destroy_process_group()
