@@ -36,6 +36,7 @@ sys.path.insert(0, os.path.join(REPO, 'context-transformer_amd'))
 sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md), --dtype bf16 only
 
 
 def build_net(size, num_fg, phase, setting, device):
@@ -119,10 +120,12 @@ def conv_roofline(rt, batch, workload):
     from ctdet import _lib
     lib = _lib.lib()
     agg = {}
+    bf16 = getattr(rt.backend, 'load_input', None) is not None       # NHWC bf16 path (--dtype bf16, configs[4])
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     for st, e0, e1 in rt.event_log:
         cfg = st.rt['desc'].config
         wino = bool(st.rt.get('wino'))
-        name = 'wino_f2x2_3x3_f32' if wino else 'conv_igemm_f32<%dx%d,%s>' % (
+        name = 'conv_bf16_nhwc' if bf16 else 'wino_f2x2_3x3_f32' if wino else 'conv_igemm_f32<%dx%d,%s>' % (
             st.kh, st.kw, lib.ct_conv_config_name(cfg - 1).decode() if cfg > 0 else 'auto')
         a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
         a[0] += e0.elapsed_time(e1) * 1e-3
@@ -136,16 +139,16 @@ def conv_roofline(rt, batch, workload):
     ach = f / t / 1e12
     traffic = pmc_traffic(name, workload)
     return {
-        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-        'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': traffic,
+        'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+        'frac': round(ach / peak, 4), 'traffic': traffic,
         'kernel': name, 'launches': n, 'avg_launch_us': round(t / n * 1e6, 2),
         'flops_per_launch': round(f / n),
         # Winograd F(2x2,3x3) executes 16/36 of the algorithmic multiply-adds: `frac` above is algorithmic
         # flops / peak (can exceed 1), `mfma_pipe_frac` is what the matrix pipe really sustained
-        'mfma_pipe_frac': round(fx / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+        'mfma_pipe_frac': round(fx / t / 1e12 / peak, 4),
         'all_conv': {'achieved': round(tot_f / tot_t / 1e12, 2),
-                     'frac': round(tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                     'mfma_pipe_frac': round(tot_x / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                     'frac': round(tot_f / tot_t / 1e12 / peak, 4),
+                     'mfma_pipe_frac': round(tot_x / tot_t / 1e12 / peak, 4),
                      'time_share_of_dominant': round(t / tot_t, 3),
                      # sum of the launch durations; with the two-stream schedule launches overlap, so this
                      # can exceed the wall time of a step (and every duration includes the contention)
@@ -178,6 +181,9 @@ def main():
     ap.add_argument('--classes', type=int, default=20)
     ap.add_argument('--phase', type=int, default=1)
     ap.add_argument('--setting', default='transfer')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="bf16: NHWC bf16 activations + bf16 MFMA convolutions (BASELINE configs[4]); NOT the "
+                         "headline metric, which is fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     a = ap.parse_args()
@@ -201,6 +207,7 @@ def main():
     T = {('transfer', 2): 20, ('incre', 2): 20}.get((a.setting, a.phase), num_fg) if a.phase == 2 else num_fg
     log('building net')
     net = build_net(a.size, num_fg, a.phase, a.setting, dev)
+    net.conv_dtype = a.dtype
     log('building pipeline (plan, weight packing%s)' % (', conv autotune' if os.environ.get('CTDET_TUNE', '1') != '0' else ''))
     priors = PriorBox(getattr(cfgs, 'VOC_%d' % a.size)).forward()
     pipe = DetectionPipeline(net, priors, a.batch, T, image_wh=(500, 375))
@@ -243,7 +250,7 @@ def main():
             'metric': 'images/sec fwd+NMS', 'value': round(total_images / dt, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': 'RFBNet-%d VGG16 inference, bs=%d per GPU, %d fg classes, phase %d%s: '
                                    'fwd + softmax/decode + per-class NMS(0.45) + top-200; name-seeded random '
                                    'weights, randn images' % (a.size, a.batch, num_fg, a.phase,

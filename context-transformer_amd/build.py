@@ -27,6 +27,7 @@ SOURCES = {
     'ct_conv.hip': [],
     'ct_wino.hip': [],
     'ct_wino_wgrad.hip': [],
+    'ct_conv_bf16.hip': [],
     'ct_pool.hip': [],
     'ct_preproc.hip': ['-ffp-contract=off'],
     'ct_attn.hip': [],

@@ -1,0 +1,399 @@
+// libctdet: bf16 channels-last convolution on the bf16 MFMA path (BASELINE.json configs[4]: "RFBNet-512 bf16 MFMA
+// convs + fp32 NMS").  Same arithmetic contract as ct_conv2d_fwd (models/RFB_Net_vgg.py:7-22 BasicConv and the plain
+// Conv2d layers: y = act(conv(x) * scale + shift [* res_scale + res])), different storage: activations are
+// [batch][h][w][channels] bf16, so the 8 consecutive input channels an MFMA lane needs at one filter tap are ONE
+// 16-byte load, and the implicit-GEMM "im2col" gather degenerates to a row copy.  Accumulation and epilogue in fp32.
+//
+//   workgroup (256 threads, 4 waves) = 128 output pixels x 128 output channels, k-step = 32 input channels of one tap
+//   A tile [128 px][32 ch] and B tile [128 cout][32 ch] staged through LDS (80-byte rows: conflict-free 16-byte
+//   accesses), double buffered, one barrier per k-step; wave tile 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 x 2 k-halves.
+//   Output either bf16 NHWC (channel slice of a wider buffer = torch.cat for free) or fp32 scattered into the
+//   flattened multibox head buffers (which ARE channels-last: models/RFB_Net_vgg.py:245-247).
+#include "ct_common.h"
+#include <algorithm>
+#include <mutex>
+#include <unordered_set>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int kInvalidOff = 0x7FFFFFF0;
+constexpr long long kMaxBufBytes = 0x7FFFFF00LL;
+constexpr int BM = 128;                        // output pixels per workgroup
+constexpr int KSMALL = 8;                      // cin <= 8 (the image): one k-step = 4 taps x 8 channels
+
+struct Bf16Args {
+    const void* in;
+    const void* w;           // [taps][cin_pad / 8][cout_pad][8] bf16
+    const float* scale;
+    const float* shift;
+    const float* lo;
+    const void* res;         // bf16 NHWC
+    void* out;               // bf16 NHWC (nseg == 0)
+    unsigned in_bytes, w_bytes;
+    int Cin, cin_pad, H, W, in_ctot, in_coff;
+    int M, cout_pad;
+    int KH, KW, stride, pad_h, pad_w, dil;
+    int OW, OHW, Npix;
+    int out_ctot, out_coff, res_ctot, res_coff;
+    float res_scale;
+    int relu, nseg;
+    ct_out_segment seg[3];
+    int tiles_m;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ unsigned short f2bf(float f)      // round to nearest even (torch's float -> bfloat16)
+{
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x7FFFFFu)) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+// BN: output channels per workgroup (128: 2x2 waves of 64x64; 64: 4x1 waves of 32 px x 64 couts)
+// BK: input channels (of one tap) per k-step / barrier;  SMALL: cin_pad == 8, a k-step is 4 taps x 8 channels
+template <int BN, int BK, bool SMALL>
+__global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
+{
+    constexpr int SPR = BK / 8;                    // 16-byte segments per tile row
+    constexpr int ROWB = BK * 2 + 16;              // LDS row: payload + 16 bytes (conflict-free 16-byte accesses)
+    constexpr int A_B = BM * ROWB, B_B = BN * ROWB;
+    constexpr int NA = BM * SPR / 256, NB = BN * SPR / 256;
+    constexpr int WAVES_M = BN == 128 ? 2 : 4;     // waves along the pixel dimension
+    constexpr int WM = BM / WAVES_M, WN = BN / (4 / WAVES_M);
+    constexpr int TM = WM / 32, TN = WN / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // A0 B0 A1 B1
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave % WAVES_M) * WM, wn0 = (wave / WAVES_M) * WN;
+    const int m0 = (blockIdx.x % a.tiles_m) * BN;          // cout tile
+    const int n0 = (blockIdx.x / a.tiles_m) * BM;          // pixel tile
+
+    // ---- staging role: 16-byte segment (tid + 256 q) of each tile
+    int pix_n[NA], pix_h[NA], pix_w[NA];
+    bool pix_ok[NA];
+#pragma unroll
+    for (int q = 0; q < NA; ++q) {
+        const int P = n0 + (tid + 256 * q) / SPR;
+        pix_ok[q] = P < a.Npix;
+        const int Pc = pix_ok[q] ? P : 0;
+        pix_n[q] = Pc / a.OHW;
+        const int s = Pc - pix_n[q] * a.OHW;
+        const int oh = s / a.OW;
+        pix_h[q] = oh * a.stride - a.pad_h;
+        pix_w[q] = (s - oh * a.OW) * a.stride - a.pad_w;
+    }
+    const int sseg = tid % SPR;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes), rw = make_rsrc(a.w, a.w_bytes);
+    const int cgroups = a.cin_pad >> 3;                    // 8-channel groups per tap in the packed weights
+    const int taps = a.KH * a.KW;
+    const int csteps = SMALL ? 1 : a.cin_pad / BK;
+    const int nsteps = SMALL ? (taps + SPR - 1) / SPR : taps * csteps;
+
+    i32x4 ra[NA], rb[NB];
+    auto load_step = [&](int step) {
+        int tap, c0;
+        if (SMALL) { tap = step * SPR + sseg; c0 = 0; }
+        else { tap = step / csteps; c0 = (step - tap * csteps) * BK + sseg * 8; }
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
+        const bool cok = c0 < a.Cin && tap < taps;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) {
+            const int ih = pix_h[q] + kh * a.dil, iw = pix_w[q] + kw * a.dil;
+            const bool ok = pix_ok[q] && cok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const int off = ok ? (((pix_n[q] * a.H + ih) * a.W + iw) * a.in_ctot + a.in_coff + c0) * 2 : kInvalidOff;
+            ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int co = m0 + (tid + 256 * q) / SPR;
+            const int woff = (co < a.cout_pad && tap < taps) ? (((tap * cgroups + (c0 >> 3)) * a.cout_pad + co) * 8) * 2
+                                                             : kInvalidOff;
+            rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff, 0, 0);
+        }
+    };
+    auto store_step = [&](int buf) {
+        unsigned char* A = lds + buf * (A_B + B_B);
+        unsigned char* B = A + A_B;
+#pragma unroll
+        for (int q = 0; q < NA; ++q)
+            *reinterpret_cast<i32x4*>(A + ((tid + 256 * q) / SPR) * ROWB + sseg * 16) = ra[q];
+#pragma unroll
+        for (int q = 0; q < NB; ++q)
+            *reinterpret_cast<i32x4*>(B + ((tid + 256 * q) / SPR) * ROWB + sseg * 16) = rb[q];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_step(0);
+    store_step(0);
+    if (nsteps > 1) load_step(1);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int buf = step & 1;
+        const unsigned char* A = lds + buf * (A_B + B_B) + (wm0 + l31) * ROWB + kg * 16;
+        const unsigned char* B = lds + buf * (A_B + B_B) + A_B + (wn0 + l31) * ROWB + kg * 16;
+        if (step + 1 < nsteps) store_step(buf ^ 1);
+        if (step + 2 < nsteps) load_step(step + 2);
+#pragma unroll
+        for (int h = 0; h < BK / 16; ++h) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+                af[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(A + t * 32 * ROWB + h * 32));
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+                bfr[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(B + t * 32 * ROWB + h * 32));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[i][j][r] = pixel n0 + wm0 + 32 i + (r&3) + 8 (r>>2) + 4 kg, cout m0 + wn0 + 32 j + l31
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int co = m0 + wn0 + 32 * j + l31;
+        if (co >= a.M) continue;
+        const float sc = a.scale[co], sh = a.shift[co];
+        const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int P = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (P >= a.Npix) continue;
+                float v = acc[i][j][r] * sc + sh;
+                if (a.res)
+                    v = v * a.res_scale +
+                        bf2f(reinterpret_cast<const unsigned short*>(a.res)[(size_t)P * a.res_ctot + a.res_coff + co]);
+                v = fmaxf(v, lo);
+                if (a.nseg == 0) {
+                    reinterpret_cast<unsigned short*>(a.out)[(size_t)P * a.out_ctot + a.out_coff + co] = f2bf(v);
+                } else {
+                    const int n = P / a.OHW, s = P - n * a.OHW;
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
+                            a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                         (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
+                }
+            }
+    }
+}
+
+// weights: nparts tensors [cout_i][cin][kh][kw] fp32 -> [tap][cin_pad/8][cout_pad][8] bf16 (zero padded)
+struct PackBf16Args {
+    const float* w[6];
+    int mbeg[7];
+    int nparts, cin, cin_pad, cout_pad, taps;
+    unsigned short* out;
+};
+
+__global__ void pack_bf16_kernel(const PackBf16Args p)
+{
+    const long total = (long)p.taps * p.cin_pad * p.cout_pad;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c8 = (int)(idx & 7);
+        long t = idx >> 3;
+        const int co = (int)(t % p.cout_pad);
+        t /= p.cout_pad;
+        const int cg = (int)(t % (p.cin_pad >> 3));
+        const int tap = (int)(t / (p.cin_pad >> 3));
+        const int ci = cg * 8 + c8;
+        float v = 0.f;
+        if (ci < p.cin && co < p.mbeg[p.nparts]) {
+            int part = 0;
+            while (co >= p.mbeg[part + 1]) ++part;
+            v = p.w[part][((size_t)(co - p.mbeg[part]) * p.cin + ci) * p.taps + tap];
+        }
+        p.out[idx] = f2bf(v);
+    }
+}
+
+// NCHW fp32 -> NHWC bf16 (channels zero padded to c_pad) and back (for tests / the image input)
+__global__ void nchw_f32_to_nhwc_bf16(const float* __restrict__ x, int batch, int C, int HW, int c_pad,
+                                      unsigned short* __restrict__ y)
+{
+    const long total = (long)batch * HW * c_pad;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c_pad);
+        const long p = idx / c_pad;
+        const int n = (int)(p / HW), s = (int)(p - (long)n * HW);
+        y[idx] = c < C ? f2bf(x[((size_t)n * C + c) * HW + s]) : (unsigned short)0;
+    }
+}
+
+__global__ void nhwc_bf16_to_nchw_f32(const unsigned short* __restrict__ y, int batch, int C, int HW, int ctot,
+                                      int coff, float* __restrict__ x)
+{
+    const long total = (long)batch * C * HW;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(idx % HW);
+        const long t = idx / HW;
+        const int c = (int)(t % C), n = (int)(t / C);
+        x[idx] = bf2f(y[((size_t)n * HW + s) * ctot + coff + c]);
+    }
+}
+
+// MaxPool2d on NHWC bf16 (floor / ceil via the output size), -inf padding like nn.MaxPool2d
+__global__ void maxpool_nhwc_bf16(const unsigned short* __restrict__ x, unsigned short* __restrict__ y, int batch,
+                                  int C, int H, int W, int OH, int OW, int k, int stride, int pad)
+{
+    const long total = (long)batch * OH * OW * C;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        long t = idx / C;
+        const int ow = (int)(t % OW);
+        t /= OW;
+        const int oh = (int)(t % OH), n = (int)(t / OH);
+        float m = -INFINITY;
+        for (int kh = 0; kh < k; ++kh)
+            for (int kw = 0; kw < k; ++kw) {
+                const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                    m = fmaxf(m, bf2f(x[(((size_t)n * H + ih) * W + iw) * C + c]));
+            }
+        y[idx] = f2bf(m);
+    }
+}
+
+inline int grid1d(long total) { return (int)std::min<long>((total + 255) / 256, 256 * 32); }
+
+}  // namespace
+
+extern "C" int ct_conv_bf16_cin_pad(int cin) { return cin <= KSMALL ? KSMALL : (cin + 63) / 64 * 64; }
+extern "C" int ct_conv_bf16_cout_pad(int cout) { return (cout + 7) / 8 * 8; }
+
+extern "C" size_t ct_conv_bf16_packed_elems(int cin, int cout, int kh, int kw)
+{
+    return (size_t)kh * kw * ct_conv_bf16_cin_pad(cin) * ct_conv_bf16_cout_pad(cout);
+}
+
+extern "C" int ct_conv_pack_weights_bf16(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
+                                         void* wpacked, ct_stream_t stream)
+{
+    CT_REQUIRE(w && cout && wpacked && nparts >= 1 && nparts <= 6, "ct_conv_pack_weights_bf16: bad arguments");
+    PackBf16Args p{};
+    p.nparts = nparts;
+    p.mbeg[0] = 0;
+    for (int i = 0; i < nparts; ++i) {
+        CT_REQUIRE(w[i] && cout[i] > 0, "ct_conv_pack_weights_bf16: null part");
+        p.w[i] = w[i];
+        p.mbeg[i + 1] = p.mbeg[i] + cout[i];
+    }
+    p.cin = cin; p.cin_pad = ct_conv_bf16_cin_pad(cin); p.cout_pad = ct_conv_bf16_cout_pad(p.mbeg[nparts]);
+    p.taps = kh * kw;
+    p.out = static_cast<unsigned short*>(wpacked);
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(grid1d((long)p.taps * p.cin_pad * p.cout_pad)), dim3(256), 0,
+                       ctdet::as_stream(stream), p);
+    CT_LAUNCH_CHECK("pack_bf16_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_nchw_f32_to_nhwc_bf16(const float* x, int batch, int channels, int hw, int c_pad, void* y,
+                                        ct_stream_t stream)
+{
+    CT_REQUIRE(x && y && batch > 0 && channels > 0 && hw > 0 && c_pad >= channels, "ct_nchw_f32_to_nhwc_bf16: bad arguments");
+    hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16, dim3(grid1d((long)batch * hw * c_pad)), dim3(256), 0,
+                       ctdet::as_stream(stream), x, batch, channels, hw, c_pad, static_cast<unsigned short*>(y));
+    CT_LAUNCH_CHECK("nchw_f32_to_nhwc_bf16");
+    return CT_OK;
+}
+
+extern "C" int ct_nhwc_bf16_to_nchw_f32(const void* y, int batch, int channels, int hw, int ctot, int coff, float* x,
+                                        ct_stream_t stream)
+{
+    CT_REQUIRE(x && y && batch > 0 && channels > 0 && hw > 0 && coff >= 0 && coff + channels <= ctot,
+               "ct_nhwc_bf16_to_nchw_f32: bad arguments");
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32, dim3(grid1d((long)batch * hw * channels)), dim3(256), 0,
+                       ctdet::as_stream(stream), static_cast<const unsigned short*>(y), batch, channels, hw, ctot,
+                       coff, x);
+    CT_LAUNCH_CHECK("nhwc_bf16_to_nchw_f32");
+    return CT_OK;
+}
+
+extern "C" int ct_maxpool2d_nhwc_bf16(const void* x, void* y, int batch, int channels, int h, int w, int oh, int ow,
+                                      int k, int stride, int pad, ct_stream_t stream)
+{
+    CT_REQUIRE(x && y && batch > 0 && channels > 0, "ct_maxpool2d_nhwc_bf16: bad arguments");
+    hipLaunchKernelGGL(maxpool_nhwc_bf16, dim3(grid1d((long)batch * oh * ow * channels)), dim3(256), 0,
+                       ctdet::as_stream(stream), static_cast<const unsigned short*>(x),
+                       static_cast<unsigned short*>(y), batch, channels, h, w, oh, ow, k, stride, pad);
+    CT_LAUNCH_CHECK("maxpool_nhwc_bf16");
+    return CT_OK;
+}
+
+extern "C" int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream)
+{
+    CT_REQUIRE(d && d->in && d->wpacked && d->scale && d->shift, "ct_conv2d_bf16_fwd: null tensor");
+    CT_REQUIRE(d->batch > 0 && d->cin > 0 && d->cout > 0 && !d->transposed, "ct_conv2d_bf16_fwd: bad shape");
+    CT_REQUIRE(d->in_coff % 8 == 0 && d->in_ctot % 8 == 0 && d->cin % 8 == 0,
+               "ct_conv2d_bf16_fwd: channel slices must be multiples of 8 (16-byte loads), got ctot %d coff %d cin %d",
+               d->in_ctot, d->in_coff, d->cin);
+    CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "ct_conv2d_bf16_fwd: input slice");
+    const int eoh = (d->h + 2 * d->pad_h - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+    const int eow = (d->w + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    CT_REQUIRE(eoh == d->oh && eow == d->ow, "ct_conv2d_bf16_fwd: oh/ow mismatch");
+    if (d->nseg == 0)
+        CT_REQUIRE(d->out && d->out_coff >= 0 && d->out_coff + d->cout <= d->out_ctot, "ct_conv2d_bf16_fwd: output slice");
+    else
+        CT_REQUIRE(d->nseg <= 3 && !d->res, "ct_conv2d_bf16_fwd: segments");
+    const long long in_bytes = (long long)d->batch * d->h * d->w * d->in_ctot * 2;
+    CT_REQUIRE(in_bytes < kMaxBufBytes, "ct_conv2d_bf16_fwd: input above 2 GiB");
+    Bf16Args a{};
+    a.in = d->in; a.w = d->wpacked; a.scale = d->scale; a.shift = d->shift; a.lo = d->lo; a.res = d->res;
+    a.out = d->out;
+    a.Cin = d->cin; a.cin_pad = ct_conv_bf16_cin_pad(d->cin); a.H = d->h; a.W = d->w;
+    a.in_ctot = d->in_ctot; a.in_coff = d->in_coff;
+    a.M = d->cout; a.cout_pad = ct_conv_bf16_cout_pad(d->cout);
+    a.in_bytes = (unsigned)in_bytes;
+    a.w_bytes = (unsigned)((size_t)d->kh * d->kw * a.cin_pad * a.cout_pad * 2);
+    a.KH = d->kh; a.KW = d->kw; a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.dil = d->dil;
+    a.OW = d->ow; a.OHW = d->oh * d->ow; a.Npix = d->batch * a.OHW;
+    a.out_ctot = d->out_ctot; a.out_coff = d->out_coff; a.res_ctot = d->res_ctot; a.res_coff = d->res_coff;
+    a.res_scale = d->res_scale; a.relu = d->relu; a.nseg = d->nseg;
+    for (int g = 0; g < d->nseg; ++g) a.seg[g] = d->seg[g];
+    const int tiles_n = (a.Npix + BM - 1) / BM;
+    hipStream_t st = ctdet::as_stream(stream);
+    auto go = [&](auto kernel, int bn, int bk) {
+        a.tiles_m = (d->cout + bn - 1) / bn;
+        const size_t smem = (size_t)2 * (BM + bn) * (bk * 2 + 16);
+        static std::mutex mu;
+        static std::unordered_set<const void*> raised;
+        if (smem > 64 * 1024) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!raised.count((const void*)kernel)) {
+                if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+                    return;
+                raised.insert((const void*)kernel);
+            }
+        }
+        hipLaunchKernelGGL(kernel, dim3(a.tiles_m * tiles_n), dim3(256), smem, st, a);
+    };
+    const bool narrow = d->cout <= 64 || (long long)((d->cout + 127) / 128) * tiles_n < 256;   // few tiles: finer ones
+    if (a.cin_pad == KSMALL) {
+        if (narrow) go(conv_bf16_nhwc<64, 32, true>, 64, 32); else go(conv_bf16_nhwc<128, 32, true>, 128, 32);
+    } else {
+        if (narrow) go(conv_bf16_nhwc<64, 64, false>, 64, 64); else go(conv_bf16_nhwc<128, 64, false>, 128, 64);
+    }
+    CT_LAUNCH_CHECK("conv_bf16_nhwc");
+    return CT_OK;
+}

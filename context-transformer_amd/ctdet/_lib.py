@@ -87,6 +87,14 @@ SIGNATURES = {
     'ct_conv_pack_weights': (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
     'ct_conv_pack_weights_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _P, _I, _I, _P]),
     'ct_conv2d_wgrad': (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P]),
+    'ct_conv_bf16_cin_pad': (_I, [_I]),
+    'ct_conv_bf16_cout_pad': (_I, [_I]),
+    'ct_conv_bf16_packed_elems': (C.c_size_t, [_I, _I, _I, _I]),
+    'ct_conv_pack_weights_bf16': (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    'ct_nchw_f32_to_nhwc_bf16': (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    'ct_nhwc_bf16_to_nchw_f32': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    'ct_maxpool2d_nhwc_bf16': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'ct_conv2d_bf16_fwd': (_I, [C.POINTER(ConvDesc), _P]),
     'ct_conv_wgrad_wino_supported': (_I, [C.POINTER(ConvDesc)]),
     'ct_conv_wgrad_wino_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'ct_conv2d_wgrad_wino': (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P, _P]),

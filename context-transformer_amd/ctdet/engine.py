@@ -620,7 +620,7 @@ class Runtime:
         mode = os.environ.get('CTDET_TUNE', '1') if tune is None else ('1' if tune else '0')
         self.tuned = False
         self.event_log = None        # set to a list to collect (step, start_event, end_event) per conv
-        if hasattr(backend, 'tune_conv'):
+        if getattr(backend, 'tune_conv', None) is not None:
             missing = [st for st in self.conv_steps() if mode == '2' or not apply_tuned(backend, st, batch)]
             if missing and mode != '0':
                 self.autotune(missing)
@@ -734,10 +734,14 @@ class Runtime:
 
     def run_backbone(self, x):
         """x [B,3,S,S] on the device -> raw (loc [B,P*4], conf [B,P*C], obj [B,P*2]) buffers (views)."""
-        if tuple(x.shape) != tuple(self.bufs['x'].shape):
-            raise _lib.CtdetError('plan was built for input %s, got %s' % (tuple(self.bufs['x'].shape), tuple(x.shape)))
+        want = (self.batch,) + tuple(self.plan.buf_shapes['x'])
+        if tuple(x.shape) != want:
+            raise _lib.CtdetError('plan was built for input %s, got %s' % (want, tuple(x.shape)))
         self.refresh_weights()
-        self.bufs['x'].copy_(x)
+        if hasattr(self.backend, 'load_input'):       # bf16 path: NCHW fp32 image -> NHWC bf16
+            self.backend.load_input(self.bufs['x'], x)
+        else:
+            self.bufs['x'].copy_(x)
         run_on_streams(self, self._run_step)
         return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
 

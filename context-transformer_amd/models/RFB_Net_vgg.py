@@ -21,6 +21,8 @@ raises IndexError there, :235-244 -- results on it are "parity unpinned").
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -214,9 +216,17 @@ class RFBNet(nn.Module):
         if next(self.parameters()).device != device:
             raise CtdetError('parameters live on %s but the net was asked to run on %s; call .cuda() '
                              'first' % (next(self.parameters()).device, device))
-        key = (batch, str(device))
+        dtype = getattr(self, 'conv_dtype', None) or os.environ.get('CTDET_DTYPE', 'f32')
+        key = (batch, str(device), dtype)
         if key not in self._runtimes:
-            self._runtimes[key] = _engine.Runtime(self, batch, _engine.HipBackend(device))
+            if dtype == 'bf16':          # BASELINE configs[4]: NHWC bf16 activations, bf16 MFMA convolutions
+                from ctdet.engine_bf16 import HipBackendBF16
+                backend = HipBackendBF16(device)
+            elif dtype == 'f32':
+                backend = _engine.HipBackend(device)
+            else:
+                raise CtdetError("conv_dtype must be 'f32' or 'bf16', got %r" % dtype)
+            self._runtimes[key] = _engine.Runtime(self, batch, backend)
         return self._runtimes[key]
 
     def _ctx_params(self):

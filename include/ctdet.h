@@ -251,6 +251,29 @@ int ct_conv2d_wino_pool_fwd(const ct_conv_desc* desc, const float* upacked, floa
 int ct_conv_pack_weights_wino_dgrad(const float* const* w, const int* cout, int nparts, int cin,
                                     float* upacked, ct_stream_t stream);
 
+/* ---- bf16 channels-last convolutions (BASELINE.json configs[4]: "bf16 MFMA convs + fp32 NMS") ----
+ * Same layers and epilogue as ct_conv2d_fwd (models/RFB_Net_vgg.py:7-22,219-248), other storage: activations
+ * are [batch][h][w][channels] bfloat16 (round-to-nearest-even of the fp32 value), accumulation and epilogue
+ * in fp32.  The descriptor is ct_conv_desc with `in`, `out`, `res` pointing at bf16 NHWC buffers (channel
+ * slices: in_ctot / in_coff / cin multiples of 8), `wpacked` from ct_conv_pack_weights_bf16, `scale` / `shift`
+ * / `lo` fp32, segments (nseg > 0) written in fp32 exactly as by ct_conv2d_fwd; m_pad / k_pad / config /
+ * transposed / ksplit unused. */
+int ct_conv_bf16_cin_pad(int cin);
+int ct_conv_bf16_cout_pad(int cout);
+/* bf16 elements of the packed weights of a (cin, cout, kh, kw) filter bank */
+size_t ct_conv_bf16_packed_elems(int cin, int cout, int kh, int kw);
+int ct_conv_pack_weights_bf16(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
+                              void* wpacked, ct_stream_t stream);
+int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream);
+/* x dev [batch][channels][hw] fp32 -> y dev [batch][hw][c_pad] bf16 (channels >= `channels` zero) and back
+ * (channel slice [coff, coff+channels) of a ctot-channel NHWC buffer -> dense NCHW fp32) */
+int ct_nchw_f32_to_nhwc_bf16(const float* x, int batch, int channels, int hw, int c_pad, void* y, ct_stream_t stream);
+int ct_nhwc_bf16_to_nchw_f32(const void* y, int batch, int channels, int hw, int ctot, int coff, float* x,
+                             ct_stream_t stream);
+/* nn.MaxPool2d on an NHWC bf16 map (models/RFB_Net_vgg.py:331-341); oh/ow decide floor or ceil mode */
+int ct_maxpool2d_nhwc_bf16(const void* x, void* y, int batch, int channels, int h, int w, int oh, int ow, int k,
+                           int stride, int pad, ct_stream_t stream);
+
 /* ------------------------------------------------------------ training side ---- */
 /* What `losses.backward()` (train.py:228) makes autograd/cuDNN do for the layers above.  The data
  * gradient of a convolution is ct_conv2d_fwd with desc.transposed = 1. */
