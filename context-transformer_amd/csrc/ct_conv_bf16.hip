@@ -19,6 +19,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kInvalidOff = 0x7FFFFFF0;
 constexpr long long kMaxBufBytes = 0x7FFFFF00LL;
 constexpr int BM = 128;                        // output pixels per workgroup
@@ -168,26 +169,21 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
     }
 
     // ---- epilogue: acc[i][j][r] = pixel n0 + wm0 + 32 i + (r&3) + 8 (r>>2) + 4 kg, cout m0 + wn0 + 32 j + l31
+    if (a.nseg > 0) {
+        // multibox heads: fp32, channels-last per segment -> a lane's cout is already the fast index
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int co = m0 + wn0 + 32 * j + l31;
-        if (co >= a.M) continue;
-        const float sc = a.scale[co], sh = a.shift[co];
-        const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
+        for (int j = 0; j < TN; ++j) {
+            const int co = m0 + wn0 + 32 * j + l31;
+            if (co >= a.M) continue;
+            const float sc = a.scale[co], sh = a.shift[co];
+            const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int P = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                if (P >= a.Npix) continue;
-                float v = acc[i][j][r] * sc + sh;
-                if (a.res)
-                    v = v * a.res_scale +
-                        bf2f(reinterpret_cast<const unsigned short*>(a.res)[(size_t)P * a.res_ctot + a.res_coff + co]);
-                v = fmaxf(v, lo);
-                if (a.nseg == 0) {
-                    reinterpret_cast<unsigned short*>(a.out)[(size_t)P * a.out_ctot + a.out_coff + co] = f2bf(v);
-                } else {
+                for (int r = 0; r < 16; ++r) {
+                    const int P = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    if (P >= a.Npix) continue;
+                    const float v = fmaxf(acc[i][j][r] * sc + sh, lo);
                     const int n = P / a.OHW, s = P - n * a.OHW;
 #pragma unroll
                     for (int g = 0; g < 3; ++g)
@@ -195,7 +191,72 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
                             a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
                                          (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
                 }
+        }
+        return;
+    }
+    // bf16 NHWC output: transpose the tile through LDS ([pixel][cout] fp32, operand buffers are free after the last
+    // barrier) so that a thread owns 8 consecutive channels of a pixel: one 16-byte store (and one 16-byte residual
+    // load) instead of eight 2-byte ones
+    constexpr int SROW = BN * 4 + 16;                       // bytes per staged pixel row
+    float* const stage = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = wn0 + 32 * j + l31;
+        const int co = m0 + col;
+        const float sc = co < a.M ? a.scale[co] : 0.f, sh = co < a.M ? a.shift[co] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                stage[row * (SROW / 4) + col] = acc[i][j][r] * sc + sh;
             }
+    }
+    __syncthreads();
+    constexpr int GPR = BN / 8;                             // 8-channel groups per pixel row
+    const bool vec_ok = ((a.out_ctot | a.out_coff) & 7) == 0 && (!a.res || ((a.res_ctot | a.res_coff) & 7) == 0);
+    for (int e = tid; e < BM * GPR; e += 256) {
+        const int row = e / GPR, g8 = e - row * GPR;
+        const int P = n0 + row, co = m0 + g8 * 8;
+        if (P >= a.Npix || co >= a.M) continue;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(stage) + row * SROW + g8 * 32);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(stage) + row * SROW + g8 * 32 + 16);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        const bool full = co + 8 <= a.M && vec_ok;
+        if (a.res) {
+            const unsigned short* rp = reinterpret_cast<const unsigned short*>(a.res) + (size_t)P * a.res_ctot + a.res_coff + co;
+            if (full) {
+                const i32x4 rr = *reinterpret_cast<const i32x4*>(rp);
+                const unsigned rw4[4] = {(unsigned)rr.x, (unsigned)rr.y, (unsigned)rr.z, (unsigned)rr.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] = v[2 * q] * a.res_scale + __uint_as_float(rw4[q] << 16);
+                    v[2 * q + 1] = v[2 * q + 1] * a.res_scale + __uint_as_float(rw4[q] & 0xFFFF0000u);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (co + q < a.M) v[q] = v[q] * a.res_scale + bf2f(rp[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float lo = a.lo ? (co + q < a.M ? a.lo[co + q] : 0.f) : (a.relu ? 0.f : -INFINITY);
+            v[q] = fmaxf(v[q], lo);
+        }
+        unsigned short* op = reinterpret_cast<unsigned short*>(a.out) + (size_t)P * a.out_ctot + a.out_coff + co;
+        if (full) {
+            i32x4 o;
+            o.x = (int)((unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16));
+            o.y = (int)((unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16));
+            o.z = (int)((unsigned)f2bf(v[4]) | ((unsigned)f2bf(v[5]) << 16));
+            o.w = (int)((unsigned)f2bf(v[6]) | ((unsigned)f2bf(v[7]) << 16));
+            *reinterpret_cast<i32x4*>(op) = o;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (co + q < a.M) op[q] = f2bf(v[q]);
+        }
     }
 }
 
@@ -375,7 +436,7 @@ extern "C" int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream)
     hipStream_t st = ctdet::as_stream(stream);
     auto go = [&](auto kernel, int bn, int bk) {
         a.tiles_m = (d->cout + bn - 1) / bn;
-        const size_t smem = (size_t)2 * (BM + bn) * (bk * 2 + 16);
+        const size_t smem = std::max((size_t)2 * (BM + bn) * (bk * 2 + 16), (size_t)BM * (bn * 4 + 16));   // operands | output staging
         static std::mutex mu;
         static std::unordered_set<const void*> raised;
         if (smem > 64 * 1024) {
