@@ -4,11 +4,19 @@
 // [batch][h][w][channels] bf16, so the 8 consecutive input channels an MFMA lane needs at one filter tap are ONE
 // 16-byte load, and the implicit-GEMM "im2col" gather degenerates to a row copy.  Accumulation and epilogue in fp32.
 //
-//   workgroup (256 threads, 4 waves) = 128 output pixels x 128 output channels, k-step = 32 input channels of one tap
-//   A tile [128 px][32 ch] and B tile [128 cout][32 ch] staged through LDS (80-byte rows: conflict-free 16-byte
-//   accesses), double buffered, one barrier per k-step; wave tile 64 x 64 = 2 x 2 v_mfma_f32_32x32x16_bf16 x 2 k-halves.
-//   Output either bf16 NHWC (channel slice of a wider buffer = torch.cat for free) or fp32 scattered into the
-//   flattened multibox head buffers (which ARE channels-last: models/RFB_Net_vgg.py:245-247).
+//   workgroup (256 threads, 4 waves) = 128 output pixels x 128 (or 64) output channels; a k-step = 64 input channels
+//   of one filter tap (for the 3-channel image, stored with 8 channels: 4 taps x 8 channels).  The A tile
+//   [128 px][64 ch] and the B tile [cout][64 ch] are staged through LDS with 16-byte accesses (144-byte rows:
+//   conflict-free), double buffered, one barrier per k-step, operand fragments of k-slice h+1 read while the
+//   v_mfma_f32_32x32x16_bf16 of slice h run; wave tile 64 x 64 (2 x 2 MFMA tiles).  XCD-aware tile order: the cout
+//   tiles of one pixel tile share an L2.
+//   Epilogue: bf16 NHWC output goes through LDS once ([pixel][cout] fp32) so that a thread owns 8 consecutive
+//   channels of a pixel -- one 16-byte store and one 16-byte residual load (2-byte accesses made the 1x1 layers
+//   epilogue-bound: 270 -> 77 us for 512->512 @38x38); a channel slice of a wider buffer is torch.cat for free.
+//   Multibox heads write fp32 into the flattened head buffers, which ARE channels-last
+//   (models/RFB_Net_vgg.py:245-247).
+//   Measured (bs 32, tools/bf16_probe.py): 512->512 @38x38 292 us = 746 TFLOP/s (30 % of the 2.5 PFLOP/s dense bf16
+//   peak; LDS traffic per MFMA and the per-step barrier are the limiters of this 128x128 / 4-wave structure).
 #include "ct_common.h"
 #include <algorithm>
 #include <mutex>
@@ -75,8 +83,17 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave % WAVES_M) * WM, wn0 = (wave / WAVES_M) * WN;
-    const int m0 = (blockIdx.x % a.tiles_m) * BN;          // cout tile
-    const int n0 = (blockIdx.x / a.tiles_m) * BM;          // pixel tile
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; every XCD gets a contiguous chunk of the (cout tile
+    // fastest) sequence, so the workgroups that share a pixel tile (same A rows) share an L2
+    int wg;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, local = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int m0 = (wg % a.tiles_m) * BN;                  // cout tile
+    const int n0 = (wg / a.tiles_m) * BM;                  // pixel tile
 
     // ---- staging role: 16-byte segment (tid + 256 q) of each tile
     int pix_n[NA], pix_h[NA], pix_w[NA];
@@ -148,22 +165,28 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
         const int buf = step & 1;
         const unsigned char* A = lds + buf * (A_B + B_B) + (wm0 + l31) * ROWB + kg * 16;
         const unsigned char* B = lds + buf * (A_B + B_B) + A_B + (wn0 + l31) * ROWB + kg * 16;
+        // operand fragments of k-slice h+1 are read while the MFMAs of slice h run
+        i32x4 fa[2][TM], fb[2][TN];
+        auto read_frag = [&](int h, int slot) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fa[slot][t] = *reinterpret_cast<const i32x4*>(A + t * 32 * ROWB + h * 32);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) fb[slot][t] = *reinterpret_cast<const i32x4*>(B + t * 32 * ROWB + h * 32);
+        };
+        read_frag(0, 0);
         if (step + 1 < nsteps) store_step(buf ^ 1);
         if (step + 2 < nsteps) load_step(step + 2);
 #pragma unroll
         for (int h = 0; h < BK / 16; ++h) {
-            bf16x8 af[TM], bfr[TN];
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-                af[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(A + t * 32 * ROWB + h * 32));
-#pragma unroll
-            for (int t = 0; t < TN; ++t)
-                bfr[t] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const i32x4*>(B + t * 32 * ROWB + h * 32));
+            const int cur = h & 1;
+            if (h + 1 < BK / 16) read_frag(h + 1, cur ^ 1);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][i]),
+                                                                        __builtin_bit_cast(bf16x8, fb[cur][j]),
+                                                                        acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
