@@ -51,6 +51,8 @@ struct Bf16Args {
     int relu, nseg;
     ct_out_segment seg[3];
     int tiles_m;
+    int ksplit, steps_per_split;    // > 1: blockIdx.y owns k-steps [y*sps, (y+1)*sps) and writes raw sums to its slab
+    float* ws;                      // [ksplit][Npix][M] fp32, reduced in order by conv_bf16_splitk_epilogue
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -157,12 +159,14 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_step(0);
+    const int s0 = blockIdx.y * a.steps_per_split;
+    const int s1 = min(nsteps, s0 + a.steps_per_split);
+    load_step(s0);
     store_step(0);
-    if (nsteps > 1) load_step(1);
+    if (s1 - s0 > 1) load_step(s0 + 1);
     __syncthreads();
-    for (int step = 0; step < nsteps; ++step) {
-        const int buf = step & 1;
+    for (int step = s0; step < s1; ++step) {
+        const int buf = (step - s0) & 1;
         const unsigned char* A = lds + buf * (A_B + B_B) + (wm0 + l31) * ROWB + kg * 16;
         const unsigned char* B = lds + buf * (A_B + B_B) + A_B + (wn0 + l31) * ROWB + kg * 16;
         // operand fragments of k-slice h+1 are read while the MFMAs of slice h run
@@ -174,8 +178,8 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
             for (int t = 0; t < TN; ++t) fb[slot][t] = *reinterpret_cast<const i32x4*>(B + t * 32 * ROWB + h * 32);
         };
         read_frag(0, 0);
-        if (step + 1 < nsteps) store_step(buf ^ 1);
-        if (step + 2 < nsteps) load_step(step + 2);
+        if (step + 1 < s1) store_step(buf ^ 1);
+        if (step + 2 < s1) load_step(step + 2);
 #pragma unroll
         for (int h = 0; h < BK / 16; ++h) {
             const int cur = h & 1;
@@ -192,6 +196,24 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
     }
 
     // ---- epilogue: acc[i][j][r] = pixel n0 + wm0 + 32 i + (r&3) + 8 (r>>2) + 4 kg, cout m0 + wn0 + 32 j + l31
+    if (a.ksplit > 1) {
+        // split-K (maps too small to fill the chip): raw partial sums to this split's slab, no atomics;
+        // conv_bf16_splitk_epilogue adds the slabs in order and applies the epilogue
+        float* const slab = a.ws + (size_t)blockIdx.y * a.Npix * a.M;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int co = m0 + wn0 + 32 * j + l31;
+            if (co >= a.M) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int P = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                    if (P < a.Npix) slab[(size_t)P * a.M + co] = acc[i][j][r];
+                }
+        }
+        return;
+    }
     if (a.nseg > 0) {
         // multibox heads: fp32, channels-last per segment -> a lane's cout is already the fast index
 #pragma unroll
@@ -279,6 +301,32 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
 #pragma unroll
             for (int q = 0; q < 8; ++q)
                 if (co + q < a.M) op[q] = f2bf(v[q]);
+        }
+    }
+}
+
+// finishing kernel of a split-K bf16 convolution: slabs summed in split order, then the fused epilogue's arithmetic
+__global__ __launch_bounds__(256) void conv_bf16_splitk_epilogue(const Bf16Args a)
+{
+    const int total = a.Npix * a.M;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int P = idx / a.M, co = idx - P * a.M;
+        float sum = a.ws[idx];
+        for (int k = 1; k < a.ksplit; ++k) sum += a.ws[(size_t)k * total + idx];
+        float v = sum * a.scale[co] + a.shift[co];
+        if (a.res)
+            v = v * a.res_scale +
+                bf2f(reinterpret_cast<const unsigned short*>(a.res)[(size_t)P * a.res_ctot + a.res_coff + co]);
+        v = fmaxf(v, a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY));
+        if (a.nseg == 0) {
+            reinterpret_cast<unsigned short*>(a.out)[(size_t)P * a.out_ctot + a.out_coff + co] = f2bf(v);
+        } else {
+            const int n = P / a.OHW, s = P - n * a.OHW;
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
+                    a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                 (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
         }
     }
 }
@@ -459,6 +507,20 @@ extern "C" int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream)
     hipStream_t st = ctdet::as_stream(stream);
     auto go = [&](auto kernel, int bn, int bk) {
         a.tiles_m = (d->cout + bn - 1) / bn;
+        const int taps = d->kh * d->kw;
+        const int nsteps = a.cin_pad == KSMALL ? (taps + bk / 8 - 1) / (bk / 8) : taps * (a.cin_pad / bk);
+        a.ksplit = 1;
+        a.steps_per_split = nsteps;
+        int want = d->ksplit;
+        const int tiles = a.tiles_m * tiles_n;
+        if (want < 0) want = tiles * 2 > 768 ? 1 : std::min(nsteps / 2, 768 / tiles);   // ~3 workgroups per CU
+        const long long slab = (long long)d->cout * a.Npix;
+        if (d->ksplit_ws && slab > 0) want = (int)std::min<long long>(want, d->ksplit_ws_floats / slab);
+        if (want > 1 && d->ksplit_ws && nsteps >= 2 && slab < 0x7FFFFFFFLL) {
+            a.steps_per_split = (nsteps + want - 1) / want;
+            a.ksplit = (nsteps + a.steps_per_split - 1) / a.steps_per_split;
+            a.ws = d->ksplit_ws;
+        }
         const size_t smem = std::max((size_t)2 * (BM + bn) * (bk * 2 + 16), (size_t)BM * (bn * 4 + 16));   // operands | output staging
         static std::mutex mu;
         static std::unordered_set<const void*> raised;
@@ -470,7 +532,7 @@ extern "C" int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream)
                 raised.insert((const void*)kernel);
             }
         }
-        hipLaunchKernelGGL(kernel, dim3(a.tiles_m * tiles_n), dim3(256), smem, st, a);
+        hipLaunchKernelGGL(kernel, dim3(a.tiles_m * tiles_n, a.ksplit), dim3(256), smem, st, a);
     };
     const bool narrow = d->cout <= 64 || (long long)((d->cout + 127) / 128) * tiles_n < 256;   // few tiles: finer ones
     if (a.cin_pad == KSMALL) {
@@ -479,5 +541,9 @@ extern "C" int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream)
         if (narrow) go(conv_bf16_nhwc<64, 64, false>, 64, 64); else go(conv_bf16_nhwc<128, 64, false>, 128, 64);
     }
     CT_LAUNCH_CHECK("conv_bf16_nhwc");
+    if (a.ksplit > 1) {
+        hipLaunchKernelGGL(conv_bf16_splitk_epilogue, dim3(std::min((a.Npix * a.M + 255) / 256, 2048)), dim3(256), 0, st, a);
+        CT_LAUNCH_CHECK("conv_bf16_splitk_epilogue");
+    }
     return CT_OK;
 }

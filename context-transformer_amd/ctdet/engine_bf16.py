@@ -9,6 +9,7 @@ Context-Transformer block) is the unchanged fp32 code.  What models/RFB_Net_vgg.
 activation precision: select with `net.conv_dtype = 'bf16'` (or CTDET_DTYPE=bf16) before the first forward.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -77,6 +78,10 @@ class HipBackendBF16(HipBackend):
             d.res, d.res_ctot, d.res_coff, d.res_scale = r.data_ptr(), r.shape[3], st.res_coff, st.res_scale
         d.relu = int(all(relus))
         d.lo = rt['lo'].data_ptr() if rt['lo'] is not None else None
+        npix = batch * st.oh * st.ow
+        if int(os.environ.get('CTDET_KSPLIT', '1')) and st.cout * npix <= (2 << 20):
+            rt['ksws'] = torch.empty(16 * st.cout * npix, device=self.device)     # split-K slabs (small maps)
+            d.ksplit, d.ksplit_ws, d.ksplit_ws_floats = -1, rt['ksws'].data_ptr(), rt['ksws'].numel()
         rt['desc'] = d
         rt['wino_ok'] = False
 

@@ -256,8 +256,8 @@ int ct_conv_pack_weights_wino_dgrad(const float* const* w, const int* cout, int 
  * are [batch][h][w][channels] bfloat16 (round-to-nearest-even of the fp32 value), accumulation and epilogue
  * in fp32.  The descriptor is ct_conv_desc with `in`, `out`, `res` pointing at bf16 NHWC buffers (channel
  * slices: in_ctot / in_coff / cin multiples of 8), `wpacked` from ct_conv_pack_weights_bf16, `scale` / `shift`
- * / `lo` fp32, segments (nseg > 0) written in fp32 exactly as by ct_conv2d_fwd; m_pad / k_pad / config /
- * transposed / ksplit unused. */
+ * / `lo` fp32, segments (nseg > 0) written in fp32 exactly as by ct_conv2d_fwd; ksplit / ksplit_ws as for
+ * ct_conv2d_fwd (slabs [ksplit][batch*oh*ow][cout] fp32); m_pad / k_pad / config / transposed unused. */
 int ct_conv_bf16_cin_pad(int cin);
 int ct_conv_bf16_cout_pad(int cout);
 /* bf16 elements of the packed weights of a (cin, cout, kh, kw) filter bank */

@@ -17,7 +17,14 @@ def _s():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def _conv_bf16(x, parts, stride, pad, dil, relu, res=None, res_scale=1.0, out_ctot=None, out_coff=0, cin_off=0, cin=None):
+def _close(got, want):
+    """One bf16 ulp (same products, fp32 accumulation in another order, one final rounding) plus the fp32
+    accumulation noise that survives where ReLU / cancellation leaves a result near zero."""
+    return ((got - want).abs() <= want.abs() * 2 ** -7 + 2e-5 * want.abs().max()).all()
+
+
+def _conv_bf16(x, parts, stride, pad, dil, relu, res=None, res_scale=1.0, out_ctot=None, out_coff=0, cin_off=0, cin=None,
+               ksplit=0):
     """x [B,ctot,H,W] fp32, parts = [w [Cout_i,Cin,k,k]]; -> [B, sum Cout, OH, OW] fp32 of the bf16 result."""
     lib = _lib.lib()
     B, ctot, H, W = x.shape
@@ -35,8 +42,9 @@ def _conv_bf16(x, parts, stride, pad, dil, relu, res=None, res_scale=1.0, out_ct
     ptrs = (C.c_void_p * len(wd))(*[w.data_ptr() for w in wd])
     couts = (C.c_int * len(wd))(*[w.shape[0] for w in wd])
     _lib.check(lib.ct_conv_pack_weights_bf16(ptrs, couts, len(wd), cin, kh, kw, wp.data_ptr(), _s()), 'pack')
-    scale = (torch.rand(cout) * 0.5 + 0.75).to(DEV)
-    shift = (torch.rand(cout) - 0.5).to(DEV)
+    gs = torch.Generator().manual_seed(1000 + cout)
+    scale = (torch.rand(cout, generator=gs) * 0.5 + 0.75).to(DEV)
+    shift = (torch.rand(cout, generator=gs) - 0.5).to(DEV)
     octot = out_ctot or cout
     yb = torch.full((B * OH * OW * octot,), 0x7FC0, dtype=torch.int16, device=DEV)       # bf16 NaN
     d = _lib.ConvDesc()
@@ -51,6 +59,9 @@ def _conv_bf16(x, parts, stride, pad, dil, relu, res=None, res_scale=1.0, out_ct
         rb = torch.empty(B * OH * OW * cout, dtype=torch.int16, device=DEV)
         _lib.check(lib.ct_nchw_f32_to_nhwc_bf16(rd.data_ptr(), B, cout, OH * OW, cout, rb.data_ptr(), _s()), 'res')
         d.res, d.res_ctot, d.res_coff, d.res_scale = rb.data_ptr(), cout, 0, res_scale
+    if ksplit:
+        ws = torch.full((16 * cout * B * OH * OW,), float('nan'), device=DEV)      # needs no initialisation
+        d.ksplit, d.ksplit_ws, d.ksplit_ws_floats = ksplit, ws.data_ptr(), ws.numel()
     _lib.check(lib.ct_conv2d_bf16_fwd(C.byref(d), _s()), 'conv bf16')
     y = torch.empty(B, cout, OH, OW, device=DEV)
     _lib.check(lib.ct_nhwc_bf16_to_nchw_f32(yb.data_ptr(), B, cout, OH * OW, octot, out_coff, y.data_ptr(), _s()), 'back')
@@ -79,7 +90,7 @@ def test_conv_bf16_vs_cpu(case):
     parts = [torch.randn(c, ctot, k, k, generator=g) * (2.0 / (ctot * k * k)) ** 0.5 for c in couts]
     got, want, _ = _conv_bf16(x, parts, stride, pad, dil, True)
     # same products, fp32 accumulation in another order, one final rounding to bf16: at most one bf16 ulp apart
-    assert ((got - want).abs() <= want.abs() * 2 ** -7 + 1e-6).all(), (got - want).abs().max()
+    assert _close(got, want), (got - want).abs().max()
 
 
 def test_conv_bf16_slices_and_residual():
@@ -89,9 +100,23 @@ def test_conv_bf16_slices_and_residual():
     res = torch.randn(2, 64, 19, 19, generator=g)
     got, want, yb = _conv_bf16(x, [w], 1, 2, 2, False, res=res, res_scale=0.5, out_ctot=104, out_coff=16, cin_off=32,
                                cin=48)
-    assert ((got - want).abs() <= want.abs() * 2 ** -7 + 1e-6).all()
+    assert _close(got, want)
     full = yb.view(2, 19, 19, 104)
     assert (full[..., :16] == 0x7FC0).all() and (full[..., 80:] == 0x7FC0).all()      # untouched channel slices
+
+
+def test_conv_bf16_split_k():
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 256, 5, 5, generator=g)
+    w = torch.randn(72, 256, 3, 3, generator=g) * 0.03
+    res = torch.randn(2, 72, 5, 5, generator=g)
+    base, want, _ = _conv_bf16(x, [w], 1, 1, 1, True, res=res, res_scale=0.7)
+    assert _close(base, want)
+    for ks in (2, 5, 1000, -1):
+        got, _, _ = _conv_bf16(x, [w], 1, 1, 1, True, res=res, res_scale=0.7, ksplit=ks)
+        assert _close(got, want), ks
+        again, _, _ = _conv_bf16(x, [w], 1, 1, 1, True, res=res, res_scale=0.7, ksplit=ks)
+        assert torch.equal(got, again), 'split-K must be run-to-run deterministic'
 
 
 @pytest.mark.parametrize('size,phase,C', [(300, 1, 20), (300, 2, 60), (512, 1, 20)])
