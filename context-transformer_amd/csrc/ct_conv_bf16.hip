@@ -407,6 +407,41 @@ __global__ void maxpool_nhwc_bf16(const unsigned short* __restrict__ x, unsigned
     }
 }
 
+// the same pool, 8 channels (16 bytes) per thread
+__global__ void maxpool_nhwc_bf16_v8(const i32x4* __restrict__ x, i32x4* __restrict__ y, int batch, int C8, int H,
+                                     int W, int OH, int OW, int k, int stride, int pad)
+{
+    const long total = (long)batch * OH * OW * C8;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C8);
+        long t = idx / C8;
+        const int ow = (int)(t % OW);
+        t /= OW;
+        const int oh = (int)(t % OH), n = (int)(t / OH);
+        float m[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = -INFINITY;
+        for (int kh = 0; kh < k; ++kh)
+            for (int kw = 0; kw < k; ++kw) {
+                const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+                if ((unsigned)ih >= (unsigned)H || (unsigned)iw >= (unsigned)W) continue;
+                const i32x4 v = x[(((size_t)n * H + ih) * W + iw) * C8 + c];
+                const unsigned w4[4] = {(unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    m[2 * q] = fmaxf(m[2 * q], __uint_as_float(w4[q] << 16));
+                    m[2 * q + 1] = fmaxf(m[2 * q + 1], __uint_as_float(w4[q] & 0xFFFF0000u));
+                }
+            }
+        i32x4 o;      // the maxima are bf16 values already: truncation is exact
+        o.x = (int)((__float_as_uint(m[0]) >> 16) | (__float_as_uint(m[1]) & 0xFFFF0000u));
+        o.y = (int)((__float_as_uint(m[2]) >> 16) | (__float_as_uint(m[3]) & 0xFFFF0000u));
+        o.z = (int)((__float_as_uint(m[4]) >> 16) | (__float_as_uint(m[5]) & 0xFFFF0000u));
+        o.w = (int)((__float_as_uint(m[6]) >> 16) | (__float_as_uint(m[7]) & 0xFFFF0000u));
+        y[idx] = o;
+    }
+}
+
 inline int grid1d(long total) { return (int)std::min<long>((total + 255) / 256, 256 * 32); }
 
 }  // namespace
@@ -466,6 +501,13 @@ extern "C" int ct_maxpool2d_nhwc_bf16(const void* x, void* y, int batch, int cha
                                       int k, int stride, int pad, ct_stream_t stream)
 {
     CT_REQUIRE(x && y && batch > 0 && channels > 0, "ct_maxpool2d_nhwc_bf16: bad arguments");
+    if (channels % 8 == 0) {
+        hipLaunchKernelGGL(maxpool_nhwc_bf16_v8, dim3(grid1d((long)batch * oh * ow * (channels / 8))), dim3(256), 0,
+                           ctdet::as_stream(stream), static_cast<const i32x4*>(x), static_cast<i32x4*>(y), batch,
+                           channels / 8, h, w, oh, ow, k, stride, pad);
+        CT_LAUNCH_CHECK("maxpool_nhwc_bf16_v8");
+        return CT_OK;
+    }
     hipLaunchKernelGGL(maxpool_nhwc_bf16, dim3(grid1d((long)batch * oh * ow * channels)), dim3(256), 0,
                        ctdet::as_stream(stream), static_cast<const unsigned short*>(x),
                        static_cast<unsigned short*>(y), batch, channels, h, w, oh, ow, k, stride, pad);

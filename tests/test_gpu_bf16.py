@@ -119,6 +119,25 @@ def test_conv_bf16_split_k():
         assert torch.equal(got, again), 'split-K must be run-to-run deterministic'
 
 
+def test_maxpool_nhwc_bf16():
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(8)
+    for (C_, H, W, k, s, p, ceil) in [(64, 30, 30, 2, 2, 0, False), (16, 15, 13, 2, 2, 0, True), (24, 9, 9, 3, 1, 1, False),
+                                      (12, 7, 7, 2, 2, 0, True)]:
+        x = torch.randn(2, C_, H, W, generator=g).bfloat16().float()
+        want = F.max_pool2d(x, k, s, p, ceil_mode=ceil)
+        OH, OW = want.shape[2:]
+        xd = x.to(DEV)
+        xb = torch.empty(2 * H * W * C_, dtype=torch.int16, device=DEV)
+        _lib.check(lib.ct_nchw_f32_to_nhwc_bf16(xd.data_ptr(), 2, C_, H * W, C_, xb.data_ptr(), _s()), 'nhwc')
+        yb = torch.empty(2 * OH * OW * C_, dtype=torch.int16, device=DEV)
+        _lib.check(lib.ct_maxpool2d_nhwc_bf16(xb.data_ptr(), yb.data_ptr(), 2, C_, H, W, OH, OW, k, s, p, _s()), 'pool')
+        y = torch.empty(2, C_, OH, OW, device=DEV)
+        _lib.check(lib.ct_nhwc_bf16_to_nchw_f32(yb.data_ptr(), 2, C_, OH * OW, C_, 0, y.data_ptr(), _s()), 'back')
+        torch.cuda.synchronize()
+        assert torch.equal(y.cpu(), want), (C_, H, W, k, s, p, ceil)
+
+
 @pytest.mark.parametrize('size,phase,C', [(300, 1, 20), (300, 2, 60), (512, 1, 20)])
 def test_rfbnet_bf16_vs_fp32(size, phase, C):
     from models.RFB_Net_vgg import build_net
