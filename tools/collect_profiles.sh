@@ -20,6 +20,12 @@ CTDET_STREAMS=1 timeout 600 python tools/layer_report.py > "$O/layer_report.txt"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/train" -o tr -- \
     python tools/train_bench.py --batch 32 --steps 10 > "$O/train_bench.log" 2>&1
 timeout 300 python tools/wgrad_probe.py > "$O/wgrad_probe.txt" 2>&1
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bf16" -o bench -- \
+    python "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --dtype bf16 > "$O/bench_bf16.json.log" 2> "$O/bench_bf16.err"
+cd "$R"
+CTDET_DTYPE=bf16 CTDET_STREAMS=1 timeout 600 python tools/layer_report.py > "$O/layer_report_bf16.txt" 2>&1
+timeout 300 python tools/bf16_probe.py > "$O/bf16_probe.txt" 2>&1
 # keep what prof_summary.py needs, drop the bulky traces
 find "$O" -name '*kernel_trace.csv' -delete
 find "$O" -name '*agent_info.csv' -delete
