@@ -19,6 +19,7 @@
 //   peak; LDS traffic per MFMA and the per-step barrier are the limiters of this 128x128 / 4-wave structure).
 #include "ct_common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <unordered_set>
 
@@ -579,6 +580,10 @@ extern "C" int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream)
     const bool narrow = d->cout <= 64 || (long long)((d->cout + 127) / 128) * tiles_n < 256;   // few tiles: finer ones
     if (a.cin_pad == KSMALL) {
         if (narrow) go(conv_bf16_nhwc<64, 32, true>, 64, 32); else go(conv_bf16_nhwc<128, 32, true>, 128, 32);
+    } else if (narrow && d->cin <= 64 && !(getenv("CTDET_BF16_SHORTK") && atoi(getenv("CTDET_BF16_SHORTK")) == 0)) {
+        // short reductions (conv1_2: 9 k-steps): the workgroup is prologue / epilogue bound, 32-channel steps halve
+        // its LDS footprint so that four instead of two of them share a CU
+        go(conv_bf16_nhwc<64, 32, false>, 64, 32);
     } else {
         if (narrow) go(conv_bf16_nhwc<64, 64, false>, 64, 64); else go(conv_bf16_nhwc<128, 64, false>, 128, 64);
     }
