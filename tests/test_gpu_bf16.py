@@ -161,6 +161,6 @@ def test_rfbnet_bf16_vs_fp32(size, phase, C):
     torch.cuda.synchronize()
     for name, a, b in zip(('loc', 'conf', 'obj'), got, ref):
         err = (a - b).abs().max().item() / b.abs().max().item()
-        assert err < 3e-2, (name, err)          # bf16 activations through ~20 layers (measured 3e-3 .. 1e-2)
+        assert err < 3e-2, (name, err)          # bf16 activations through ~25 layers (measured 0.9e-2 .. 1.8e-2)
         assert err > 0, name                    # really the other path
     assert got[0].dtype == torch.float32
