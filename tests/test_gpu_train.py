@@ -1,5 +1,6 @@
 """Training-side parity on the MI355X: weight/data gradients, batch-stat BatchNorm, pool backward
 and the whole-backbone backward pass against torch-CPU autograd over the oracle."""
+import math
 import types
 
 import numpy as np
@@ -234,3 +235,27 @@ def test_direct_wgrad_above_2gib():
     _lib.check(lib.ct_conv2d_wgrad(C.byref(d), dz.data_ptr(), Cout, 0, dw.data_ptr(), _s()), 'wgrad > 2 GiB')
     torch.cuda.synchronize()
     assert rel_err(dw.cpu().double(), w.grad) < 1e-5
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch():
+    """End to end: train-mode forward, MultiBoxLoss, HIP backward (two streams), SGD -- 15 steps on one batch."""
+    from layers.functions import PriorBox
+    from layers.modules.multibox_loss_combined import MultiBoxLoss_combined
+    import data as cfgs
+    net = _net(300, 20)
+    net = net.cuda().train()
+    net.device = 'cuda'
+    priors = PriorBox(cfgs.VOC_300).forward().cuda()
+    crit = MultiBoxLoss_combined(21, 0.5, True, 0, True, 3, 0.5, False)
+    opt = torch.optim.SGD(net.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    x = synth.images(4, 300, 'randn', 77).cuda()
+    tg = [t.cuda() for t in synth.targets(4, 21, 5)]
+    losses = []
+    for _ in range(15):
+        opt.zero_grad(set_to_none=True)
+        loss = sum(crit(net(x), priors, tg).values())
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(math.isfinite(v) for v in losses), losses
+    assert losses[-1] < 0.5 * losses[0], losses
