@@ -37,3 +37,16 @@ extern "C" int ct_device_info(int device, int* cu_count, int* lds_bytes_per_cu, 
     }
     return CT_OK;
 }
+
+// The reference's only native symbol, with its own (C++) linkage and argument list: utils/nms/gpu_nms.hpp:1-2,
+// defined by utils/nms/nms_kernel.cu:91-144.  A build of the reference's gpu_nms.pyx links against libctdet
+// unchanged (the mangled name is _Z4_nmsPiS_PKfiifi).  Like the original it returns nothing; failures are
+// printed to stderr (the original prints the CUDA error and carries on, nms_kernel.cu:12-19) and num_out is 0.
+void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim,
+          float nms_overlap_thresh, int device_id)
+{
+    if (ct_nms_sorted_host(keep_out, num_out, boxes_host, boxes_num, boxes_dim, nms_overlap_thresh, device_id) != CT_OK) {
+        fprintf(stderr, "_nms (libctdet): %s\n", ct_last_error_string());
+        if (num_out) *num_out = 0;
+    }
+}

@@ -192,30 +192,37 @@ __global__ __launch_bounds__(256) void match_pass1(const float* __restrict__ tru
     __shared__ unsigned long long gbest[kMaxGT];
     const int b = blockIdx.y;
     const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        const float* t = truths + (size_t)(g0 + g) * 6;
-        gtb[g] = make_float4(t[0], t[1], t[2], t[3]);
-        gbest[g] = 0ull;
-    }
-    __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < P) {
-        const float4 pf = point_form(priors[p]);
-        float bo = -INFINITY;
-        int bi = 0;
-        for (int g = 0; g < G; ++g) {
-            const float ov = iou_plain(gtb[g], pf);
-            if (ov > bo) { bo = ov; bi = g; }          // first maximal GT wins
-            const unsigned long long key =
-                ((unsigned long long)__float_as_uint(ov) << 32) | (unsigned)(~(unsigned)p);
-            atomicMax(&gbest[g], key);
+    const float4 pf = point_form(priors[p < P ? p : 0]);
+    float bo = -INFINITY;
+    int bi = 0;
+    // ground-truth boxes in chunks of kMaxGT through LDS: no limit on the number of boxes per image
+    for (int c0 = 0; c0 < G || c0 == 0; c0 += kMaxGT) {
+        const int n = min(G - c0, kMaxGT);
+        for (int g = threadIdx.x; g < n; g += blockDim.x) {
+            const float* t = truths + (size_t)(g0 + c0 + g) * 6;
+            gtb[g] = make_float4(t[0], t[1], t[2], t[3]);
+            gbest[g] = 0ull;
         }
+        __syncthreads();
+        if (p < P) {
+            for (int g = 0; g < n; ++g) {
+                const float ov = iou_plain(gtb[g], pf);
+                if (ov > bo) { bo = ov; bi = c0 + g; }          // first maximal GT wins
+                const unsigned long long key =
+                    ((unsigned long long)__float_as_uint(ov) << 32) | (unsigned)(~(unsigned)p);
+                atomicMax(&gbest[g], key);
+            }
+        }
+        __syncthreads();
+        for (int g = threadIdx.x; g < n; g += blockDim.x)
+            atomicMax(&gt_best[(size_t)b * max_gt + c0 + g], gbest[g]);
+        __syncthreads();
+    }
+    if (p < P) {
         best_ov[(size_t)b * P + p] = bo;
         best_idx[(size_t)b * P + p] = bi;
     }
-    __syncthreads();
-    for (int g = threadIdx.x; g < G; g += blockDim.x)
-        atomicMax(&gt_best[(size_t)b * max_gt + g], gbest[g]);
 }
 
 // pass 2: force-match (later GT wins), labels, encode, outputs
@@ -232,17 +239,21 @@ __global__ __launch_bounds__(256) void match_pass2(const float* __restrict__ tru
     __shared__ int bprior[kMaxGT];
     const int b = blockIdx.y;
     const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
-    for (int g = threadIdx.x; g < G; g += blockDim.x)
-        bprior[g] = (int)(~(unsigned)(gt_best[(size_t)b * max_gt + g] & 0xFFFFFFFFull));
-    __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
-    const size_t o = (size_t)b * P + p;
+    const size_t o = (size_t)b * P + (p < P ? p : 0);
     float ov = best_ov[o];
     int gi = best_idx[o];
-    if (overlap) overlap[o] = ov;
-    for (int g = 0; g < G; ++g)
-        if (bprior[g] == p) { ov = 2.f; gi = g; }
+    for (int c0 = 0; c0 < G; c0 += kMaxGT) {            // chunks of kMaxGT boxes, in order: the later GT wins
+        const int n = min(G - c0, kMaxGT);
+        __syncthreads();
+        for (int g = threadIdx.x; g < n; g += blockDim.x)
+            bprior[g] = (int)(~(unsigned)(gt_best[(size_t)b * max_gt + c0 + g] & 0xFFFFFFFFull));
+        __syncthreads();
+        for (int g = 0; g < n; ++g)
+            if (bprior[g] == p) { ov = 2.f; gi = c0 + g; }
+    }
+    if (p >= P) return;
+    if (overlap) overlap[o] = best_ov[o];
     float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
     float label = 0.f, weight = 1.f;
     if (G > 0) {
@@ -356,7 +367,7 @@ extern "C" int ct_match_batched(const float* truths, const int* gt_off, int batc
 {
     CT_REQUIRE(truths && gt_off && priors && loc_t && conf_t && obj_t && workspace, "ct_match_batched: null");
     CT_REQUIRE(batch > 0 && num_priors > 0, "ct_match_batched: bad shape");
-    CT_REQUIRE(max_gt >= 1 && max_gt <= kMaxGT, "ct_match_batched: max_gt=%d (1..%d)", max_gt, kMaxGT);
+    CT_REQUIRE(max_gt >= 1, "ct_match_batched: max_gt=%d", max_gt);
     if (workspace_bytes < ct_match_workspace_bytes(batch, num_priors, max_gt))
         return ctdet::fail(CT_ERR_WORKSPACE, "ct_match_batched: workspace %zu < %zu", workspace_bytes,
                            ct_match_workspace_bytes(batch, num_priors, max_gt));

@@ -370,6 +370,7 @@ struct BnBwdArgs {
     int batch, C, HW, dy_ctot, dy_coff, y_ctot, y_coff, dres_ctot, dres_coff, dres_accumulate, z_ctot, z_coff;
     float eps, rscale;
     int relu;
+    int frozen;              // 1: mean/var are constants (nn.BatchNorm2d in eval mode): no statistics terms in dz
 };
 
 __device__ __forceinline__ float masked_dy(const BnBwdArgs& a, int n, int c, int i)
@@ -451,7 +452,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdArgs a)
         const float g = gm * a.rscale;
         const size_t zi = ((size_t)n * a.z_ctot + a.z_coff + c) * a.HW + i;
         const float xh = (a.z[zi] - a.mean[c]) * inv;
-        a.dz[zi] = a.gamma[c] * inv * (g - a.dbeta[c] / cnt - xh * a.dgamma[c] / cnt);
+        a.dz[zi] = a.frozen ? a.gamma[c] * inv * g
+                            : a.gamma[c] * inv * (g - a.dbeta[c] / cnt - xh * a.dgamma[c] / cnt);
     }
 }
 
@@ -769,13 +771,13 @@ extern "C" int ct_bn_train_apply(const float* z, const float* mean, const float*
     return CT_OK;
 }
 
-extern "C" int ct_bn_train_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot,
-                                    int y_coff, const float* z, const float* mean, const float* var,
-                                    const float* gamma, float eps, int relu, const float* lo,
-                                    float res_scale, float* dres, int dres_ctot, int dres_coff,
-                                    int dres_accumulate, float* dz, float* dgamma, float* dbeta,
-                                    int z_ctot, int z_coff, int batch, int channels, int hw,
-                                    void* scratch, ct_stream_t stream)
+static int bn_backward_impl(int frozen, const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot,
+                            int y_coff, const float* z, const float* mean, const float* var,
+                            const float* gamma, float eps, int relu, const float* lo,
+                            float res_scale, float* dres, int dres_ctot, int dres_coff,
+                            int dres_accumulate, float* dz, float* dgamma, float* dbeta,
+                            int z_ctot, int z_coff, int batch, int channels, int hw,
+                            void* scratch, ct_stream_t stream)
 {
     CT_REQUIRE(dy && z && mean && var && gamma && dz && dgamma && dbeta, "ct_bn_train_backward: null pointer");
     CT_REQUIRE(!(relu || lo) || y, "ct_bn_train_backward: ReLU mask needs the forward output");
@@ -786,6 +788,7 @@ extern "C" int ct_bn_train_backward(const float* dy, int dy_ctot, int dy_coff, c
     a.y_ctot = y_ctot; a.y_coff = y_coff; a.dres_ctot = dres_ctot; a.dres_coff = dres_coff;
     a.dres_accumulate = dres_accumulate; a.eps = eps; a.rscale = res_scale; a.relu = relu;
     a.z_ctot = z_ctot; a.z_coff = z_coff;
+    a.frozen = frozen;
     hipStream_t st = ctdet::as_stream(stream);
     const long per_channel = (long)batch * hw;
     const int slices = (int)std::max<long>(1, std::min<long>((1024 + channels - 1) / channels, per_channel / 2048));
@@ -805,6 +808,32 @@ extern "C" int ct_bn_train_backward(const float* dy, int dy_ctot, int dy_coff, c
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for((long)batch * channels * hw)), dim3(256), 0, st, a);
     CT_LAUNCH_CHECK("bn_bwd_apply_kernel");
     return CT_OK;
+}
+
+extern "C" int ct_bn_train_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot,
+                                    int y_coff, const float* z, const float* mean, const float* var,
+                                    const float* gamma, float eps, int relu, const float* lo,
+                                    float res_scale, float* dres, int dres_ctot, int dres_coff,
+                                    int dres_accumulate, float* dz, float* dgamma, float* dbeta,
+                                    int z_ctot, int z_coff, int batch, int channels, int hw,
+                                    void* scratch, ct_stream_t stream)
+{
+    return bn_backward_impl(0, dy, dy_ctot, dy_coff, y, y_ctot, y_coff, z, mean, var, gamma, eps, relu, lo, res_scale,
+                            dres, dres_ctot, dres_coff, dres_accumulate, dz, dgamma, dbeta, z_ctot, z_coff, batch,
+                            channels, hw, scratch, stream);
+}
+
+extern "C" int ct_bn_eval_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot,
+                                   int y_coff, const float* z, const float* running_mean, const float* running_var,
+                                   const float* gamma, float eps, int relu, const float* lo,
+                                   float res_scale, float* dres, int dres_ctot, int dres_coff,
+                                   int dres_accumulate, float* dz, float* dgamma, float* dbeta,
+                                   int z_ctot, int z_coff, int batch, int channels, int hw,
+                                   void* scratch, ct_stream_t stream)
+{
+    return bn_backward_impl(1, dy, dy_ctot, dy_coff, y, y_ctot, y_coff, z, running_mean, running_var, gamma, eps, relu,
+                            lo, res_scale, dres, dres_ctot, dres_coff, dres_accumulate, dz, dgamma, dbeta, z_ctot,
+                            z_coff, batch, channels, hw, scratch, stream);
 }
 
 extern "C" int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot,

@@ -137,4 +137,6 @@ def global_normalizer(n_local, device):
         return n_local
     t = n_local.detach().to(device=device, dtype=torch.float64).reshape(1).clone()
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return (t / dist.get_world_size()).to(n_local.dtype).reshape(n_local.shape)
+    # a float quotient: 7 positives over 2 ranks is 3.5, not 3 (an integer cast would change the loss scale)
+    out = t / dist.get_world_size()
+    return (out if not n_local.dtype.is_floating_point else out.to(n_local.dtype)).reshape(n_local.shape)

@@ -487,8 +487,12 @@ class HipBackend:
             if p.bias is not None:
                 v.append((p.bias.data_ptr(), p.bias._version))
             if p.bn is not None:
-                for t in (p.bn.weight, p.bn.bias, p.bn.running_mean, p.bn.running_var):
-                    v.append((t.data_ptr(), t._version))
+                # num_batches_tracked stands in for the running statistics: the training engine updates
+                # running_mean / running_var through raw pointers (no version bump) but bumps this counter
+                # once per training forward, so an eval runtime re-folds its epilogue after any train step
+                for t in (p.bn.weight, p.bn.bias, p.bn.running_mean, p.bn.running_var, p.bn.num_batches_tracked):
+                    if t is not None:
+                        v.append((t.data_ptr(), t._version))
         return v
 
     def run_conv(self, st):

@@ -153,8 +153,8 @@ class TrainRuntime:
             else None
         for s_ in self.state.values():
             s_.ev_dz = torch.cuda.Event()
-        self._nbt = [p.bn.num_batches_tracked for st in self.plan.steps if st.kind == 'conv' for p in st.parts
-                     if p.bn is not None]
+        self._bns = [p.bn for st in self.plan.steps if st.kind == 'conv' for p in st.parts if p.bn is not None]
+        self._nbt = [bn.num_batches_tracked for bn in self._bns]
         # Gradient arena: ONE flat fp32 buffer in production order.  The weight / bias / BatchNorm gradient kernels
         # write straight into their slice (no per-parameter copies), the bucketed all-reduce runs on slices of it,
         # and backward() hands autograd views of a single snapshot.
@@ -222,6 +222,7 @@ class TrainRuntime:
 
     def forward(self, x, use_ctx=True):
         lib, B = self.lib, self.batch
+        self.generation = getattr(self, 'generation', 0) + 1      # saved activations belong to THIS forward
         self.used_ctx = bool(use_ctx and self.ctx is not None)
         if tuple(x.shape) != tuple(self.bufs['x'].shape):
             raise _lib.CtdetError('training plan was built for input %s, got %s'
@@ -247,16 +248,22 @@ class TrainRuntime:
             hw = st.oh * st.ow
             dst = self.bufs[st.dst]
             off = 0
+            s.frozen = [not p.bn.training for p in st.parts]
             for i, p in enumerate(st.parts):
                 bn = p.bn
-                _lib.check(lib.ct_bn_train_stats(z.data_ptr(), B, z.shape[1], off, p.cout, hw,
-                                                 s.mean[i].data_ptr(), s.var[i].data_ptr(), float(bn.momentum),
-                                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
-                                                 s.scratch[i].data_ptr(), self._s()),
-                           st.name + ' bn stats')
+                if s.frozen[i]:
+                    # nn.BatchNorm2d in eval() mode inside a training net: running statistics, no update
+                    mean_t, var_t = bn.running_mean, bn.running_var
+                else:
+                    mean_t, var_t = s.mean[i], s.var[i]
+                    _lib.check(lib.ct_bn_train_stats(z.data_ptr(), B, z.shape[1], off, p.cout, hw,
+                                                     mean_t.data_ptr(), var_t.data_ptr(), float(bn.momentum),
+                                                     bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                                                     s.scratch[i].data_ptr(), self._s()),
+                               st.name + ' bn stats')
                 res = self.bufs[st.res] if st.res is not None else None
                 _lib.check(lib.ct_bn_train_apply(
-                    z.data_ptr(), s.mean[i].data_ptr(), s.var[i].data_ptr(), bn.weight.data_ptr(),
+                    z.data_ptr(), mean_t.data_ptr(), var_t.data_ptr(), bn.weight.data_ptr(),
                     bn.bias.data_ptr(), float(bn.eps), int(p.relu), None,
                     res.data_ptr() if res is not None else None, res.shape[1] if res is not None else 0,
                     st.res_coff, float(st.res_scale), dst.data_ptr(), dst.shape[1], st.dst_coff + off,
@@ -264,8 +271,9 @@ class TrainRuntime:
                 off += p.cout
         # Norm branch and heads on the side stream, like the inference runtime (same schedule builder)
         run_on_streams(self, fwd_step)
-        if self._nbt:
-            torch._foreach_add_(self._nbt, 1)       # nn.BatchNorm2d's num_batches_tracked, one launch for all layers
+        nbt = [t for t, bn in zip(self._nbt, self._bns) if bn.training]
+        if nbt:
+            torch._foreach_add_(nbt, 1)             # nn.BatchNorm2d's num_batches_tracked, one launch for all layers
         if self.used_ctx:
             d = self.net.num_classes
             out = self.ctx.forward(self.bufs['conf'].view(B, self.P, d), self.bufs['pool'].view(B, self.plan.M, d),
@@ -357,9 +365,11 @@ class TrainRuntime:
                             dres, dres_ctot = dr.data_ptr(), dr.shape[1]
                             dres_acc = int(overlaps(st.res, st.res_coff, st.res_coff + p.cout))
                             written.setdefault(st.res, []).append((st.res_coff, st.res_coff + p.cout))
-                        _lib.check(lib.ct_bn_train_backward(
+                        frozen = s.frozen[i]
+                        mean_t, var_t = (p.bn.running_mean, p.bn.running_var) if frozen else (s.mean[i], s.var[i])
+                        _lib.check((lib.ct_bn_eval_backward if frozen else lib.ct_bn_train_backward)(
                             gy.data_ptr(), gy.shape[1], st.dst_coff + off, y.data_ptr(), y.shape[1], st.dst_coff + off,
-                            z.data_ptr(), s.mean[i].data_ptr(), s.var[i].data_ptr(), p.bn.weight.data_ptr(),
+                            z.data_ptr(), mean_t.data_ptr(), var_t.data_ptr(), p.bn.weight.data_ptr(),
                             float(p.bn.eps), int(p.relu), None, float(st.res_scale), dres, dres_ctot, st.res_coff,
                             dres_acc, s.dz.data_ptr(), s.dgamma[i].data_ptr(), s.dbeta[i].data_ptr(), ctot, off,
                             B, p.cout, hw, s.scratch[i].data_ptr(), self._s()), st.name + ' bn bwd')
@@ -426,9 +436,16 @@ class BackboneFunction(torch.autograd.Function):
     def forward(ctx, rt, x, use_ctx, *params):
         ctx.rt = rt
         loc, conf, obj = rt.forward(x, use_ctx)
+        ctx.generation = rt.generation
         return loc.clone(), conf.clone(), obj.clone()
 
     @staticmethod
     def backward(ctx, dloc, dconf, dobj):
+        if ctx.rt.generation != ctx.generation:
+            # the activations / BatchNorm statistics this backward needs live in buffers the runtime reuses
+            raise _lib.CtdetError(
+                'RFBNet training runtime: backward() of forward #%d called after forward #%d overwrote its saved '
+                'activations; run loss.backward() before the next model(x) of the same batch size (the engine keeps '
+                'one set of activation buffers per batch size)' % (ctx.generation, ctx.rt.generation))
         grads = ctx.rt.backward(dloc, dconf, dobj)
         return (None, None, None) + tuple(grads)

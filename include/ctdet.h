@@ -316,6 +316,15 @@ int ct_bn_train_backward(const float* dy, int dy_ctot, int dy_coff, const float*
                          float* dres, int dres_ctot, int dres_coff, int dres_accumulate,
                          float* dz, float* dgamma, float* dbeta, int z_ctot, int z_coff,
                          int batch, int channels, int hw, void* scratch, ct_stream_t stream);
+/* The same backward for an nn.BatchNorm2d that sits in eval() mode inside a training network (frozen
+ * statistics: ct_bn_train_apply was given running_mean / running_var): mean and variance are constants, so
+ * dz = gamma / sqrt(var+eps) * dy_masked, dgamma = sum dy_masked * xhat, dbeta = sum dy_masked. */
+int ct_bn_eval_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot, int y_coff,
+                        const float* z, const float* running_mean, const float* running_var, const float* gamma,
+                        float eps, int relu, const float* lo, float res_scale,
+                        float* dres, int dres_ctot, int dres_coff, int dres_accumulate,
+                        float* dz, float* dgamma, float* dbeta, int z_ctot, int z_coff,
+                        int batch, int channels, int hw, void* scratch, ct_stream_t stream);
 /* y = act(conv + bias): dz = dy * (y > 0 if relu) into a channel slice, dbias[c] = sum dz (may be NULL). */
 int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot, int y_coff,
                          int relu, int batch, int channels, int hw, float* dz, int dz_ctot, int dz_coff,

@@ -21,3 +21,49 @@ def test_header_is_c99_and_c_caller_links(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert 'cpu_nms keeps 2: 0 2' in r.stdout
+
+
+@pytest.mark.skipif(shutil.which('g++') is None, reason='g++ not available')
+def test_reference_native_symbol_is_exported_with_cxx_linkage(tmp_path):
+    """utils/nms/gpu_nms.hpp:1-2 declares `void _nms(int*, int*, const float*, int, int, float, int)` with C++
+    linkage; libctdet exports exactly that symbol, so a translation unit that only knows the reference's prototype
+    (examples/cpp_caller.cpp) links against it."""
+    r = subprocess.run(['nm', '-D', '--defined-only', os.path.join(LIBDIR, 'libctdet.so')], capture_output=True, text=True)
+    assert r.returncode == 0 and ' T _Z4_nmsPiS_PKfiifi' in r.stdout
+    exe = str(tmp_path / 'cpp_caller')
+    r = subprocess.run(['g++', '-Wall', '-Werror', os.path.join(REPO, 'examples', 'cpp_caller.cpp'), '-L' + LIBDIR, '-lctdet',
+                        '-Wl,-rpath,' + LIBDIR, '-Wl,-z,now', '-o', exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+REF_PYX = '/root/reference/utils/nms/gpu_nms.pyx'
+
+
+@pytest.mark.skipif(not os.path.exists(REF_PYX) or shutil.which('g++') is None, reason='reference tree / g++ not here')
+def test_reference_gpu_nms_pyx_links_against_libctdet(tmp_path):
+    """The reference's Cython binding (utils/nms/gpu_nms.pyx) built against libctdet instead of its nvcc object.
+    The .pyx is compiled from where it lies with ONE numpy-2 API patch applied to a temp copy (`np.int_t` no longer
+    exists in Cython 3's numpy.pxd; it is the platform `long`, i.e. `np.intp_t` here) -- its `cdef extern from
+    "gpu_nms.hpp"` block and the `_nms` call are untouched.  Importing the module resolves `_nms` (RTLD_NOW);
+    running it needs a GPU and is covered by tests/test_gpu_kernels.py through the same symbol."""
+    cython = pytest.importorskip('Cython')
+    import sysconfig
+    import numpy as np
+    src = open(REF_PYX).read()
+    assert 'cdef extern from "gpu_nms.hpp"' in src and '_nms(&keep[0], &num_out, &sorted_dets[0, 0]' in src
+    pyx = tmp_path / 'gpu_nms.pyx'
+    pyx.write_text(src.replace('np.int_t', 'np.intp_t').replace('np.float thresh', 'float thresh'))
+    cpp = str(tmp_path / 'gpu_nms.cpp')
+    r = subprocess.run(['python', '-m', 'cython', '--cplus', '-3', str(pyx), '-o', cpp], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    so = str(tmp_path / ('gpu_nms' + sysconfig.get_config_var('EXT_SUFFIX')))
+    cmd = ['g++', '-shared', '-fPIC', '-O1', '-w', cpp, '-I' + os.path.dirname(REF_PYX), '-I' + np.get_include(),
+           '-I' + sysconfig.get_paths()['include'], '-L' + LIBDIR, '-lctdet', '-Wl,-rpath,' + LIBDIR, '-Wl,-z,now', '-o', so]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run(['nm', '-D', '--undefined-only', so], capture_output=True, text=True)
+    assert '_Z4_nmsPiS_PKfiifi' in r.stdout                   # the binding really calls the C++-linkage symbol
+    # import in a fresh interpreter (torch first: libctdet must bind to torch's HIP runtime, see ctdet/_lib.py)
+    code = 'import torch, sys; sys.path.insert(0, %r); import gpu_nms; print(callable(gpu_nms.gpu_nms))' % str(tmp_path)
+    r = subprocess.run(['python', '-c', code], capture_output=True, text=True)
+    assert r.returncode == 0 and 'True' in r.stdout, r.stderr[-2000:]

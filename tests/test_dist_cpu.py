@@ -79,8 +79,8 @@ def _bucket_worker(rank, world, port, q):
     bk.finish()
     assert bk.flat.data_ptr() == arena.data_ptr() and torch.isnan(arena[sum(numels):]).all()
     assert joins == sorted(bk.last_in_bucket.values()), (joins, bk.last_in_bucket)
-    n = cdist.global_normalizer(torch.tensor(10 + 4 * rank), 'cpu')
-    q.put((rank, [bk.view(i).numpy().copy() for i in range(len(numels))], len(bk.bucket_span), int(n)))
+    n = cdist.global_normalizer(torch.tensor(10 + 5 * rank), 'cpu')       # integer count, odd global sum
+    q.put((rank, [bk.view(i).numpy().copy() for i in range(len(numels))], len(bk.bucket_span), float(n)))
     torch.distributed.destroy_process_group()
 
 
@@ -105,7 +105,7 @@ def test_grad_bucketer_two_ranks():
         want.append(sum(gs) / world)
     for rank in range(world):
         assert res[rank][2] >= 2                                 # really bucketed
-        assert res[rank][3] == 12                                # (10 + 14) / 2
+        assert res[rank][3] == 12.5                              # (10 + 15) / 2, not truncated
         for a, b in zip(res[rank][1], want):
             assert np.allclose(a, b.numpy(), atol=1e-6)
 

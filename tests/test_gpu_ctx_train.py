@@ -121,42 +121,48 @@ def _net(size, C, setting):
     return net
 
 
-@pytest.mark.parametrize('setting', ['transfer', 'incre'])
-def test_phase2_training_step_vs_oracle_autograd(setting):
-    """configs[3] in miniature: RFBNet-300 + Context-Transformer, one training step at bs 2."""
+@pytest.mark.parametrize('size,setting', [(300, 'transfer'), (300, 'incre'), (512, 'transfer')])
+def test_phase2_training_step_vs_oracle_autograd(size, setting):
+    """One training step of RFBNet + Context-Transformer at bs 2 (train.py:206-242 on models/RFB_Net_vgg.py:253-271).
+    size 512 is BASELINE configs[3]'s real network (RFBNet-512 fine-tune); there the reference itself raises
+    IndexError (:243), so that case is judged against the build's own restatement: "parity unpinned"."""
     from layers.functions import PriorBox
     from layers.modules.multibox_loss_combined import MultiBoxLoss_combined
-    from data import VOC_300
+    import data as cfgs
+    VOC_300 = getattr(cfgs, 'VOC_%d' % size)
     C = 15 if setting == 'incre' else 60
-    net = _net(300, C, setting).train()
+    net = _net(size, C, setting).train()
     T = net.OBJ_Target.weight.shape[0]
     ncls = (C if setting == 'incre' else 0) + T + 1
-    x = synth.images(2, 300, 'randn', 4321)
+    x = synth.images(2, size, 'randn', 4321)
     sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     out = net(x.cuda())
     leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and 'running' not in k
             and k != 'scale'}
     sdo = dict(sd)
     sdo.update(leaf)
-    oo = rfbnet_ref.forward(sdo, x, 300, C, phase=2, setting=setting, training=True)
+    oo = rfbnet_ref.forward(sdo, x, size, C, phase=2, setting=setting, training=True)
     # batch-2 BatchNorm (1x1 and 3x3 maps) in front of a sharp softmax and a cosine classifier is
     # ill-conditioned, so: (1) loc / obj / raw conf against a float64 evaluation of the oracle, relative
     # to what torch-CPU fp32 achieves; (2) the block itself on the DEVICE's own conf / pooled conf
     # against the oracle block in float64 at 1e-4; (3) the end-to-end conf only loosely.
     with torch.no_grad():
         sd64 = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
-        o64 = rfbnet_ref.forward(sd64, x.double(), 300, C, phase=2, setting=setting, training=True)
-        c64 = rfbnet_ref.forward(sd64, x.double(), 300, C, phase=2, setting=setting, training=True, init=True)
-        c32 = rfbnet_ref.forward(sd, x, 300, C, phase=2, setting=setting, training=True, init=True)
+        o64 = rfbnet_ref.forward(sd64, x.double(), size, C, phase=2, setting=setting, training=True)
+        c64 = rfbnet_ref.forward(sd64, x.double(), size, C, phase=2, setting=setting, training=True, init=True)
+        c32 = rfbnet_ref.forward(sd, x, size, C, phase=2, setting=setting, training=True, init=True)
     trt = net.train_runtime(2)
     raw = trt.bufs['conf'].view(2, -1, C)
     for a, b, c, n in ((out[0], oo[0], o64[0], 'loc'), (out[2], oo[2], o64[2], 'obj'), (raw, c32, c64, 'raw conf')):
         e_gpu, e_cpu = rel_err(a.detach().cpu(), c.float()), rel_err(b.detach(), c.float())
         assert a.shape == b.shape and e_gpu < max(1e-4, 5 * e_cpu), (n, e_gpu, e_cpu)
     with torch.no_grad():
+        pooled = trt.bufs['pool'].view(2, -1, C).cpu()
         blk = rfbnet_ref.context_block({k: v for k, v in sd64.items() if v.is_floating_point()}, raw.cpu().double(),
-                                       trt.bufs['pool'].view(2, -1, C).cpu().double(), setting)
-    assert rel_err(out[1].detach().cpu(), blk.float()) < 1e-4
+                                       pooled.double(), setting)
+        blk32 = rfbnet_ref.context_block({k: v for k, v in sd.items() if v.is_floating_point()}, raw.cpu(), pooled, setting)
+    # 1e-4, or what torch-CPU fp32 achieves on the same inputs where the un-scaled logits make fp32 itself worse (512)
+    assert rel_err(out[1].detach().cpu(), blk.float()) < max(1e-4, 3 * rel_err(blk32, blk.float()))
     assert out[1].shape == oo[1].shape and rel_err(out[1].detach().cpu(), o64[1].float()) < 1e-2
     # init=True returns the raw conf logits of the base head in training mode too
     ci = net(x.cuda(), init=True)

@@ -1,0 +1,220 @@
+"""Data-parallel training path on ONE MI355X (BASELINE configs[3]): what `train.py:206-242,296-297`
+does with DataParallel, here as one process per rank -- checked without an 8-GPU node:
+
+  * the whole-network gradient against torch-CPU float64 autograd at 1e-4 (BatchNorm in eval mode, so the
+    function is smooth and batch-size independent; the batch-statistics case is in test_gpu_train.py);
+  * two processes on the same device (gloo): each runs the HIP backward on its half of a bs-8 batch through
+    GradBucketer + the global loss normaliser; the averaged gradient equals the one-process full-batch one;
+  * the engine's guards (stale BatchNorm folding, backward after a second forward, > 256 ground-truth boxes).
+"""
+import os
+import socket
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import rel_err
+from ctdet import _lib, ops, synth
+from oracle import box_ref, loss_ref, rfbnet_ref
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail('the gpu tests need a HIP device; none visible')
+
+
+def _net(size, C, phase=1, setting='transfer'):
+    from models.RFB_Net_vgg import build_net
+    net = build_net(types.SimpleNamespace(method='ours', phase=phase, setting=setting), size, C)
+    net.load_state_dict(synth.fill_state_dict(net.state_dict()), strict=True)
+    net = net.cuda()
+    net.device = 'cuda'
+    return net
+
+
+def _freeze_bn(net):
+    """What a fine-tuning script does to keep BatchNorm statistics fixed: the nn.BatchNorm2d modules in eval()."""
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.eval()
+    return net
+
+
+def test_frozen_bn_network_gradients_match_fp64_autograd():
+    """Every parameter gradient of RFBNet-300 (bs 8, BatchNorm in eval mode) against float64 autograd through the
+    oracle at 1e-4 normalised.  The loss is a fixed random linear functional of (loc, conf, obj), so nothing but
+    the network's own backward kernels (dgrad / wgrad direct + Winograd, bias/ReLU, frozen-BN, pools, head gather)
+    is between the output gradient and the parameters."""
+    B = 8
+    net = _freeze_bn(_net(300, 20).train())
+    x = synth.images(B, 300, 'randn', 2024)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    out = net(x.cuda())
+    g = torch.Generator().manual_seed(5)
+    R = [torch.randn(t.shape, generator=g) / t.numel() ** 0.5 for t in out]
+    loss = sum((t * r.cuda()).sum() for t, r in zip(out, R))
+    loss.backward()
+    # oracle in float64: eval-mode BatchNorm, raw head outputs (exactly what the frozen-BN training forward computes)
+    leaf = {k: v.double().requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and 'running' not in k}
+    sdo = {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}
+    sdo.update(leaf)
+    oo = rfbnet_ref.forward(sdo, x.double(), 300, 20, raw=True)
+    for a, b, n in zip(out, oo, ('loc', 'conf', 'obj')):
+        assert rel_err(a.detach().cpu(), b.detach().float()) < 1e-4, n
+    sum((t * r.double()).sum() for t, r in zip(oo, R)).backward()
+    worst = {}
+    for name, prm in net.named_parameters():
+        assert prm.grad is not None, name
+        want = leaf[name].grad
+        e = rel_err(prm.grad.cpu().double(), want)
+        if e >= 1e-4:
+            worst[name] = e
+    assert not worst, sorted(worst.items(), key=lambda kv: -kv[1])[:12]
+    # frozen statistics were not touched
+    bn = net.Norm.branch0[0].bn
+    assert int(bn.num_batches_tracked) == 0 and torch.equal(bn.running_mean.cpu(), sd['Norm.branch0.0.bn.running_mean'])
+
+
+# ------------------------------------------------------------------ two ranks on one device
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_step(net, batch, x, targets, sync):
+    from layers.functions import PriorBox
+    from layers.modules.multibox_loss_combined import MultiBoxLoss_combined
+    from data import VOC_300
+    priors = PriorBox(VOC_300).forward().cuda()
+    crit = MultiBoxLoss_combined(21, 0.5, True, 0, True, 3, 0.5, False)
+    crit.sync_normalizer = sync
+    if sync:
+        net.train_runtime(batch).enable_grad_sync(bucket_bytes=16 << 20)      # several buckets
+    ld = crit(net(x.cuda()), priors, [t.cuda() for t in targets])
+    sum(ld.values()).backward()
+    torch.cuda.synchronize()
+    flat = torch.cat([p.grad.flatten() for p in net.parameters() if p.grad is not None]).cpu()
+    return flat, {k: float(v) for k, v in ld.items()}
+
+
+def _dp_worker(rank, world, port, q):
+    try:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        torch.cuda.set_device(0)                    # both ranks share the one GPU of the box
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+        net = _freeze_bn(_net(300, 20).train())
+        B = 8 // world
+        x = synth.images(8, 300, 'randn', 31)[rank * B:(rank + 1) * B]
+        tg = synth.targets(8, 21, 17)[rank * B:(rank + 1) * B]
+        flat, ld = _dp_step(net, B, x, tg, True)
+        nb = len(net.train_runtime(B).bucketer.bucket_span)
+        q.put((rank, flat.numpy(), ld, nb, None))
+        dist.destroy_process_group()
+    except Exception as e:      # surface the failure in the parent instead of a queue timeout
+        import traceback
+        q.put((rank, None, None, 0, traceback.format_exc()))
+        raise
+
+
+def test_two_rank_gradient_equals_full_batch_gradient():
+    """train.py:296-297 (DataParallel splits ONE batch) + multibox_loss_combined.py:119-122 (N over the whole
+    batch): two single-GPU ranks, each with half of the bs-8 batch, all-reduce (mean) of the flat gradient in
+    buckets issued from inside the HIP backward, loss normaliser made global -- equals the bs-8 step of one
+    process."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    # the single-process reference runs here while the ranks work
+    net = _freeze_bn(_net(300, 20).train())
+    full, ld_full = _dp_step(net, 8, synth.images(8, 300, 'randn', 31), synth.targets(8, 21, 17), False)
+    res = sorted([q.get(timeout=900) for _ in range(world)], key=lambda t: t[0])
+    for p in ps:
+        p.join(120)
+    for r in res:
+        assert r[4] is None, r[4]
+    for p in ps:
+        assert p.exitcode == 0
+    g0, g1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
+    assert res[0][3] >= 3                                    # really bucketed
+    assert torch.equal(g0, g1)                               # both ranks hold the same averaged gradient
+    assert g0.shape == full.shape
+    # per-parameter normalised error (the weight-gradient kernels sum pixels in a batch-dependent order)
+    off, bad = 0, {}
+    for name, prm in net.named_parameters():
+        if prm.grad is None:
+            continue
+        n = prm.numel()
+        e = rel_err(g0[off:off + n], full[off:off + n])
+        if e >= 1e-5:
+            bad[name] = e
+        off += n
+    assert off == full.numel() and not bad, sorted(bad.items(), key=lambda kv: -kv[1])[:10]
+    # per-rank losses are normalised by N_global / world: their mean is the full-batch loss
+    for k in ld_full:
+        assert abs(0.5 * (res[0][2][k] + res[1][2][k]) - ld_full[k]) < 1e-5 * max(1.0, abs(ld_full[k])), k
+
+
+# ------------------------------------------------------------------ guards
+def test_backward_after_second_forward_raises():
+    net = _net(300, 20).train()
+    x = synth.images(2, 300, 'randn', 3).cuda()
+    o1 = net(x)
+    o2 = net(x * 0.5)
+    with pytest.raises(_lib.CtdetError, match='overwrote'):
+        (o1[0].sum() + o2[0].sum()).backward()
+    o3 = net(x)                 # a fresh forward/backward pair still works
+    o3[0].sum().backward()
+    assert net.base[0].weight.grad is not None
+
+
+def test_eval_runtime_refolds_batchnorm_after_a_training_forward():
+    """A train-mode forward updates running_mean / running_var through raw pointers; the eval runtime built BEFORE
+    must pick the new statistics up even when no parameter changed in between."""
+    net = _net(300, 20).eval()
+    x = synth.images(2, 300, 'randn', 8)
+    with torch.no_grad():
+        before = [t.clone() for t in net.forward_raw(x.cuda())]
+    net.train()
+    with torch.no_grad():
+        for _ in range(3):
+            net(x.cuda() * 3.0 + 1.0)
+    net.eval()
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        after = net.forward_raw(x.cuda())
+        want = rfbnet_ref.forward(sd, x, 300, 20, raw=True)
+    assert not torch.equal(before[1], after[1])
+    for a, b, n in zip(after, want, ('loc', 'conf', 'obj')):
+        assert rel_err(a.cpu(), b) < 1e-4, n
+
+
+def test_match_more_than_256_ground_truth_boxes():
+    """utils/box_utils.py:83-132 has no limit on the number of boxes per image."""
+    priors = box_ref.prior_box(box_ref.ANCHOR_CFGS['VOC_300'])
+    rng = np.random.RandomState(3)
+    G = 700
+    xy = rng.uniform(0, 0.8, (G, 2))
+    wh = rng.uniform(0.05, 0.2, (G, 2))
+    t = torch.from_numpy(np.concatenate([xy, xy + wh, rng.randint(1, 21, (G, 1)), np.ones((G, 1))], 1).astype(np.float32))
+    batch = [t, t[:300], t[100:357], synth.targets(1, 21, 5)[0]]
+    loc_t, conf_t, obj_t, ovl = ops.match_batched([b.cuda() for b in batch], priors.cuda(), 0.5, [0.1, 0.2], True)
+    for i, b in enumerate(batch):
+        wl, wc, wo, wov = box_ref.match(0.5, b[:, :4], priors, [0.1, 0.2], b[:, 4:])
+        assert torch.equal(conf_t[i].cpu(), wc), i
+        assert torch.equal(obj_t[i].cpu(), wo), i
+        assert torch.equal(ovl[i].cpu(), wov), i
+        np.testing.assert_allclose(loc_t[i].cpu().numpy(), wl.numpy(), rtol=1e-5, atol=2e-5)

@@ -445,3 +445,21 @@ def test_c_caller_runs_the_nms_contract_on_the_device(tmp_path):
     r = subprocess.run([exe, 'gpu'], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert '_nms contract keeps 2: 0 2' in r.stdout
+
+
+def test_cpp_caller_runs_the_reference_symbol_on_the_device(tmp_path):
+    """examples/cpp_caller.cpp knows only the reference's prototype (utils/nms/gpu_nms.hpp:1-2, C++ linkage) and gets
+    the known answer from libctdet's `_nms`."""
+    import os
+    import shutil
+    import subprocess
+    if shutil.which('g++') is None:
+        pytest.skip('g++ not available')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(repo, 'context-transformer_amd', 'lib')
+    exe = str(tmp_path / 'cpp_caller')
+    subprocess.check_call(['g++', os.path.join(repo, 'examples', 'cpp_caller.cpp'), '-L' + libdir, '-lctdet',
+                           '-Wl,-rpath,' + libdir, '-o', exe])
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert '_nms keeps 2: 0 2' in r.stdout

@@ -1,8 +1,9 @@
 """solver LR groups / schedule against goldens produced by the reference's
 utils/solver.py on the reference's RFBNet, and the checkpoint loading rules of
 utils/checkpointer.py (module. strip, base. prefix, shape-mismatch skip, phase-2 weights-only,
-resume tag) -- the reference checkpointer needs `termcolor`, absent here, so those rules are
-pinned by behaviour tests citing its lines rather than by execution."""
+resume tag), pinned by tests/golden/checkpointer.npz: the reference's DetectionCheckpointer /
+PeriodicCheckpointer executed on the reference's RFBNet over the scenarios of tests/ckpt_cases.py
+(tools/gen_goldens.py `checkpointer`), plus behaviour tests citing its lines."""
 import os
 import types
 
@@ -117,3 +118,19 @@ def test_vgg16_reducedfc_gets_base_prefix(tmp_path):
     c.load(path)
     assert all(torch.equal(net.state_dict()['base.' + k], v) for k, v in base.items())
     assert not c.incompatible.unexpected_keys and all(not k.startswith('base.') for k in c.incompatible.missing_keys)
+
+
+def test_checkpointer_matches_the_reference_on_recorded_scenarios(tmp_path):
+    """utils/checkpointer.py:169-207 (_load_model), :259-297 (DetectionCheckpointer.load), :48-71 (save), :300-349
+    (PeriodicCheckpointer): same files, same model keys -> the same tensors change, the same dict comes back, the
+    same checkpointables get loaded / dropped, the same files are written."""
+    import ckpt_cases
+    want = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'checkpointer.npz'))
+
+    def make_model(phase):
+        return build_net(types.SimpleNamespace(method='ours', phase=phase, setting='transfer'), 300, 60)
+    got = ckpt_cases.run(make_model, ck, str(tmp_path))
+    assert sorted(got) == sorted(want.files)
+    for k in sorted(got):
+        assert got[k] == [str(v) for v in want[k]], k
+    assert len(got['A.changed']) == 28 and got['A.n_ckpt'] == ['0'] and got['C.opt_loaded'] == ['True']

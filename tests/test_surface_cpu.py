@@ -149,3 +149,45 @@ def test_plan_wiring_against_oracle(size, C, phase, setting, B):
             assert plan.M == 1858 // 1 if C else True
     else:
         assert plan.P == 32756
+
+
+@pytest.mark.parametrize('tag,size,C,phase,setting', [('300_p2_transfer', 300, 60, 2, 'transfer'),
+                                                       ('300_p2_incre', 300, 15, 2, 'incre'), ('512_p1', 512, 20, 1, 'transfer')])
+def test_init_weight_rules_match_reference(golden, tag, size, C, phase, setting):
+    """models/RFB_Net_vgg.py:297-314 + :157-188 through the reference's own constructor (tests/golden/init.npz):
+    every state-dict entry is initialised by the same RULE -- all zeros (every bias, Wz, fc_base), all ones (BN
+    gamma, running_var), kaiming-normal fan_out (BasicConv convs, theta/phi/g), torch's default uniform (the plain
+    nn.Conv2d of base / heads, OBJ_Target) -- with the same spread, and the same entries are trainable."""
+    from models.RFB_Net_vgg import build_net
+    g = golden('init.npz')
+    torch.manual_seed(5)
+    net = build_net(types.SimpleNamespace(method='ours', phase=phase, setting=setting), size, C)
+    keys = [str(k) for k in g[tag + '_keys']]
+    sd = net.state_dict()
+    assert list(sd.keys()) == keys
+    trainable = {k: v.requires_grad for k, v in net.named_parameters()}
+    for k, (std, mean, amax, numel, rg) in zip(keys, g[tag + '_stats']):
+        a = sd[k].double()
+        assert a.numel() == int(numel), k
+        assert bool(rg) == bool(trainable.get(k, False)), k
+        if amax == 0.0:                                      # zeros rule
+            assert float(a.abs().max()) == 0.0, k
+        elif std == 0.0 and a.numel() > 1:                   # constant rule (ones) / scalar entries
+            assert float(a.std()) == 0.0 and float(a.mean()) == mean, k
+        elif a.numel() == 1:
+            assert float(a.mean()) == mean, k                # `scale` = 5
+        else:
+            n = a.numel()
+            tol = 6.0 / n ** 0.5 + 1e-3                     # sampling spread of a std estimate
+            assert abs(float(a.std()) / std - 1.0) < tol, (k, float(a.std()), std)
+            assert abs(float(a.mean())) < 6.0 * std / n ** 0.5 + 1e-12, k
+            # max|x| / std: sqrt(3) for a uniform law, > 3.5 for 4096+ normal samples
+            uniform_ref, uniform_own = amax / std < 2.0, float(a.abs().max()) / float(a.std()) < 2.0
+            if n >= 4096:                                    # bounded (uniform) vs unbounded (normal) family
+                assert uniform_ref == uniform_own, (k, amax / std, float(a.abs().max()) / float(a.std()))
+    if phase == 2:
+        gen = torch.Generator().manual_seed(77)
+        net.OBJ_Target.weight.data = torch.randn(net.OBJ_Target.weight.shape, generator=gen)
+        net.normalize()
+        assert np.array_equal(net.OBJ_Target.weight.data.numpy(), g[tag + '_normalized'])     # :316-318, same expression
+        assert torch.allclose(net.OBJ_Target.weight.data.norm(dim=1), torch.ones(net.OBJ_Target.weight.shape[0]), atol=1e-6)

@@ -466,8 +466,69 @@ def gen_reweight():
     save('reweight.npz', st)
 
 
+# ---------------------------------------------------------------------------
+def gen_checkpointer():
+    """The reference's utils/checkpointer.py (DetectionCheckpointer.load :259-297, _load_model :169-207, save /
+    PeriodicCheckpointer :48-71,:300-349) executed on the reference's own RFBNet over the scenarios of
+    tests/ckpt_cases.py.  The module imports `termcolor` (absent here) only to colour two log messages
+    (:362,:380); a stand-in module whose `colored` returns its text unchanged is injected for the import."""
+    stub = types.ModuleType('termcolor')
+    stub.colored = lambda text, *a, **k: text
+    sys.modules.setdefault('termcolor', stub)
+    spec = importlib.util.spec_from_file_location('ref_checkpointer', os.path.join(REF, 'utils/checkpointer.py'))
+    rc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rc)
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    import ckpt_cases
+
+    def make_model(phase):
+        return build_net(types.SimpleNamespace(method='ours', phase=phase, setting='transfer'), 300, 60)
+    with tempfile.TemporaryDirectory() as tmp:
+        obs = ckpt_cases.run(make_model, rc, tmp)
+    st = {k: np.array(v) for k, v in obs.items()}
+    for k in sorted(obs):
+        print('  %-16s %s' % (k, obs[k] if len(obs[k]) <= 4 else '%d entries, first %s' % (len(obs[k]), obs[k][:2])))
+    save('checkpointer.npz', st)
+
+
+# ---------------------------------------------------------------------------
+def gen_init():
+    """models/RFB_Net_vgg.py:297-318 (`init_weight`, `normalize`) and the Context-Transformer initialisation
+    (:157-188): per state-dict key the statistics of what the reference's constructor leaves behind
+    (std, mean, max |x|, numel, requires_grad) -- the values themselves depend on the RNG stream, the RULE
+    (zeros / ones / normal with a given std / uniform with a given bound) does not -- and `normalize()` on a
+    seeded classifier."""
+    st = {}
+    for tag, (size, C, phase, setting) in {'300_p2_transfer': (300, 60, 2, 'transfer'), '300_p2_incre': (300, 15, 2, 'incre'),
+                                           '512_p1': (512, 20, 1, 'transfer')}.items():
+        torch.manual_seed(11)
+        net = build_net(types.SimpleNamespace(method='ours', phase=phase, setting=setting), size, C)
+        grads = dict((k, v.requires_grad) for k, v in net.named_parameters())
+        keys, rows = [], []
+        for k, v in net.state_dict().items():
+            if k == 'Wz':
+                v = torch.zeros_like(v)          # torch.FloatTensor(60).fill_(0) at :171/:188
+            a = v.double()
+            keys.append(k)
+            rows.append([float(a.std()) if a.numel() > 1 else 0.0, float(a.mean()), float(a.abs().max()), a.numel(),
+                         float(grads.get(k, False))])
+        st[tag + '_keys'] = np.array(keys)
+        st[tag + '_stats'] = np.array(rows)
+        if phase == 2:
+            g = torch.Generator().manual_seed(77)
+            w = torch.randn(net.OBJ_Target.weight.shape, generator=g)
+            net.OBJ_Target.weight.data = w.clone()
+            net.normalize()
+            st[tag + '_normalized'] = net.OBJ_Target.weight.data.numpy().copy()
+    save('init.npz', st)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['box', 'nms', 'model', 'loss', 'pipeline', 'voc', 'solver', 'reweight']
+    which = sys.argv[1:] or ['init', 'box', 'nms', 'model', 'loss', 'pipeline', 'voc', 'solver', 'reweight', 'checkpointer']
+    if 'checkpointer' in which:
+        gen_checkpointer()
+    if 'init' in which:
+        gen_init()
     if 'box' in which:
         gen_box_ops()
     if 'nms' in which:
