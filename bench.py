@@ -10,18 +10,28 @@ RFBNet engine (fused HIP convs) -> fused softmax/decode/score fusion -> per (ima
 threshold + sort + NMS(0.45) -> per-image top-200 (test.py:130-161 generalised to a batch).
 Workload = BASELINE.json configs[1]: RFBNet-300 VGG16, bs=32 per GPU, fp32, 20 foreground
 classes, name-seeded random weights (no checkpoints/datasets offline).  Images shard across
-ranks with no data-path collective (inference), so scaling is weak: every rank processes its
-own 32 images; value = all images / max-over-ranks time.
+ranks with no data-path collective (inference).  `--scaling weak` (default): every rank owns
+--batch images; `--scaling strong`: ONE batch of --batch images is split over the ranks, the
+reference's DataParallel scatter (train.py:296-297).  value = all images / max-over-ranks time.
 
-Extra objects on the JSON line:
-  roofline      the dominant kernel (the fp32-MFMA implicit-GEMM conv instantiation that
-                accumulates the most time): algorithmic FLOPs of its launches / their duration
-                measured with HIP events on the launch stream inside the timed region
-                (peak = 157.3 TFLOP/s dense fp32 MFMA, MI355X_MICROARCH.md).
-  cpu_baseline  the CPU oracle (port of the reference path: stock torch-CPU fp32 ops + C NMS)
-                on a bounded sample (BASELINE configs[0] shape, 4 images), rank 0, N=1 only.
+Extra objects on the JSON line (N=1, rank 0):
+  roofline      dominant kernel = the conv instantiation with the most accumulated time, from HIP
+                events recorded on the launch stream around every conv launch INSIDE the timed region.
+                `achieved`/`frac` count the multiply-adds the kernel's algorithm executes on the matrix
+                pipe (Winograd F(2x2,3x3): 16/36 of the direct-convolution count) against the dense fp32
+                MFMA peak; `algorithmic_*` is the direct-convolution FLOP count of SURVEY 8(d) over the
+                same time (can exceed the peak -- that is the Winograd saving, not a roofline fraction).
+                `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/).
+    .stages     context attention / score fusion / select+sort / NMS kernels: per-launch HIP events
+                recorded by the library (ct_profile_enable) in a few extra steps after the timed region,
+                against the roofline that bounds each, `traffic` from the same PMC passes.
+  cpu_baseline  the CPU oracle (port of the reference path: stock torch-CPU fp32 ops + C NMS) on a bounded
+                sample (BASELINE configs[0] shape), all physical cores and one thread, split by stage.
+  other_configs the other single-GPU configurations BASELINE.json names (512, +Context-Transformer, the
+                bs-4 shard of a strong-scaled batch), a few steps each in the same process.
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -37,6 +47,8 @@ sys.path.insert(0, REPO)
 
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md), --dtype bf16 only
+PEAK_HBM_GBS = 8000.0               # HBM3E spec (6.3 TB/s achievable, MI355X_MICROARCH.md)
+WINOGRAD_MULT_RATIO = 16.0 / 36.0   # F(2x2,3x3): multiplications executed / direct-convolution multiplications
 
 
 def build_net(size, num_fg, phase, setting, device):
@@ -50,53 +62,70 @@ def build_net(size, num_fg, phase, setting, device):
     return net
 
 
+def physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n), 'psutil physical cores'
+    except Exception:
+        pass
+    return int(os.cpu_count() or 1), 'os.cpu_count() logical CPUs'
+
+
 def cpu_baseline(size, num_fg, images=4, reps=3):
-    """Oracle (port) timed on the host cores: forward + detect + per-class NMS + top-200."""
+    """Oracle (port) timed on the host cores, SURVEY 8(d): forward / Detect / per-class NMS + top-200 timed
+    separately and end to end, with all physical cores and with one thread."""
     from ctdet import synth
     from oracle import box_ref, nms_ref, rfbnet_ref
     nms_ref.build_c()
     threads = int(os.environ.get('CTDET_CPU_THREADS', 0))
+    src = 'CTDET_CPU_THREADS'
     if threads <= 0:
-        try:
-            import psutil
-            threads = psutil.cpu_count(logical=False) or os.cpu_count() or 1     # physical cores
-        except Exception:
-            threads = os.cpu_count() or 1
-    torch.set_num_threads(threads)
+        threads, src = physical_cores()
     sd = synth.fill_state_dict(rfbnet_ref.param_shapes(size, num_fg, 1))
-    x = synth.images(images, size, 'randn', 1234)
     priors = box_ref.prior_box(box_ref.ANCHOR_CFGS['VOC_%d' % size])
-    times = []
-    with torch.no_grad():
-        for r in range(reps + 1):
-            t0 = time.perf_counter()
-            loc, conf, obj = rfbnet_ref.forward(sd, x, size, num_fg)
-            boxes, scores = box_ref.detect(loc, conf, obj, priors)
-            for i in range(images):
-                nms_ref.postprocess_image(boxes[i].numpy(), scores[i].numpy(), (500, 375), nms_fn=nms_ref.nms_c)
-            dt = time.perf_counter() - t0
-            if r > 0:
-                times.append(dt)
-    med = float(np.median(times))
-    return {'value': round(images / med, 3), 'unit': 'images/s', 'cores': threads, 'kind': 'port',
+
+    def run(n_img, n_threads, n_reps):
+        torch.set_num_threads(n_threads)
+        x = synth.images(n_img, size, 'randn', 1234)
+        rows = []
+        with torch.no_grad():
+            for r in range(n_reps + 1):
+                t0 = time.perf_counter()
+                loc, conf, obj = rfbnet_ref.forward(sd, x, size, num_fg)
+                t1 = time.perf_counter()
+                boxes, scores = box_ref.detect(loc, conf, obj, priors)
+                t2 = time.perf_counter()
+                for i in range(n_img):
+                    nms_ref.postprocess_image(boxes[i].numpy(), scores[i].numpy(), (500, 375), nms_fn=nms_ref.nms_c)
+                t3 = time.perf_counter()
+                if r > 0:
+                    rows.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
+        med = np.median(np.array(rows), axis=0)
+        return {'images_per_s': round(n_img / float(med[0]), 3),
+                'ms_per_image': {'forward': round(float(med[1]) / n_img * 1e3, 2),
+                                 'detect': round(float(med[2]) / n_img * 1e3, 2),
+                                 'nms_top200': round(float(med[3]) / n_img * 1e3, 2)}}
+    full = run(images, threads, reps)
+    one = run(2, 1, 1)          # bounded: two images, one timed run after one warm-up
+    torch.set_num_threads(threads)
+    return {'value': full['images_per_s'], 'unit': 'images/s', 'cores': threads, 'cores_source': src, 'kind': 'port',
+            'stages_ms_per_image': full['ms_per_image'],
+            'one_thread': {'value': one['images_per_s'], 'unit': 'images/s', 'cores': 1,
+                           'stages_ms_per_image': one['ms_per_image'], 'sample': '2 images, 1 run after 1 warm-up'},
             'sample': '%d synthetic %dx%d images (BASELINE configs[0] shape): torch-CPU fp32 forward + '
                       'Detect + per-class C NMS + top-200, median of %d runs after 1 warm-up'
                       % (images, size, size, reps)}
 
 
-def pmc_traffic(event_name, workload):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, 2*FETCH+WRITE per
-    MI355X_MICROARCH.md).  Only passes recorded for THIS workload (`__workload__` entry of the file)
-    count; None when no pass covers this kernel on this workload."""
+def load_pmc(workload):
+    """{kernel name prefix: HBM bytes per launch} from the newest committed rocprofv3 PMC passes recorded for THIS
+    workload (profiles/*_pmc_traffic*.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, 2*FETCH+WRITE per
+    MI355X_MICROARCH.md)."""
     import glob
-    import re
-    m = re.match(r'conv_igemm_f32<(\d+)x(\d+),(\d+)x(\d+)', event_name)
-    if not m and not event_name.startswith('wino_'):
-        return None
-    kh, kw, bm, bn = m.groups() if m else (None,) * 4
-    best = None
-    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_pmc_traffic.json'))):
+    best = {}
+    for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_pmc_traffic*.json'))):
         try:
             table = json.load(open(path))
         except (OSError, ValueError):
@@ -104,17 +133,26 @@ def pmc_traffic(event_name, workload):
         if table.get('__workload__', {'size': 300, 'batch': 32, 'phase': 1, 'classes': 20}) != workload:
             continue
         for k, v in table.items():
-            if not m:
-                if k.startswith(event_name):
-                    best = v['hbm_bytes']
-                continue
-            f = [x.strip() for x in k[k.find('<') + 1:k.find('>')].split(',')] if '<' in k else []
-            if k.startswith('conv_igemm_f32') and len(f) >= 5 and f[0] == kh and f[1] == kw and f[3] == bm and f[4] == bn:
-                best = v['hbm_bytes']
+            if k != '__workload__':
+                best[k] = (v['hbm_bytes'], os.path.basename(path))
     return best
 
 
-def conv_roofline(rt, batch, workload):
+def pmc_lookup(pmc, name):
+    """HBM bytes per launch of kernel `name` (bench naming) in the PMC table (rocprof naming)."""
+    import re
+    m = re.match(r'conv_igemm_f32<(\d+)x(\d+),(\d+)x(\d+)', name)
+    for k, (v, _) in pmc.items():
+        if m:
+            f = [x.strip() for x in k[k.find('<') + 1:k.find('>')].split(',')] if '<' in k else []
+            if k.startswith('conv_igemm_f32') and len(f) >= 5 and (f[0], f[1], f[3], f[4]) == m.groups():
+                return v
+        elif k.startswith(name):
+            return v
+    return None
+
+
+def conv_roofline(rt, batch, pmc):
     """Per-instantiation totals from the HIP events the engine recorded around every conv launch
     of the timed region; reports the instantiation with the most accumulated time."""
     from ctdet import _lib
@@ -125,30 +163,34 @@ def conv_roofline(rt, batch, workload):
     for st, e0, e1 in rt.event_log:
         cfg = st.rt['desc'].config
         wino = bool(st.rt.get('wino'))
-        name = 'conv_bf16_nhwc' if bf16 else 'wino_f2x2_3x3_f32' if wino else 'conv_igemm_f32<%dx%d,%s>' % (
-            st.kh, st.kw, lib.ct_conv_config_name(cfg - 1).decode() if cfg > 0 else 'auto')
+        name = 'conv_bf16_nhwc' if bf16 else st.rt.get('kernel_name') or ('wino_f2x2_3x3_f32' if wino else
+               'conv_igemm_f32<%dx%d,%s>' % (st.kh, st.kw, lib.ct_conv_config_name(cfg - 1).decode() if cfg > 0 else 'auto'))
         a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
         a[0] += e0.elapsed_time(e1) * 1e-3
-        a[1] += st.flops(batch)                # ALGORITHMIC flops (direct convolution)
+        a[1] += st.flops(batch)                # direct-convolution flops
         a[2] += 1
-        a[3] += st.flops(batch) * (16.0 / 36.0 if wino else 1.0)      # multiply-adds actually sent to the MFMA pipe
+        a[3] += st.flops(batch) * (WINOGRAD_MULT_RATIO if wino else 1.0)     # multiply-adds sent to the MFMA pipe
     tot_t = sum(a[0] for a in agg.values())
     tot_f = sum(a[1] for a in agg.values())
     tot_x = sum(a[3] for a in agg.values())
     name, (t, f, n, fx) = max(agg.items(), key=lambda kv: kv[1][0])
-    ach = f / t / 1e12
-    traffic = pmc_traffic(name, workload)
+    wino = name.startswith('wino')
+    ach = fx / t / 1e12
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-        'frac': round(ach / peak, 4), 'traffic': traffic,
+        'frac': round(ach / peak, 4), 'traffic': pmc_lookup(pmc, name),
         'kernel': name, 'launches': n, 'avg_launch_us': round(t / n * 1e6, 2),
-        'flops_per_launch': round(f / n),
-        # Winograd F(2x2,3x3) executes 16/36 of the algorithmic multiply-adds: `frac` above is algorithmic
-        # flops / peak (can exceed 1), `mfma_pipe_frac` is what the matrix pipe really sustained
-        'mfma_pipe_frac': round(fx / t / 1e12 / peak, 4),
-        'all_conv': {'achieved': round(tot_f / tot_t / 1e12, 2),
-                     'frac': round(tot_f / tot_t / 1e12 / peak, 4),
-                     'mfma_pipe_frac': round(tot_x / tot_t / 1e12 / peak, 4),
+        'flops_per_launch': round(fx / n),
+        'flops_definition': 'multiply-adds x2 executed on the matrix pipe per launch' +
+                            (' = direct-convolution flops x 16/36 (Winograd F(2x2,3x3))' if wino else ''),
+        'algorithmic_flops_per_launch': round(f / n),
+        'algorithmic_achieved': round(f / t / 1e12, 2),
+        'algorithmic_frac': round(f / t / 1e12 / peak, 4),
+        'winograd_mult_ratio': round(WINOGRAD_MULT_RATIO, 4) if wino else 1.0,
+        'all_conv': {'achieved': round(tot_x / tot_t / 1e12, 2),
+                     'frac': round(tot_x / tot_t / 1e12 / peak, 4),
+                     'algorithmic_achieved': round(tot_f / tot_t / 1e12, 2),
+                     'algorithmic_frac': round(tot_f / tot_t / 1e12 / peak, 4),
                      'time_share_of_dominant': round(t / tot_t, 3),
                      # sum of the launch durations; with the two-stream schedule launches overlap, so this
                      # can exceed the wall time of a step (and every duration includes the contention)
@@ -158,6 +200,64 @@ def conv_roofline(rt, batch, workload):
     }
 
 
+def stage_rooflines(pipe, x, steps, pmc):
+    """Per-launch HIP events from the library's own profile scopes (ct_profile_enable) over `steps` extra steps."""
+    from ctdet import _lib
+    lib = _lib.lib()
+    B, P, T = pipe.batch, pipe.P, pipe.T
+    torch.cuda.synchronize()
+    graph_mode, pipe.use_graph = pipe.use_graph, False      # per-launch events need eager launches
+    _lib.check(lib.ct_profile_enable(1), 'ct_profile_enable')
+    for _ in range(steps):
+        pipe.run(x)
+    torch.cuda.synchronize()
+    pipe.use_graph = graph_mode
+    n = C.c_int(0)
+    _lib.check(lib.ct_profile_collect(None, 0, C.byref(n)), 'ct_profile_collect')
+    recs = (_lib.ProfileRecord * max(n.value, 1))()
+    _lib.check(lib.ct_profile_collect(recs, n.value, C.byref(n)), 'ct_profile_collect')
+    agg = {}
+    for i in range(n.value):
+        a = agg.setdefault(recs[i].name.decode(), [0.0, 0])
+        a[0] += recs[i].ms * 1e-3
+        a[1] += 1
+    _lib.check(lib.ct_profile_enable(0), 'ct_profile_enable')
+    cand = int((pipe.scores[:, :, 1:] > pipe.conf_thresh).sum().item())      # candidates over all (image, class)
+    net = pipe.net
+    work = {
+        # SURVEY 8(d): loc 16P + conf 4CP + obj 8P in, boxes 16P + scores 4(T+1)P out per image, priors 16P once
+        'detect_kernel': ('hbm', B * P * (16 + 4 * pipe.scores_in_ch + 8 + 16 + 4 * (T + 1)) + 16 * P),
+        # threshold scan of every score + 8 B key/index and 20 B row per candidate written for the sort
+        'select_sort_kernel': ('hbm', B * P * (T + 1) * 4 + cand * 28),
+        # 20 B row in + 4 B kept index out per candidate (SURVEY 8d "20N in + 4N out"), both NMS passes share it
+        'nms_segments_kernel': ('hbm', cand * 24),
+    }
+    if net.method == 'ours' and net.phase == 2:
+        d, M = net.num_classes, pipe.rt.plan.M
+        work['ctx_attn_kernel'] = ('mfma', B * 4.0 * P * M * d)      # QK^T and PV contractions, 2 flop per multiply-add
+        # SURVEY 8(d): read conf P*d*4 + pooled conf M*d*4, write P*T*4 per image (4.17 MB at 300 / transfer)
+        work['ctx_attn_kernel.hbm'] = ('hbm', B * (P * d * 4 + M * d * 4 + P * pipe.scores_in_ch * 4))
+    out = {}
+    for key, (bound, amount) in work.items():
+        kname = key.split('.')[0]
+        if kname not in agg:
+            continue
+        t, cnt = agg[kname]
+        per_launch = amount / (cnt / steps)
+        avg = t / cnt
+        if bound == 'mfma':
+            ach, peak, unit = per_launch / avg / 1e12, PEAK_F32_MFMA_TFLOPS, 'TFLOP/s'
+        else:
+            ach, peak, unit = per_launch / avg / 1e9, PEAK_HBM_GBS, 'GB/s'
+        out[key] = {'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4),
+                    'launches_per_step': round(cnt / steps, 2), 'avg_launch_us': round(avg * 1e6, 2),
+                    'algorithmic_per_launch': int(per_launch), 'traffic': pmc_lookup(pmc, kname)}
+    out['other_kernels_us_per_step'] = {k: round(v[0] / steps * 1e6, 2) for k, v in sorted(agg.items())
+                                        if k not in [w.split('.')[0] for w in work]}
+    out['candidates_per_step'] = cand
+    return out
+
+
 def log(msg):
     if os.environ.get('CTDET_BENCH_VERBOSE', '1') != '0' and int(os.environ.get('RANK', 0)) == 0:
         sys.stderr.write('[bench %7.1fs] %s\n' % (time.perf_counter() - _T0, msg))
@@ -165,6 +265,41 @@ def log(msg):
 
 
 _T0 = time.perf_counter()
+
+
+def make_pipeline(size, num_fg, phase, setting, batch, dtype, dev):
+    from ctdet.pipeline import DetectionPipeline
+    from layers.functions import PriorBox
+    import data as cfgs
+    T = 20 if phase == 2 else num_fg
+    net = build_net(size, num_fg, phase, setting, dev)
+    net.conv_dtype = dtype
+    priors = PriorBox(getattr(cfgs, 'VOC_%d' % size)).forward()
+    pipe = DetectionPipeline(net, priors, batch, T, image_wh=(500, 375))
+    pipe.scores_in_ch = T            # channels of the conf tensor the score-fusion kernel reads
+    return pipe
+
+
+def quick_config(size, num_fg, phase, setting, batch, dtype, dev, steps=5, warmup=4):
+    """ms/step and images/s of another configuration, same step definition, in this process."""
+    from ctdet import synth
+    pipe = make_pipeline(size, num_fg, phase, setting, batch, dtype, dev)
+    x = synth.images(batch, size, 'randn', 4321).to(dev)
+    for _ in range(warmup):
+        pipe.run(x)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.run(x)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    flops = pipe.rt.plan.conv_flops()
+    res = {'ms_per_step': round(dt * 1e3, 3), 'images_per_s': round(batch / dt, 1), 'batch': batch, 'steps': steps,
+           'conv_gflop_per_image': round(flops / batch / 1e9, 2),
+           'conv_algorithmic_tflops': round(flops / dt / 1e12, 1)}
+    del pipe, x
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -177,15 +312,18 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--size', type=int, default=300)
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU')
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU (weak scaling) / per job (strong scaling)')
     ap.add_argument('--classes', type=int, default=20)
     ap.add_argument('--phase', type=int, default=1)
     ap.add_argument('--setting', default='transfer')
+    ap.add_argument('--scaling', default=os.environ.get('CTDET_BENCH_SCALING', 'weak'), choices=['weak', 'strong'],
+                    help='strong: ONE batch of --batch images split over the ranks (train.py:296-297 DataParallel scatter)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="bf16: NHWC bf16 activations + bf16 MFMA convolutions (BASELINE configs[4]); NOT the "
                          "headline metric, which is fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-other-configs', action='store_true')
     a = ap.parse_args()
 
     from ctdet import dist as cdist
@@ -199,19 +337,20 @@ def main():
     cdist.init('nccl')           # RCCL; only used for the timing barrier / max-over-ranks
 
     from ctdet import synth
-    from ctdet.pipeline import DetectionPipeline
-    from layers.functions import PriorBox
-    import data as cfgs
-
     num_fg = a.classes
-    T = {('transfer', 2): 20, ('incre', 2): 20}.get((a.setting, a.phase), num_fg) if a.phase == 2 else num_fg
-    log('building net')
-    net = build_net(a.size, num_fg, a.phase, a.setting, dev)
-    net.conv_dtype = a.dtype
-    log('building pipeline (plan, weight packing%s)' % (', conv autotune' if os.environ.get('CTDET_TUNE', '1') != '0' else ''))
-    priors = PriorBox(getattr(cfgs, 'VOC_%d' % a.size)).forward()
-    pipe = DetectionPipeline(net, priors, a.batch, T, image_wh=(500, 375))
-    x = synth.images(a.batch, a.size, 'randn', 1234 + rank).to(dev)
+    if a.scaling == 'strong':
+        b0, b1 = cdist.shard(a.batch, rank, world)       # contiguous image shard of the one global batch
+        batch, global_batch = b1 - b0, a.batch
+        if batch == 0:
+            raise SystemExit('--scaling strong: batch %d cannot be split over %d ranks' % (a.batch, world))
+    else:
+        batch, global_batch = a.batch, a.batch * world
+    log('building net + pipeline (plan, weight packing%s)' % (', conv autotune' if os.environ.get('CTDET_TUNE', '1') != '0' else ''))
+    pipe = make_pipeline(a.size, num_fg, a.phase, a.setting, batch, a.dtype, dev)
+    x = synth.images(global_batch if a.scaling == 'strong' else batch, a.size, 'randn', 1234 + (0 if a.scaling == 'strong' else rank))
+    if a.scaling == 'strong':
+        x = x[b0:b1]
+    x = x.to(dev)
 
     def sync():
         cdist.barrier(dev)
@@ -221,7 +360,9 @@ def main():
         pipe.run(x)
     torch.cuda.synchronize(dev)
     log('timed region')
-    if not a.no_roofline and rank == 0:
+    want_roof = not a.no_roofline and rank == 0
+    graph_mode = bool(pipe.use_graph)
+    if want_roof and not graph_mode:
         pipe.rt.event_log = []          # HIP events around every conv launch of the timed region
     sync()
     t0 = time.perf_counter()
@@ -232,11 +373,44 @@ def main():
     dt = cdist.max_over_ranks(dt, dev)
 
     log('timed region done: %.2f ms/step' % (dt / a.steps * 1e3))
+    workload = {'size': a.size, 'batch': batch, 'phase': a.phase, 'classes': a.classes}
     roof = None
+    events_from = 'the timed region'
+    if want_roof and graph_mode:
+        # the timed region replays a hipGraph, inside which no per-launch events can be recorded: the same K steps
+        # again as eager launches with the events around every conv launch
+        log('event pass (eager launches of the same steps)')
+        pipe.rt.event_log = []
+        for _ in range(a.steps):
+            pipe.run(x)
+        torch.cuda.synchronize(dev)
+        events_from = 'an eager pass of the same %d steps right after the timed region (the timed region replays a ' \
+                      'hipGraph)' % a.steps
     if pipe.rt.event_log:
-        roof = conv_roofline(pipe.rt, a.batch, {'size': a.size, 'batch': a.batch, 'phase': a.phase,
-                                                    'classes': a.classes})
+        pmc = load_pmc(workload)
+        roof = conv_roofline(pipe.rt, batch, pmc)
+        roof['events_from'] = events_from
         pipe.rt.event_log = None
+        log('stage rooflines (library profile scopes, 5 extra steps)')
+        roof['stages'] = stage_rooflines(pipe, x, 5, pmc)
+        roof['traffic_source'] = sorted({v[1] for v in pmc.values()}) or None
+    counts = int(pipe.post.out_count.sum().item())
+    conv_gflop = round(pipe.rt.plan.conv_flops() / batch / 1e9, 2)
+    tuned = bool(pipe.rt.tuned)
+    other = None
+    if rank == 0 and world == 1 and not a.no_other_configs and a.dtype == 'f32' and \
+            (a.size, a.phase, a.classes, a.batch) == (300, 1, 20, 32):
+        del pipe
+        torch.cuda.empty_cache()
+        other = {}
+        for key, cfg in (('rfb512_bs32', (512, 20, 1, 'transfer', 32)),
+                         ('rfb300_ctx_bs32', (300, 60, 2, 'transfer', 32)),
+                         ('rfb512_ctx_bs32', (512, 60, 2, 'transfer', 32)),
+                         ('rfb300_bs4_strong_shard', (300, 20, 1, 'transfer', 4))):
+            log('other config %s' % key)
+            other[key] = quick_config(*cfg, 'f32', dev, steps=20 if cfg[4] == 4 else 5)
+        other['rfb300_bs4_strong_shard']['note'] = \
+            'the per-GPU shard when ONE bs-32 batch is split over 8 GPUs (--scaling strong); no collective on the path'
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log('cpu baseline (oracle on host cores)')
@@ -244,21 +418,22 @@ def main():
         log('cpu baseline done')
 
     if rank == 0:
-        total_images = a.batch * world * a.steps
-        counts = pipe.post.out_count.sum().item()
+        total_images = global_batch * a.steps
         line = {
             'metric': 'images/sec fwd+NMS', 'value': round(total_images / dt, 2), 'unit': 'images/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': a.scaling,
+            'launch_mode': 'hipGraph replay' if graph_mode else 'eager launches',
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
             'config': {'workload': 'RFBNet-%d VGG16 inference, bs=%d per GPU, %d fg classes, phase %d%s: '
                                    'fwd + softmax/decode + per-class NMS(0.45) + top-200; name-seeded random '
-                                   'weights, randn images' % (a.size, a.batch, num_fg, a.phase,
+                                   'weights, randn images' % (a.size, batch, num_fg, a.phase,
                                                               ' ' + a.setting if a.phase == 2 else ''),
-                       'global_batch': a.batch * world, 'parallelism': 'dp%d (image shards, no collective)' % world,
-                       'conv_gflop_per_image': round(pipe.rt.plan.conv_flops() / a.batch / 1e9, 2),
-                       'detections_per_batch': int(counts), 'conv_autotuned': bool(pipe.rt.tuned)},
-            'roofline': roof, 'cpu_baseline': cpu,
+                       'global_batch': global_batch,
+                       'parallelism': 'dp%d (image shards, no collective, %s scaling)' % (world, a.scaling),
+                       'conv_gflop_per_image': conv_gflop,
+                       'detections_per_batch': counts, 'conv_autotuned': tuned},
+            'roofline': roof, 'cpu_baseline': cpu, 'other_configs': other,
         }
         print(json.dumps(line))
     if world > 1:

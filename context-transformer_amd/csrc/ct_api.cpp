@@ -1,6 +1,9 @@
 // libctdet: error reporting, ABI version and device query.
 #include "ct_common.h"
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 namespace ctdet {
 
@@ -19,7 +22,65 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
+// ---- per-launch event timing (measurement only) ----
+namespace {
+struct ProfRec { const char* name; hipEvent_t e0, e1; bool stopped; };
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;
+}  // namespace
+
+bool prof_enabled() { return g_prof_on.load(std::memory_order_relaxed); }
+
+void prof_start(const char* name, hipStream_t st, int* slot)
+{
+    ProfRec r{name, nullptr, nullptr, false};
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    if (hipEventRecord(r.e0, st) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(r);
+    *slot = (int)g_prof.size() - 1;
+}
+
+void prof_stop(hipStream_t st, int slot)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < (int)g_prof.size() && hipEventRecord(g_prof[slot].e1, st) == hipSuccess) g_prof[slot].stopped = true;
+}
+
 }  // namespace ctdet
+
+extern "C" int ct_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(ctdet::g_prof_mu);
+    for (auto& r : ctdet::g_prof) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+    }
+    ctdet::g_prof.clear();
+    ctdet::g_prof_on.store(on != 0);
+    return CT_OK;
+}
+
+extern "C" int ct_profile_collect(ct_profile_record* out, int max_records, int* num_records)
+{
+    CT_REQUIRE(num_records && (out || max_records == 0), "ct_profile_collect: null pointer");
+    std::lock_guard<std::mutex> lk(ctdet::g_prof_mu);
+    int n = 0;
+    for (auto& r : ctdet::g_prof) {
+        if (!r.stopped) continue;
+        if (n < max_records) {
+            CT_HIP(hipEventSynchronize(r.e1));
+            float ms = 0.f;
+            CT_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+            out[n].name = r.name;
+            out[n].ms = ms;
+        }
+        ++n;
+    }
+    *num_records = n;
+    return CT_OK;
+}
 
 extern "C" int ct_abi_version(void) { return CTDET_ABI_VERSION; }
 

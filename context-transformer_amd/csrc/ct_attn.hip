@@ -283,18 +283,18 @@ int forward_impl(const float* conf, const float* pool, int batch, int num_priors
     const int ostride = (prm->fc_w ? d : 0) + prm->t;
     const dim3 blk(256);
     float* none = nullptr;
-    hipLaunchKernelGGL(ctx_project_kernel, dim3(w.P_pad / 64, batch), blk, 0, st, conf, num_priors,
-                       w.P_pad, d, prm->theta_w, prm->theta_b, w.Qs, none, none, none, 0);
+    { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_kernel, dim3(w.P_pad / 64, batch), blk, 0, st, conf, num_priors,
+                       w.P_pad, d, prm->theta_w, prm->theta_b, w.Qs, none, none, none, 0); }
     CT_LAUNCH_CHECK("ctx_project_kernel(theta)");
-    hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
-                       w.M_pad, d, prm->phi_w, prm->phi_b, none, w.Kt, none, none, 0);
+    { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
+                       w.M_pad, d, prm->phi_w, prm->phi_b, none, w.Kt, none, none, 0); }
     CT_LAUNCH_CHECK("ctx_project_kernel(phi)");
-    hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
-                       w.M_pad, d, prm->g_w, prm->g_b, none, none, w.Vs, none, 0);
+    { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
+                       w.M_pad, d, prm->g_w, prm->g_b, none, none, w.Vs, none, 0); }
     CT_LAUNCH_CHECK("ctx_project_kernel(g)");
     if (prm->fc_w) {
-        hipLaunchKernelGGL(ctx_project_kernel, dim3((num_priors + 63) / 64, batch), blk, 0, st, conf,
-                           num_priors, num_priors, d, prm->fc_w, prm->fc_b, none, none, none, out, ostride);
+        { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_kernel, dim3((num_priors + 63) / 64, batch), blk, 0, st, conf,
+                           num_priors, num_priors, d, prm->fc_w, prm->fc_b, none, none, none, out, ostride); }
         CT_LAUNCH_CHECK("ctx_project_kernel(fc_base)");
     }
     AttnArgs a{};
@@ -304,7 +304,7 @@ int forward_impl(const float* conf, const float* pool, int batch, int num_priors
     a.P = num_priors; a.P_pad = w.P_pad; a.M = num_ctx; a.M_pad = w.M_pad;
     a.d = d; a.T = prm->t; a.ostride = ostride; a.ooff = prm->fc_w ? d : 0;
     a.scale = prm->scale;
-    hipLaunchKernelGGL(ctx_attn_kernel, dim3(w.P_pad / QB, batch), blk, 0, st, a);
+    { CT_PROF("ctx_attn_kernel", st); hipLaunchKernelGGL(ctx_attn_kernel, dim3(w.P_pad / QB, batch), blk, 0, st, a); }
     CT_LAUNCH_CHECK("ctx_attn_kernel");
     return CT_OK;
 }

@@ -322,13 +322,13 @@ extern "C" int ct_detect_fused(const float* loc, const float* conf, const float*
         CT_REQUIRE(smem <= 160 * 1024, "ct_detect_fused: num_fg=%d needs %zu bytes of LDS", num_fg, smem);
     }
     if (apply_softmax)
-        hipLaunchKernelGGL(detect_kernel<true>, grid, block, smem, st, (const float4*)loc, conf,
+        { CT_PROF("detect_kernel", st); hipLaunchKernelGGL(detect_kernel<true>, grid, block, smem, st, (const float4*)loc, conf,
                            (const float2*)obj, (const float4*)priors, batch, num_priors, num_fg, var0,
-                           var1, scale4, scale_per_image, (float4*)boxes, scores);
+                           var1, scale4, scale_per_image, (float4*)boxes, scores); }
     else
-        hipLaunchKernelGGL(detect_kernel<false>, grid, block, smem, st, (const float4*)loc, conf,
+        { CT_PROF("detect_kernel", st); hipLaunchKernelGGL(detect_kernel<false>, grid, block, smem, st, (const float4*)loc, conf,
                            (const float2*)obj, (const float4*)priors, batch, num_priors, num_fg, var0,
-                           var1, scale4, scale_per_image, (float4*)boxes, scores);
+                           var1, scale4, scale_per_image, (float4*)boxes, scores); }
     CT_LAUNCH_CHECK("detect_kernel");
     return CT_OK;
 }

@@ -34,6 +34,20 @@ inline hipStream_t as_stream(ct_stream_t s) { return reinterpret_cast<hipStream_
         if (!(cond)) return ::ctdet::fail(CT_ERR_INVALID, __VA_ARGS__);                 \
     } while (0)
 
+// Per-launch HIP-event timing for the measurement tools (ct_profile_enable / ct_profile_collect): a ProfScope
+// around a launch records a start and a stop event on the launch stream when profiling is on, and costs one
+// relaxed load when it is off.
+bool prof_enabled();
+void prof_start(const char* name, hipStream_t st, int* slot);
+void prof_stop(hipStream_t st, int slot);
+struct ProfScope {
+    hipStream_t st;
+    int slot = -1;
+    ProfScope(const char* name, hipStream_t s) : st(s) { if (prof_enabled()) prof_start(name, s, &slot); }
+    ~ProfScope() { if (slot >= 0) prof_stop(st, slot); }
+};
+#define CT_PROF(name, stream) ::ctdet::ProfScope _ct_prof_scope_##__LINE__(name, stream)
+
 template <typename T>
 __host__ __device__ inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 

@@ -238,6 +238,7 @@ int launch_nms(const float* dets, const int* seg_off, const int* seg_len, int se
 #define CT_NMS_LAUNCH(GE, PL)                                                                  \
     hipLaunchKernelGGL((nms_segments_kernel<GE, PL>), grid, block, 0, st, dets, seg_off, seg_len, \
                        seg_stride, th, keep, keep_count)
+    CT_PROF("nms_segments_kernel", st);
     switch (ge & 3) {            // bit0: >=, bit1: plain IoU
         case 0: CT_NMS_LAUNCH(false, false); break;
         case 1: CT_NMS_LAUNCH(true, false); break;

@@ -407,31 +407,31 @@ extern "C" int ct_postprocess_batched(const float* boxes, const float* scores, i
     const int np2 = std::max(next_pow2(num_priors), 2);
     hipStream_t st = ctdet::as_stream(stream);
     CT_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
-    hipLaunchKernelGGL(select_sort_kernel, dim3(S), dim3(kSortThreads), 0, st, boxes, scores, num_priors,
-                       num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count);
+    { CT_PROF("select_sort_kernel", st); hipLaunchKernelGGL(select_sort_kernel, dim3(S), dim3(kSortThreads), 0, st, boxes, scores, num_priors,
+                       num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count); }
     CT_LAUNCH_CHECK("select_sort_kernel");
     int rc;
     constexpr int kPrefix = 256;          // candidates per class in the bounding pass
     if (max_per_image > 0 && num_priors > kPrefix) {
         // pass 1: NMS of every class's best kPrefix candidates -> exact lower bound of the top-k
         // threshold -> cut every segment there (see prefix_cut_kernel); pass 2: NMS of what is left
-        hipLaunchKernelGGL(clamp_len_kernel, dim3((S + 255) / 256), dim3(256), 0, st, w.seg_count, S, kPrefix, w.seg_len);
+        { CT_PROF("clamp_len_kernel", st); hipLaunchKernelGGL(clamp_len_kernel, dim3((S + 255) / 256), dim3(256), 0, st, w.seg_count, S, kPrefix, w.seg_len); }
         CT_LAUNCH_CHECK("clamp_len_kernel");
         rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_len, num_priors, S, nms_thresh, ge, w.keep, w.keep_count, st);
         if (rc != CT_OK) return rc;
-        hipLaunchKernelGGL(prefix_cut_kernel, dim3(batch, num_fg), dim3(256), 0, st, w.dets_sorted, w.keep, w.keep_count,
-                           w.seg_count, num_priors, num_fg, max_per_image, w.seg_len);
+        { CT_PROF("prefix_cut_kernel", st); hipLaunchKernelGGL(prefix_cut_kernel, dim3(batch, num_fg), dim3(256), 0, st, w.dets_sorted, w.keep, w.keep_count,
+                           w.seg_count, num_priors, num_fg, max_per_image, w.seg_len); }
         CT_LAUNCH_CHECK("prefix_cut_kernel");
         rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_len, num_priors, S, nms_thresh, ge, w.keep, w.keep_count, st);
     } else {
         rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_count, num_priors, S, nms_thresh, ge, w.keep, w.keep_count, st);
     }
     if (rc != CT_OK) return rc;
-    hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(256), 0, st, w.dets_sorted, w.keep, w.keep_count,
-                       num_priors, num_fg, max_per_image, out_cap, out_count, overflow);
+    { CT_PROF("topk_kernel", st); hipLaunchKernelGGL(topk_kernel, dim3(batch), dim3(256), 0, st, w.dets_sorted, w.keep, w.keep_count,
+                       num_priors, num_fg, max_per_image, out_cap, out_count, overflow); }
     CT_LAUNCH_CHECK("topk_kernel");
-    hipLaunchKernelGGL(gather_kernel, dim3(S), dim3(256), 0, st, w.dets_sorted, w.sorted_idx, w.keep,
-                       out_count, num_priors, out_cap, out_dets, out_index);
+    { CT_PROF("gather_kernel", st); hipLaunchKernelGGL(gather_kernel, dim3(S), dim3(256), 0, st, w.dets_sorted, w.sorted_idx, w.keep,
+                       out_count, num_priors, out_cap, out_dets, out_index); }
     CT_LAUNCH_CHECK("gather_kernel");
     return CT_OK;
 }

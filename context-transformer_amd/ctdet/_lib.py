@@ -41,6 +41,10 @@ class ConvDesc(C.Structure):
     ]
 
 
+class ProfileRecord(C.Structure):
+    _fields_ = [('name', C.c_char_p), ('ms', C.c_float)]
+
+
 class CtxParams(C.Structure):
     _fields_ = [('theta_w', C.c_void_p), ('theta_b', C.c_void_p), ('phi_w', C.c_void_p),
                 ('phi_b', C.c_void_p), ('g_w', C.c_void_p), ('g_b', C.c_void_p),
@@ -65,6 +69,8 @@ SIGNATURES = {
     'ct_abi_version': (_I, []),
     'ct_last_error_string': (C.c_char_p, []),
     'ct_device_info': (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
+    'ct_profile_enable': (_I, [_I]),
+    'ct_profile_collect': (_I, [C.POINTER(ProfileRecord), _I, C.POINTER(_I)]),
     'ct_nms_sorted_host': (_I, [_P, _P, _P, _I, _I, _F, _I]),
     'ct_nms_sorted_host_mode': (_I, [_P, _P, _P, _I, _I, _F, _I, _I]),
     'ct_nms_batched_workspace_bytes': (_Z, [_I, _I]),

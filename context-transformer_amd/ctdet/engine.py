@@ -736,8 +736,8 @@ class Runtime:
         else:
             raise ValueError(st.kind)
 
-    def run_backbone(self, x):
-        """x [B,3,S,S] on the device -> raw (loc [B,P*4], conf [B,P*C], obj [B,P*2]) buffers (views)."""
+    def load_input(self, x):
+        """Shape check, re-pack of changed weights, copy of x [B,3,S,S] into the plan's input buffer."""
         want = (self.batch,) + tuple(self.plan.buf_shapes['x'])
         if tuple(x.shape) != want:
             raise _lib.CtdetError('plan was built for input %s, got %s' % (want, tuple(x.shape)))
@@ -746,8 +746,16 @@ class Runtime:
             self.backend.load_input(self.bufs['x'], x)
         else:
             self.bufs['x'].copy_(x)
+
+    def run_loaded(self):
+        """The launches of the backbone on the input buffer (no allocation, no host synchronisation: capturable)."""
         run_on_streams(self, self._run_step)
         return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
+
+    def run_backbone(self, x):
+        """x [B,3,S,S] on the device -> raw (loc [B,P*4], conf [B,P*C], obj [B,P*2]) buffers (views)."""
+        self.load_input(x)
+        return self.run_loaded()
 
     def conv_steps(self):
         return [s for s in self.plan.steps if s.kind == 'conv']

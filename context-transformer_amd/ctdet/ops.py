@@ -277,20 +277,30 @@ def _ctx_prm(params, d, T, incre):
     return prm
 
 
-def ctx_attention(conf, pool, params, setting_incre=False):
+def ctx_attention(conf, pool, params, setting_incre=False, out=None, ws=None):
     """models/RFB_Net_vgg.py:253-271.  params: dict of device tensors theta_w, theta_b, phi_w, phi_b,
-    g_w, g_b, wz, obj_w[, fc_w, fc_b] and float `scale`."""
+    g_w, g_b, wz, obj_w[, fc_w, fc_b] and float `scale`.  `out` / `ws`: caller-owned output and workspace
+    (ctx_attention_buffers) so a captured / allocation-free forward can reuse them."""
     B, P, d = conf.shape
     M = pool.shape[1]
     T = params['obj_w'].shape[0]
     prm = _ctx_prm(params, d, T, setting_incre)
-    out = torch.empty(B, P, (d if setting_incre else 0) + T, device=conf.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(B, P, (d if setting_incre else 0) + T, device=conf.device, dtype=torch.float32)
     ws_bytes = lib().ct_ctx_attention_workspace_bytes(B, P, M, d)
-    ws = torch.empty(ws_bytes, device=conf.device, dtype=torch.uint8)
+    if ws is None:
+        ws = torch.empty(ws_bytes, device=conf.device, dtype=torch.uint8)
     check(lib().ct_ctx_attention_fwd(_dev(conf, 'conf'), _dev(pool, 'pool'), B, P, M, C.byref(prm),
                                      _dev(out, 'out'), _dev(ws, 'ws', torch.uint8), ws_bytes, _stream()),
           'ct_ctx_attention_fwd')
     return out
+
+
+def ctx_attention_buffers(B, P, M, d, T, setting_incre, device):
+    """(out, ws) for ctx_attention with these sizes."""
+    out = torch.empty(B, P, (d if setting_incre else 0) + T, device=device, dtype=torch.float32)
+    ws = torch.empty(lib().ct_ctx_attention_workspace_bytes(B, P, M, d), device=device, dtype=torch.uint8)
+    return out, ws
 
 
 class CtxTrainer:

@@ -217,7 +217,7 @@ class TrainRuntime:
     # ------------------------------------------------------------------ forward
     def _ctx_tensors(self):
         p = {k: v.detach() for k, v in self.ctx_params.items()}
-        p['scale'] = float(self.net.scale.item())
+        p['scale'] = self.net._scale_value()
         return p
 
     def forward(self, x, use_ctx=True):

@@ -229,18 +229,30 @@ class RFBNet(nn.Module):
             self._runtimes[key] = _engine.Runtime(self, batch, backend)
         return self._runtimes[key]
 
+    def _scale_value(self):
+        """float(self.scale) without a device round trip per forward (re-read only when the parameter changed)."""
+        key = (self.scale.data_ptr(), self.scale._version)
+        if getattr(self, '_scale_cache', (None, None))[0] != key:
+            self._scale_cache = (key, float(self.scale.item()))
+        return self._scale_cache[1]
+
     def _ctx_params(self):
         p = dict(theta_w=self.theta.weight, theta_b=self.theta.bias, phi_w=self.phi.weight,
                  phi_b=self.phi.bias, g_w=self.g.weight, g_b=self.g.bias, wz=self.Wz,
-                 obj_w=self.OBJ_Target.weight, scale=float(self.scale.item()))
+                 obj_w=self.OBJ_Target.weight, scale=self._scale_value())
         if self.setting == 'incre':
             p.update(fc_w=self.fc_base.weight, fc_b=self.fc_base.bias)
         return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in p.items()}
 
-    def forward_raw(self, x, init=False):
-        """-> (loc [B,P,4], conf logits [B,P,C or T], obj logits [B,P,2]) without the eval softmaxes."""
-        x = x.to(self._device(), torch.float32).contiguous()
-        num = x.shape[0]
+    def forward_raw(self, x, init=False, _input_loaded=False, _batch=None):
+        """-> (loc [B,P,4], conf logits [B,P,C or T], obj logits [B,P,2]) without the eval softmaxes.
+        `_input_loaded` (DetectionPipeline): the runtime's input buffer already holds the batch (Runtime.load_input),
+        only the launches are issued -- the form a hipGraph captures."""
+        if _input_loaded:
+            num = _batch
+        else:
+            x = x.to(self._device(), torch.float32).contiguous()
+            num = x.shape[0]
         if self.training:
             # batch-statistics BatchNorm + autograd: the whole backbone is one autograd function
             # whose backward is the HIP backward pass (ctdet.train_engine)
@@ -251,14 +263,19 @@ class RFBNet(nn.Module):
             if not (self.method == 'ours' and self.phase == 2):
                 conf = conf.view(num, -1, self.num_classes)
             return loc.view(num, -1, 4), conf, obj.view(num, -1, 2)
-        rt = self.runtime(x.shape[0])
-        loc, conf, obj = rt.run_backbone(x)
+        rt = self.runtime(num)
+        loc, conf, obj = rt.run_loaded() if _input_loaded else rt.run_backbone(x)
         conf = conf.view(num, -1, self.num_classes)
         if init:
             return conf
         if self.method == 'ours' and self.phase == 2:
             pool = rt.bufs['pool'].view(num, -1, self.num_classes)
-            conf = _ops.ctx_attention(conf, pool, self._ctx_params(), self.setting == 'incre')
+            if 'ctx_out' not in rt.bufs:          # output + workspace owned by the runtime: no allocation per call
+                rt.bufs['ctx_out'], rt.bufs['ctx_ws'] = _ops.ctx_attention_buffers(
+                    num, conf.shape[1], pool.shape[1], self.num_classes, self.OBJ_Target.weight.shape[0],
+                    self.setting == 'incre', conf.device)
+            conf = _ops.ctx_attention(conf, pool, self._ctx_params(), self.setting == 'incre',
+                                      out=rt.bufs['ctx_out'], ws=rt.bufs['ctx_ws'])
         return loc.view(num, -1, 4), conf, obj.view(num, -1, 2)
 
     def train_runtime(self, batch, device=None):

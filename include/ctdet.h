@@ -44,6 +44,17 @@ const char* ct_last_error_string(void);
 /* arch: e.g. "gfx950"; any out pointer may be NULL. */
 int ct_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
 
+/* Measurement aid (bench.py `roofline.stages`): while enabled, the post-processing, score-fusion and attention
+ * entry points bracket each of their kernel launches with HIP events on the launch stream.
+ * ct_profile_enable(on) clears the records; ct_profile_collect waits for the recorded events and returns
+ * (kernel name, milliseconds) per launch in launch order; *num_records = records available (may exceed max). */
+typedef struct ct_profile_record {
+    const char* name;   /* static string owned by the library */
+    float ms;
+} ct_profile_record;
+int ct_profile_enable(int on);
+int ct_profile_collect(ct_profile_record* out, int max_records, int* num_records);
+
 /* ------------------------------------------------------------------ NMS ---- */
 
 /* Drop-in for the reference's only native symbol:

@@ -153,9 +153,19 @@ def test_phase2_training_step_vs_oracle_autograd(size, setting):
         c32 = rfbnet_ref.forward(sd, x, size, C, phase=2, setting=setting, training=True, init=True)
     trt = net.train_runtime(2)
     raw = trt.bufs['conf'].view(2, -1, C)
+    # priors of the 2x2 / 1x1 (512) or 3x3 / 1x1 (300) maps: their BasicConv layers normalise over 2 x {1, 4, 9}
+    # samples, where d / sqrt(d^2 + eps) turns an fp32 rounding difference into an O(1e-4) one; they are judged
+    # separately from the maps with real statistics
+    ntail = {300: 3 * 3 * 4 + 4, 512: 2 * 2 * 4 + 4}[size]
     for a, b, c, n in ((out[0], oo[0], o64[0], 'loc'), (out[2], oo[2], o64[2], 'obj'), (raw, c32, c64, 'raw conf')):
-        e_gpu, e_cpu = rel_err(a.detach().cpu(), c.float()), rel_err(b.detach(), c.float())
-        assert a.shape == b.shape and e_gpu < max(1e-4, 5 * e_cpu), (n, e_gpu, e_cpu)
+        assert a.shape == b.shape, n
+        a, b, c = a.detach().cpu(), b.detach(), c.float()
+        scale = float(c.abs().max())
+        err = lambda u, v: float((u - v).abs().max()) / scale
+        e_gpu, e_cpu = err(a[:, :-ntail], c[:, :-ntail]), err(b[:, :-ntail], c[:, :-ntail])
+        t_gpu, t_cpu = err(a[:, -ntail:], c[:, -ntail:]), err(b[:, -ntail:], c[:, -ntail:])
+        assert e_gpu < max(1e-4, 5 * e_cpu), (n, 'maps with >= 32 samples per channel', e_gpu, e_cpu, t_gpu, t_cpu)
+        assert t_gpu < max(1e-3, 20 * t_cpu), (n, 'tail maps', t_gpu, t_cpu)
     with torch.no_grad():
         pooled = trt.bufs['pool'].view(2, -1, C).cpu()
         blk = rfbnet_ref.context_block({k: v for k, v in sd64.items() if v.is_floating_point()}, raw.cpu().double(),

@@ -262,3 +262,38 @@ def test_full_size_pipeline_properties():
             if len(d) > 1 and i % 8 == 0:                        # kept boxes do not suppress each other
                 assert list(nms(d, 0.45)) == list(range(len(d)))
     assert total >= 32 * 150
+
+
+def test_hipgraph_replay_equals_eager_launches():
+    """DetectionPipeline captures its step (two streams, ~100 launches) into a hipGraph after two eager steps; the
+    replays give bit-identical detections, keep doing so after a weight update (re-packing happens outside the
+    graph into the same buffers), a per-image scale change and a new input -- and really are replays."""
+    from layers.functions import PriorBox
+    from data import VOC_300
+    priors = PriorBox(VOC_300).forward()
+    B = 4
+    xs = [synth.images(B, 300, 'randn', 100 + i).cuda() for i in range(3)]
+
+    def collect(graph):
+        net = _net(300, 60, 2, 'transfer')           # with the Context-Transformer block on the path
+        pipe = DetectionPipeline(net, priors, B, 20, graph=graph)
+        out = []
+        for it in range(6):
+            if it == 3:
+                with torch.no_grad():
+                    net.conf[1].bias.add_(0.25)
+                    net.Wz.mul_(1.5)
+            wh = torch.tensor([[500., 375.], [640., 480.], [300. + it, 300.], [1000., 200.]]) if it >= 4 else None
+            pipe.run(xs[it % 3], image_wh=wh)
+            out.append(([[d.copy() for d in img] for img in pipe.results()], pipe.scores.clone()))
+        return out, pipe
+
+    eager, pe = collect(False)
+    graph, pg = collect(True)
+    assert pe._graph is None and pg._graph is not None, 'the graph path did not capture'
+    for it, ((da, sa), (db, sb)) in enumerate(zip(eager, graph)):
+        assert torch.equal(sa, sb), it
+        for ia, ib in zip(da, db):
+            for a, b in zip(ia, ib):
+                assert np.array_equal(a, b), it
+    assert not torch.equal(eager[2][1], eager[5][1])            # the weight update changed the scores (same input)
