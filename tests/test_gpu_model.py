@@ -264,13 +264,14 @@ def test_full_size_pipeline_properties():
     assert total >= 32 * 150
 
 
-def test_hipgraph_replay_equals_eager_launches():
+def test_hipgraph_replay_equals_eager_launches(monkeypatch):
     """DetectionPipeline captures its step (two streams, ~100 launches) into a hipGraph after two eager steps; the
     replays give bit-identical detections, keep doing so after a weight update (re-packing happens outside the
     graph into the same buffers), a per-image scale change and a new input -- and really are replays."""
     from layers.functions import PriorBox
     from data import VOC_300
-    priors = PriorBox(VOC_300).forward()
+    monkeypatch.setenv('CTDET_TUNE', '0')       # shapes missing from the committed table would be timed live: the two
+    priors = PriorBox(VOC_300).forward()        # pipelines below could then pick different tiles (other rounding)
     B = 4
     xs = [synth.images(B, 300, 'randn', 100 + i).cuda() for i in range(3)]
 

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""One Winograd layer, N launches (for rocprofv3 --pmc passes and A/B timing):
+   python tools/wino_one.py [shape ...]    shapes: base.2 base.7 base.12 base.19 base.24 head.0"""
+import os, sys
+import torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, 'context-transformer_amd')); sys.path.insert(0, REPO)
+from ctdet import _lib, engine
+DEV = 'cuda:0'
+SHAPES = {  # B, Cin, H, W, Cout
+    'base.2': (32, 64, 300, 300, 64), 'base.5': (32, 64, 150, 150, 128), 'base.7': (32, 128, 150, 150, 128),
+    'base.10': (32, 128, 75, 75, 256), 'base.12': (32, 256, 75, 75, 256), 'base.17': (32, 256, 38, 38, 512),
+    'base.19': (32, 512, 38, 38, 512), 'base.24': (32, 512, 19, 19, 512), 'head.0': (32, 512, 38, 38, 156),
+    'base.19.b4': (4, 512, 38, 38, 512), 'base.2.b4': (4, 64, 300, 300, 64),
+}
+names = sys.argv[1:] or ['base.2', 'base.7', 'base.12', 'base.19', 'base.24']
+iters = int(os.environ.get('ITERS', 10))
+be = engine.HipBackend(DEV)
+for name in names:
+    B, Cin, H, W, Cout = SHAPES[name]
+    w = torch.nn.Parameter(torch.randn(Cout, Cin, 3, 3, device=DEV) * 0.05, requires_grad=False)
+    b = torch.nn.Parameter(torch.zeros(Cout, device=DEV), requires_grad=False)
+    st = engine.ConvStep(name, [engine.ConvPart(w, b, None, True)], Cin, 3, 3, 1, 1, 1, 1, 'x', 0, H, W, 'y', 0)
+    bufs = {'x': torch.randn(B, Cin, H, W, device=DEV), 'y': torch.empty(B, Cout, H, W, device=DEV)}
+    be.prepare_conv(st, bufs, B)
+    be.enable_wino(st)
+    for _ in range(2):
+        be.run_conv(st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        be.run_conv(st)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    fl = st.flops(B)
+    print('%-10s %4d->%-4d @%3dx%-3d bs%-2d  %8.1f us  %6.1f TF algorithmic  %5.1f TF executed = %.3f of 157.3'
+          % (name, Cin, Cout, H, W, B, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 * 16 / 36, fl / ms / 1e9 * 16 / 36 / 157.3), flush=True)
