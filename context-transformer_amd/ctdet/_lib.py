@@ -123,6 +123,8 @@ SIGNATURES = {
     'ct_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P]),
     'ct_maxpool2d_fwd': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     'ct_preproc_resize': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    'ct_preproc_augment': (_I, [_P, _P, _I, _I, _P, _P, _P]),
+    'ct_mixup_blend': (_I, [_P, _P, _P, _I, _L, _P, _P]),
     'ct_ctx_pool_fwd': (_I, [_P, _LL, _P, _LL, _I, _I, _I, _I, _I, _P]),
     'ct_ctx_attention_workspace_bytes': (_Z, [_I, _I, _I, _I]),
     'ct_ctx_attention_fwd': (_I, [_P, _P, _I, _I, _I, C.POINTER(CtxParams), _P, _P, _Z, _P]),

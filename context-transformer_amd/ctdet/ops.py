@@ -248,6 +248,81 @@ class Preprocessor:
         return out
 
 
+class AugPlan(C.Structure):
+    """One image's augmentation decisions (csrc/ct_preproc.hip AugPlan, 96 bytes)."""
+    _fields_ = [('src_off', C.c_longlong), ('H', C.c_int), ('W', C.c_int),
+                ('crop_l', C.c_int), ('crop_t', C.c_int), ('crop_w', C.c_int), ('crop_h', C.c_int),
+                ('exp_w', C.c_int), ('exp_h', C.c_int), ('exp_left', C.c_int), ('exp_top', C.c_int),
+                ('mirror', C.c_int), ('interp', C.c_int), ('flags', C.c_int), ('hue_delta', C.c_int),
+                ('beta', C.c_float), ('alpha', C.c_float), ('sat_alpha', C.c_float), ('fill', C.c_float * 3),
+                ('pad0', C.c_float), ('pad1', C.c_float)]
+
+
+assert C.sizeof(AugPlan) == 96
+
+
+class Augmenter:
+    """Batched training-time augmentation (data/data_augment.py:164-221) on the device: the host hands over the
+    uint8 images and one AugPlan per image (the random decisions); ONE launch writes float32 [B,3,S,S]."""
+
+    def __init__(self, size, means, device, max_batch=32, max_pixels=512 * 512):
+        self.size, self.device, self.max_batch = size, torch.device(device), max_batch
+        self.means_f = [float(m) for m in means]
+        self.means = (C.c_float * 3)(*self.means_f)
+        self.cap = max_batch * max_pixels * 3
+        self.stage = torch.empty(self.cap, dtype=torch.uint8).pin_memory()
+        self.dev = torch.empty(self.cap, dtype=torch.uint8, device=self.device)
+        self.plan_h = torch.empty(max_batch * 96, dtype=torch.uint8).pin_memory()
+        self.plan_d = torch.empty(max_batch * 96, dtype=torch.uint8, device=self.device)
+        self.copied = None
+
+    def __call__(self, images, plans, out=None):
+        n = len(images)
+        if n == 0 or n > self.max_batch or len(plans) != n:
+            raise ValueError('Augmenter: batch of %d images / %d plans (max %d)' % (n, len(plans), self.max_batch))
+        if self.copied is not None:
+            self.copied.synchronize()
+        recs = (AugPlan * n)()
+        pos = 0
+        for i, (img, p) in enumerate(zip(images, plans)):
+            a = np.ascontiguousarray(img)
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3 or (a.shape[0], a.shape[1]) != (p['H'], p['W']):
+                raise ValueError('Augmenter: image %d is %s %s, plan says %dx%d' % (i, a.dtype, a.shape, p['H'], p['W']))
+            if pos + a.size > self.cap:
+                raise _lib.CtdetError('Augmenter: staging capacity %d bytes exceeded' % self.cap)
+            self.stage[pos:pos + a.size] = torch.from_numpy(a.reshape(-1))
+            r = recs[i]
+            r.src_off, r.H, r.W = pos, p['H'], p['W']
+            r.crop_l, r.crop_t, r.crop_w, r.crop_h = p['crop']
+            r.exp_w, r.exp_h, r.exp_left, r.exp_top = p['exp']
+            r.mirror, r.interp, r.flags, r.hue_delta = p['mirror'], p['interp'], p['flags'], p['hue']
+            r.beta, r.alpha, r.sat_alpha = p['beta'], p['alpha'], p['sat']
+            for c in range(3):
+                r.fill[c] = self.means_f[c]
+            pos += (a.size + 15) // 16 * 16
+        self.plan_h[:n * 96] = torch.frombuffer(bytearray(bytes(recs)), dtype=torch.uint8)
+        self.dev[:pos].copy_(self.stage[:pos], non_blocking=True)
+        self.plan_d[:n * 96].copy_(self.plan_h[:n * 96], non_blocking=True)
+        self.copied = torch.cuda.Event()
+        self.copied.record()
+        if out is None:
+            out = torch.empty(n, 3, self.size, self.size, device=self.device, dtype=torch.float32)
+        check(lib().ct_preproc_augment(_dev(self.dev, 'src', torch.uint8), _dev(self.plan_d, 'plans', torch.uint8), n,
+                                       self.size, C.cast(self.means, C.c_void_p), _dev(out, 'out'), _stream()),
+              'ct_preproc_augment')
+        return out
+
+
+def mixup_blend(img1, img2, lambd):
+    """img1 * lambd + img2 * (1 - lambd) per image (data/voc0712.py:262); lambd: float or [B] tensor."""
+    B = img1.shape[0]
+    lam = torch.as_tensor(lambd, dtype=torch.float32, device=img1.device).expand(B).contiguous()
+    out = torch.empty_like(img1)
+    check(lib().ct_mixup_blend(_dev(img1, 'img1'), _dev(img2, 'img2'), _dev(lam, 'lambd'), B, img1.numel() // B,
+                               _dev(out, 'out'), _stream()), 'ct_mixup_blend')
+    return out
+
+
 # ------------------------------------------------------------------ pooling / attention
 def maxpool2d(x, k, stride, pad=0, ceil_mode=False):
     B, Cn, H, W = x.shape

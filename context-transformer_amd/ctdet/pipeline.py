@@ -39,6 +39,10 @@ class DetectionPipeline:
         self.boxes = torch.empty(batch, self.P, 4, device=self.device)
         self.scores = torch.empty(batch, self.P, num_fg + 1, device=self.device)
         self.use_graph = (os.environ.get('CTDET_GRAPH', '1') != '0') if graph is None else bool(graph)
+        if len(getattr(self.rt, 'sides', None) or []) > 1:
+            # more than one side stream (CTDET_STREAMS > 2): ROCm 7.2 crashes in hipStreamEndCapture on that fork/join
+            # pattern (measured); those schedules launch eagerly
+            self.use_graph = False
         self._graph, self._eager_runs, self._graph_key = None, 0, None
 
     def set_image_wh(self, image_wh):

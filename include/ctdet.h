@@ -356,6 +356,19 @@ int ct_head_grad_gather(const ct_out_segment* segs, int nseg, int batch, int cha
 int ct_preproc_resize(const unsigned char* src, const long long* offsets, const int* hw, int batch,
                       int size, const float* means3, float* out, ct_stream_t stream);
 
+/* Training-time augmentation, data/data_augment.py:164-221 (`preproc.__call__`): crop -> photometric distortion
+ * (8-bit HSV space) -> expand on a mean-filled canvas -> mirror -> resize -> minus means -> CHW, one gather launch
+ * per batch.  `plans` = device array of `batch` 96-byte records (ctdet/ops.py AugPlan: source offset / size, crop
+ * rectangle, canvas size and placement, mirror flag, interpolation 0 linear / 1 nearest / 2 area, distortion flags
+ * 1 brightness 2 contrast 4 hue 8 saturation with their parameters, canvas fill) holding the random DECISIONS the
+ * host logic drew like the reference does.  Pixel arithmetic restates OpenCV's published 8-bit formulas (cv2 is
+ * not in this image): tolerance-based parity. */
+int ct_preproc_augment(const unsigned char* src, const void* plans, int batch, int size, const float* means3,
+                       float* out, ct_stream_t stream);
+/* mixup of two image batches, data/voc0712.py:262: out = img1 * lambd[n] + img2 * (1 - lambd[n]). */
+int ct_mixup_blend(const float* img1, const float* img2, const float* lambd, int batch, long per_image,
+                   float* out, ct_stream_t stream);
+
 /* torch.nn.MaxPool2d of models/RFB_Net_vgg.py:328-330,338 (2x2 s2 [ceil], 3x3 s1 p1) on an NCHW
  * buffer: planes = batch*channels; windows are clipped to the input (ceil_mode semantics are
  * encoded in oh/ow by the caller). */

@@ -523,12 +523,56 @@ def gen_init():
     save('init.npz', st)
 
 
+# ---------------------------------------------------------------------------
+def gen_augment():
+    """data/data_augment.py:164-221 (`preproc.__call__`) executed for its TARGET path and its random-number
+    consumption.  The module needs cv2 (absent) for pixels only: a stand-in whose `cvtColor` returns its input and
+    whose `resize` returns a blank image lets the reference's own `_crop` / `_distort` / `_expand` / `_mirror` /
+    box arithmetic run and draw exactly the random numbers it always draws; the images it returns are discarded.
+    Stored per case: the input targets, image shape, seed, the returned targets and a digest of the generator state
+    after the call (pins the NUMBER and order of draws, i.e. every decision branch)."""
+    import random
+    cv2 = types.ModuleType('cv2')
+    for i, n in enumerate(('INTER_LINEAR', 'INTER_CUBIC', 'INTER_AREA', 'INTER_NEAREST', 'INTER_LANCZOS4',
+                           'COLOR_BGR2HSV', 'COLOR_HSV2BGR')):
+        setattr(cv2, n, i)
+    cv2.cvtColor = lambda img, code: img
+    cv2.resize = lambda img, size, interpolation=None: np.zeros((size[1], size[0], 3), dtype=np.uint8)
+    sys.modules.setdefault('cv2', cv2)
+    spec = importlib.util.spec_from_file_location('ref_data_augment', os.path.join(REF, 'data/data_augment.py'))
+    da = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(da)
+    st = {}
+    rng = np.random.RandomState(5)
+    ncase = 48
+    for k in range(ncase):
+        h, w = int(rng.randint(120, 400)), int(rng.randint(120, 500))
+        G = int(rng.randint(1, 6))
+        xy = rng.uniform(0, 0.6, (G, 2)) * (w, h)
+        wh = rng.uniform(0.08, 0.4, (G, 2)) * (w, h)
+        lab = rng.randint(0, 20, (G, 1)).astype(np.float64)
+        tg = np.hstack([xy, np.minimum(xy + wh, (w - 1, h - 1)), lab])
+        cls = None if k % 4 else int(lab[0, 0])
+        random.seed(1000 + k)
+        pre = da.preproc(300, (104, 117, 123), 0.6)
+        img = np.zeros((h, w, 3), dtype=np.uint8)
+        _, tout = pre(img, tg.copy(), cls) if cls is not None else pre(img, tg.copy())
+        st['case%d_in' % k] = tg
+        st['case%d_shape' % k] = np.array([h, w, -1 if cls is None else cls])
+        st['case%d_out' % k] = np.asarray(tout, dtype=np.float64)
+        st['case%d_state' % k] = np.frombuffer(hashlib.sha256(repr(random.getstate()).encode()).digest()[:8], dtype=np.uint8)
+    st['ncase'] = np.array(ncase)
+    save('augment.npz', st)
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['init', 'box', 'nms', 'model', 'loss', 'pipeline', 'voc', 'solver', 'reweight', 'checkpointer']
+    which = sys.argv[1:] or ['init', 'augment', 'box', 'nms', 'model', 'loss', 'pipeline', 'voc', 'solver', 'reweight', 'checkpointer']
     if 'checkpointer' in which:
         gen_checkpointer()
     if 'init' in which:
         gen_init()
+    if 'augment' in which:
+        gen_augment()
     if 'box' in which:
         gen_box_ops()
     if 'nms' in which:
