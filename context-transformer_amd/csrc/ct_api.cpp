@@ -48,7 +48,62 @@ void prof_stop(hipStream_t st, int slot)
     if (slot < (int)g_prof.size() && hipEventRecord(g_prof[slot].e1, st) == hipSuccess) g_prof[slot].stopped = true;
 }
 
+// ---- recorded weight packing (training steps) ----
+namespace {
+thread_local bool t_pack_rec = false;
+thread_local std::vector<unsigned char> t_pack_items[2];
+}  // namespace
+
+bool pack_recording() { return t_pack_rec; }
+
+void pack_record(int kind, const void* args, size_t bytes)
+{
+    const unsigned char* b = static_cast<const unsigned char*>(args);
+    t_pack_items[kind & 1].insert(t_pack_items[kind & 1].end(), b, b + bytes);
+}
+
 }  // namespace ctdet
+
+extern "C" int ct_pack_record_begin(void)
+{
+    ctdet::t_pack_items[0].clear();
+    ctdet::t_pack_items[1].clear();
+    ctdet::t_pack_rec = true;
+    return CT_OK;
+}
+
+extern "C" size_t ct_pack_record_bytes(void)
+{
+    return ctdet::align_up(ctdet::t_pack_items[0].size(), 256) + ctdet::align_up(ctdet::t_pack_items[1].size(), 256) + 256;
+}
+
+extern "C" int ct_pack_record_end(void* table_dev, size_t table_bytes, int* num_direct, int* num_wino, ct_stream_t stream)
+{
+    ctdet::t_pack_rec = false;
+    CT_REQUIRE(table_dev && num_direct && num_wino, "ct_pack_record_end: null pointer");
+    if (table_bytes < ct_pack_record_bytes())
+        return ctdet::fail(CT_ERR_WORKSPACE, "ct_pack_record_end: table %zu < %zu bytes", table_bytes, ct_pack_record_bytes());
+    hipStream_t st = ctdet::as_stream(stream);
+    const size_t n0 = ctdet::t_pack_items[0].size(), n1 = ctdet::t_pack_items[1].size();
+    unsigned char* t = static_cast<unsigned char*>(table_dev);
+    if (n0) CT_HIP(hipMemcpyAsync(t, ctdet::t_pack_items[0].data(), n0, hipMemcpyHostToDevice, st));
+    if (n1) CT_HIP(hipMemcpyAsync(t + ctdet::align_up(n0, 256), ctdet::t_pack_items[1].data(), n1, hipMemcpyHostToDevice, st));
+    CT_HIP(hipStreamSynchronize(st));                   // the host vectors may be reused after this returns
+    *num_direct = (int)(n0 / ctdet::pack_direct_item_bytes());
+    *num_wino = (int)(n1 / ctdet::pack_wino_item_bytes());
+    return CT_OK;
+}
+
+extern "C" int ct_pack_run(const void* table_dev, int num_direct, int num_wino, ct_stream_t stream)
+{
+    CT_REQUIRE(table_dev && num_direct >= 0 && num_wino >= 0, "ct_pack_run: bad arguments");
+    hipStream_t st = ctdet::as_stream(stream);
+    const unsigned char* t = static_cast<const unsigned char*>(table_dev);
+    int rc = ctdet::launch_pack_direct_batched(t, num_direct, st);
+    if (rc != CT_OK) return rc;
+    return ctdet::launch_pack_wino_batched(t + ctdet::align_up((size_t)num_direct * ctdet::pack_direct_item_bytes(), 256),
+                                           num_wino, st);
+}
 
 extern "C" int ct_profile_enable(int on)
 {

@@ -48,6 +48,16 @@ struct ProfScope {
 };
 #define CT_PROF(name, stream) ::ctdet::ProfScope _ct_prof_scope_##__LINE__(name, stream)
 
+// Recording of weight-packing launches (ct_pack_record_begin / _end / ct_pack_run): while a recording is open on the
+// calling thread the pack entry points append their kernel arguments here instead of launching; the recorded table
+// is replayed each training step by two batched launches.  kind 0: direct layouts (ct_conv.hip PackArgs), 1: Winograd.
+bool pack_recording();
+void pack_record(int kind, const void* args, size_t bytes);
+int launch_pack_direct_batched(const void* items_dev, int n, hipStream_t st);
+int launch_pack_wino_batched(const void* items_dev, int n, hipStream_t st);
+size_t pack_direct_item_bytes();
+size_t pack_wino_item_bytes();
+
 template <typename T>
 __host__ __device__ inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
 

@@ -361,11 +361,10 @@ struct PackArgs {
     float* out;
 };
 
-__global__ void pack_weights_kernel(const PackArgs p)
+__device__ __forceinline__ void pack_weights_body(const PackArgs& p, long first, long stride)
 {
     const long total = (long)p.K_pad * p.M_pad;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = first; idx < total; idx += stride) {
         const int k = (int)(idx / p.M_pad), m = (int)(idx - (long)k * p.M_pad);
         float v = 0.f;
         if (!p.dgrad) {
@@ -384,6 +383,18 @@ __global__ void pack_weights_kernel(const PackArgs p)
         }
         p.out[idx] = v;
     }
+}
+
+__global__ void pack_weights_kernel(const PackArgs p)
+{
+    pack_weights_body(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+// all layers of a training step in one launch: blockIdx.y = recorded item (ct_pack_run)
+__global__ void pack_weights_batched_kernel(const PackArgs* __restrict__ items)
+{
+    const PackArgs p = items[blockIdx.y];
+    pack_weights_body(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 __global__ void fold_epilogue_kernel(const float* gamma, const float* beta, const float* mean,
@@ -533,10 +544,24 @@ static int pack_impl(const float* const* w, const int* cout, int nparts, int cin
     p.K_pad = k_pad;
     p.M_pad = m_pad;
     p.out = wpacked;
+    if (ctdet::pack_recording()) {
+        ctdet::pack_record(0, &p, sizeof(p));
+        return CT_OK;
+    }
     const long total = (long)k_pad * m_pad;
     const int blocks = (int)std::min<long>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, ctdet::as_stream(stream), p);
     CT_LAUNCH_CHECK("pack_weights_kernel");
+    return CT_OK;
+}
+
+size_t ctdet::pack_direct_item_bytes() { return sizeof(PackArgs); }
+
+int ctdet::launch_pack_direct_batched(const void* items_dev, int n, hipStream_t st)
+{
+    if (n <= 0) return CT_OK;
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(96, n), dim3(256), 0, st, (const PackArgs*)items_dev);
+    CT_LAUNCH_CHECK("pack_weights_batched_kernel");
     return CT_OK;
 }
 

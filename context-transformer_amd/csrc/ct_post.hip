@@ -56,14 +56,20 @@ __device__ void lds_substages(u64* sk, int nloc, int k, int jstart, int gbase)
 }
 
 __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
-    const float* __restrict__ boxes, const float* __restrict__ scores, int P, int T, float thresh,
+    const float* __restrict__ boxes, const float* __restrict__ scores, int batch, int P, int T, float thresh,
     int npow2_cap, u64* __restrict__ keys_ws, float* __restrict__ dets_sorted,
     int* __restrict__ sorted_idx, int* __restrict__ seg_count)
 {
     __shared__ u64 sk[kLdsKeys];
     __shared__ int s_cnt;
-    const int seg = blockIdx.x;
-    const int b = seg / T, cls = 1 + seg % T;
+    // blockIdx -> (image, class) so that all classes of an image run on ONE XCD (block q is dispatched to XCD q % 8):
+    // a class column of scores[b][P][T+1] is a strided read that touches every cache line of the image's score
+    // array, so the T workgroups of an image share those lines through one L2 instead of fetching the array once
+    // per XCD (round 2 PMC: 432 MB fetched per launch against 81 MB algorithmic)
+    const int b = ((int)(blockIdx.x >> 3) / T) * 8 + (int)(blockIdx.x & 7);
+    const int cls = 1 + (int)(blockIdx.x >> 3) % T;
+    if (b >= batch) return;
+    const int seg = b * T + (cls - 1);
     const int tid = threadIdx.x, lane = tid & 63;
     u64* keys = keys_ws + (size_t)seg * npow2_cap;
     if (tid == 0) s_cnt = 0;
@@ -407,7 +413,7 @@ extern "C" int ct_postprocess_batched(const float* boxes, const float* scores, i
     const int np2 = std::max(next_pow2(num_priors), 2);
     hipStream_t st = ctdet::as_stream(stream);
     CT_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
-    { CT_PROF("select_sort_kernel", st); hipLaunchKernelGGL(select_sort_kernel, dim3(S), dim3(kSortThreads), 0, st, boxes, scores, num_priors,
+    { CT_PROF("select_sort_kernel", st); hipLaunchKernelGGL(select_sort_kernel, dim3(8 * ((batch + 7) / 8) * num_fg), dim3(kSortThreads), 0, st, boxes, scores, batch, num_priors,
                        num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count); }
     CT_LAUNCH_CHECK("select_sort_kernel");
     int rc;

@@ -377,10 +377,10 @@ struct WinoPackArgs {
     float* U;
 };
 
-__global__ void wino_pack_kernel(const WinoPackArgs p)
+__device__ __forceinline__ void wino_pack_body(const WinoPackArgs& p, long first, long stride)
 {
     const long total = (long)p.kblocks * p.chunks * CHUNK_FLOATS;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = first; idx < total; idx += stride) {
         // register layout: [wave 8][piece 4][lane 64][4]: piece = (x, s-pair), element = (s parity, cout half);
         // wave w / lane (l31, hh) gets exactly the A fragments it feeds to its MFMAs, as four float4
         const int e = (int)(idx & 3), ln = (int)((idx >> 2) & 63), pc = (int)((idx >> 8) & 3), wv = (int)((idx >> 10) & 7);
@@ -416,6 +416,18 @@ __global__ void wino_pack_kernel(const WinoPackArgs p)
         }
         p.U[idx] = val;
     }
+}
+
+__global__ void wino_pack_kernel(const WinoPackArgs p)
+{
+    wino_pack_body(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+// all Winograd layers of a training step in one launch: blockIdx.y = recorded item (ct_pack_run)
+__global__ void wino_pack_batched_kernel(const WinoPackArgs* __restrict__ items)
+{
+    const WinoPackArgs p = items[blockIdx.y];
+    wino_pack_body(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 bool wino_ok(const ct_conv_desc* d)
@@ -458,6 +470,10 @@ int pack_wino(const float* const* w, const int* cout, int nparts, int cin, int d
     p.chunks = p.cin / CC;
     p.kblocks = (p.cout + KB - 1) / KB;
     p.U = upacked;
+    if (ctdet::pack_recording()) {
+        ctdet::pack_record(1, &p, sizeof(p));
+        return CT_OK;
+    }
     const long total = (long)p.kblocks * p.chunks * CHUNK_FLOATS;
     hipLaunchKernelGGL(wino_pack_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
                        ctdet::as_stream(stream), p);
@@ -465,6 +481,16 @@ int pack_wino(const float* const* w, const int* cout, int nparts, int cin, int d
     return CT_OK;
 }
 }  // namespace
+
+size_t ctdet::pack_wino_item_bytes() { return sizeof(WinoPackArgs); }
+
+int ctdet::launch_pack_wino_batched(const void* items_dev, int n, hipStream_t st)
+{
+    if (n <= 0) return CT_OK;
+    hipLaunchKernelGGL(wino_pack_batched_kernel, dim3(192, n), dim3(256), 0, st, (const WinoPackArgs*)items_dev);
+    CT_LAUNCH_CHECK("wino_pack_batched_kernel");
+    return CT_OK;
+}
 
 extern "C" int ct_conv_pack_weights_wino(const float* const* w, const int* cout, int nparts, int cin,
                                          float* upacked, ct_stream_t stream)

@@ -69,6 +69,10 @@ SIGNATURES = {
     'ct_abi_version': (_I, []),
     'ct_last_error_string': (C.c_char_p, []),
     'ct_device_info': (_I, [_I, C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
+    'ct_pack_record_begin': (_I, []),
+    'ct_pack_record_bytes': (_Z, []),
+    'ct_pack_record_end': (_I, [_P, _Z, C.POINTER(_I), C.POINTER(_I), _P]),
+    'ct_pack_run': (_I, [_P, _I, _I, _P]),
     'ct_profile_enable': (_I, [_I]),
     'ct_profile_collect': (_I, [C.POINTER(ProfileRecord), _I, C.POINTER(_I)]),
     'ct_nms_sorted_host': (_I, [_P, _P, _P, _I, _I, _F, _I]),

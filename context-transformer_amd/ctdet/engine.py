@@ -444,8 +444,9 @@ class HipBackend:
         _lib.check(self.lib.ct_conv_pack_weights_wino(ptrs, couts, n, st.cin, st.rt['U'].data_ptr(), self._stream()),
                    'ct_conv_pack_weights_wino')
 
-    def pack_conv(self, st):
-        """(Re)pack weights and fold the epilogue from the CURRENT parameter values."""
+    def pack_conv(self, st, weights=True):
+        """(Re)pack weights and fold the epilogue from the CURRENT parameter values.  weights=False: only the epilogue
+        (the training engine re-packs all weights of a step in one batched launch, ct_pack_run)."""
         rt, lib = st.rt, self.lib
         n = len(st.parts)
         ws = [p.weight.detach() for p in st.parts]
@@ -454,7 +455,9 @@ class HipBackend:
                 raise _lib.CtdetError('%s: parameters must be contiguous fp32 on the HIP device' % st.name)
         ptrs = (C.c_void_p * n)(*[wt.data_ptr() for wt in ws])
         couts = (C.c_int * n)(*[p.cout for p in st.parts])
-        if rt.get('wino'):                      # only the layout the launch reads; the other one is packed on demand
+        if not weights:
+            pass
+        elif rt.get('wino'):                    # only the layout the launch reads; the other one is packed on demand
             self._pack_wino(st)
             rt['wpk_stale'] = True
         else:

@@ -40,6 +40,8 @@ class TrainRuntime:
         self.bufs = {n: al((batch,) + tuple(s)) for n, s in self.plan.buf_shapes.items()}
         self.grads = {n: al((batch,) + tuple(s)) for n, s in self.plan.buf_shapes.items() if n != 'x'}
         self.state = {}
+        self._batched_packs = os.environ.get('CTDET_PACK_BATCH', '1') != '0'
+        self._pack_table, self._pack_ptrs, self._pack_counts = None, None, (0, 0)
         self.params = []            # ordered parameters that receive gradients
         self._pindex = {}
         self.ctx = None
@@ -214,6 +216,48 @@ class TrainRuntime:
     def _s(self):
         return C.c_void_p(torch.cuda.current_stream(self.be.device).cuda_stream)
 
+    # ------------------------------------------------------------------ weight packing
+    def _pack_dgrad(self, st, s):
+        """The data-gradient layout of one fused conv from the current weights."""
+        n = len(st.parts)
+        ptrs = (C.c_void_p * n)(*[p.weight.data_ptr() for p in st.parts])
+        couts = (C.c_int * n)(*[p.cout for p in st.parts])
+        if s.dgrad_wino is not None:
+            _lib.check(self.lib.ct_conv_pack_weights_wino_dgrad(ptrs, couts, n, st.cin, s.U_d.data_ptr(), self._s()),
+                       st.name + ' pack dgrad (winograd)')
+        else:
+            _lib.check(self.lib.ct_conv_pack_weights_dgrad(ptrs, couts, n, st.cin, st.kh, st.kw, s.wpk_d.data_ptr(),
+                                                           s.mpad_d, s.kpad_d, self._s()), st.name + ' pack dgrad')
+
+    def _repack_all(self):
+        """Every optimizer step changes every weight, and every fused conv needs its forward and its data-gradient
+        layout: ~130 small pack launches per step.  They are recorded ONCE (ct_pack_record_*) and replayed as two
+        batched launches at the start of each forward (the backward pass of the same step reads the same weights).
+        CTDET_PACK_BATCH=0 keeps the per-layer launches."""
+        if not self._batched_packs:
+            return
+        ptrs = [p.data_ptr() for p in self.params]
+        if self._pack_table is None or ptrs != self._pack_ptrs:
+            lib = self.lib
+            _lib.check(lib.ct_pack_record_begin(), 'ct_pack_record_begin')
+            try:
+                for st in self.plan.steps:
+                    if st.kind != 'conv':
+                        continue
+                    s = self.state[st.name]
+                    self.be.pack_conv(s.fwd)
+                    if s.dgrad is not None:
+                        self._pack_dgrad(st, s)
+            finally:
+                nbytes = lib.ct_pack_record_bytes()
+                self._pack_table = torch.empty(nbytes, dtype=torch.uint8, device=self.be.device)
+                nd, nw = C.c_int(0), C.c_int(0)
+                _lib.check(lib.ct_pack_record_end(self._pack_table.data_ptr(), nbytes, C.byref(nd), C.byref(nw), self._s()),
+                           'ct_pack_record_end')
+            self._pack_counts, self._pack_ptrs = (nd.value, nw.value), ptrs
+        _lib.check(self.lib.ct_pack_run(self._pack_table.data_ptr(), self._pack_counts[0], self._pack_counts[1], self._s()),
+                   'ct_pack_run')
+
     # ------------------------------------------------------------------ forward
     def _ctx_tensors(self):
         p = {k: v.detach() for k, v in self.ctx_params.items()}
@@ -228,6 +272,7 @@ class TrainRuntime:
             raise _lib.CtdetError('training plan was built for input %s, got %s'
                                   % (tuple(self.bufs['x'].shape), tuple(x.shape)))
         self.bufs['x'].copy_(x)
+        self._repack_all()
 
         def fwd_step(st):
             if st.kind == 'pool':
@@ -240,7 +285,7 @@ class TrainRuntime:
             if st.kind != 'conv':
                 raise _lib.CtdetError('step %s has no training implementation' % st.name)
             s = self.state[st.name]
-            self.be.pack_conv(s.fwd)
+            self.be.pack_conv(s.fwd, weights=not self._batched_packs)       # epilogue vectors (bias fold)
             self.be.run_conv(s.fwd)
             if not s.is_bn:
                 return
@@ -402,20 +447,16 @@ class TrainRuntime:
                 off += p.cout
             # data gradient into the producer's gradient buffer (accumulate if already written)
             if s.dgrad is not None:
-                n = len(st.parts)
-                ptrs = (C.c_void_p * n)(*[p.weight.data_ptr() for p in st.parts])
-                couts = (C.c_int * n)(*[p.cout for p in st.parts])
                 acc = overlaps(st.src, st.src_coff, st.src_coff + st.cin)
                 if s.dgrad_wino is not None:
-                    _lib.check(lib.ct_conv_pack_weights_wino_dgrad(ptrs, couts, n, st.cin, s.U_d.data_ptr(), self._s()),
-                               st.name + ' pack dgrad (winograd)')
+                    if not self._batched_packs:
+                        self._pack_dgrad(st, s)
                     s.dgrad_wino.res = self.grads[st.src].data_ptr() if acc else None
                     _lib.check(lib.ct_conv2d_wino_fwd(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self._s()),
                                st.name + ' dgrad (winograd)')
                 else:
-                    _lib.check(lib.ct_conv_pack_weights_dgrad(ptrs, couts, n, st.cin, st.kh, st.kw,
-                                                              s.wpk_d.data_ptr(), s.mpad_d, s.kpad_d, self._s()),
-                               st.name + ' pack dgrad')
+                    if not self._batched_packs:
+                        self._pack_dgrad(st, s)
                     s.dgrad.res = self.grads[st.src].data_ptr() if acc else None
                     _lib.check(lib.ct_conv2d_fwd(C.byref(s.dgrad), self._s()), st.name + ' dgrad')
                 written.setdefault(st.src, []).append((st.src_coff, st.src_coff + st.cin))

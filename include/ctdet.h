@@ -44,6 +44,17 @@ const char* ct_last_error_string(void);
 /* arch: e.g. "gfx950"; any out pointer may be NULL. */
 int ct_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
 
+/* Batched weight packing for training steps (every optimizer step changes every weight, and each fused conv needs
+ * its forward AND its data-gradient layout re-packed: ~130 small launches per step).  Between
+ * ct_pack_record_begin() and ct_pack_record_end() the ct_conv_pack_weights* entry points called on THIS thread
+ * record their arguments instead of launching; _end copies the table to caller memory (ct_pack_record_bytes());
+ * ct_pack_run() then re-packs everything recorded in two launches.  The table holds the weight and output
+ * pointers: record again when a parameter is re-allocated. */
+int ct_pack_record_begin(void);
+size_t ct_pack_record_bytes(void);
+int ct_pack_record_end(void* table_dev, size_t table_bytes, int* num_direct, int* num_wino, ct_stream_t stream);
+int ct_pack_run(const void* table_dev, int num_direct, int num_wino, ct_stream_t stream);
+
 /* Measurement aid (bench.py `roofline.stages`): while enabled, the post-processing, score-fusion and attention
  * entry points bracket each of their kernel launches with HIP events on the launch stream.
  * ct_profile_enable(on) clears the records; ct_profile_collect waits for the recorded events and returns

@@ -1,33 +1,49 @@
 #!/bin/bash
 # Collect the measurement artefacts behind profiles/ on a GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh [tag]        -> gpurun_out/prof_<tag>/...
-# then condense with tools/prof_summary.py (see profiles/README.md).  The PMC passes run on their own, with
-# --kernel-trace only (never together with --stats or the sys/runtime trace domains).
+#   bash tools/collect_profiles.sh [tag]        -> gpurun_out/prof_<tag>/...  and the condensed files in profiles/ layout
+# The PMC passes run on their own, with --kernel-trace only (never together with --stats or the sys/runtime trace
+# domains).  Workloads: the headline (RFBNet-300 bs 32), 300 + Context-Transformer, RFBNet-512, the bf16 mode at the
+# per-GPU shape of BASELINE configs[4] (512, bs 16), the training step.
 set -u
 TAG=${1:-final}
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -o bench -- \
-    python "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline > "$O/bench.json.log" 2> "$O/bench.err"
-timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -o f -- \
-    python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
-timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$O/pmc_write" -o w -- \
-    python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-roofline > /dev/null 2>&1
+run_set() {   # name, workload (size,batch,phase,classes), extra bench args...
+  local name=$1 wl=$2; shift 2
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/${name}_stats" -o bench -- \
+      python "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs "$@" > "$O/${name}_bench.json.log" 2> "$O/${name}_bench.err"
+  for C in FETCH_SIZE WRITE_SIZE; do
+    CTDET_GRAPH=0 timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$O/${name}_pmc_$C" -o p -- \
+        python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-roofline "$@" > /dev/null 2>&1
+  done
+  python "$R/tools/prof_summary.py" --stats "$(ls $O/${name}_stats/*kernel_stats.csv | head -1)" \
+      --fetch "$(ls $O/${name}_pmc_FETCH_SIZE/*counter_collection.csv | head -1)" \
+      --write "$(ls $O/${name}_pmc_WRITE_SIZE/*counter_collection.csv | head -1)" \
+      --tag "${TAG}_${name}" --workload "$wl" --cmd "python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs $*" \
+      --out "$O/condensed" > /dev/null
+}
+run_set rfb300 300,32,1,20
+run_set rfb300ctx 300,32,2,60 --phase 2 --classes 60
+run_set rfb512 512,32,1,20 --size 512
+run_set bf16_512b16 512,16,1,20 --size 512 --batch 16 --dtype bf16
 cd "$R"
+python bench.py --steps 20 --warmup 5 > "$O/bench_full.json.log" 2> "$O/bench_full.err"
 CTDET_STREAMS=1 timeout 600 python tools/layer_report.py > "$O/layer_report.txt" 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/train" -o tr -- \
-    python tools/train_bench.py --batch 32 --steps 10 > "$O/train_bench.log" 2>&1
-timeout 300 python tools/wgrad_probe.py > "$O/wgrad_probe.txt" 2>&1
+CTDET_STREAMS=1 timeout 600 python tools/layer_report.py --size 512 > "$O/layer_report_512.txt" 2>&1
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bf16" -o bench -- \
-    python "$R/bench.py" --steps 20 --warmup 5 --no-cpu-baseline --dtype bf16 > "$O/bench_bf16.json.log" 2> "$O/bench_bf16.err"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/train_stats" -o tr -- \
+    python "$R/tools/train_bench.py" --batch 32 --steps 10 > "$O/train_bench.log" 2>&1
 cd "$R"
-CTDET_DTYPE=bf16 CTDET_STREAMS=1 timeout 600 python tools/layer_report.py > "$O/layer_report_bf16.txt" 2>&1
-timeout 300 python tools/bf16_probe.py > "$O/bf16_probe.txt" 2>&1
+for cfg in "--size 300 --batch 32" "--size 300 --batch 32 --phase 2 --classes 60" "--size 512 --batch 8 --phase 2 --classes 60"; do
+  timeout 300 python tools/train_bench.py $cfg --steps 6 2>&1 | tail -1 >> "$O/train_configs.txt"
+done
+timeout 300 python tools/nms_probe.py > "$O/nms_probe.txt" 2>&1
+timeout 300 python tools/attn_probe.py > "$O/attn_probe.txt" 2>&1
 # keep what prof_summary.py needs, drop the bulky traces
 find "$O" -name '*kernel_trace.csv' -delete
 find "$O" -name '*agent_info.csv' -delete
-ls -laR "$O" | head -40
-tail -1 "$O/bench.json.log"
+find "$O" -name '*counter_collection.csv' -delete
+ls -la "$O" "$O/condensed" | head -60
+tail -c 600 "$O/bench_full.json.log"

@@ -15,9 +15,10 @@ ap.add_argument('--write')
 ap.add_argument('--tag', default='r01')
 ap.add_argument('--cmd', default='python bench.py --steps 20 --warmup 5 --no-cpu-baseline')
 ap.add_argument('--workload', default='300,32,1,20', help='size,batch,phase,classes of the profiled bench run')
+ap.add_argument('--out', default=None, help='output directory (default: profiles/)')
 a = ap.parse_args()
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-out_dir = os.path.join(REPO, 'profiles')
+out_dir = a.out or os.path.join(REPO, 'profiles')
 os.makedirs(out_dir, exist_ok=True)
 
 
@@ -46,7 +47,7 @@ for kind, path in (('FETCH_SIZE', a.fetch), ('WRITE_SIZE', a.write)):
 
 lines = ['# rocprofv3 summary %s' % a.tag, '',
          'Command: `rocprofv3 --kernel-trace --stats --output-format csv -- %s` on one MI355X' % a.cmd,
-         '(PMC columns: separate passes `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` with `--kernel-trace`, 3 steps;',
+         '(PMC columns: separate passes `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` with `--kernel-trace`, 3 eager steps;',
          'values are the average per launch in KiB as reported; MI355X_MICROARCH.md: FETCH_SIZE under-reports wide',
          'coalesced reads by 2x on gfx950, so the HBM column doubles it before adding WRITE_SIZE.)', '',
          '| kernel | calls | total ms | avg us | % | FETCH KiB/launch | WRITE KiB/launch | HBM MB/launch (2*F+W) |',
