@@ -360,7 +360,7 @@ def main():
         pipe.run(x)
     torch.cuda.synchronize(dev)
     log('timed region')
-    want_roof = not a.no_roofline and rank == 0
+    want_roof = not a.no_roofline and rank == 0 and world == 1      # N > 1 runs only report throughput
     graph_mode = bool(pipe.use_graph)
     if want_roof and not graph_mode:
         pipe.rt.event_log = []          # HIP events around every conv launch of the timed region
