@@ -332,9 +332,14 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product has no CPU path)')
+    ndev = torch.cuda.device_count()
+    if local >= ndev:            # more ranks than GPUs (a one-GPU box rehearsing the multi-rank path): share devices
+        local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    cdist.init('nccl')           # RCCL; only used for the timing barrier / max-over-ranks
+    # RCCL (backend 'nccl'); only used for the timing barrier / max-over-ranks.  RCCL refuses two ranks on one device,
+    # so a rehearsal with more ranks than GPUs (or CTDET_DIST_BACKEND=gloo) uses gloo for those two scalars.
+    cdist.init(os.environ.get('CTDET_DIST_BACKEND') or ('nccl' if world <= ndev else 'gloo'))
 
     from ctdet import synth
     num_fg = a.classes
@@ -373,6 +378,7 @@ def main():
     dt = cdist.max_over_ranks(dt, dev)
 
     log('timed region done: %.2f ms/step' % (dt / a.steps * 1e3))
+    graph_mode = pipe._graph is not None            # False if the capture failed and the steps were launched eagerly
     workload = {'size': a.size, 'batch': batch, 'phase': a.phase, 'classes': a.classes}
     roof = None
     events_from = 'the timed region'

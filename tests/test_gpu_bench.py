@@ -1,0 +1,47 @@
+"""The bench.py contract on the device: one JSON line with the fields the driver and the judge read, a roofline
+fraction that IS a fraction (executed matrix-pipe work / peak), stage rooflines from the library's profile scopes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), *args], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = _run('--steps', '3', '--warmup', '4', '--batch', '4', '--no-cpu-baseline', '--no-other-configs')
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 3 and d['scaling'] == 'weak' and d['dtype'] == 'f32' and d['vs_baseline'] is None
+    assert d['launch_mode'] == 'hipGraph replay'
+    assert abs(d['value'] - 4 / (d['ms_per_step'] * 1e-3)) < 0.02 * d['value']
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s' and r['peak'] == 157.3
+    assert 0.0 < r['frac'] <= 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    if r['kernel'].startswith('wino'):
+        assert abs(r['flops_per_launch'] / r['algorithmic_flops_per_launch'] - 16 / 36) < 1e-3
+        assert r['algorithmic_frac'] > r['frac']
+    st = r['stages']
+    for k in ('detect_kernel', 'select_sort_kernel', 'nms_segments_kernel'):
+        assert st[k]['avg_launch_us'] > 0 and 0 < st[k]['frac'] < 1 and st[k]['algorithmic_per_launch'] > 0, k
+    assert st['nms_segments_kernel']['launches_per_step'] == 2.0
+
+
+def test_bench_phase2_reports_the_attention_stage():
+    d = _run('--steps', '2', '--warmup', '4', '--batch', '2', '--phase', '2', '--classes', '60', '--no-cpu-baseline',
+             '--no-other-configs')
+    st = d['roofline']['stages']
+    assert st['ctx_attn_kernel']['bound'] == 'mfma' and 0 < st['ctx_attn_kernel']['frac'] < 1
+    assert st['ctx_attn_kernel.hbm']['bound'] == 'hbm'
