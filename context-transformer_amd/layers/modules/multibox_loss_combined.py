@@ -39,29 +39,35 @@ class MultiBoxLoss_combined(nn.Module):
         labels, weights = conf_t[:, :, 0], conf_t[:, :, 1]
         pos = labels > 0
         num_pos = (weights * pos.float()).sum(1, keepdim=True).long()
+        # Every term below is a MASKED SUM over all priors instead of the reference's boolean gather (`x[pos]`,
+        # `x[pos | neg]`): the same numbers (a masked-out row contributes exactly 0 to the value and to the gradient),
+        # but no `nonzero` behind the indexing, i.e. no host synchronisation in the middle of the training step -- the
+        # host keeps issuing the backward pass while the forward still runs (tools/train_bench.py at small batches).
 
         # localisation: smooth-L1 on positives, weighted by the mixup weight (:81-85)
-        l1 = F.smooth_l1_loss(loc_data[pos], loc_t[pos], reduction='none').sum(1)
-        loss_l = (l1 * weights[pos]).sum()
+        l1 = F.smooth_l1_loss(loc_data, loc_t, reduction='none').sum(2)
+        loss_l = (l1 * (weights * pos.float())).sum()
 
         # hard negatives ranked by objectness loss, 3:1 (:88-96)
+        obj_flat = obj_data.reshape(-1, 2)
+        obj_lab = obj_t.long().view(-1)
         with torch.no_grad():
-            ce = F.cross_entropy(obj_data.reshape(-1, 2), obj_t.long().view(-1), reduction='none')
-            ce[obj_t.view(-1)] = 0
+            ce = F.cross_entropy(obj_flat, obj_lab, reduction='none')
+            ce = ce.masked_fill(obj_t.view(-1), 0.0)
             rank = ce.view(num, -1).sort(1, descending=True)[1].sort(1)[1]
             num_neg = torch.clamp(self.negpos_ratio * num_pos, max=num_priors - 1)
             neg = rank < num_neg.expand_as(rank)
-        mask = pos | neg
-        w = weights[mask]
-        loss_obj = (F.cross_entropy(obj_data[mask], obj_t[mask].long(), reduction='none') * w).sum()
+            w = (weights * (pos | neg).float()).view(-1)
+        loss_obj = (F.cross_entropy(obj_flat, obj_lab, reduction='none') * w).sum()
 
         # class loss on objectness-fused logits (:106-117)
         flat_conf = conf_data.reshape(-1, self.num_classes - 1)
-        flat_obj = obj_data.reshape(-1, 2)
-        bg = flat_obj[:, :1] + torch.log(torch.exp(flat_conf).sum(dim=1, keepdim=True))
-        fg = flat_obj[:, 1:2].expand_as(flat_conf) + flat_conf
-        logit = torch.cat((bg, fg), 1).view(num, -1, self.num_classes)
-        loss_c = (F.cross_entropy(logit[mask], labels[mask].long(), reduction='none') * w).sum()
+        # log(sum(exp(conf))) of :108 as logsumexp: same value, and an unselected row with a huge logit cannot put
+        # inf * 0 = NaN into the masked sum
+        bg = obj_flat[:, :1] + torch.logsumexp(flat_conf, dim=1, keepdim=True)
+        fg = obj_flat[:, 1:2].expand_as(flat_conf) + flat_conf
+        logit = torch.cat((bg, fg), 1)
+        loss_c = (F.cross_entropy(logit, labels.long().view(-1), reduction='none') * w).sum()
 
         n = num_pos.sum()
         if self.sync_normalizer:          # data-parallel: N over the global batch (see ctdet.dist)
