@@ -283,40 +283,59 @@ extern "C" int ct_nms_sorted_host_mode(int* keep_out, int* num_out, const float*
     int prev = -1;
     CT_HIP(hipGetDevice(&prev));
     if (prev != device_id) CT_HIP(hipSetDevice(device_id));
-    // rows -> [x1,y1,x2,y2,score] (score column is unused by the kernel)
-    std::vector<float> packed((size_t)boxes_num * 5);
-    for (int i = 0; i < boxes_num; ++i) {
-        const float* r = boxes_host + (size_t)i * boxes_dim;
-        float* o = &packed[(size_t)i * 5];
-        o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
-        o[4] = boxes_dim > 4 ? r[4] : 0.f;
-    }
-    const size_t det_bytes = ctdet::align_up(packed.size() * 4, 256);
+    // One device buffer per thread and device, grown on demand and kept between calls (test.py:152 calls this 20 times
+    // per image; a hipMalloc / hipFree pair per call cost more than the kernel), one H2D and one D2H copy per call:
+    //   [meta 256 B: seg_off[2], count][keep n ints][rows n x (x1,y1,x2,y2,score)]
+    struct Scratch { int device = -1; char* ptr = nullptr; size_t bytes = 0; };
+    static thread_local Scratch scratch;
     const size_t keep_bytes = ctdet::align_up((size_t)boxes_num * 4, 256);
-    char* dev = nullptr;
+    const size_t det_bytes = ctdet::align_up((size_t)boxes_num * 5 * 4, 256);
+    const size_t need = 256 + keep_bytes + det_bytes;
     int rc = CT_OK;
-    hipError_t e = hipMalloc((void**)&dev, det_bytes + keep_bytes + 256);
+    hipError_t e = hipSuccess;
+    if (scratch.device != device_id || scratch.bytes < need) {
+        if (scratch.ptr) {
+            int cur = device_id;
+            if (scratch.device != device_id) (void)hipSetDevice(scratch.device);
+            (void)hipFree(scratch.ptr);
+            if (scratch.device != cur) (void)hipSetDevice(cur);
+            scratch = Scratch{};
+        }
+        const size_t want = std::max(need, (size_t)1 << 20);
+        e = hipMalloc((void**)&scratch.ptr, want);
+        if (e == hipSuccess) { scratch.device = device_id; scratch.bytes = want; }
+        else scratch = Scratch{};
+    }
     if (e != hipSuccess) {
         rc = ctdet::fail(CT_ERR_HIP, "hipMalloc failed: %s", hipGetErrorString(e));
     } else {
-        float* d_dets = (float*)dev;
-        int* d_keep = (int*)(dev + det_bytes);
-        int* d_meta = (int*)(dev + det_bytes + keep_bytes);   // [0..1] seg_off, [2] count
-        const int meta[3] = {0, boxes_num, 0};
-        e = hipMemcpy(d_dets, packed.data(), packed.size() * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(d_meta, meta, sizeof(meta), hipMemcpyHostToDevice);
+        std::vector<char> host(need);
+        int* meta = reinterpret_cast<int*>(host.data());
+        meta[0] = 0; meta[1] = boxes_num; meta[2] = 0;
+        float* rows = reinterpret_cast<float*>(host.data() + 256 + keep_bytes);
+        for (int i = 0; i < boxes_num; ++i) {       // rows -> [x1,y1,x2,y2,score] (the kernel does not read the score)
+            const float* r = boxes_host + (size_t)i * boxes_dim;
+            float* o = rows + (size_t)i * 5;
+            o[0] = r[0]; o[1] = r[1]; o[2] = r[2]; o[3] = r[3];
+            o[4] = boxes_dim > 4 ? r[4] : 0.f;
+        }
+        char* dev = scratch.ptr;
+        int* d_meta = reinterpret_cast<int*>(dev);
+        int* d_keep = reinterpret_cast<int*>(dev + 256);
+        float* d_dets = reinterpret_cast<float*>(dev + 256 + keep_bytes);
+        e = hipMemcpy(dev, host.data(), need, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             rc = launch_nms(d_dets, d_meta, nullptr, 0, 1, thresh, ge, d_keep, d_meta + 2, nullptr);
             if (rc == CT_OK) {
-                int cnt = 0;
-                e = hipMemcpy(&cnt, d_meta + 2, 4, hipMemcpyDeviceToHost);
-                if (e == hipSuccess && cnt > 0)
-                    e = hipMemcpy(keep_out, d_keep, (size_t)cnt * 4, hipMemcpyDeviceToHost);
-                if (e == hipSuccess) *num_out = cnt;
+                e = hipMemcpy(host.data(), dev, 256 + (size_t)boxes_num * 4, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) {
+                    const int cnt = meta[2];
+                    if (cnt > 0) memcpy(keep_out, host.data() + 256, (size_t)cnt * 4);
+                    *num_out = cnt;
+                }
             }
         }
         if (e != hipSuccess) rc = ctdet::fail(CT_ERR_HIP, "ct_nms_sorted_host: %s", hipGetErrorString(e));
-        (void)hipFree(dev);
     }
     if (prev != device_id) (void)hipSetDevice(prev);
     return rc;

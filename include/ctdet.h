@@ -76,7 +76,8 @@ int ct_profile_collect(ct_profile_record* out, int max_records, int* num_records
  * score, row = [x1,y1,x2,y2,score,...] (boxes_dim >= 4 floats per row), +1 pixel
  * convention, suppress IoU > thresh, keep_out = ascending indices into the sorted array.
  * Differences: returns a status instead of printing CUDA errors; does not change the
- * process-global current device (it is restored). */
+ * process-global current device (it is restored); the temporary device buffer is kept per thread between calls
+ * (grown on demand) instead of being allocated and freed every time. */
 int ct_nms_sorted_host(int* keep_out, int* num_out, const float* boxes_host, int boxes_num,
                        int boxes_dim, float nms_overlap_thresh, int device_id);
 /* NMS mode flags (the `mode` / `ge` argument of the NMS entry points). */

@@ -62,3 +62,14 @@ scores2 = scores2.cuda()
 for topk in (200, 0):
     ms = t(lambda: pipe.post.run(boxes, scores2, max_per_image=topk), 10)
     print('R2 trained-like (50..400 per class), max_per_image=%d: %.3f ms' % (topk, ms))
+
+# the reference's own call protocol (test.py:152): one host call per (image, class) through the `_nms` contract
+from utils.nms_wrapper import nms
+import time
+for n in (50, 300, 2000):
+    d = synth.clustered_dets(n)
+    nms(d, 0.45)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        nms(d, 0.45)
+    print('utils.nms_wrapper.nms (host `_nms` contract: H2D + kernel + D2H), %4d boxes: %.1f us per call' % (n, (time.perf_counter() - t0) / 50 * 1e6))
