@@ -110,3 +110,69 @@ def test_do_test_harness_ragged_batches(tmp_path):
     # per-image transform callable (reference protocol) gives the same detections as the batched one
     one = harness.detect_dataset(net, priors, _Dataset(imgs), lambda im: tf(im), 20, batch=4)
     assert all(np.array_equal(one[j][i], all_boxes[j][i]) for j in range(1, 21) for i in range(n))
+
+
+def test_do_test_harness_vs_oracle_loop_and_map():
+    """The batched harness against the reference's sequential loop (test.py:121-161) evaluated by the CPU oracle on
+    the same images and weights, and the VOC07 mean AP of both on a synthetic ground truth: the offline stand-in for
+    BASELINE's "mAP within +-0.1 of the reference" (no dataset or trained weights exist here).  Device and CPU
+    activations differ in the last bits, so single detections may differ; the lists must agree almost everywhere and
+    the mean AP within 0.1 points."""
+    from data import VOC_300, BaseTransform
+    from ctdet import evaluate
+    from layers.functions import PriorBox
+    from models.RFB_Net_vgg import build_net
+    from oracle import box_ref, nms_ref, rfbnet_ref
+    net = build_net(types.SimpleNamespace(method='ours', phase=1, setting='transfer'), 300, 20)
+    sd = synth.fill_state_dict(net.state_dict())
+    sd['base.0.weight'] = sd['base.0.weight'] / 64
+    net.load_state_dict(sd, strict=True)
+    net = net.eval().cuda()
+    net.device = 'cuda'
+    priors = PriorBox(VOC_300).forward()
+    imgs = [im for im in _images(7, 21) if im.shape[0] > 1][:6]
+    n = len(imgs)
+    tf = BaseTransform(300, MEANS, (2, 0, 1), max_batch=4)
+    got = harness.detect_dataset(net, priors.cuda(), _Dataset(imgs), tf, 20, batch=4)       # ragged: 4 + 2
+    # the reference loop on the CPU oracle, one image at a time
+    sdc = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    want = [[[] for _ in range(n)] for _ in range(21)]
+    with torch.no_grad():
+        for i, im in enumerate(imgs):
+            x = torch.from_numpy(preproc_ref.base_transform(im, 300, MEANS))[None]
+            loc, conf, obj = rfbnet_ref.forward(sdc, x, 300, 20)
+            boxes, scores = box_ref.detect(loc, conf, obj, priors)
+            per = nms_ref.postprocess_image(boxes[0].numpy(), scores[0].numpy(), (im.shape[1], im.shape[0]), nms_fn=nms_ref.nms_c)
+            for j in range(1, 21):
+                want[j][i] = per[j]
+    # row-level agreement.  With random weights the scores are crowded (thousands of candidates within 1e-3 of each
+    # other), so the per-image "200 best" cut and single suppressions flip on last-bit differences: count the rows both
+    # lists share instead of demanding equal lists
+    shared = na = nb = 0
+    for j in range(1, 21):
+        for i in range(n):
+            a, b = got[j][i], want[j][i]
+            na += len(a)
+            nb += len(b)
+            if len(a) and len(b):
+                d = np.abs(a[:, None, :] - b[None, :, :])
+                close = (d[:, :, :4].max(2) < 1e-2) & (d[:, :, 4] < 1e-5)
+                shared += int(close.any(1).sum())
+    assert na > 400 and nb > 400 and shared >= 0.9 * max(na, nb), (shared, na, nb)
+    # synthetic ground truth: a jittered subset of the oracle's own confident detections (so AP is neither 0 nor 1)
+    rng = np.random.RandomState(4)
+    classes = ['__background__'] + ['c%d' % j for j in range(1, 21)]
+    ids = ['img%03d' % i for i in range(n)]
+    gt = {c: {} for c in classes[1:]}
+    for j in range(1, 21):
+        for i in range(n):
+            d = want[j][i]
+            pick = d[:: max(1, len(d) // 3)][:3] if len(d) else d
+            if len(pick):
+                bb = np.round(pick[:, :4] + rng.uniform(-3, 3, (len(pick), 4))).astype(int)
+                gt[classes[j]][ids[i]] = {'bbox': bb, 'difficult': np.zeros(len(bb), bool)}
+    ap_dev, map_dev = evaluate.evaluate_detections(got, ids, gt, classes)
+    ap_cpu, map_cpu = evaluate.evaluate_detections(want, ids, gt, classes)
+    assert 0.05 < map_cpu < 0.999, map_cpu
+    assert abs(map_dev - map_cpu) * 100 <= 0.1, (map_dev, map_cpu)
+    assert max(abs(ap_dev[c] - ap_cpu[c]) for c in ap_cpu) * 100 <= 1.0
