@@ -48,7 +48,9 @@ sys.path.insert(0, REPO)
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md), --dtype bf16 only
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (6.3 TB/s achievable, MI355X_MICROARCH.md)
-WINOGRAD_MULT_RATIO = 16.0 / 36.0   # F(2x2,3x3): multiplications executed / direct-convolution multiplications
+# multiplications executed / direct-convolution multiplications: F(2x2,3x3) 16 per 4 outputs x 9, F(4x4,3x3) 36 per 16 x 9
+WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0}
+WINOGRAD_KERNEL = {2: 'wino_f2x2_3x3_f32', 4: 'wino_f4x4_3x3_f32'}
 
 
 def build_net(size, num_fg, phase, setting, device):
@@ -162,19 +164,19 @@ def conv_roofline(rt, batch, pmc):
     peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
     for st, e0, e1 in rt.event_log:
         cfg = st.rt['desc'].config
-        wino = bool(st.rt.get('wino'))
-        name = 'conv_bf16_nhwc' if bf16 else st.rt.get('kernel_name') or ('wino_f2x2_3x3_f32' if wino else
+        wino = int(st.rt.get('wino') or 0)              # 0, 2 = F(2x2,3x3), 4 = F(4x4,3x3)
+        name = 'conv_bf16_nhwc' if bf16 else st.rt.get('kernel_name') or (WINOGRAD_KERNEL[wino] if wino else
                'conv_igemm_f32<%dx%d,%s>' % (st.kh, st.kw, lib.ct_conv_config_name(cfg - 1).decode() if cfg > 0 else 'auto'))
         a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
         a[0] += e0.elapsed_time(e1) * 1e-3
         a[1] += st.flops(batch)                # direct-convolution flops
         a[2] += 1
-        a[3] += st.flops(batch) * (WINOGRAD_MULT_RATIO if wino else 1.0)     # multiply-adds sent to the MFMA pipe
+        a[3] += st.flops(batch) * (WINOGRAD_MULT_RATIO[wino] if wino else 1.0)     # multiply-adds sent to the MFMA pipe
     tot_t = sum(a[0] for a in agg.values())
     tot_f = sum(a[1] for a in agg.values())
     tot_x = sum(a[3] for a in agg.values())
     name, (t, f, n, fx) = max(agg.items(), key=lambda kv: kv[1][0])
-    wino = name.startswith('wino')
+    wino = {v: k for k, v in WINOGRAD_KERNEL.items()}.get(name, 0)
     ach = fx / t / 1e12
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
@@ -182,11 +184,17 @@ def conv_roofline(rt, batch, pmc):
         'kernel': name, 'launches': n, 'avg_launch_us': round(t / n * 1e6, 2),
         'flops_per_launch': round(fx / n),
         'flops_definition': 'multiply-adds x2 executed on the matrix pipe per launch' +
-                            (' = direct-convolution flops x 16/36 (Winograd F(2x2,3x3))' if wino else ''),
+                            (' = direct-convolution flops x %s (Winograd F(%dx%d,3x3), output-tile padding not counted)'
+                             % ({2: '16/36', 4: '36/144'}[wino], wino, wino) if wino else ''),
         'algorithmic_flops_per_launch': round(f / n),
         'algorithmic_achieved': round(f / t / 1e12, 2),
         'algorithmic_frac': round(f / t / 1e12 / peak, 4),
-        'winograd_mult_ratio': round(WINOGRAD_MULT_RATIO, 4) if wino else 1.0,
+        'winograd_mult_ratio': round(WINOGRAD_MULT_RATIO[wino], 4) if wino else 1.0,
+        'by_kernel': {k: {'launches_per_step': round(v[2] / max(1, len(rt.event_log)) * len(rt.conv_steps()), 1),
+                          'ms_per_step': round(v[0] / max(1, len(rt.event_log)) * len(rt.conv_steps()) * 1e3, 3),
+                          'executed_frac': round(v[3] / v[0] / 1e12 / peak, 4),
+                          'algorithmic_frac': round(v[1] / v[0] / 1e12 / peak, 4)}
+                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:4]},
         'all_conv': {'achieved': round(tot_x / tot_t / 1e12, 2),
                      'frac': round(tot_x / tot_t / 1e12 / peak, 4),
                      'algorithmic_achieved': round(tot_f / tot_t / 1e12, 2),

@@ -26,6 +26,7 @@ SOURCES = {
     'ct_api.cpp': [],
     'ct_conv.hip': [],
     'ct_wino.hip': [],
+    'ct_wino4.hip': [],
     'ct_wino_wgrad.hip': [],
     'ct_conv_bf16.hip': [],
     'ct_pool.hip': [],

@@ -1,0 +1,548 @@
+// libctdet: Winograd F(4x4,3x3) convolution on the fp32 MFMA path -- the large-tile variant of ct_wino.hip for the
+// 3x3 / stride 1 / dilation 1 / pad 1 layers of the RFBNet-VGG stack (models/RFB_Net_vgg.py:219-227).  Same
+// ct_conv_desc contract and fused epilogue as ct_conv2d_wino_fwd; 36 multiplications per 16 outputs instead of
+// F(2x2,3x3)'s 16 per 4: 4x fewer than the direct convolution, 1.78x fewer than F(2x2,3x3).
+//
+//   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        per 4x4 output tile, 6x6 input patch d
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// (interpolation points 0, +-1, +-2, inf: fp32 error about 1e-5 of the output range on the VGG shapes, measured in
+// tests/test_gpu_wino.py against fp64.)
+//
+// One fused kernel; only the pre-transformed weights U ever exist in HBM in the transform domain:
+//   workgroup (512 threads, 8 waves) = 32 output tiles x 64 output channels, loops over 8-channel chunks
+//     * wave w = (transform-point group xg = w>>1 of 9 points, cout half w&1): nine 32x32 accumulator blocks
+//       (144 registers), 36 v_mfma_f32_32x32x2_f32 per chunk.  A fragments (U) are never in LDS: the pack kernel
+//       stores per (cout block, chunk, wave, point, lane) the 4 floats that lane feeds to its MFMAs, one coalesced
+//       16-byte load per point and chunk, re-issued into the same registers right after their last use (a whole
+//       chunk of latency).  B fragments (V) are one conflict-free ds_read_b32 each;
+//     * patch loader: a LANE PAIR owns one (tile, channel) patch.  Each lane loads three columns of the six rows
+//       (six 12-byte buffer loads), runs the column pass B^T d on them, swaps three rows with its partner through
+//       DPP (quad_perm 1,0,3,2: no LDS, no full 36-value patch in one lane's registers) and finishes the row pass
+//       for three of the six transform rows: 18 ds_write_b32 per lane and chunk;
+//     * V double-buffered in LDS (2 x 36 KB), one barrier per chunk;
+//   after the channel loop the accumulators go through LDS in two passes of 32 couts (144 KB), each thread applies
+//   A^T M A for two (cout, tile) pairs per pass and the usual epilogue (*scale + shift, residual, ReLU / per-channel
+//   floor, optional fused 2x2 max-pool -- a 4x4 tile holds four pooling windows --, NCHW or head scatter).
+#include "ct_common.h"
+#include <algorithm>
+#include <mutex>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef int i32x3 __attribute__((ext_vector_type(3)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int kInvalidOff = 0x7FFFFFF0;
+constexpr long long kMaxBufBytes = 0x7FFFFF00LL;
+constexpr int CC = 8;                       // channels per chunk
+constexpr int TB = 32;                      // tiles per workgroup
+constexpr int KB = 64;                      // output channels per workgroup
+constexpr int NXI = 36;                     // transform points
+constexpr int XS = 256;                     // floats per point and chunk: [channel pair 4][h 2][tile 32]
+constexpr int VSKEW = 16;                   // points 18..35 (written by the odd lane of a pair) start 16 banks later
+constexpr int VBUF = NXI * XS + 32;         // 9248 floats = 36 KB: V of one chunk
+constexpr int UCHUNK = 8 * 9 * 64 * 4;      // 18432 floats: U of one (cout block, chunk): [wave][point 9][lane][4]
+constexpr int MXI = 32 * 32;                // output staging M[point][cout 32][tile 32]
+constexpr int W4_LDS_BYTES = NXI * MXI * 4; // 144 KB (the main loop uses 72 KB)
+
+struct Wino4Args {
+    const float* in;
+    const float* U;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    const float* lo;
+    float* out;
+    unsigned in_bytes, out_bytes, res_bytes;
+    int Cin, H, W, in_ctot, in_coff;
+    int M, chunks, kblocks;
+    int TY, TX, NT, tile_blocks;
+    int out_ctot, out_coff, res_ctot, res_coff;
+    float res_scale;
+    int relu;
+    float* pool_out;         // optional fused 2x2 / stride 2 max-pool of the activation (NCHW), else null
+    int pool_ctot, pool_coff, pool_oh, pool_ow, write_full;
+    int nseg;                // > 0: channels-last scatter into the flattened head buffers (ct_out_segment)
+    ct_out_segment seg[3];
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// x -> B^T x (also the row pass: V = (B^T d) B means B^T applied along the other index)
+__device__ __forceinline__ void bt6(const float (&d)[6], float (&o)[6])
+{
+    const float a = fmaf(-4.f, d[2], d[4]);
+    const float b = fmaf(-4.f, d[1], d[3]);
+    const float c = d[4] - d[2];
+    const float e = 2.f * (d[3] - d[1]);
+    o[0] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+    o[1] = a + b;
+    o[2] = a - b;
+    o[3] = c + e;
+    o[4] = c - e;
+    o[5] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+}
+
+// m -> A^T m
+__device__ __forceinline__ void at4(const float (&m)[6], float (&y)[4])
+{
+    const float p = m[1] + m[2], n = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
+    y[0] = m[0] + p + r;
+    y[1] = fmaf(2.f, s, n);
+    y[2] = fmaf(4.f, r, p);
+    y[3] = fmaf(8.f, s, n) + m[5];
+}
+
+__device__ __forceinline__ float swap_pair(float x)       // value of the other lane of the pair (lane ^ 1)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+
+__global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xg = wave >> 1, kbk = wave & 1;
+    // blockIdx -> (XCD-local sequence, cout block fastest), as in ct_wino.hip: the cout blocks of a tile block run
+    // together on one XCD and share its input patches through that XCD's L2
+    const int jx = blockIdx.x >> 3;
+    const int kb = jx % a.kblocks;
+    const int tblk = (jx / a.kblocks) * 8 + (blockIdx.x & 7);
+    if (tblk >= a.tile_blocks) return;
+    const int tb0 = tblk * TB;
+    const int HW = a.H * a.W;
+
+    // ---- patch-loader role: tile = lane>>1, column half q = lane&1 (columns 3q..3q+2), channel-in-chunk = wave
+    const int pt = lane >> 1;
+    const bool q = lane & 1;
+    int voffr[6];
+    bool lp, m0, m1, m2;
+    {
+        const int T = tb0 + pt;
+        const bool live = T < a.NT;
+        const int n = T / (a.TY * a.TX);
+        const int rem = T - n * (a.TY * a.TX);
+        const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        const int y0 = 4 * ty - 1, xs = 4 * tx - 1 + (q ? 3 : 0);
+        lp = xs < 0;                             // left padding column: load from x = 0 and shift the unpack by one
+        m0 = !lp && xs < a.W;
+        m1 = xs + 1 < a.W;
+        m2 = xs + 2 < a.W;
+        const long base = (((long)n * a.in_ctot + a.in_coff) * a.H + y0) * (long)a.W + xs + (lp ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
+            voffr[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+
+    i32x3 raw[6];
+    float t[6][3];
+    auto load_patch = [&](int c) {
+        const int soff = (c * CC + wave) * HW * 4;               // wave-uniform channel offset (bytes)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, voffr[i], soff, 0);
+    };
+    // column pass for local column c: t[.][c] = B^T d[.][c]
+    auto col_pass = [&](int c) {
+        float d[6], o[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const f32x3 v = __builtin_bit_cast(f32x3, raw[i]);
+            if (c == 0) d[i] = m0 ? v.x : 0.f;
+            else if (c == 1) d[i] = m1 ? (lp ? v.x : v.y) : 0.f;
+            else d[i] = m2 ? (lp ? v.y : v.z) : 0.f;
+        }
+        bt6(d, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t[i][c] = o[i];
+    };
+    // transform rows r (lanes q = 0) / r + 3 (lanes q = 1): the three columns of the other half come from the partner
+    const int s_w = wave >> 1, h_w = wave & 1;
+    float* const Vw = lds + (q ? 18 * XS + VSKEW : 0) + s_w * 64 + h_w * 32 + pt;
+    auto row_pass = [&](int r, int buf) {
+        float x[6], v[6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float snd = q ? t[r][c] : t[r + 3][c];
+            const float rcv = swap_pair(snd);
+            x[c] = q ? rcv : t[r][c];
+            x[3 + c] = q ? t[r + 3][c] : rcv;
+        }
+        bt6(x, v);
+        float* vw = Vw + buf * VBUF + r * 6 * XS;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) vw[j * XS] = v[j];
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // ---- weights in registers: u[j] = the 4 A-fragment floats (channel pairs s = 0..3) of transform point 9 xg + j
+    const f32x4* Ug = reinterpret_cast<const f32x4*>(a.U + (size_t)kb * a.chunks * UCHUNK) + wave * (9 * 64) + lane;
+    f32x4 u[9];
+    const int last = a.chunks - 1;
+    const float* const Vr = lds + (9 * xg) * XS + (xg >= 2 ? VSKEW : 0) + lane;
+
+#pragma unroll
+    for (int j = 0; j < 9; ++j) u[j] = Ug[j * 64];
+    load_patch(0);
+    col_pass(0); col_pass(1); col_pass(2);
+    row_pass(0, 0); row_pass(1, 0); row_pass(2, 0);
+    load_patch(min(1, last));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+#define W4_PIN() __builtin_amdgcn_sched_barrier(0)
+    for (int c = 0; c < a.chunks; ++c) {
+        const int buf = c & 1;
+        const int cn = min(c + 1, last), cp = min(c + 2, last);
+        const float* vr = Vr + buf * VBUF;
+        const f32x4* un = Ug + (size_t)cn * (UCHUNK / 4);
+        float b[2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[0][s] = vr[s * 64];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            if (j + 1 < 9) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[(j + 1) & 1][s] = vr[(j + 1) * XS + s * 64];
+            }
+            __builtin_amdgcn_s_setprio(1);          // the MFMA issue wins the arbitration against the other wave's VALU work
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[j].x, b[j & 1][0], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[j].y, b[j & 1][1], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[j].z, b[j & 1][2], acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[j].w, b[j & 1][3], acc[j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            u[j] = un[j * 64];
+            // side work behind the MFMAs: transform of patch(c+1) into the other V buffer, then patch(c+2) -> registers
+            if (j == 0) { col_pass(0); col_pass(1); }
+            if (j == 1) { col_pass(2); row_pass(0, buf ^ 1); }
+            if (j == 2) row_pass(1, buf ^ 1);
+            if (j == 3) row_pass(2, buf ^ 1);
+            if (j == 4) load_patch(cp);
+            W4_PIN();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+#undef W4_PIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- output transform: two passes of 32 couts through LDS  M[point][cout 32][tile 32]
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
+    const int OH = a.H, OW = a.W;                      // pad 1, stride 1: same spatial size
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                // accumulator row r = 8 pass + rr holds cout kl = (r&3) + 8 (r>>2) + 4h of this wave's half
+                const int kk = kbk * 16 + (rr & 3) + 8 * (rr >> 2) + 4 * h;
+                lds[(9 * xg + j) * MXI + kk * 32 + l31] = pass == 0 ? acc[j][rr] : acc[j][8 + rr];
+            }
+        __syncthreads();
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 512 * it;
+            const int kk = idx >> 5, tl = idx & 31;
+            const int co = kb * KB + (kk >> 4) * 32 + 16 * pass + (kk & 15);
+            const int T = tb0 + tl;
+            if (T >= a.NT || co >= a.M) continue;
+            const int n = T / (a.TY * a.TX);
+            const int rem = T - n * (a.TY * a.TX);
+            const int ty = rem / a.TX, tx = rem - ty * a.TX;
+            const int oy = 4 * ty, ox = 4 * tx;
+            float z[4][6];
+            const float* mp = lds + kk * 32 + tl;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float m[6], y[4];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) m[i] = mp[(i * 6 + j) * MXI];
+                at4(m, y);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[i][j] = y[i];
+            }
+            const float sc = a.scale[co], sh = a.shift[co];
+            const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
+            const bool c1 = ox + 1 < OW, c2 = ox + 2 < OW, c3 = ox + 3 < OW;
+            float pl[2][2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int yy = oy + i;
+                if (yy >= OH) continue;
+                float v[4];
+                at4(z[i], v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = v[j] * sc + sh;
+                if (a.res) {
+                    const unsigned ro = (unsigned)(((((size_t)n * a.res_ctot + a.res_coff + co) * OH + yy) * OW + ox) * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool ok = j == 0 || (j == 1 ? c1 : j == 2 ? c2 : c3);
+                        const float r = __builtin_bit_cast(
+                            float, __builtin_amdgcn_raw_buffer_load_b32(rres, ok ? ro + 4 * j : (unsigned)kInvalidOff, 0, 0));
+                        v[j] = v[j] * a.res_scale + r;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo);
+                pl[i >> 1][0] = fmaxf(pl[i >> 1][0], c1 ? fmaxf(v[0], v[1]) : v[0]);
+                if (c2) pl[i >> 1][1] = fmaxf(pl[i >> 1][1], c3 ? fmaxf(v[2], v[3]) : v[2]);
+                if (!a.write_full) continue;
+                if (a.nseg > 0) {          // heads: permute(0,2,3,1) + view + cat of models/RFB_Net_vgg.py:239-248
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end) {
+                            float* dst = a.seg[g].ptr + (size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                         (size_t)(yy * OW + ox) * a.seg[g].pix_stride + (co - a.seg[g].co_begin);
+                            dst[0] = v[0];
+                            if (c1) dst[a.seg[g].pix_stride] = v[1];
+                            if (c2) dst[2 * a.seg[g].pix_stride] = v[2];
+                            if (c3) dst[3 * a.seg[g].pix_stride] = v[3];
+                        }
+                    continue;
+                }
+                const unsigned oo = (unsigned)(((((size_t)n * a.out_ctot + a.out_coff + co) * OH + yy) * OW + ox) * 4);
+                if (c3) {
+                    i32x4 pk;
+                    pk.x = __builtin_bit_cast(int, v[0]);
+                    pk.y = __builtin_bit_cast(int, v[1]);
+                    pk.z = __builtin_bit_cast(int, v[2]);
+                    pk.w = __builtin_bit_cast(int, v[3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(pk, rout, oo, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[0]), rout, oo, 0, 0);
+                    if (c1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[1]), rout, oo + 4, 0, 0);
+                    if (c2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[2]), rout, oo + 8, 0, 0);
+                }
+            }
+            // a 4x4 output tile holds the four windows (2ty + pi, 2tx + pj) of MaxPool2d(2, 2[, ceil_mode])
+            // (models/RFB_Net_vgg.py:328-330)
+            if (a.pool_out) {
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                    for (int pj = 0; pj < 2; ++pj) {
+                        const int py = 2 * ty + pi, px = 2 * tx + pj;
+                        if (py < a.pool_oh && px < a.pool_ow && oy + 2 * pi < OH && ox + 2 * pj < OW)
+                            a.pool_out[(((size_t)n * a.pool_ctot + a.pool_coff + co) * a.pool_oh + py) * a.pool_ow + px] = pl[pi][pj];
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// U[kb][chunk][wave 8][point 9][lane 64][4]: (G g G^T)[xi] values in MFMA A-fragment order (zero padded couts)
+struct Wino4PackArgs {
+    const float* w[6];
+    int mbeg[7];
+    int nparts, cin, cout, chunks, kblocks;
+    int dgrad;               // 1: weights of the data-gradient convolution (channels swapped, taps flipped)
+    int cin_fwd;
+    float* U;
+};
+
+__device__ __forceinline__ void g_row(int r, float (&o)[3])
+{
+    switch (r) {
+    case 0: o[0] = 0.25f; o[1] = 0.f; o[2] = 0.f; break;
+    case 1: o[0] = -1.f / 6; o[1] = -1.f / 6; o[2] = -1.f / 6; break;
+    case 2: o[0] = -1.f / 6; o[1] = 1.f / 6; o[2] = -1.f / 6; break;
+    case 3: o[0] = 1.f / 24; o[1] = 1.f / 12; o[2] = 1.f / 6; break;
+    case 4: o[0] = 1.f / 24; o[1] = -1.f / 12; o[2] = 1.f / 6; break;
+    default: o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; break;
+    }
+}
+
+__device__ __forceinline__ void wino4_pack_body(const Wino4PackArgs& p, long first, long stride)
+{
+    const long total = (long)p.kblocks * p.chunks * UCHUNK;
+    for (long idx = first; idx < total; idx += stride) {
+        const int s = (int)(idx & 3), ln = (int)((idx >> 2) & 63);
+        long rest = idx >> 8;
+        const int j = (int)(rest % 9);
+        rest /= 9;
+        const int wv = (int)(rest & 7);
+        rest >>= 3;
+        const int chunk = (int)(rest % p.chunks);
+        const int kb = (int)(rest / p.chunks);
+        const int hh = ln >> 5;
+        const int co = kb * KB + (wv & 1) * 32 + (ln & 31), ci = chunk * CC + 2 * s + hh;
+        const int xi = 9 * (wv >> 1) + j;
+        float val = 0.f;
+        if (co < p.cout) {
+            // forward: g = w[co][ci];  data gradient: this conv's (co, ci) = forward (ci, co), taps rotated 180 deg
+            const int fco = p.dgrad ? ci : co, fci = p.dgrad ? co : ci;
+            int part = 0;
+            while (part + 1 < p.nparts && fco >= p.mbeg[part + 1]) ++part;
+            const float* g = p.w[part] + ((size_t)(fco - p.mbeg[part]) * p.cin_fwd + fci) * 9;
+            float Ga[3], Gb[3];
+            g_row(xi / 6, Ga);
+            g_row(xi % 6, Gb);
+            for (int i = 0; i < 3; ++i)
+                for (int jj = 0; jj < 3; ++jj)
+                    val += Ga[i] * (p.dgrad ? g[(2 - i) * 3 + (2 - jj)] : g[i * 3 + jj]) * Gb[jj];
+        }
+        p.U[idx] = val;
+    }
+}
+
+__global__ void wino4_pack_kernel(const Wino4PackArgs p)
+{
+    wino4_pack_body(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+bool wino4_ok(const ct_conv_desc* d)
+{
+    return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+           d->cin % CC == 0 && d->nseg >= 0 && d->nseg <= 3 && (d->nseg == 0 || !d->res) && !d->transposed &&
+           d->oh == d->h && d->ow == d->w;
+}
+
+int pack_wino4(const float* const* w, const int* cout, int nparts, int cin, int dgrad, float* upacked,
+               ct_stream_t stream, const char* who)
+{
+    CT_REQUIRE(w && cout && upacked && nparts >= 1 && nparts <= 6, "%s: bad argument", who);
+    Wino4PackArgs p{};
+    int tot = 0;
+    for (int i = 0; i < nparts; ++i) {
+        CT_REQUIRE(w[i] && cout[i] > 0, "%s: part %d", who, i);
+        p.w[i] = w[i];
+        p.mbeg[i] = tot;
+        tot += cout[i];
+    }
+    p.mbeg[nparts] = tot;
+    p.nparts = nparts;
+    p.dgrad = dgrad;
+    p.cin_fwd = cin;
+    p.cin = dgrad ? tot : cin;          // input channels of THIS convolution
+    p.cout = dgrad ? cin : tot;
+    CT_REQUIRE(p.cin > 0 && p.cin % CC == 0, "%s: %d input channels, must be a multiple of %d", who, p.cin, CC);
+    p.chunks = p.cin / CC;
+    p.kblocks = (p.cout + KB - 1) / KB;
+    p.U = upacked;
+    const long total = (long)p.kblocks * p.chunks * UCHUNK;
+    hipLaunchKernelGGL(wino4_pack_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
+                       ctdet::as_stream(stream), p);
+    CT_LAUNCH_CHECK("wino4_pack_kernel");
+    return CT_OK;
+}
+
+}  // namespace
+
+extern "C" int ct_conv_wino4_supported(const ct_conv_desc* d) { return d && wino4_ok(d) ? 1 : 0; }
+
+extern "C" size_t ct_conv_wino4_packed_floats(int cin, int cout)
+{
+    if (cin <= 0 || cout <= 0 || cin % CC) return 0;
+    return (size_t)((cout + KB - 1) / KB) * (cin / CC) * UCHUNK;
+}
+
+extern "C" int ct_conv_pack_weights_wino4(const float* const* w, const int* cout, int nparts, int cin,
+                                          float* upacked, ct_stream_t stream)
+{
+    return pack_wino4(w, cout, nparts, cin, 0, upacked, stream, "ct_conv_pack_weights_wino4");
+}
+
+extern "C" int ct_conv_pack_weights_wino4_dgrad(const float* const* w, const int* cout, int nparts, int cin,
+                                                float* upacked, ct_stream_t stream)
+{
+    return pack_wino4(w, cout, nparts, cin, 1, upacked, stream, "ct_conv_pack_weights_wino4_dgrad");
+}
+
+extern "C" int ct_conv2d_wino4_pool_fwd(const ct_conv_desc* d, const float* upacked, float* pool_out, int pool_ctot,
+                                        int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream)
+{
+    CT_REQUIRE(d && upacked, "ct_conv2d_wino4_fwd: null pointer");
+    CT_REQUIRE(d->in && (d->out || d->nseg > 0) && d->scale && d->shift, "ct_conv2d_wino4_fwd: null tensor");
+    if (!wino4_ok(d))
+        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wino4_fwd: needs 3x3 stride 1 dilation 1 pad 1, cin %% 8 == 0 "
+                           "(got %dx%d s%d d%d p%d cin=%d nseg=%d)", d->kh, d->kw, d->stride, d->dil,
+                           d->pad_h, d->cin, d->nseg);
+    CT_REQUIRE(d->batch > 0 && d->cout > 0, "ct_conv2d_wino4_fwd: bad shape");
+    CT_REQUIRE(write_full || pool_out, "ct_conv2d_wino4_pool_fwd: nothing to write");
+    if (pool_out) {
+        CT_REQUIRE(pool_coff >= 0 && pool_coff + d->cout <= pool_ctot, "ct_conv2d_wino4_pool_fwd: pooled output slice");
+        CT_REQUIRE((pool_oh == d->oh / 2 || pool_oh == (d->oh + 1) / 2) && (pool_ow == d->ow / 2 || pool_ow == (d->ow + 1) / 2),
+                   "ct_conv2d_wino4_pool_fwd: pooled size %dx%d for a %dx%d map", pool_oh, pool_ow, d->oh, d->ow);
+    }
+    CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "ct_conv2d_wino4_fwd: input slice");
+    if (d->nseg == 0)
+        CT_REQUIRE(d->out_coff >= 0 && d->out_coff + d->cout <= d->out_ctot, "ct_conv2d_wino4_fwd: output slice");
+    else {
+        CT_REQUIRE(!pool_out && write_full, "ct_conv2d_wino4_fwd: pooling with segmented output");
+        for (int g = 0; g < d->nseg; ++g) CT_REQUIRE(d->seg[g].ptr, "ct_conv2d_wino4_fwd: null segment");
+    }
+    CT_REQUIRE(!d->res || (d->res_coff >= 0 && d->res_coff + d->cout <= d->res_ctot), "ct_conv2d_wino4_fwd: residual slice");
+    const long long img_in_bytes = (long long)d->in_ctot * d->h * d->w * 4;
+    CT_REQUIRE(img_in_bytes < kMaxBufBytes, "ct_conv2d_wino4_fwd: one image exceeds 2 GiB");
+    const long long img_out_bytes = d->nseg ? 4 : (long long)d->out_ctot * d->oh * d->ow * 4;
+    const long long img_res_bytes = d->res ? (long long)d->res_ctot * d->oh * d->ow * 4 : 0;
+    CT_REQUIRE(img_out_bytes < kMaxBufBytes && img_res_bytes < kMaxBufBytes, "ct_conv2d_wino4_fwd: one image exceeds 2 GiB");
+    const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / std::max(img_in_bytes, std::max(img_out_bytes, img_res_bytes)));
+    hipStream_t st = ctdet::as_stream(stream);
+    {
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute((const void*)wino_f4x4_3x3_f32, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           W4_LDS_BYTES);
+        });
+        CT_HIP(attr_err);
+    }
+    const int OHW = d->oh * d->ow;
+    for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
+        const int nb = std::min(max_chunk, d->batch - b0);
+        Wino4Args a{};
+        a.in = d->in + (size_t)b0 * d->in_ctot * d->h * d->w;
+        a.U = upacked;
+        a.scale = d->scale; a.shift = d->shift; a.lo = d->lo;
+        a.res = d->res ? d->res + (size_t)b0 * d->res_ctot * OHW : nullptr;
+        a.out = d->nseg ? nullptr : d->out + (size_t)b0 * d->out_ctot * OHW;
+        a.nseg = d->nseg;
+        for (int g = 0; g < d->nseg; ++g) {
+            a.seg[g] = d->seg[g];
+            a.seg[g].ptr += (size_t)b0 * d->seg[g].img_stride;
+        }
+        a.in_bytes = (unsigned)(img_in_bytes * nb);
+        a.out_bytes = (unsigned)(img_out_bytes * nb);
+        a.res_bytes = (unsigned)(img_res_bytes * nb);
+        a.Cin = d->cin; a.H = d->h; a.W = d->w; a.in_ctot = d->in_ctot; a.in_coff = d->in_coff;
+        a.M = d->cout; a.chunks = d->cin / CC;
+        a.TY = (d->oh + 3) / 4; a.TX = (d->ow + 3) / 4;
+        a.NT = nb * a.TY * a.TX;
+        a.tile_blocks = (a.NT + TB - 1) / TB;
+        a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
+        a.res_ctot = d->res_ctot; a.res_coff = d->res_coff; a.res_scale = d->res_scale;
+        a.relu = d->relu;
+        a.pool_out = pool_out ? pool_out + (size_t)b0 * pool_ctot * pool_oh * pool_ow : nullptr;
+        a.pool_ctot = pool_ctot; a.pool_coff = pool_coff; a.pool_oh = pool_oh; a.pool_ow = pool_ow;
+        a.write_full = write_full;
+        a.kblocks = (d->cout + KB - 1) / KB;
+        // 8 XCD-local sequences of (tile block group, cout block); sequences past the last tile block exit at once
+        const int groups = (a.tile_blocks + 7) / 8;
+        hipLaunchKernelGGL(wino_f4x4_3x3_f32, dim3(8 * groups * a.kblocks), dim3(512), W4_LDS_BYTES, st, a);
+        CT_LAUNCH_CHECK("wino_f4x4_3x3_f32");
+    }
+    return CT_OK;
+}
+
+extern "C" int ct_conv2d_wino4_fwd(const ct_conv_desc* d, const float* upacked, ct_stream_t stream)
+{
+    return ct_conv2d_wino4_pool_fwd(d, upacked, nullptr, 0, 0, 0, 0, 1, stream);
+}

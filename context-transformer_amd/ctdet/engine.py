@@ -344,6 +344,7 @@ class Plan:
 
 # ======================================================================================
 WINO = -1          # ConvStep.rt['config'] value selecting the Winograd F(2x2,3x3) kernel
+WINO4 = -2         # ... the Winograd F(4x4,3x3) kernel
 
 
 class HipBackend:
@@ -419,11 +420,12 @@ class HipBackend:
             d.ksplit, d.ksplit_ws, d.ksplit_ws_floats = -1, rt['ksws'].data_ptr(), rt['ksws'].numel()
         rt['desc'] = d
         rt['wino_ok'] = bool(lib.ct_conv_wino_supported(C.byref(d)))
-        if rt.get('config', 0) == WINO:
-            self.enable_wino(st)
+        if rt.get('config', 0) in (WINO, WINO4):
+            self.enable_wino(st, tile=2 if rt['config'] == WINO else 4)
 
-    def enable_wino(self, st, on=True):
-        """Route this conv through the Winograd F(2x2,3x3) kernel (3x3 s1 d1 p1 layers only)."""
+    def enable_wino(self, st, on=True, tile=None):
+        """Route this conv through a Winograd kernel (3x3 s1 d1 p1 layers only): tile 2 = F(2x2,3x3),
+        tile 4 = F(4x4,3x3).  st.rt['wino'] holds the tile size in use."""
         rt = st.rt
         if not on:
             rt['wino'] = False
@@ -432,15 +434,24 @@ class HipBackend:
             return
         if not rt.get('wino_ok'):
             raise _lib.CtdetError('%s: geometry has no Winograd path' % st.name)
-        if 'U' not in rt:
-            rt['U'] = self.alloc((self.lib.ct_conv_wino_packed_floats(st.cin, st.cout),))
-        rt['wino'] = True
+        tile = int(tile or 2)
+        if tile not in (2, 4):
+            raise _lib.CtdetError('%s: Winograd tile %r (2 or 4)' % (st.name, tile))
+        key = 'U' if tile == 2 else 'U4'
+        if key not in rt:
+            sizeof = self.lib.ct_conv_wino_packed_floats if tile == 2 else self.lib.ct_conv_wino4_packed_floats
+            rt[key] = self.alloc((sizeof(st.cin, st.cout),))
+        rt['wino'] = tile
         self._pack_wino(st)
 
     def _pack_wino(self, st):
         n = len(st.parts)
         ptrs = (C.c_void_p * n)(*[p.weight.detach().data_ptr() for p in st.parts])
         couts = (C.c_int * n)(*[p.cout for p in st.parts])
+        if st.rt['wino'] == 4:
+            _lib.check(self.lib.ct_conv_pack_weights_wino4(ptrs, couts, n, st.cin, st.rt['U4'].data_ptr(), self._stream()),
+                       'ct_conv_pack_weights_wino4')
+            return
         _lib.check(self.lib.ct_conv_pack_weights_wino(ptrs, couts, n, st.cin, st.rt['U'].data_ptr(), self._stream()),
                    'ct_conv_pack_weights_wino')
 
@@ -499,15 +510,19 @@ class HipBackend:
         return v
 
     def run_conv(self, st):
-        if st.rt.get('wino'):
+        tile = st.rt.get('wino')
+        if tile:
+            lib = self.lib
+            U = st.rt['U4' if tile == 4 else 'U'].data_ptr()
             pool = st.rt.get('pool')
             if pool is not None:        # fused MaxPool2d(2, 2): (pooled buffer, oh, ow, write_full)
                 t, poh, pow_, full = pool
-                _lib.check(self.lib.ct_conv2d_wino_pool_fwd(C.byref(st.rt['desc']), st.rt['U'].data_ptr(), t.data_ptr(),
-                                                            t.shape[1], 0, poh, pow_, int(full), self._stream()), st.name)
+                fn = lib.ct_conv2d_wino4_pool_fwd if tile == 4 else lib.ct_conv2d_wino_pool_fwd
+                _lib.check(fn(C.byref(st.rt['desc']), U, t.data_ptr(), t.shape[1], 0, poh, pow_, int(full),
+                              self._stream()), st.name)
                 return
-            _lib.check(self.lib.ct_conv2d_wino_fwd(C.byref(st.rt['desc']), st.rt['U'].data_ptr(), self._stream()),
-                       st.name)
+            fn = lib.ct_conv2d_wino4_fwd if tile == 4 else lib.ct_conv2d_wino_fwd
+            _lib.check(fn(C.byref(st.rt['desc']), U, self._stream()), st.name)
             return
         _lib.check(self.lib.ct_conv2d_fwd(C.byref(st.rt['desc']), self._stream()), st.name)
 
@@ -549,29 +564,43 @@ class HipBackend:
         st.rt['desc'].config = best + 1
         st.rt['config'] = best + 1
         if st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
-            self.enable_wino(st)
-            self.run_conv(st)
-            torch.cuda.synchronize(self.device)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
+            best_tile = 0
+            for tile in wino_tiles():
+                self.enable_wino(st, tile=tile)
                 self.run_conv(st)
-            e1.record()
-            torch.cuda.synchronize(self.device)
-            t = e0.elapsed_time(e1) / iters
-            times.append(t)
-            if t >= best_t:
+                torch.cuda.synchronize(self.device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    self.run_conv(st)
+                e1.record()
+                torch.cuda.synchronize(self.device)
+                t = e0.elapsed_time(e1) / iters
+                times.append(t)
+                if t < best_t:
+                    best_tile, best_t = tile, t
+            if best_tile:
+                self.enable_wino(st, tile=best_tile)
+            else:
                 self.enable_wino(st, False)
         st.rt['tune_ms'] = times
         return best, times
 
 
-def apply_tuned(backend, st, batch):
-    """Give a prepared conv step the committed tile choice for its shape; False if the table has none."""
+def wino_tiles():
+    """Winograd variants the tuner may pick: CTDET_WINO_TILES = '2', '4' or '2,4' (default)."""
+    return tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4').split(',') if t)
+
+
+def apply_tuned(backend, st, batch, wino4=True):
+    """Give a prepared conv step the committed tile choice for its shape; False if the table has none.
+    wino4=False (the training engine: its batched weight re-pack knows the F(2x2,3x3) layout only) maps a
+    'wino4' entry to 'wino'."""
     cfg = tune_table().get(st.tune_key(batch))
     names = [backend.lib.ct_conv_config_name(i).decode() for i in range(backend.lib.ct_conv_num_configs())]
-    if cfg == 'wino' and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
-        backend.enable_wino(st)
+    if cfg in ('wino', 'wino4') and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
+        tile = 4 if cfg == 'wino4' and wino4 and 4 in wino_tiles() else 2
+        backend.enable_wino(st, tile=tile)
         return True
     if cfg in names:
         st.rt['config'] = names.index(cfg) + 1
@@ -711,7 +740,7 @@ class Runtime:
 
     def tuned_configs(self):
         lib = self.backend.lib
-        return {st.tune_key(self.batch): ('wino' if st.rt.get('wino') else
+        return {st.tune_key(self.batch): ({2: 'wino', 4: 'wino4'}[st.rt['wino']] if st.rt.get('wino') else
                                           lib.ct_conv_config_name(st.rt['desc'].config - 1).decode())
                 for st in self.conv_steps() if st.rt['desc'].config > 0 or st.rt.get('wino')}
 

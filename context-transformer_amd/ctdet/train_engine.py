@@ -76,7 +76,7 @@ class TrainRuntime:
                                    st.kh, st.kw, st.stride, st.ph, st.pw, st.dil, st.src, st.src_coff, st.h,
                                    st.w, zname, 0)
                 backend.prepare_conv(s.zstep, self.bufs, batch)
-                apply_tuned(backend, s.zstep, batch)
+                apply_tuned(backend, s.zstep, batch, wino4=False)
                 s.fwd = s.zstep
                 s.mean = [al((p.cout,)) for p in st.parts]
                 s.var = [al((p.cout,)) for p in st.parts]
@@ -85,7 +85,7 @@ class TrainRuntime:
                 s.scratch = [al((2 * p.cout,), torch.float64) for p in st.parts]     # sliced BN reductions
             else:
                 backend.prepare_conv(st, self.bufs, batch)
-                apply_tuned(backend, st, batch)
+                apply_tuned(backend, st, batch, wino4=False)
                 s.fwd = st
                 s.dbias = [al((p.cout,)) for p in st.parts]
             # data-gradient launch (not needed for the image itself)

@@ -274,6 +274,21 @@ int ct_conv2d_wino_pool_fwd(const ct_conv_desc* desc, const float* upacked, floa
 int ct_conv_pack_weights_wino_dgrad(const float* const* w, const int* cout, int nparts, int cin,
                                     float* upacked, ct_stream_t stream);
 
+/* Winograd F(4x4,3x3): the large-tile variant of the five entry points above, same contracts (same layers:
+ * models/RFB_Net_vgg.py:7-22,219-227; same descriptor, epilogue, pooling fusion -- a 4x4 tile holds four pooling
+ * windows -- and head scatter), its own packed layout (ct_conv_wino4_packed_floats floats).  36 multiplications per
+ * 16 outputs: 4x fewer than the direct convolution, 1.78x fewer than F(2x2,3x3); fp32 rounding error about 1e-5 of
+ * the output range (interpolation points 0, +-1, +-2, inf) against 1e-6 for F(2x2,3x3). */
+int ct_conv_wino4_supported(const ct_conv_desc* desc);
+size_t ct_conv_wino4_packed_floats(int cin, int cout);
+int ct_conv_pack_weights_wino4(const float* const* w, const int* cout, int nparts, int cin, float* upacked,
+                               ct_stream_t stream);
+int ct_conv_pack_weights_wino4_dgrad(const float* const* w, const int* cout, int nparts, int cin,
+                                     float* upacked, ct_stream_t stream);
+int ct_conv2d_wino4_fwd(const ct_conv_desc* desc, const float* upacked, ct_stream_t stream);
+int ct_conv2d_wino4_pool_fwd(const ct_conv_desc* desc, const float* upacked, float* pool_out, int pool_ctot,
+                             int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
+
 /* ---- bf16 channels-last convolutions (BASELINE.json configs[4]: "bf16 MFMA convs + fp32 NMS") ----
  * Same layers and epilogue as ct_conv2d_fwd (models/RFB_Net_vgg.py:7-22,219-248), other storage: activations
  * are [batch][h][w][channels] bfloat16 (round-to-nearest-even of the fp32 value), accumulation and epilogue

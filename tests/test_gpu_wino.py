@@ -1,5 +1,6 @@
-"""Winograd F(2x2,3x3) convolution (ct_conv2d_wino_fwd) against torch-CPU conv2d and against the direct
-implicit-GEMM kernel: same descriptor, same fused epilogues, 1e-4 relative."""
+"""Winograd F(2x2,3x3) and F(4x4,3x3) convolutions (ct_conv2d_wino_fwd, ct_conv2d_wino4_fwd) against torch-CPU conv2d
+and against the direct implicit-GEMM kernel: same descriptor, same fused epilogues, 1e-4 relative (north_star's fp32
+bar; F(4x4,3x3)'s own rounding is about 2e-5 of the output range at 512 input channels, checked below against fp64)."""
 import zlib
 
 import pytest
@@ -12,6 +13,8 @@ from test_gpu_kernels import _bn, _ref_conv, _run_conv
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 W = engine.WINO
+VARIANTS = [engine.WINO, engine.WINO4]
+VIDS = ['f2x2', 'f4x4']
 
 CASES = [  # name, B, Cin, H, W, Cout
     ('vgg', 2, 64, 38, 38, 128), ('odd_hw', 3, 16, 19, 17, 70), ('one_pixel', 2, 8, 1, 1, 5), ('tiny', 2, 24, 5, 5, 64),
@@ -20,8 +23,9 @@ CASES = [  # name, B, Cin, H, W, Cout
 ]
 
 
+@pytest.mark.parametrize('W', VARIANTS, ids=VIDS)
 @pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
-def test_wino_matches_reference(case):
+def test_wino_matches_reference(case, W):
     name, B, Cin, H, Wd, Cout = case
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     x = torch.randn(B, Cin, H, Wd, generator=g)
@@ -34,7 +38,8 @@ def test_wino_matches_reference(case):
     assert rel_err(got, direct) < TOL
 
 
-def test_wino_fused_epilogues():
+@pytest.mark.parametrize('W', VARIANTS, ids=VIDS)
+def test_wino_fused_epilogues(W):
     g = torch.Generator().manual_seed(11)
     x = torch.randn(2, 96, 19, 19, generator=g)
     # BN + ReLU, mixed ReLU parts in one launch (per-channel floor)
@@ -56,7 +61,8 @@ def test_wino_fused_epilogues():
     assert torch.isnan(got[:, :8]).all() and torch.isnan(got[:, 72:]).all()
 
 
-def test_wino_rejects_other_geometries():
+@pytest.mark.parametrize('W', VARIANTS, ids=VIDS)
+def test_wino_rejects_other_geometries(W):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, 16, 9, 9, generator=g)
     for (k, stride, pad, dil, cin) in ((3, 2, 1, 1, 16), (3, 1, 2, 2, 16), (1, 1, 0, 1, 16), (3, 1, 0, 1, 16)):
@@ -69,8 +75,10 @@ def test_wino_rejects_other_geometries():
 
 
 @pytest.mark.parametrize('case', [(2, 16, 20, 20, 24, False, 1), (2, 16, 75, 75, 40, True, 0), (1, 8, 19, 17, 70, False, 0),
-                                  (2, 8, 19, 17, 9, True, 1), (1, 8, 1, 1, 5, True, 0)])
-def test_wino_fused_maxpool(case):
+                                  (2, 8, 19, 17, 9, True, 1), (1, 8, 1, 1, 5, True, 0), (2, 8, 38, 38, 70, False, 1),
+                                  (1, 16, 23, 18, 33, True, 1), (1, 16, 23, 18, 33, False, 0)])
+@pytest.mark.parametrize('W', VARIANTS, ids=VIDS)
+def test_wino_fused_maxpool(case, W):
     """MaxPool2d(2, 2[, ceil_mode]) behind the conv (models/RFB_Net_vgg.py:328-330) from the Winograd epilogue."""
     import torch.nn.functional as F
     B, Cin, H, Wd, Cout, ceil, full = case
@@ -103,7 +111,7 @@ def test_wino_fused_maxpool(case):
         assert torch.isnan(bufs['y']).all()                                             # full-resolution map skipped
 
 
-@pytest.mark.parametrize('use_wino', [True, False])
+@pytest.mark.parametrize('use_wino', [engine.WINO, engine.WINO4, 0], ids=VIDS + ['direct'])
 def test_head_scatter_output(use_wino):
     """Multibox head (models/RFB_Net_vgg.py:239-248): one fused loc|conf|obj conv writing channels-last into
     three flattened buffers at a prior offset -- Winograd and direct kernels against permute/view/cat."""
@@ -121,9 +129,9 @@ def test_head_scatter_output(use_wino):
                engine.Segment('obj', A * (4 + Cc), A * (6 + Cc), A * 2, pbase * 2)]
     bufs = {'x': x.cuda(), 'loc': torch.full((B, P * 4), float('nan'), device='cuda'),
             'conf': torch.full((B, P * Cc), float('nan'), device='cuda'), 'obj': torch.full((B, P * 2), float('nan'), device='cuda')}
-    st.rt['config'] = W if use_wino else 0
+    st.rt['config'] = use_wino
     be.prepare_conv(st, bufs, B)
-    assert bool(st.rt.get('wino')) == use_wino
+    assert (st.rt.get('wino') or 0) == {engine.WINO: 2, engine.WINO4: 4, 0: 0}[use_wino]
     be.run_conv(st)
     torch.cuda.synchronize()
     import torch.nn.functional as F
@@ -135,7 +143,7 @@ def test_head_scatter_output(use_wino):
         assert torch.isnan(got[:, :lo]).all() and torch.isnan(got[:, hi:]).all(), name
 
 
-@pytest.mark.parametrize('use_wino', [True, False])
+@pytest.mark.parametrize('use_wino', [engine.WINO, engine.WINO4, 0], ids=VIDS + ['direct'])
 def test_conv_input_above_2gib_is_chunked(use_wino):
     """BASELINE configs[4] shapes put more than 2 GiB into one activation (32x64x512x512 fp32): the buffer
     descriptors are 32-bit, so both kernels split the batch -- the images on both sides of the split must be right."""
@@ -146,7 +154,52 @@ def test_conv_input_above_2gib_is_chunked(use_wino):
     assert x.numel() * 4 > 2 ** 31
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
     b = torch.rand(Cout, generator=g) - 0.5
-    got = _run_conv(x, [(w, b, None, True)], 1, 1, 1, config=W if use_wino else 0)
+    got = _run_conv(x, [(w, b, None, True)], 1, 1, 1, config=use_wino)
     for n in (0, 30, 31, 32):                 # first image, both sides of the 2 GiB boundary, last image
         want = F.relu(F.conv2d(x[n:n + 1], w, b, 1, 1))
         assert rel_err(got[n:n + 1], want) < TOL, n
+
+
+@pytest.mark.parametrize('W,bound', [(engine.WINO, 3e-6), (engine.WINO4, 5e-5)], ids=VIDS)
+def test_wino_rounding_error_vs_fp64(W, bound):
+    """The transform-domain rounding of each variant on the deepest VGG shape (512 input channels, post-ReLU input):
+    max error over the output range against an fp64 convolution.  Measured 1e-6 for F(2x2,3x3) and 2e-5 for
+    F(4x4,3x3) (interpolation points 0, +-1, +-2, inf; transform entries up to 8)."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 512, 38, 38, generator=g).relu()
+    w = torch.randn(512, 512, 3, 3, generator=g) * (2.0 / (512 * 9)) ** 0.5
+    b = torch.rand(512, generator=g) - 0.5
+    want = F.relu(F.conv2d(x.double(), w.double(), b.double(), 1, 1))
+    got = _run_conv(x, [(w, b, None, True)], 1, 1, 1, config=W)
+    err = float((got.double() - want).abs().max() / want.abs().max())
+    assert err < bound, err
+
+
+def test_wino4_dgrad_weights():
+    """ct_conv_pack_weights_wino4_dgrad: the data-gradient convolution (channels swapped, taps rotated) through the
+    F(4x4,3x3) kernel equals autograd's input gradient of the forward convolution."""
+    import ctypes as C
+    import torch.nn.functional as F
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(8)
+    B, Cin, Cout, H, Wd = 2, 24, 40, 13, 10
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.1
+    dy = torch.randn(B, Cout, H, Wd, generator=g)
+    x = torch.zeros(B, Cin, H, Wd, requires_grad=True)
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    wd, dyd = w.cuda(), dy.cuda()
+    U = torch.empty(lib.ct_conv_wino4_packed_floats(Cout, Cin), device='cuda')
+    ptrs = (C.c_void_p * 1)(wd.data_ptr())
+    couts = (C.c_int * 1)(Cout)
+    _lib.check(lib.ct_conv_pack_weights_wino4_dgrad(ptrs, couts, 1, Cin, U.data_ptr(), None), 'pack')
+    dx = torch.full((B, Cin, H, Wd), float('nan'), device='cuda')
+    one, zero = torch.ones(Cin, device='cuda'), torch.zeros(Cin, device='cuda')
+    d = _lib.ConvDesc()
+    d.in_, d.batch, d.cin, d.h, d.w, d.in_ctot, d.in_coff = dyd.data_ptr(), B, Cout, H, Wd, Cout, 0
+    d.cout, d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil = Cin, 3, 3, 1, 1, 1, 1
+    d.oh, d.ow, d.out, d.out_ctot, d.out_coff = H, Wd, dx.data_ptr(), Cin, 0
+    d.scale, d.shift = one.data_ptr(), zero.data_ptr()
+    _lib.check(lib.ct_conv2d_wino4_fwd(C.byref(d), U.data_ptr(), None), 'wino4 dgrad')
+    torch.cuda.synchronize()
+    assert rel_err(dx.cpu(), x.grad) < TOL

@@ -12,6 +12,7 @@ SHAPES = {  # B, Cin, H, W, Cout
     'base.10': (32, 128, 75, 75, 256), 'base.12': (32, 256, 75, 75, 256), 'base.17': (32, 256, 38, 38, 512),
     'base.19': (32, 512, 38, 38, 512), 'base.24': (32, 512, 19, 19, 512), 'head.0': (32, 512, 38, 38, 156),
     'base.19.b4': (4, 512, 38, 38, 512), 'base.2.b4': (4, 64, 300, 300, 64),
+    'small': (2, 16, 21, 37, 40), 'tiny': (1, 8, 8, 8, 64), 'b2.b2': (2, 64, 300, 300, 64),
 }
 names = sys.argv[1:] or ['base.2', 'base.7', 'base.12', 'base.19', 'base.24']
 iters = int(os.environ.get('ITERS', 10))
@@ -23,16 +24,26 @@ for name in names:
     st = engine.ConvStep(name, [engine.ConvPart(w, b, None, True)], Cin, 3, 3, 1, 1, 1, 1, 'x', 0, H, W, 'y', 0)
     bufs = {'x': torch.randn(B, Cin, H, W, device=DEV), 'y': torch.empty(B, Cout, H, W, device=DEV)}
     be.prepare_conv(st, bufs, B)
-    be.enable_wino(st)
-    for _ in range(2):
-        be.run_conv(st)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        be.run_conv(st)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    fl = st.flops(B)
-    print('%-10s %4d->%-4d @%3dx%-3d bs%-2d  %8.1f us  %6.1f TF algorithmic  %5.1f TF executed = %.3f of 157.3'
-          % (name, Cin, Cout, H, W, B, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 * 16 / 36, fl / ms / 1e9 * 16 / 36 / 157.3), flush=True)
+    ref = None
+    if os.environ.get('CHECK', '1') != '0' and B * Cin * H * W <= 64 << 20:
+        ref = torch.relu(torch.nn.functional.conv2d(bufs['x'].double(), w.double(), b.double(), padding=1))
+    for tile in [int(t) for t in os.environ.get('TILES', '2,4').split(',')]:
+        be.enable_wino(st, tile=tile)
+        bufs['y'].fill_(float('nan'))
+        for _ in range(2):
+            be.run_conv(st)
+        torch.cuda.synchronize()
+        err = ''
+        if ref is not None:
+            err = '  max err %.2e of range' % ((bufs['y'].double() - ref).abs().max() / ref.abs().max()).item()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            be.run_conv(st)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        fl = st.flops(B)
+        ex = (16 / 36) if tile == 2 else 0.25
+        print('%-10s F%d %4d->%-4d @%3dx%-3d bs%-2d  %8.1f us  %6.1f TF algorithmic  %5.1f TF executed = %.3f of 157.3%s'
+              % (name, tile, Cin, Cout, H, W, B, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 * ex, fl / ms / 1e9 * ex / 157.3, err),
+              flush=True)
