@@ -21,6 +21,7 @@
 //   each thread applies A^T M A for a (channel, tile) pair and the usual epilogue
 //   (*scale + shift, residual, ReLU / per-channel floor, optional fused 2x2 max-pool, NCHW or head scatter).
 #include "ct_common.h"
+#include "ct_wino_pack.h"
 #include <algorithm>
 #include <mutex>
 
@@ -34,6 +35,7 @@ constexpr int TB = 64;                      // tiles per workgroup
 constexpr int KB = 64;                      // output channels per workgroup
 constexpr int XI_STRIDE = (CC / 2) * 64 * 2;          // 512 floats: [s][row 64][h 2]
 constexpr int CHUNK_FLOATS = 16 * XI_STRIDE;          // 8192 floats = 32 KB (U or V of one chunk)
+static_assert(CHUNK_FLOATS == ctdet::kWino2ChunkFloats && CC == ctdet::kWinoCC && KB == ctdet::kWinoKB, "pack layout");
 constexpr int WINO_LDS_BYTES = 16 * 64 * 40 * 4;           // 160 KB: output staging M[16][64][40] (the main loop uses 64 KB)
 
 struct WinoArgs {
@@ -367,67 +369,16 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
     }
 }
 
-// U[kb][chunk][wave][piece][lane][4]: (G g G^T)[xi] values in MFMA A-fragment order (zero padded couts)
-struct WinoPackArgs {
-    const float* w[6];
-    int mbeg[7];
-    int nparts, cin, cout, chunks, kblocks;
-    int dgrad;               // 1: weights of the data-gradient convolution (channels swapped, taps flipped)
-    int cin_fwd;
-    float* U;
-};
-
-__device__ __forceinline__ void wino_pack_body(const WinoPackArgs& p, long first, long stride)
+__global__ void wino_pack_kernel(const ctdet::WinoPackArgs p)
 {
-    const long total = (long)p.kblocks * p.chunks * CHUNK_FLOATS;
-    for (long idx = first; idx < total; idx += stride) {
-        // register layout: [wave 8][piece 4][lane 64][4]: piece = (x, s-pair), element = (s parity, cout half);
-        // wave w / lane (l31, hh) gets exactly the A fragments it feeds to its MFMAs, as four float4
-        const int e = (int)(idx & 3), ln = (int)((idx >> 2) & 63), pc = (int)((idx >> 8) & 3), wv = (int)((idx >> 10) & 7);
-        const int hh = ln >> 5;
-        const int k = (ln & 31) + 32 * (e & 1);
-        const int s = 2 * (pc & 1) + (e >> 1);
-        const int xi = 2 * wv + (pc >> 1);
-        const long rest = idx >> 13;
-        const int chunk = (int)(rest % p.chunks);
-        const int kb = (int)(rest / p.chunks);
-        const int co = kb * KB + k, ci = chunk * CC + 2 * s + hh;
-        float val = 0.f;
-        if (co < p.cout) {
-            // forward: g = w[co][ci];  data gradient: this conv's (co, ci) = forward (ci, co), taps rotated 180 deg
-            const int fco = p.dgrad ? ci : co, fci = p.dgrad ? co : ci;
-            int part = 0;
-            while (part + 1 < p.nparts && fco >= p.mbeg[part + 1]) ++part;
-            const float* g = p.w[part] + ((size_t)(fco - p.mbeg[part]) * p.cin_fwd + fci) * 9;
-            const int ar = xi >> 2, bc = xi & 3;
-            // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
-            float Ga[3], Gb[3];
-            auto grow = [](int r, float* o) {
-                if (r == 0) { o[0] = 1.f; o[1] = 0.f; o[2] = 0.f; }
-                else if (r == 1) { o[0] = .5f; o[1] = .5f; o[2] = .5f; }
-                else if (r == 2) { o[0] = .5f; o[1] = -.5f; o[2] = .5f; }
-                else { o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; }
-            };
-            grow(ar, Ga);
-            grow(bc, Gb);
-            for (int i = 0; i < 3; ++i)
-                for (int j = 0; j < 3; ++j)
-                    val += Ga[i] * (p.dgrad ? g[(2 - i) * 3 + (2 - j)] : g[i * 3 + j]) * Gb[j];
-        }
-        p.U[idx] = val;
-    }
-}
-
-__global__ void wino_pack_kernel(const WinoPackArgs p)
-{
-    wino_pack_body(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+    ctdet::wino_pack_any(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 // all Winograd layers of a training step in one launch: blockIdx.y = recorded item (ct_pack_run)
-__global__ void wino_pack_batched_kernel(const WinoPackArgs* __restrict__ items)
+__global__ void wino_pack_batched_kernel(const ctdet::WinoPackArgs* __restrict__ items)
 {
-    const WinoPackArgs p = items[blockIdx.y];
-    wino_pack_body(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+    const ctdet::WinoPackArgs p = items[blockIdx.y];
+    ctdet::wino_pack_any(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 bool wino_ok(const ct_conv_desc* d)
@@ -447,12 +398,11 @@ extern "C" size_t ct_conv_wino_packed_floats(int cin, int cout)
     return (size_t)((cout + KB - 1) / KB) * (cin / CC) * CHUNK_FLOATS;
 }
 
-namespace {
-int pack_wino(const float* const* w, const int* cout, int nparts, int cin, int dgrad, float* upacked,
-              ct_stream_t stream, const char* who)
+int ctdet::pack_wino_any(const float* const* w, const int* cout, int nparts, int cin, int dgrad, int tile, float* upacked,
+                         ct_stream_t stream, const char* who)
 {
     CT_REQUIRE(w && cout && upacked && nparts >= 1 && nparts <= 6, "%s: bad argument", who);
-    WinoPackArgs p{};
+    ctdet::WinoPackArgs p{};
     int tot = 0;
     for (int i = 0; i < nparts; ++i) {
         CT_REQUIRE(w[i] && cout[i] > 0, "%s: part %d", who, i);
@@ -463,6 +413,7 @@ int pack_wino(const float* const* w, const int* cout, int nparts, int cin, int d
     p.mbeg[nparts] = tot;
     p.nparts = nparts;
     p.dgrad = dgrad;
+    p.tile = tile;
     p.cin_fwd = cin;
     p.cin = dgrad ? tot : cin;          // input channels of THIS convolution
     p.cout = dgrad ? cin : tot;
@@ -474,20 +425,19 @@ int pack_wino(const float* const* w, const int* cout, int nparts, int cin, int d
         ctdet::pack_record(1, &p, sizeof(p));
         return CT_OK;
     }
-    const long total = (long)p.kblocks * p.chunks * CHUNK_FLOATS;
+    const long total = (long)p.kblocks * p.chunks * (tile == 4 ? ctdet::kWino4ChunkFloats : ctdet::kWino2ChunkFloats);
     hipLaunchKernelGGL(wino_pack_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
                        ctdet::as_stream(stream), p);
     CT_LAUNCH_CHECK("wino_pack_kernel");
     return CT_OK;
 }
-}  // namespace
 
-size_t ctdet::pack_wino_item_bytes() { return sizeof(WinoPackArgs); }
+size_t ctdet::pack_wino_item_bytes() { return sizeof(ctdet::WinoPackArgs); }
 
 int ctdet::launch_pack_wino_batched(const void* items_dev, int n, hipStream_t st)
 {
     if (n <= 0) return CT_OK;
-    hipLaunchKernelGGL(wino_pack_batched_kernel, dim3(192, n), dim3(256), 0, st, (const WinoPackArgs*)items_dev);
+    hipLaunchKernelGGL(wino_pack_batched_kernel, dim3(192, n), dim3(256), 0, st, (const ctdet::WinoPackArgs*)items_dev);
     CT_LAUNCH_CHECK("wino_pack_batched_kernel");
     return CT_OK;
 }
@@ -495,13 +445,13 @@ int ctdet::launch_pack_wino_batched(const void* items_dev, int n, hipStream_t st
 extern "C" int ct_conv_pack_weights_wino(const float* const* w, const int* cout, int nparts, int cin,
                                          float* upacked, ct_stream_t stream)
 {
-    return pack_wino(w, cout, nparts, cin, 0, upacked, stream, "ct_conv_pack_weights_wino");
+    return ctdet::pack_wino_any(w, cout, nparts, cin, 0, 2, upacked, stream, "ct_conv_pack_weights_wino");
 }
 
 extern "C" int ct_conv_pack_weights_wino_dgrad(const float* const* w, const int* cout, int nparts, int cin,
                                                float* upacked, ct_stream_t stream)
 {
-    return pack_wino(w, cout, nparts, cin, 1, upacked, stream, "ct_conv_pack_weights_wino_dgrad");
+    return ctdet::pack_wino_any(w, cout, nparts, cin, 1, 2, upacked, stream, "ct_conv_pack_weights_wino_dgrad");
 }
 
 extern "C" int ct_conv2d_wino_pool_fwd(const ct_conv_desc* d, const float* upacked, float* pool_out, int pool_ctot,

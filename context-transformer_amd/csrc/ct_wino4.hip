@@ -26,6 +26,7 @@
 //   A^T M A for two (cout, tile) pairs per pass and the usual epilogue (*scale + shift, residual, ReLU / per-channel
 //   floor, optional fused 2x2 max-pool -- a 4x4 tile holds four pooling windows --, NCHW or head scatter).
 #include "ct_common.h"
+#include "ct_wino_pack.h"
 #include <algorithm>
 #include <mutex>
 
@@ -45,7 +46,7 @@ constexpr int NXI = 36;                     // transform points
 constexpr int XS = 256;                     // floats per point and chunk: [channel pair 4][h 2][tile 32]
 constexpr int VSKEW = 16;                   // points 18..35 (written by the odd lane of a pair) start 16 banks later
 constexpr int VBUF = NXI * XS + 32;         // 9248 floats = 36 KB: V of one chunk
-constexpr int UCHUNK = 8 * 9 * 64 * 4;      // 18432 floats: U of one (cout block, chunk): [wave][point 9][lane][4]
+constexpr int UCHUNK = ctdet::kWino4ChunkFloats;   // 18432 floats: U of one (cout block, chunk): [wave][point 9][lane][4]
 constexpr int MXI = 32 * 32;                // output staging M[point][cout 32][tile 32]
 constexpr int W4_LDS_BYTES = NXI * MXI * 4; // 144 KB (the main loop uses 72 KB)
 
@@ -347,100 +348,11 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
     }
 }
 
-// U[kb][chunk][wave 8][point 9][lane 64][4]: (G g G^T)[xi] values in MFMA A-fragment order (zero padded couts)
-struct Wino4PackArgs {
-    const float* w[6];
-    int mbeg[7];
-    int nparts, cin, cout, chunks, kblocks;
-    int dgrad;               // 1: weights of the data-gradient convolution (channels swapped, taps flipped)
-    int cin_fwd;
-    float* U;
-};
-
-__device__ __forceinline__ void g_row(int r, float (&o)[3])
-{
-    switch (r) {
-    case 0: o[0] = 0.25f; o[1] = 0.f; o[2] = 0.f; break;
-    case 1: o[0] = -1.f / 6; o[1] = -1.f / 6; o[2] = -1.f / 6; break;
-    case 2: o[0] = -1.f / 6; o[1] = 1.f / 6; o[2] = -1.f / 6; break;
-    case 3: o[0] = 1.f / 24; o[1] = 1.f / 12; o[2] = 1.f / 6; break;
-    case 4: o[0] = 1.f / 24; o[1] = -1.f / 12; o[2] = 1.f / 6; break;
-    default: o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; break;
-    }
-}
-
-__device__ __forceinline__ void wino4_pack_body(const Wino4PackArgs& p, long first, long stride)
-{
-    const long total = (long)p.kblocks * p.chunks * UCHUNK;
-    for (long idx = first; idx < total; idx += stride) {
-        const int s = (int)(idx & 3), ln = (int)((idx >> 2) & 63);
-        long rest = idx >> 8;
-        const int j = (int)(rest % 9);
-        rest /= 9;
-        const int wv = (int)(rest & 7);
-        rest >>= 3;
-        const int chunk = (int)(rest % p.chunks);
-        const int kb = (int)(rest / p.chunks);
-        const int hh = ln >> 5;
-        const int co = kb * KB + (wv & 1) * 32 + (ln & 31), ci = chunk * CC + 2 * s + hh;
-        const int xi = 9 * (wv >> 1) + j;
-        float val = 0.f;
-        if (co < p.cout) {
-            // forward: g = w[co][ci];  data gradient: this conv's (co, ci) = forward (ci, co), taps rotated 180 deg
-            const int fco = p.dgrad ? ci : co, fci = p.dgrad ? co : ci;
-            int part = 0;
-            while (part + 1 < p.nparts && fco >= p.mbeg[part + 1]) ++part;
-            const float* g = p.w[part] + ((size_t)(fco - p.mbeg[part]) * p.cin_fwd + fci) * 9;
-            float Ga[3], Gb[3];
-            g_row(xi / 6, Ga);
-            g_row(xi % 6, Gb);
-            for (int i = 0; i < 3; ++i)
-                for (int jj = 0; jj < 3; ++jj)
-                    val += Ga[i] * (p.dgrad ? g[(2 - i) * 3 + (2 - jj)] : g[i * 3 + jj]) * Gb[jj];
-        }
-        p.U[idx] = val;
-    }
-}
-
-__global__ void wino4_pack_kernel(const Wino4PackArgs p)
-{
-    wino4_pack_body(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
-}
-
 bool wino4_ok(const ct_conv_desc* d)
 {
     return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
            d->cin % CC == 0 && d->nseg >= 0 && d->nseg <= 3 && (d->nseg == 0 || !d->res) && !d->transposed &&
            d->oh == d->h && d->ow == d->w;
-}
-
-int pack_wino4(const float* const* w, const int* cout, int nparts, int cin, int dgrad, float* upacked,
-               ct_stream_t stream, const char* who)
-{
-    CT_REQUIRE(w && cout && upacked && nparts >= 1 && nparts <= 6, "%s: bad argument", who);
-    Wino4PackArgs p{};
-    int tot = 0;
-    for (int i = 0; i < nparts; ++i) {
-        CT_REQUIRE(w[i] && cout[i] > 0, "%s: part %d", who, i);
-        p.w[i] = w[i];
-        p.mbeg[i] = tot;
-        tot += cout[i];
-    }
-    p.mbeg[nparts] = tot;
-    p.nparts = nparts;
-    p.dgrad = dgrad;
-    p.cin_fwd = cin;
-    p.cin = dgrad ? tot : cin;          // input channels of THIS convolution
-    p.cout = dgrad ? cin : tot;
-    CT_REQUIRE(p.cin > 0 && p.cin % CC == 0, "%s: %d input channels, must be a multiple of %d", who, p.cin, CC);
-    p.chunks = p.cin / CC;
-    p.kblocks = (p.cout + KB - 1) / KB;
-    p.U = upacked;
-    const long total = (long)p.kblocks * p.chunks * UCHUNK;
-    hipLaunchKernelGGL(wino4_pack_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
-                       ctdet::as_stream(stream), p);
-    CT_LAUNCH_CHECK("wino4_pack_kernel");
-    return CT_OK;
 }
 
 }  // namespace
@@ -456,13 +368,13 @@ extern "C" size_t ct_conv_wino4_packed_floats(int cin, int cout)
 extern "C" int ct_conv_pack_weights_wino4(const float* const* w, const int* cout, int nparts, int cin,
                                           float* upacked, ct_stream_t stream)
 {
-    return pack_wino4(w, cout, nparts, cin, 0, upacked, stream, "ct_conv_pack_weights_wino4");
+    return ctdet::pack_wino_any(w, cout, nparts, cin, 0, 4, upacked, stream, "ct_conv_pack_weights_wino4");
 }
 
 extern "C" int ct_conv_pack_weights_wino4_dgrad(const float* const* w, const int* cout, int nparts, int cin,
                                                 float* upacked, ct_stream_t stream)
 {
-    return pack_wino4(w, cout, nparts, cin, 1, upacked, stream, "ct_conv_pack_weights_wino4_dgrad");
+    return ctdet::pack_wino_any(w, cout, nparts, cin, 1, 4, upacked, stream, "ct_conv_pack_weights_wino4_dgrad");
 }
 
 extern "C" int ct_conv2d_wino4_pool_fwd(const ct_conv_desc* d, const float* upacked, float* pool_out, int pool_ctot,

@@ -1,0 +1,123 @@
+// Weight pre-transform U = G g G^T for the two Winograd kernels (ct_wino.hip F(2x2,3x3), ct_wino4.hip F(4x4,3x3)), in
+// the register order their MFMA A fragments are loaded in.  One argument record for both so that the training
+// engine's recorded, batched re-pack (ct_pack_run) replays a mixed list with one launch.  Internal header.
+#pragma once
+#include "ct_common.h"
+
+namespace ctdet {
+
+struct WinoPackArgs {
+    const float* w[6];
+    int mbeg[7];
+    int nparts, cin, cout, chunks, kblocks;
+    int dgrad;               // 1: weights of the data-gradient convolution (channels swapped, taps flipped)
+    int cin_fwd;
+    int tile;                // 2: F(2x2,3x3) layout, 4: F(4x4,3x3) layout
+    float* U;
+};
+
+constexpr int kWinoCC = 8;                          // input channels per chunk (both kernels)
+constexpr int kWinoKB = 64;                         // output channels per workgroup (both kernels)
+constexpr int kWino2ChunkFloats = 16 * 4 * 64 * 2;  // F(2x2): [wave 8][piece 4][lane 64][4]
+constexpr int kWino4ChunkFloats = 8 * 9 * 64 * 4;   // F(4x4): [wave 8][point 9][lane 64][4]
+
+// forward: g = w[co][ci];  data gradient: this conv's (co, ci) = forward (ci, co), taps rotated 180 degrees
+__device__ __forceinline__ const float* wino_taps(const WinoPackArgs& p, int co, int ci)
+{
+    const int fco = p.dgrad ? ci : co, fci = p.dgrad ? co : ci;
+    int part = 0;
+    while (part + 1 < p.nparts && fco >= p.mbeg[part + 1]) ++part;
+    return p.w[part] + ((size_t)(fco - p.mbeg[part]) * p.cin_fwd + fci) * 9;
+}
+
+__device__ __forceinline__ float wino_ggt(const WinoPackArgs& p, const float* g, const float (&Ga)[3], const float (&Gb)[3])
+{
+    float val = 0.f;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            val += Ga[i] * (p.dgrad ? g[(2 - i) * 3 + (2 - j)] : g[i * 3 + j]) * Gb[j];
+    return val;
+}
+
+// U[kb][chunk][wave][piece][lane][4]: piece = (x, s-pair), element = (s parity, cout half); wave w / lane (l31, hh)
+// gets exactly the A fragments it feeds to its MFMAs, as four float4
+__device__ __forceinline__ void wino2_pack_body(const WinoPackArgs& p, long first, long stride)
+{
+    const long total = (long)p.kblocks * p.chunks * kWino2ChunkFloats;
+    for (long idx = first; idx < total; idx += stride) {
+        const int e = (int)(idx & 3), ln = (int)((idx >> 2) & 63), pc = (int)((idx >> 8) & 3), wv = (int)((idx >> 10) & 7);
+        const int hh = ln >> 5;
+        const int k = (ln & 31) + 32 * (e & 1);
+        const int s = 2 * (pc & 1) + (e >> 1);
+        const int xi = 2 * wv + (pc >> 1);
+        const long rest = idx >> 13;
+        const int chunk = (int)(rest % p.chunks);
+        const int kb = (int)(rest / p.chunks);
+        const int co = kb * kWinoKB + k, ci = chunk * kWinoCC + 2 * s + hh;
+        float val = 0.f;
+        if (co < p.cout) {
+            // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+            float Ga[3], Gb[3];
+            auto grow = [](int r, float (&o)[3]) {
+                if (r == 0) { o[0] = 1.f; o[1] = 0.f; o[2] = 0.f; }
+                else if (r == 1) { o[0] = .5f; o[1] = .5f; o[2] = .5f; }
+                else if (r == 2) { o[0] = .5f; o[1] = -.5f; o[2] = .5f; }
+                else { o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; }
+            };
+            grow(xi >> 2, Ga);
+            grow(xi & 3, Gb);
+            val = wino_ggt(p, wino_taps(p, co, ci), Ga, Gb);
+        }
+        p.U[idx] = val;
+    }
+}
+
+// U[kb][chunk][wave 8][point 9][lane 64][4]: wave = (point group, cout half), element = channel pair s
+__device__ __forceinline__ void wino4_pack_body(const WinoPackArgs& p, long first, long stride)
+{
+    const long total = (long)p.kblocks * p.chunks * kWino4ChunkFloats;
+    for (long idx = first; idx < total; idx += stride) {
+        const int s = (int)(idx & 3), ln = (int)((idx >> 2) & 63);
+        long rest = idx >> 8;
+        const int j = (int)(rest % 9);
+        rest /= 9;
+        const int wv = (int)(rest & 7);
+        rest >>= 3;
+        const int chunk = (int)(rest % p.chunks);
+        const int kb = (int)(rest / p.chunks);
+        const int hh = ln >> 5;
+        const int co = kb * kWinoKB + (wv & 1) * 32 + (ln & 31), ci = chunk * kWinoCC + 2 * s + hh;
+        const int xi = 9 * (wv >> 1) + j;
+        float val = 0.f;
+        if (co < p.cout) {
+            // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+            float Ga[3], Gb[3];
+            auto grow = [](int r, float (&o)[3]) {
+                switch (r) {
+                case 0: o[0] = 0.25f; o[1] = 0.f; o[2] = 0.f; break;
+                case 1: o[0] = -1.f / 6; o[1] = -1.f / 6; o[2] = -1.f / 6; break;
+                case 2: o[0] = -1.f / 6; o[1] = 1.f / 6; o[2] = -1.f / 6; break;
+                case 3: o[0] = 1.f / 24; o[1] = 1.f / 12; o[2] = 1.f / 6; break;
+                case 4: o[0] = 1.f / 24; o[1] = -1.f / 12; o[2] = 1.f / 6; break;
+                default: o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; break;
+                }
+            };
+            grow(xi / 6, Ga);
+            grow(xi % 6, Gb);
+            val = wino_ggt(p, wino_taps(p, co, ci), Ga, Gb);
+        }
+        p.U[idx] = val;
+    }
+}
+
+__device__ __forceinline__ void wino_pack_any(const WinoPackArgs& p, long first, long stride)
+{
+    if (p.tile == 4) wino4_pack_body(p, first, stride);
+    else wino2_pack_body(p, first, stride);
+}
+
+// fills and validates a record; launches it, or appends it to the open recording (ct_pack_record_begin)
+int pack_wino_any(const float* const* w, const int* cout, int nparts, int cin, int dgrad, int tile, float* upacked,
+                  ct_stream_t stream, const char* who);
+
+}  // namespace ctdet

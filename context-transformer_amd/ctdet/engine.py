@@ -594,8 +594,7 @@ def wino_tiles():
 
 def apply_tuned(backend, st, batch, wino4=True):
     """Give a prepared conv step the committed tile choice for its shape; False if the table has none.
-    wino4=False (the training engine: its batched weight re-pack knows the F(2x2,3x3) layout only) maps a
-    'wino4' entry to 'wino'."""
+    wino4=False maps a 'wino4' entry to 'wino' (F(2x2,3x3): a tenth of the rounding error)."""
     cfg = tune_table().get(st.tune_key(batch))
     names = [backend.lib.ct_conv_config_name(i).decode() for i in range(backend.lib.ct_conv_num_configs())]
     if cfg in ('wino', 'wino4') and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':

@@ -58,6 +58,8 @@ class TrainRuntime:
             for prm in self.ctx_params.values():
                 self._reg(prm)
         wino_ws = 0
+        # CTDET_TRAIN_WINO4=0 keeps forward and data-gradient convolutions on F(2x2,3x3) where the table says F(4x4,3x3)
+        wino4 = os.environ.get('CTDET_TRAIN_WINO4', '1') != '0'
         for st in self.plan.steps:
             if st.kind != 'conv':
                 continue
@@ -76,7 +78,7 @@ class TrainRuntime:
                                    st.kh, st.kw, st.stride, st.ph, st.pw, st.dil, st.src, st.src_coff, st.h,
                                    st.w, zname, 0)
                 backend.prepare_conv(s.zstep, self.bufs, batch)
-                apply_tuned(backend, s.zstep, batch, wino4=False)
+                apply_tuned(backend, s.zstep, batch, wino4=wino4)
                 s.fwd = s.zstep
                 s.mean = [al((p.cout,)) for p in st.parts]
                 s.var = [al((p.cout,)) for p in st.parts]
@@ -85,7 +87,7 @@ class TrainRuntime:
                 s.scratch = [al((2 * p.cout,), torch.float64) for p in st.parts]     # sliced BN reductions
             else:
                 backend.prepare_conv(st, self.bufs, batch)
-                apply_tuned(backend, st, batch, wino4=False)
+                apply_tuned(backend, st, batch, wino4=wino4)
                 s.fwd = st
                 s.dbias = [al((p.cout,)) for p in st.parts]
             # data-gradient launch (not needed for the image itself)
@@ -123,7 +125,10 @@ class TrainRuntime:
                     w2.kh = w2.kw = 3
                     if self.lib.ct_conv_wino_supported(C.byref(w2)):
                         s.dgrad_wino = w2
-                        s.U_d = al((self.lib.ct_conv_wino_packed_floats(ctot, st.cin),))
+                        # same tile size as the forward launch of this layer (same map, channels swapped)
+                        s.dgrad_tile = 4 if s.fwd.rt.get('wino') == 4 else 2
+                        sizeof = self.lib.ct_conv_wino4_packed_floats if s.dgrad_tile == 4 else self.lib.ct_conv_wino_packed_floats
+                        s.U_d = al((sizeof(ctot, st.cin),))
             # weight-gradient descriptor = forward geometry on the forward input
             w = _lib.ConvDesc()
             src = self.bufs[st.src]
@@ -223,8 +228,8 @@ class TrainRuntime:
         ptrs = (C.c_void_p * n)(*[p.weight.data_ptr() for p in st.parts])
         couts = (C.c_int * n)(*[p.cout for p in st.parts])
         if s.dgrad_wino is not None:
-            _lib.check(self.lib.ct_conv_pack_weights_wino_dgrad(ptrs, couts, n, st.cin, s.U_d.data_ptr(), self._s()),
-                       st.name + ' pack dgrad (winograd)')
+            pack = self.lib.ct_conv_pack_weights_wino4_dgrad if s.dgrad_tile == 4 else self.lib.ct_conv_pack_weights_wino_dgrad
+            _lib.check(pack(ptrs, couts, n, st.cin, s.U_d.data_ptr(), self._s()), st.name + ' pack dgrad (winograd)')
         else:
             _lib.check(self.lib.ct_conv_pack_weights_dgrad(ptrs, couts, n, st.cin, st.kh, st.kw, s.wpk_d.data_ptr(),
                                                            s.mpad_d, s.kpad_d, self._s()), st.name + ' pack dgrad')
@@ -452,8 +457,8 @@ class TrainRuntime:
                     if not self._batched_packs:
                         self._pack_dgrad(st, s)
                     s.dgrad_wino.res = self.grads[st.src].data_ptr() if acc else None
-                    _lib.check(lib.ct_conv2d_wino_fwd(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self._s()),
-                               st.name + ' dgrad (winograd)')
+                    run = lib.ct_conv2d_wino4_fwd if s.dgrad_tile == 4 else lib.ct_conv2d_wino_fwd
+                    _lib.check(run(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self._s()), st.name + ' dgrad (winograd)')
                 else:
                     if not self._batched_packs:
                         self._pack_dgrad(st, s)
