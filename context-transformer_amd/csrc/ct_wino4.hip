@@ -186,10 +186,6 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
     };
 
     f32x16 acc[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     // ---- weights in registers: u[j] = the 4 A-fragment floats (channel pairs s = 0..3) of transform point 9 xg + j
     const f32x4* Ug = reinterpret_cast<const f32x4*>(a.U + (size_t)kb * a.chunks * UCHUNK) + wave * (9 * 64) + lane;
@@ -197,44 +193,94 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
     const int last = a.chunks - 1;
     const float* const Vr = lds + (9 * xg) * XS + (xg >= 2 ? VSKEW : 0) + lane;
 
+    // prologue: the patches of chunks 0 AND 1 and the weights of chunk 0 leave together (one memory latency, not two
+    // in a row; the accumulators are not live yet, so the second patch has registers to wait in)
+    load_patch(0);
+    i32x3 raw1[6];
+    {
+        const int soff = (min(1, last) * CC + wave) * HW * 4;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) raw1[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, voffr[i], soff, 0);
+    }
 #pragma unroll
     for (int j = 0; j < 9; ++j) u[j] = Ug[j * 64];
-    load_patch(0);
     col_pass(0); col_pass(1); col_pass(2);
     row_pass(0, 0); row_pass(1, 0); row_pass(2, 0);
-    load_patch(min(1, last));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) raw[i] = raw1[i];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
 #define W4_PIN() __builtin_amdgcn_sched_barrier(0)
+    // One chunk = 36 MFMA slots.  A wave's next MFMA cannot start before the partner wave's MFMA leaves the SIMD's matrix
+    // pipe (64 cycles each), and an in-order wave issues nothing while it waits on an MFMA -- so every slot carries its
+    // share of the side work BEHIND its MFMA, where it overlaps the partner's: a slice of the transform of patch(c+1)
+    // (slots 0..14), one patch row load of chunk c+2 (slots 15..20), the next point's B fragments, the next chunk's U.
     for (int c = 0; c < a.chunks; ++c) {
         const int buf = c & 1;
         const int cn = min(c + 1, last), cp = min(c + 2, last);
         const float* vr = Vr + buf * VBUF;
         const f32x4* un = Ug + (size_t)cn * (UCHUNK / 4);
+        const int soff_p = (cp * CC + wave) * HW * 4;
+        float* const vwn = Vw + (buf ^ 1) * VBUF;
         float b[2][4];
+        float d[6], o[6], x[6], v[6];
 #pragma unroll
         for (int s = 0; s < 4; ++s) b[0][s] = vr[s * 64];
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-            if (j + 1 < 9) {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) b[(j + 1) & 1][s] = vr[(j + 1) * XS + s * 64];
+            for (int s = 0; s < 4; ++s) {
+                const int m = 4 * j + s;
+                const float ua = s == 0 ? u[j].x : s == 1 ? u[j].y : s == 2 ? u[j].z : u[j].w;
+                __builtin_amdgcn_s_setprio(1);          // the MFMA wins the issue arbitration against the partner's VALU work
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua, b[j & 1][s], acc[j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (j + 1 < 9 && s < 2) {               // B fragments of the next point: two reads per slot
+                    b[(j + 1) & 1][2 * s] = vr[(j + 1) * XS + (2 * s) * 64];
+                    b[(j + 1) & 1][2 * s + 1] = vr[(j + 1) * XS + (2 * s + 1) * 64];
+                }
+                if (s == 3) u[j] = un[j * 64];
+                if (m < 6) {                            // column passes: unpack + mask, then B^T
+                    const int cc = m >> 1;
+                    if ((m & 1) == 0) {
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            const f32x3 q3 = __builtin_bit_cast(f32x3, raw[i]);
+                            if (cc == 0) d[i] = m0 ? q3.x : 0.f;
+                            else if (cc == 1) d[i] = m1 ? (lp ? q3.x : q3.y) : 0.f;
+                            else d[i] = m2 ? (lp ? q3.y : q3.z) : 0.f;
+                        }
+                    } else {
+                        bt6(d, o);
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) t[i][cc] = o[i];
+                    }
+                } else if (m < 15) {                    // row passes: exchange, B^T, store
+                    const int r = (m - 6) / 3, part = (m - 6) % 3;
+                    if (part == 0) {
+#pragma unroll
+                        for (int cc = 0; cc < 3; ++cc) {
+                            const float snd = q ? t[r][cc] : t[r + 3][cc];
+                            const float rcv = swap_pair(snd);
+                            x[cc] = q ? rcv : t[r][cc];
+                            x[3 + cc] = q ? t[r + 3][cc] : rcv;
+                        }
+                    } else if (part == 1) {
+                        bt6(x, v);
+                    } else {
+#pragma unroll
+                        for (int jj = 0; jj < 6; ++jj) vwn[(r * 6 + jj) * XS] = v[jj];
+                    }
+                } else if (m < 21) {
+                    raw[m - 15] = __builtin_amdgcn_raw_buffer_load_b96(rin, voffr[m - 15], soff_p, 0);
+                }
+                W4_PIN();
             }
-            __builtin_amdgcn_s_setprio(1);          // the MFMA issue wins the arbitration against the other wave's VALU work
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[j].x, b[j & 1][0], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[j].y, b[j & 1][1], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[j].z, b[j & 1][2], acc[j], 0, 0, 0);
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[j].w, b[j & 1][3], acc[j], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            u[j] = un[j * 64];
-            // side work behind the MFMAs: transform of patch(c+1) into the other V buffer, then patch(c+2) -> registers
-            if (j == 0) { col_pass(0); col_pass(1); }
-            if (j == 1) { col_pass(2); row_pass(0, buf ^ 1); }
-            if (j == 2) row_pass(1, buf ^ 1);
-            if (j == 3) row_pass(2, buf ^ 1);
-            if (j == 4) load_patch(cp);
-            W4_PIN();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
