@@ -28,6 +28,7 @@
 #include "ct_common.h"
 #include "ct_wino_pack.h"
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 namespace {
@@ -69,6 +70,12 @@ struct Wino4Args {
     int pool_ctot, pool_coff, pool_oh, pool_ow, write_full;
     int nseg;                // > 0: channels-last scatter into the flattened head buffers (ct_out_segment)
     ct_out_segment seg[3];
+    // split over input channels (small maps: too few tiles to fill the chip): blockIdx.y owns chunks
+    // [y * chunks_per_slice, ...) and stores its raw output-transformed sums in slab ws[y][cout][pixel];
+    // wino4_slab_epilogue adds the slabs in slice order and applies the epilogue (no atomics: results do not depend
+    // on timing)
+    float* ws;
+    int slices, chunks_per_slice, Npix;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -190,20 +197,22 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
     // ---- weights in registers: u[j] = the 4 A-fragment floats (channel pairs s = 0..3) of transform point 9 xg + j
     const f32x4* Ug = reinterpret_cast<const f32x4*>(a.U + (size_t)kb * a.chunks * UCHUNK) + wave * (9 * 64) + lane;
     f32x4 u[9];
-    const int last = a.chunks - 1;
+    const int c_begin = blockIdx.y * a.chunks_per_slice;
+    const int c_end = min(a.chunks, c_begin + a.chunks_per_slice);
+    const int last = c_end - 1;
     const float* const Vr = lds + (9 * xg) * XS + (xg >= 2 ? VSKEW : 0) + lane;
 
     // prologue: the patches of chunks 0 AND 1 and the weights of chunk 0 leave together (one memory latency, not two
     // in a row; the accumulators are not live yet, so the second patch has registers to wait in)
-    load_patch(0);
+    load_patch(c_begin);
     i32x3 raw1[6];
     {
-        const int soff = (min(1, last) * CC + wave) * HW * 4;
+        const int soff = (min(c_begin + 1, last) * CC + wave) * HW * 4;
 #pragma unroll
         for (int i = 0; i < 6; ++i) raw1[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, voffr[i], soff, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 9; ++j) u[j] = Ug[j * 64];
+    for (int j = 0; j < 9; ++j) u[j] = Ug[(size_t)c_begin * (UCHUNK / 4) + j * 64];
     col_pass(0); col_pass(1); col_pass(2);
     row_pass(0, 0); row_pass(1, 0); row_pass(2, 0);
 #pragma unroll
@@ -220,8 +229,8 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
     // pipe (64 cycles each), and an in-order wave issues nothing while it waits on an MFMA -- so every slot carries its
     // share of the side work BEHIND its MFMA, where it overlaps the partner's: a slice of the transform of patch(c+1)
     // (slots 0..14), one patch row load of chunk c+2 (slots 15..20), the next point's B fragments, the next chunk's U.
-    for (int c = 0; c < a.chunks; ++c) {
-        const int buf = c & 1;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
         const int cn = min(c + 1, last), cp = min(c + 2, last);
         const float* vr = Vr + buf * VBUF;
         const f32x4* un = Ug + (size_t)cn * (UCHUNK / 4);
@@ -323,9 +332,25 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) z[i][j] = y[i];
             }
+            const bool c1 = ox + 1 < OW, c2 = ox + 2 < OW, c3 = ox + 3 < OW;
+            if (a.ws) {
+                float* slab = a.ws + ((size_t)blockIdx.y * a.M + co) * a.Npix + (size_t)n * OH * OW + ox;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int yy = oy + i;
+                    if (yy >= OH) continue;
+                    float v[4];
+                    at4(z[i], v);
+                    float* row = slab + yy * OW;
+                    row[0] = v[0];
+                    if (c1) row[1] = v[1];
+                    if (c2) row[2] = v[2];
+                    if (c3) row[3] = v[3];
+                }
+                continue;
+            }
             const float sc = a.scale[co], sh = a.shift[co];
             const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
-            const bool c1 = ox + 1 < OW, c2 = ox + 2 < OW, c3 = ox + 3 < OW;
             float pl[2][2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -391,6 +416,32 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
             }
         }
         __syncthreads();
+    }
+}
+
+// epilogue of a channel-split launch: sum of the slabs in slice order, then the same arithmetic as the fused one
+__global__ __launch_bounds__(256) void wino4_slab_epilogue(const Wino4Args a)
+{
+    const int OHW = a.H * a.W;
+    const long total = (long)a.M * a.Npix;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+        const int co = (int)(idx / a.Npix), P = (int)(idx - (long)co * a.Npix);
+        const int n = P / OHW, sp = P - n * OHW;
+        float sum = a.ws[idx];
+        for (int k = 1; k < a.slices; ++k) sum += a.ws[(size_t)k * total + idx];
+        float v = sum * a.scale[co] + a.shift[co];
+        if (a.res) v = v * a.res_scale + a.res[((size_t)n * a.res_ctot + a.res_coff + co) * OHW + sp];
+        if (a.lo) v = fmaxf(v, a.lo[co]);
+        else if (a.relu) v = fmaxf(v, 0.f);
+        if (a.nseg == 0) {
+            a.out[((size_t)n * a.out_ctot + a.out_coff + co) * OHW + sp] = v;
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
+                    a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                 (size_t)sp * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
+        }
     }
 }
 
@@ -492,10 +543,33 @@ extern "C" int ct_conv2d_wino4_pool_fwd(const ct_conv_desc* d, const float* upac
         a.pool_ctot = pool_ctot; a.pool_coff = pool_coff; a.pool_oh = pool_oh; a.pool_ow = pool_ow;
         a.write_full = write_full;
         a.kblocks = (d->cout + KB - 1) / KB;
+        // split over input channels when the (tile block, cout block) grid cannot fill the chip (desc->ksplit: -1 auto,
+        // > 1 forced, else off; needs the caller's slab workspace and an unchunked, unpooled launch)
+        a.slices = 1;
+        a.chunks_per_slice = a.chunks;
+        a.Npix = nb * OHW;
+        a.ws = nullptr;
+        if (d->ksplit_ws && nb == d->batch && !pool_out && (d->ksplit == -1 || d->ksplit > 1)) {
+            static const int target = getenv("CTDET_W4_SPLIT_TARGET") ? atoi(getenv("CTDET_W4_SPLIT_TARGET")) : 256;
+            const int wgs = a.tile_blocks * a.kblocks;
+            int want = d->ksplit > 1 ? d->ksplit : target / std::max(wgs, 1);      // auto: at most one workgroup per CU in total
+            const long long slab = (long long)d->cout * a.Npix;
+            want = (int)std::min<long long>(std::min(want, a.chunks / 4), d->ksplit_ws_floats / std::max<long long>(slab, 1));
+            if (want > 1) {
+                a.chunks_per_slice = (a.chunks + want - 1) / want;
+                a.slices = (a.chunks + a.chunks_per_slice - 1) / a.chunks_per_slice;
+                a.ws = d->ksplit_ws;
+            }
+        }
         // 8 XCD-local sequences of (tile block group, cout block); sequences past the last tile block exit at once
         const int groups = (a.tile_blocks + 7) / 8;
-        hipLaunchKernelGGL(wino_f4x4_3x3_f32, dim3(8 * groups * a.kblocks), dim3(512), W4_LDS_BYTES, st, a);
+        hipLaunchKernelGGL(wino_f4x4_3x3_f32, dim3(8 * groups * a.kblocks, a.slices), dim3(512), W4_LDS_BYTES, st, a);
         CT_LAUNCH_CHECK("wino_f4x4_3x3_f32");
+        if (a.slices > 1) {
+            const long total = (long)a.M * a.Npix;
+            hipLaunchKernelGGL(wino4_slab_epilogue, dim3((int)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, st, a);
+            CT_LAUNCH_CHECK("wino4_slab_epilogue");
+        }
     }
     return CT_OK;
 }

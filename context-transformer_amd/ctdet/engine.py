@@ -415,9 +415,14 @@ class HipBackend:
         d.config = max(rt.get('config', 0), 0)
         # split-K workspace for maps that cannot fill the chip (the library decides per launch whether to use it)
         npix = batch * st.oh * st.ow
-        if int(os.environ.get('CTDET_KSPLIT', '1')) and st.cout * npix <= (2 << 20):
-            rt['ksws'] = torch.empty(16 * st.cout * npix, device=self.device)
-            d.ksplit, d.ksplit_ws, d.ksplit_ws_floats = -1, rt['ksws'].data_ptr(), rt['ksws'].numel()
+        if int(os.environ.get('CTDET_KSPLIT', '1')):
+            # 16 slabs for the small maps; 4 for the mid-sized 3x3 layers, where only the F(4x4,3x3) kernel splits
+            # (over input channels: a 32-tile x 64-cout workgroup grid is 16x coarser than the direct kernel's)
+            slabs = 16 if st.cout * npix <= (2 << 20) else \
+                4 if st.cout * npix <= (8 << 20) and (st.kh, st.kw, st.stride, st.dil) == (3, 3, 1, 1) else 0
+            if slabs:
+                rt['ksws'] = torch.empty(slabs * st.cout * npix, device=self.device)
+                d.ksplit, d.ksplit_ws, d.ksplit_ws_floats = -1, rt['ksws'].data_ptr(), rt['ksws'].numel()
         rt['desc'] = d
         rt['wino_ok'] = bool(lib.ct_conv_wino_supported(C.byref(d)))
         if rt.get('config', 0) in (WINO, WINO4):
@@ -667,14 +672,18 @@ class Runtime:
         """MaxPool2d(2, 2) directly behind a Winograd conv: the 2x2 output tile is the pooling window, so
         the conv writes the pooled map itself (and skips its full-resolution output if nothing else reads it)."""
         steps = self.plan.steps
-        if os.environ.get('CTDET_FUSE_POOL', '1') == '0':
-            return
+        fuse = os.environ.get('CTDET_FUSE_POOL', '1') != '0'
         for pi, ps in enumerate(steps):
             if ps.kind != 'pool' or (ps.k, ps.stride, ps.pad) != (2, 2, 0):
                 continue
             prod = [st for st in steps if st.kind == 'conv' and not st.segs and st.dst == ps.src]
             if len(prod) != 1 or not prod[0].rt.get('wino') or prod[0].dst_coff != 0 or prod[0].cout != ps.ch \
                     or prod[0].res is not None:
+                continue
+            # a fusable producer never splits its channel sum (the fused form cannot): CTDET_FUSE_POOL=0 then
+            # changes the launches, not the arithmetic
+            prod[0].rt['desc'].ksplit = 0
+            if not fuse:
                 continue
             others = [st for st in steps if st is not ps and (getattr(st, 'src', None) == ps.src or
                                                               getattr(st, 'res', None) == ps.src)]

@@ -278,7 +278,11 @@ int ct_conv_pack_weights_wino_dgrad(const float* const* w, const int* cout, int 
  * models/RFB_Net_vgg.py:7-22,219-227; same descriptor, epilogue, pooling fusion -- a 4x4 tile holds four pooling
  * windows -- and head scatter), its own packed layout (ct_conv_wino4_packed_floats floats).  36 multiplications per
  * 16 outputs: 4x fewer than the direct convolution, 1.78x fewer than F(2x2,3x3); fp32 rounding error about 1e-5 of
- * the output range (interpolation points 0, +-1, +-2, inf) against 1e-6 for F(2x2,3x3). */
+ * the output range (interpolation points 0, +-1, +-2, inf) against 1e-6 for F(2x2,3x3).
+ * desc->ksplit / ksplit_ws are honoured by ct_conv2d_wino4_fwd as a split over INPUT CHANNELS (ksplit -1: the library
+ * decides, > 1: that many slices, else off): each slice stores its output-transformed partial sums in its slab
+ * ws[slice][cout][batch*oh*ow] and a finishing kernel adds them in slice order -- for maps whose 32-tile x 64-cout
+ * workgroup grid cannot fill the chip (small batches).  Not combined with the fused pooling. */
 int ct_conv_wino4_supported(const ct_conv_desc* desc);
 size_t ct_conv_wino4_packed_floats(int cin, int cout);
 int ct_conv_pack_weights_wino4(const float* const* w, const int* cout, int nparts, int cin, float* upacked,

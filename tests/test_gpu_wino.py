@@ -203,3 +203,22 @@ def test_wino4_dgrad_weights():
     _lib.check(lib.ct_conv2d_wino4_fwd(C.byref(d), U.data_ptr(), None), 'wino4 dgrad')
     torch.cuda.synchronize()
     assert rel_err(dx.cpu(), x.grad) < TOL
+
+
+def test_wino4_channel_split_matches_single_pass():
+    """F(4x4,3x3) split over input channels (ct_conv_desc.ksplit): slabs + finishing kernel against the fused single
+    pass and the reference, with BN, residual and ReLU in the finishing epilogue; two runs are bit-identical."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(2, 256, 19, 19, generator=g)
+    w = torch.randn(72, 256, 3, 3, generator=g) * 0.03
+    bn = _bn(72, g)
+    res = torch.randn(2, 72, 19, 19, generator=g)
+    want = _ref_conv(x, [(w, None, bn, True)], 1, 1, 1, res=res, res_scale=0.7)
+    base = _run_conv(x, [(w, None, bn, True)], 1, 1, 1, config=engine.WINO4, res=res, res_scale=0.7, ksplit=0)
+    assert rel_err(base, want) < TOL
+    for ks in (2, 5, 8, -1):
+        got = _run_conv(x, [(w, None, bn, True)], 1, 1, 1, config=engine.WINO4, res=res, res_scale=0.7, ksplit=ks)
+        assert rel_err(got, want) < TOL, ks
+        assert rel_err(got, base) < 1e-5, ks
+        again = _run_conv(x, [(w, None, bn, True)], 1, 1, 1, config=engine.WINO4, res=res, res_scale=0.7, ksplit=ks)
+        assert torch.equal(got, again), ks

@@ -12,6 +12,8 @@ SHAPES = {  # B, Cin, H, W, Cout
     'base.10': (32, 128, 75, 75, 256), 'base.12': (32, 256, 75, 75, 256), 'base.17': (32, 256, 38, 38, 512),
     'base.19': (32, 512, 38, 38, 512), 'base.24': (32, 512, 19, 19, 512), 'head.0': (32, 512, 38, 38, 156),
     'base.19.b4': (4, 512, 38, 38, 512), 'base.2.b4': (4, 64, 300, 300, 64),
+    'base.24.b4': (4, 512, 19, 19, 512), 'head.0.b4': (4, 512, 38, 38, 156), 'head.1.b4': (4, 1024, 19, 19, 156),
+    'base.24.b8': (8, 512, 19, 19, 512),
     'small': (2, 16, 21, 37, 40), 'tiny': (1, 8, 8, 8, 64), 'b2.b2': (2, 64, 300, 300, 64),
 }
 names = sys.argv[1:] or ['base.2', 'base.7', 'base.12', 'base.19', 'base.24']
