@@ -570,7 +570,7 @@ class HipBackend:
         st.rt['config'] = best + 1
         if st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
             best_tile = 0
-            for tile in wino_tiles():
+            for tile in wino_tiles(self):
                 self.enable_wino(st, tile=tile)
                 self.run_conv(st)
                 torch.cuda.synchronize(self.device)
@@ -592,9 +592,23 @@ class HipBackend:
         return best, times
 
 
-def wino_tiles():
-    """Winograd variants the tuner may pick: CTDET_WINO_TILES = '2', '4' or '2,4' (default)."""
-    return tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4').split(',') if t)
+def wino_tiles(backend=None):
+    """Winograd variants the tuner may pick: CTDET_WINO_TILES = '2', '4' or '2,4' (default), minus what the
+    runtime that owns `backend` excluded (wino4_allowed)."""
+    tiles = tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4').split(',') if t)
+    allowed = getattr(backend, 'wino_tile_set', None)
+    return tiles if allowed is None else tuple(t for t in tiles if t in allowed)
+
+
+def wino4_allowed(net):
+    """F(4x4,3x3) only where nothing downstream amplifies its rounding.  Its whole-network error on the raw
+    loc / conf / obj outputs is 2.5e-6 of their range (F(2x2,3x3): 1.7e-6; tools/wino_accuracy.py), but with the
+    Context-Transformer block active (method 'ours', phase 2: models/RFB_Net_vgg.py:253-271) the near-arg-max context
+    softmax turns that into 1.5e-4 of the block's output range against the reference's fp32 CPU arithmetic --
+    F(2x2,3x3) 0.6..1.1e-4, the CPU path itself 0.5e-4 from fp64 -- which is past the 1e-4 parity contract.  Those
+    inference runtimes keep F(2x2,3x3) unless CTDET_WINO4_CTX=1."""
+    ctx = getattr(net, 'method', None) == 'ours' and getattr(net, 'phase', 1) == 2
+    return not ctx or os.environ.get('CTDET_WINO4_CTX', '0') == '1'
 
 
 def apply_tuned(backend, st, batch, wino4=True):
@@ -603,7 +617,7 @@ def apply_tuned(backend, st, batch, wino4=True):
     cfg = tune_table().get(st.tune_key(batch))
     names = [backend.lib.ct_conv_config_name(i).decode() for i in range(backend.lib.ct_conv_num_configs())]
     if cfg in ('wino', 'wino4') and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
-        tile = 4 if cfg == 'wino4' and wino4 and 4 in wino_tiles() else 2
+        tile = 4 if cfg == 'wino4' and wino4 and 4 in wino_tiles(backend) else 2
         backend.enable_wino(st, tile=tile)
         return True
     if cfg in names:
@@ -658,6 +672,8 @@ class Runtime:
         # tile config per conv: committed table first (names, so it survives config reordering),
         # live autotune only for shapes the table does not know (CTDET_TUNE=0 disables, =2 forces)
         mode = os.environ.get('CTDET_TUNE', '1') if tune is None else ('1' if tune else '0')
+        if not wino4_allowed(net):
+            backend.wino_tile_set = (2,)
         self.tuned = False
         self.event_log = None        # set to a list to collect (step, start_event, end_event) per conv
         if getattr(backend, 'tune_conv', None) is not None:
