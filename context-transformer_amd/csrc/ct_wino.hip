@@ -425,7 +425,7 @@ int ctdet::pack_wino_any(const float* const* w, const int* cout, int nparts, int
         ctdet::pack_record(1, &p, sizeof(p));
         return CT_OK;
     }
-    const long total = (long)p.kblocks * p.chunks * (tile == 4 ? ctdet::kWino4ChunkFloats : ctdet::kWino2ChunkFloats);
+    const long total = (long)p.kblocks * p.chunks * (tile == 4 ? 512 : ctdet::kWino2ChunkFloats);      // threads
     hipLaunchKernelGGL(wino_pack_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
                        ctdet::as_stream(stream), p);
     CT_LAUNCH_CHECK("wino_pack_kernel");

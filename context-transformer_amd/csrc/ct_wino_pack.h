@@ -72,41 +72,59 @@ __device__ __forceinline__ void wino2_pack_body(const WinoPackArgs& p, long firs
     }
 }
 
-// U[kb][chunk][wave 8][point 9][lane 64][4]: wave = (point group, cout half), element = channel pair s
+// U[kb][chunk][wave 8][point 9][lane 64][4]: wave = (point group, cout half), element = channel pair s.
+// One thread = one (cout, cin) filter: G g G^T once (6x3 then 6x6), 36 stores; the 64 threads of a wave cover
+// (16 lanes x 4 channel pairs) = 256 contiguous bytes of every point's plane.
 __device__ __forceinline__ void wino4_pack_body(const WinoPackArgs& p, long first, long stride)
 {
-    const long total = (long)p.kblocks * p.chunks * kWino4ChunkFloats;
+    const long total = (long)p.kblocks * p.chunks * 512;          // [kb][chunk][cout half 2][lane 64][s 4]
     for (long idx = first; idx < total; idx += stride) {
-        const int s = (int)(idx & 3), ln = (int)((idx >> 2) & 63);
-        long rest = idx >> 8;
-        const int j = (int)(rest % 9);
-        rest /= 9;
-        const int wv = (int)(rest & 7);
-        rest >>= 3;
+        const int s = (int)(idx & 3), ln = (int)((idx >> 2) & 63), half = (int)((idx >> 8) & 1);
+        const long rest = idx >> 9;
         const int chunk = (int)(rest % p.chunks);
         const int kb = (int)(rest / p.chunks);
         const int hh = ln >> 5;
-        const int co = kb * kWinoKB + (wv & 1) * 32 + (ln & 31), ci = chunk * kWinoCC + 2 * s + hh;
-        const int xi = 9 * (wv >> 1) + j;
-        float val = 0.f;
+        const int co = kb * kWinoKB + half * 32 + (ln & 31), ci = chunk * kWinoCC + 2 * s + hh;
+        float g[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g[i][j] = 0.f;
         if (co < p.cout) {
-            // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-            float Ga[3], Gb[3];
-            auto grow = [](int r, float (&o)[3]) {
-                switch (r) {
-                case 0: o[0] = 0.25f; o[1] = 0.f; o[2] = 0.f; break;
-                case 1: o[0] = -1.f / 6; o[1] = -1.f / 6; o[2] = -1.f / 6; break;
-                case 2: o[0] = -1.f / 6; o[1] = 1.f / 6; o[2] = -1.f / 6; break;
-                case 3: o[0] = 1.f / 24; o[1] = 1.f / 12; o[2] = 1.f / 6; break;
-                case 4: o[0] = 1.f / 24; o[1] = -1.f / 12; o[2] = 1.f / 6; break;
-                default: o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; break;
-                }
-            };
-            grow(xi / 6, Ga);
-            grow(xi % 6, Gb);
-            val = wino_ggt(p, wino_taps(p, co, ci), Ga, Gb);
+            const float* w = wino_taps(p, co, ci);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) g[i][j] = p.dgrad ? w[(2 - i) * 3 + (2 - j)] : w[i * 3 + j];
         }
-        p.U[idx] = val;
+        // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+        auto gmul = [](float a0, float a1, float a2, float (&o)[6]) {
+            o[0] = 0.25f * a0;
+            o[1] = (-1.f / 6) * a0 + (-1.f / 6) * a1 + (-1.f / 6) * a2;
+            o[2] = (-1.f / 6) * a0 + (1.f / 6) * a1 + (-1.f / 6) * a2;
+            o[3] = (1.f / 24) * a0 + (1.f / 12) * a1 + (1.f / 6) * a2;
+            o[4] = (1.f / 24) * a0 + (-1.f / 12) * a1 + (1.f / 6) * a2;
+            o[5] = a2;
+        };
+        float t[6][3];                                            // G g
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float o[6];
+            gmul(g[0][j], g[1][j], g[2][j], o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+        }
+        float* base = p.U + ((size_t)kb * p.chunks + chunk) * kWino4ChunkFloats + ln * 4 + s;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float o[6];                                           // (G g) G^T, row i
+            gmul(t[i][0], t[i][1], t[i][2], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int xi = i * 6 + j;
+                base[((2 * (xi / 9) + half) * 9 + xi % 9) * 256] = o[j];
+            }
+        }
     }
 }
 
