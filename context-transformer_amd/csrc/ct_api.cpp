@@ -56,6 +56,12 @@ thread_local std::vector<unsigned char> t_pack_items[2];
 
 bool pack_recording() { return t_pack_rec; }
 
+namespace {
+thread_local bool t_prezeroed = false;
+}
+bool scratch_prezeroed() { return t_prezeroed; }
+void set_scratch_prezeroed(bool on) { t_prezeroed = on; }
+
 void pack_record(int kind, const void* args, size_t bytes)
 {
     const unsigned char* b = static_cast<const unsigned char*>(args);
@@ -63,6 +69,12 @@ void pack_record(int kind, const void* args, size_t bytes)
 }
 
 }  // namespace ctdet
+
+extern "C" int ct_scratch_prezeroed(int on)
+{
+    ctdet::set_scratch_prezeroed(on != 0);
+    return CT_OK;
+}
 
 extern "C" int ct_pack_record_begin(void)
 {

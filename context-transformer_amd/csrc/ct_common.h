@@ -52,6 +52,10 @@ struct ProfScope {
 // calling thread the pack entry points append their kernel arguments here instead of launching; the recorded table
 // is replayed each training step by two batched launches.  kind 0: direct layouts (ct_conv.hip PackArgs), 1: Winograd.
 bool pack_recording();
+// ct_scratch_prezeroed(1): the caller zeroes every accumulation buffer of the training kernels itself (one memset
+// per pass over an arena) and the library skips its ~150 small per-launch memsets
+bool scratch_prezeroed();
+void set_scratch_prezeroed(bool on);
 void pack_record(int kind, const void* args, size_t bytes);
 int launch_pack_direct_batched(const void* items_dev, int n, hipStream_t st);
 int launch_pack_wino_batched(const void* items_dev, int n, hipStream_t st);

@@ -684,7 +684,7 @@ static int wgrad_impl(const ct_conv_desc* d, const float* dz, int dz_ctot, int d
     a.pix_per_split = ((a.Npix + splits - 1) / splits + 63) / 64 * 64;
     splits = (a.Npix + a.pix_per_split - 1) / a.pix_per_split;
     hipStream_t st = ctdet::as_stream(stream);
-    if (zero) CT_HIP(hipMemsetAsync(dw, 0, (size_t)d->cout * a.Ncols * 4, st));
+    if (zero && !ctdet::scratch_prezeroed()) CT_HIP(hipMemsetAsync(dw, 0, (size_t)d->cout * a.Ncols * 4, st));
     const bool tapmajor = d->cin % bt == 0 && !(getenv("CTDET_WGRAD_GENERIC"));
     const bool tapmajor_for_smem = tapmajor;
     const dim3 grid(tiles, splits), block(256);
@@ -737,7 +737,7 @@ extern "C" int ct_bn_train_stats(const float* z, int batch, int ctot, int coff, 
     const float unbias = cntf > 1.f ? cntf / (cntf - 1.f) : 1.f;
     if (scratch && slices > 1) {
         const int per_slice = (int)((per_channel + slices - 1) / slices);
-        CT_HIP(hipMemsetAsync(scratch, 0, (size_t)2 * channels * sizeof(double), st));
+        if (!ctdet::scratch_prezeroed()) CT_HIP(hipMemsetAsync(scratch, 0, (size_t)2 * channels * sizeof(double), st));
         hipLaunchKernelGGL(bn_stats_part_kernel, dim3(channels, slices), dim3(256), 0, st, z, batch, ctot, coff,
                            channels, hw, per_slice, (double*)scratch);
         CT_LAUNCH_CHECK("bn_stats_part_kernel");
@@ -794,7 +794,7 @@ static int bn_backward_impl(int frozen, const float* dy, int dy_ctot, int dy_cof
     const int slices = (int)std::max<long>(1, std::min<long>((1024 + channels - 1) / channels, per_channel / 2048));
     if (scratch && slices > 1) {
         const int per_slice = (int)((per_channel + slices - 1) / slices);
-        CT_HIP(hipMemsetAsync(scratch, 0, (size_t)2 * channels * sizeof(double), st));
+        if (!ctdet::scratch_prezeroed()) CT_HIP(hipMemsetAsync(scratch, 0, (size_t)2 * channels * sizeof(double), st));
         hipLaunchKernelGGL(bn_bwd_reduce_part_kernel, dim3(channels, slices), dim3(256), 0, st, a, per_slice,
                            (double*)scratch);
         CT_LAUNCH_CHECK("bn_bwd_reduce_part_kernel");
@@ -849,7 +849,7 @@ extern "C" int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, c
     int per_slice = (int)((per_channel + slices - 1) / slices);
     per_slice = (per_slice + 3) / 4 * 4;
     slices = (int)((per_channel + per_slice - 1) / per_slice);
-    if (dbias) CT_HIP(hipMemsetAsync(dbias, 0, (size_t)channels * 4, st));
+    if (dbias && !ctdet::scratch_prezeroed()) CT_HIP(hipMemsetAsync(dbias, 0, (size_t)channels * 4, st));
     hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(channels, slices), dim3(256), 0, st, dy, dy_ctot, dy_coff, y,
                        y_ctot, y_coff, relu, batch, channels, hw, dz, dz_ctot, dz_coff, dbias, per_slice);
     CT_LAUNCH_CHECK("bias_act_bwd_kernel");

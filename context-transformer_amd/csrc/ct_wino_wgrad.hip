@@ -325,7 +325,7 @@ extern "C" int ct_conv2d_wgrad_wino(const ct_conv_desc* d, const float* dz, int 
     }
     float* dU = static_cast<float*>(workspace);
     const int KC = d->cout * d->cin;
-    CT_HIP(hipMemsetAsync(dU, 0, (size_t)16 * KC * 4, st));
+    if (!ctdet::scratch_prezeroed()) CT_HIP(hipMemsetAsync(dU, 0, (size_t)16 * KC * 4, st));
     const int kblocks = (d->cout + 63) / 64, cblocks = (d->cin + 63) / 64;
     for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
         const int nb = std::min(max_chunk, d->batch - b0);

@@ -152,7 +152,27 @@ class TrainRuntime:
                     self._reg(p.bn.bias)
                 elif p.bias is not None:
                     self._reg(p.bias)
+        # Accumulation buffers the library would otherwise zero with one small memset per launch (~150 per step): the
+        # BatchNorm reduction scratch (both passes), the Winograd weight-gradient workspaces (one per layer instead of a
+        # shared one) and -- through the gradient arena below -- the bias / split weight gradients.  CTDET_PREZERO=0 keeps
+        # the per-launch memsets.
+        self.prezero = os.environ.get('CTDET_PREZERO', '1') != '0'
         self.wgrad_ws = al((max(wino_ws // 4, 1),))
+        if self.prezero:
+            bn_floats = sum(t.numel() for s_ in self.state.values() for t in getattr(s_, 'scratch', []))
+            self.bn_scratch = al((max(bn_floats, 1),), torch.float64)
+            o = 0
+            for s_ in self.state.values():
+                for i, t in enumerate(getattr(s_, 'scratch', [])):
+                    s_.scratch[i] = self.bn_scratch[o:o + t.numel()]
+                    o += t.numel()
+            sizes = [(s_, int(self.lib.ct_conv_wgrad_wino_workspace_bytes(C.byref(s_.wgrad))) // 4)
+                     for s_ in self.state.values() if s_.wgrad_wino]
+            self.wgrad_ws_all = al((max(sum((n + 63) // 64 * 64 for _, n in sizes), 1),))
+            o = 0
+            for s_, n in sizes:
+                s_.wgrad_ws = self.wgrad_ws_all[o:o + n]
+                o += (n + 63) // 64 * 64
         self.backend = backend
         Runtime._build_schedule(self)           # forward: Norm branch / heads on a side stream (CTDET_STREAMS)
         # weight gradients on their own stream (CTDET_TRAIN_STREAMS=1 keeps everything on the caller's stream)
@@ -278,6 +298,9 @@ class TrainRuntime:
                                   % (tuple(self.bufs['x'].shape), tuple(x.shape)))
         self.bufs['x'].copy_(x)
         self._repack_all()
+        if self.prezero:
+            self.bn_scratch.zero_()                 # one memset instead of one per BatchNorm statistics launch
+        _lib.check(lib.ct_scratch_prezeroed(int(self.prezero)), 'ct_scratch_prezeroed')
 
         def fwd_step(st):
             if st.kind == 'pool':
@@ -320,7 +343,10 @@ class TrainRuntime:
                     z.shape[1], off, B, p.cout, hw, self._s()), st.name + ' bn apply')
                 off += p.cout
         # Norm branch and heads on the side stream, like the inference runtime (same schedule builder)
-        run_on_streams(self, fwd_step)
+        try:
+            run_on_streams(self, fwd_step)
+        finally:
+            lib.ct_scratch_prezeroed(0)
         nbt = [t for t, bn in zip(self._nbt, self._bns) if bn.training]
         if nbt:
             torch._foreach_add_(nbt, 1)             # nn.BatchNorm2d's num_batches_tracked, one launch for all layers
@@ -357,6 +383,12 @@ class TrainRuntime:
         grads_out = [None] * len(self.params)
         main = torch.cuda.current_stream(self.be.device)
         side = self.wg_stream
+        if self.prezero:
+            # three memsets for the whole pass: gradient arena (bias / split weight gradients accumulate into it),
+            # BatchNorm reduction scratch, Winograd weight-gradient workspaces
+            self.arena.zero_()
+            self.bn_scratch.zero_()
+            self.wgrad_ws_all.zero_()
         if side is not None:
             side.wait_stream(main)
         join = (lambda: main.wait_stream(side)) if side is not None else None
@@ -375,6 +407,24 @@ class TrainRuntime:
         if ctx_grads is not None:
             for k, prm in self.ctx_params.items():
                 put(prm, ctx_grads[k])
+        _lib.check(lib.ct_scratch_prezeroed(int(self.prezero)), 'ct_scratch_prezeroed')
+        try:
+            self._backward_steps(flat, written, overlaps, put, main, side)
+        finally:
+            lib.ct_scratch_prezeroed(0)
+        if side is not None:
+            main.wait_stream(side)
+        if bk is not None:
+            bk.finish()
+        snap = self.arena.clone()                   # the arena is rewritten by the next backward
+        for prm in self.params:
+            grads_out[self._pindex[id(prm)]] = self._arena_view(prm, snap)
+        return grads_out
+
+    def _backward_steps(self, flat, written, overlaps, put, main, side):
+        """Reverse walk over the plan: per fused conv the epilogue gradient, the weight gradient (side stream) and the
+        data gradient."""
+        lib, B = self.lib, self.batch
         for st in reversed(self.plan.steps):
             if st.kind == 'ctxpool':
                 continue
@@ -441,7 +491,7 @@ class TrainRuntime:
             with torch.cuda.stream(side if side is not None else main):
                 if s.wgrad_wino:
                     _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
-                                                        self.wgrad_ws.data_ptr(), self._s()),
+                                                        (s.wgrad_ws if self.prezero else self.wgrad_ws).data_ptr(), self._s()),
                                st.name + ' wgrad (winograd)')
                 else:
                     _lib.check(lib.ct_conv2d_wgrad(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
@@ -465,14 +515,6 @@ class TrainRuntime:
                     s.dgrad.res = self.grads[st.src].data_ptr() if acc else None
                     _lib.check(lib.ct_conv2d_fwd(C.byref(s.dgrad), self._s()), st.name + ' dgrad')
                 written.setdefault(st.src, []).append((st.src_coff, st.src_coff + st.cin))
-        if side is not None:
-            main.wait_stream(side)
-        if bk is not None:
-            bk.finish()
-        snap = self.arena.clone()                   # the arena is rewritten by the next backward
-        for prm in self.params:
-            grads_out[self._pindex[id(prm)]] = self._arena_view(prm, snap)
-        return grads_out
 
 
 class BackboneFunction(torch.autograd.Function):

@@ -44,6 +44,13 @@ const char* ct_last_error_string(void);
 /* arch: e.g. "gfx950"; any out pointer may be NULL. */
 int ct_device_info(int device, int* cu_count, int* lds_bytes_per_cu, char* arch, int arch_len);
 
+/* Training scratch zeroing.  The accumulating training kernels (BatchNorm statistics / backward reductions, bias
+ * gradients, split weight gradients, the Winograd weight-gradient workspace) zero their accumulation buffer with one
+ * small memset per launch (~150 per training step).  ct_scratch_prezeroed(1) (per calling thread) makes the caller
+ * responsible instead: ctdet/train_engine.py keeps those buffers in three arenas and zeroes each with ONE memset per
+ * pass.  ct_scratch_prezeroed(0) restores the default. */
+int ct_scratch_prezeroed(int on);
+
 /* Batched weight packing for training steps (every optimizer step changes every weight, and each fused conv needs
  * its forward AND its data-gradient layout re-packed: ~130 small launches per step).  Between
  * ct_pack_record_begin() and ct_pack_record_end() the ct_conv_pack_weights* entry points called on THIS thread
