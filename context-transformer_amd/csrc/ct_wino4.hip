@@ -28,6 +28,7 @@
 #include "ct_common.h"
 #include "ct_wino_pack.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <mutex>
 
@@ -76,6 +77,13 @@ struct Wino4Args {
     // on timing)
     float* ws;
     int slices, chunks_per_slice, Npix;
+    // stream-K (desc->ksplit == -2: the launch has the device to itself): a persistent grid of 8 x wgs_per_xcd
+    // workgroups; the (work item, chunk) units of every XCD's item sequence are cut into equal contiguous ranges, so the
+    // last round of a launch is as full as the others.  A range that starts or ends inside an item stores that item's
+    // output-transformed partial sums in one of its two slab slots (sk_ws[(block * 2 + slot)][cout 64][tile 32][16]);
+    // wino4_streamk_fixup adds an item's slabs in chunk order and applies the epilogue.
+    int streamk;
+    float* sk_ws;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -113,17 +121,109 @@ __device__ __forceinline__ float swap_pair(float x)       // value of the other 
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
 }
 
-__global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
+// Epilogue of one (cout, 4x4 output tile): y = the output-transformed sums.  Channel-split launches (a.ws) store them
+// raw; everything else gets scale/shift, residual, floor, the four 2x2 pooling windows, NCHW or head-scatter stores.
+__device__ __forceinline__ void emit_tile(const Wino4Args& a, const __amdgpu_buffer_rsrc_t rout,
+                                          const __amdgpu_buffer_rsrc_t rres, const int n, const int ty, const int tx,
+                                          const int co, const float (&y)[4][4])
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int OH = a.H, OW = a.W;                      // pad 1, stride 1: same spatial size
+    const int oy = 4 * ty, ox = 4 * tx;
+    const bool c1 = ox + 1 < OW, c2 = ox + 2 < OW, c3 = ox + 3 < OW;
+    if (a.ws) {
+        float* slab = a.ws + ((size_t)blockIdx.y * a.M + co) * a.Npix + (size_t)n * OH * OW + ox;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = oy + i;
+            if (yy >= OH) continue;
+            float* row = slab + yy * OW;
+            row[0] = y[i][0];
+            if (c1) row[1] = y[i][1];
+            if (c2) row[2] = y[i][2];
+            if (c3) row[3] = y[i][3];
+        }
+        return;
+    }
+    const float sc = a.scale[co], sh = a.shift[co];
+    const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
+    float pl[2][2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yy = oy + i;
+        if (yy >= OH) continue;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = y[i][j] * sc + sh;
+        if (a.res) {
+            const unsigned ro = (unsigned)(((((size_t)n * a.res_ctot + a.res_coff + co) * OH + yy) * OW + ox) * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = j == 0 || (j == 1 ? c1 : j == 2 ? c2 : c3);
+                const float r = __builtin_bit_cast(
+                    float, __builtin_amdgcn_raw_buffer_load_b32(rres, ok ? ro + 4 * j : (unsigned)kInvalidOff, 0, 0));
+                v[j] = v[j] * a.res_scale + r;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo);
+        pl[i >> 1][0] = fmaxf(pl[i >> 1][0], c1 ? fmaxf(v[0], v[1]) : v[0]);
+        if (c2) pl[i >> 1][1] = fmaxf(pl[i >> 1][1], c3 ? fmaxf(v[2], v[3]) : v[2]);
+        if (!a.write_full) continue;
+        if (a.nseg > 0) {          // heads: permute(0,2,3,1) + view + cat of models/RFB_Net_vgg.py:239-248
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end) {
+                    float* dst = a.seg[g].ptr + (size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                 (size_t)(yy * OW + ox) * a.seg[g].pix_stride + (co - a.seg[g].co_begin);
+                    dst[0] = v[0];
+                    if (c1) dst[a.seg[g].pix_stride] = v[1];
+                    if (c2) dst[2 * a.seg[g].pix_stride] = v[2];
+                    if (c3) dst[3 * a.seg[g].pix_stride] = v[3];
+                }
+            continue;
+        }
+        const unsigned oo = (unsigned)(((((size_t)n * a.out_ctot + a.out_coff + co) * OH + yy) * OW + ox) * 4);
+        if (c3) {
+            i32x4 pk;
+            pk.x = __builtin_bit_cast(int, v[0]);
+            pk.y = __builtin_bit_cast(int, v[1]);
+            pk.z = __builtin_bit_cast(int, v[2]);
+            pk.w = __builtin_bit_cast(int, v[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(pk, rout, oo, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[0]), rout, oo, 0, 0);
+            if (c1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[1]), rout, oo + 4, 0, 0);
+            if (c2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[2]), rout, oo + 8, 0, 0);
+        }
+    }
+    // a 4x4 output tile holds the four windows (2ty + pi, 2tx + pj) of MaxPool2d(2, 2[, ceil_mode])
+    // (models/RFB_Net_vgg.py:328-330)
+    if (a.pool_out) {
+#pragma unroll
+        for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+            for (int pj = 0; pj < 2; ++pj) {
+                const int py = 2 * ty + pi, px = 2 * tx + pj;
+                if (py < a.pool_oh && px < a.pool_ow && oy + 2 * pi < OH && ox + 2 * pj < OW)
+                    a.pool_out[(((size_t)n * a.pool_ctot + a.pool_coff + co) * a.pool_oh + py) * a.pool_ow + px] = pl[pi][pj];
+            }
+    }
+}
+
+// One segment of work: chunks [c_begin, c_end) of work item vb (virtual block index: XCD = vb & 7).  sk_slab == nullptr:
+// the segment covers what its launch mode expects and ends in the fused epilogue (or the channel-split slab of a.ws);
+// else the output-transformed partial sums go to sk_slab[cout 64][tile 32][16].
+__device__ __forceinline__ void wino4_segment(const Wino4Args& a, const int vb, const int c_begin, const int c_end,
+                                              float* const sk_slab, float* const lds)
+{
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xg = wave >> 1, kbk = wave & 1;
     // blockIdx -> (XCD-local sequence, cout block fastest), as in ct_wino.hip: the cout blocks of a tile block run
     // together on one XCD and share its input patches through that XCD's L2
-    const int jx = blockIdx.x >> 3;
+    const int jx = vb >> 3;
     const int kb = jx % a.kblocks;
-    const int tblk = (jx / a.kblocks) * 8 + (blockIdx.x & 7);
+    const int tblk = (jx / a.kblocks) * 8 + (vb & 7);
     if (tblk >= a.tile_blocks) return;
     const int tb0 = tblk * TB;
     const int HW = a.H * a.W;
@@ -197,8 +297,6 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
     // ---- weights in registers: u[j] = the 4 A-fragment floats (channel pairs s = 0..3) of transform point 9 xg + j
     const f32x4* Ug = reinterpret_cast<const f32x4*>(a.U + (size_t)kb * a.chunks * UCHUNK) + wave * (9 * 64) + lane;
     f32x4 u[9];
-    const int c_begin = blockIdx.y * a.chunks_per_slice;
-    const int c_end = min(a.chunks, c_begin + a.chunks_per_slice);
     const int last = c_end - 1;
     const float* const Vr = lds + (9 * xg) * XS + (xg >= 2 ? VSKEW : 0) + lane;
 
@@ -300,7 +398,6 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
     // ---- output transform: two passes of 32 couts through LDS  M[point][cout 32][tile 32]
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
-    const int OH = a.H, OW = a.W;                      // pad 1, stride 1: same spatial size
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
         for (int j = 0; j < 9; ++j)
@@ -320,7 +417,6 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
             const int n = T / (a.TY * a.TX);
             const int rem = T - n * (a.TY * a.TX);
             const int ty = rem / a.TX, tx = rem - ty * a.TX;
-            const int oy = 4 * ty, ox = 4 * tx;
             float z[4][6];
             const float* mp = lds + kk * 32 + tl;
 #pragma unroll
@@ -332,90 +428,104 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) z[i][j] = y[i];
             }
-            const bool c1 = ox + 1 < OW, c2 = ox + 2 < OW, c3 = ox + 3 < OW;
-            if (a.ws) {
-                float* slab = a.ws + ((size_t)blockIdx.y * a.M + co) * a.Npix + (size_t)n * OH * OW + ox;
+            float y[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) at4(z[i], y[i]);
+            if (sk_slab) {
+                f32x4* dst = reinterpret_cast<f32x4*>(sk_slab + ((size_t)((kk >> 4) * 32 + 16 * pass + (kk & 15)) * 32 + tl) * 16);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int yy = oy + i;
-                    if (yy >= OH) continue;
-                    float v[4];
-                    at4(z[i], v);
-                    float* row = slab + yy * OW;
-                    row[0] = v[0];
-                    if (c1) row[1] = v[1];
-                    if (c2) row[2] = v[2];
-                    if (c3) row[3] = v[3];
+                    f32x4 v4;
+                    v4.x = y[i][0]; v4.y = y[i][1]; v4.z = y[i][2]; v4.w = y[i][3];
+                    dst[i] = v4;
                 }
                 continue;
             }
-            const float sc = a.scale[co], sh = a.shift[co];
-            const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
-            float pl[2][2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int yy = oy + i;
-                if (yy >= OH) continue;
-                float v[4];
-                at4(z[i], v);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = v[j] * sc + sh;
-                if (a.res) {
-                    const unsigned ro = (unsigned)(((((size_t)n * a.res_ctot + a.res_coff + co) * OH + yy) * OW + ox) * 4);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool ok = j == 0 || (j == 1 ? c1 : j == 2 ? c2 : c3);
-                        const float r = __builtin_bit_cast(
-                            float, __builtin_amdgcn_raw_buffer_load_b32(rres, ok ? ro + 4 * j : (unsigned)kInvalidOff, 0, 0));
-                        v[j] = v[j] * a.res_scale + r;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo);
-                pl[i >> 1][0] = fmaxf(pl[i >> 1][0], c1 ? fmaxf(v[0], v[1]) : v[0]);
-                if (c2) pl[i >> 1][1] = fmaxf(pl[i >> 1][1], c3 ? fmaxf(v[2], v[3]) : v[2]);
-                if (!a.write_full) continue;
-                if (a.nseg > 0) {          // heads: permute(0,2,3,1) + view + cat of models/RFB_Net_vgg.py:239-248
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-                        if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end) {
-                            float* dst = a.seg[g].ptr + (size_t)n * a.seg[g].img_stride + a.seg[g].base +
-                                         (size_t)(yy * OW + ox) * a.seg[g].pix_stride + (co - a.seg[g].co_begin);
-                            dst[0] = v[0];
-                            if (c1) dst[a.seg[g].pix_stride] = v[1];
-                            if (c2) dst[2 * a.seg[g].pix_stride] = v[2];
-                            if (c3) dst[3 * a.seg[g].pix_stride] = v[3];
-                        }
-                    continue;
-                }
-                const unsigned oo = (unsigned)(((((size_t)n * a.out_ctot + a.out_coff + co) * OH + yy) * OW + ox) * 4);
-                if (c3) {
-                    i32x4 pk;
-                    pk.x = __builtin_bit_cast(int, v[0]);
-                    pk.y = __builtin_bit_cast(int, v[1]);
-                    pk.z = __builtin_bit_cast(int, v[2]);
-                    pk.w = __builtin_bit_cast(int, v[3]);
-                    __builtin_amdgcn_raw_buffer_store_b128(pk, rout, oo, 0, 0);
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[0]), rout, oo, 0, 0);
-                    if (c1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[1]), rout, oo + 4, 0, 0);
-                    if (c2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[2]), rout, oo + 8, 0, 0);
-                }
-            }
-            // a 4x4 output tile holds the four windows (2ty + pi, 2tx + pj) of MaxPool2d(2, 2[, ceil_mode])
-            // (models/RFB_Net_vgg.py:328-330)
-            if (a.pool_out) {
-#pragma unroll
-                for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-                    for (int pj = 0; pj < 2; ++pj) {
-                        const int py = 2 * ty + pi, px = 2 * tx + pj;
-                        if (py < a.pool_oh && px < a.pool_ow && oy + 2 * pi < OH && ox + 2 * pj < OW)
-                            a.pool_out[(((size_t)n * a.pool_ctot + a.pool_coff + co) * a.pool_oh + py) * a.pool_ow + px] = pl[pi][pj];
-                    }
-            }
+            emit_tile(a, rout, rres, n, ty, tx, co, y);
         }
         __syncthreads();
+    }
+}
+
+// Schedule of XCD x (= block & 7) in a stream-K launch.  Its work items jx = 0 .. Jx-1 (virtual block 8 jx + x) go to
+// its W workgroups in full rounds first -- workgroup w takes items w, W + w, ... whole, in the same order as the plain
+// grid, so the cout blocks of a tile block still run side by side on the XCD's L2 -- and only the last, partial round
+// (items R W .. Jx-1) is cut by chunks: its (item, chunk) units are divided into W equal contiguous ranges.
+struct SkSched { int Jx, R, U; };
+__device__ __forceinline__ SkSched sk_sched(const Wino4Args& a, int x, int W)
+{
+    SkSched s;
+    const int nx = a.tile_blocks > x ? (a.tile_blocks - x + 7) / 8 : 0;
+    s.Jx = nx * a.kblocks;
+    s.R = s.Jx / W;
+    const int units = (s.Jx - s.R * W) * a.chunks;
+    s.U = (units + W - 1) / W;
+    return s;
+}
+
+__global__ __launch_bounds__(512) void wino_f4x4_3x3_f32(const Wino4Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    if (!a.streamk) {
+        const int c_begin = blockIdx.y * a.chunks_per_slice;
+        wino4_segment(a, blockIdx.x, c_begin, min(a.chunks, c_begin + a.chunks_per_slice), nullptr, lds);
+        return;
+    }
+    const int x = blockIdx.x & 7, w = blockIdx.x >> 3, W = gridDim.x >> 3;
+    const SkSched sc = sk_sched(a, x, W);
+    for (int r = 0; r < sc.R; ++r) wino4_segment(a, (r * W + w) * 8 + x, 0, a.chunks, nullptr, lds);
+    const int units = (sc.Jx - sc.R * W) * a.chunks;
+    const int u_end = min((w + 1) * sc.U, units);
+    bool first = true;
+    for (int u = w * sc.U; u < u_end;) {
+        const int t = u / a.chunks, c0 = u - t * a.chunks;
+        const int c1 = min(a.chunks, c0 + (u_end - u));
+        const bool whole = c0 == 0 && c1 == a.chunks;
+        float* slab = whole ? nullptr : a.sk_ws + ((size_t)blockIdx.x * 2 + (first ? 0 : 1)) * (KB * TB * 16);
+        wino4_segment(a, (sc.R * W + t) * 8 + x, c0, c1, slab, lds);
+        u += c1 - c0;
+        first = false;
+    }
+}
+
+// Items of the last round that the stream-K schedule cut: sum of their slabs in chunk order, then the fused epilogue.
+// One block per item of the plain grid; everything but the cut items returns at once.
+__global__ __launch_bounds__(256) void wino4_streamk_fixup(const Wino4Args a, const int W)
+{
+    const int vb = blockIdx.x, x = vb & 7, jx = vb >> 3;
+    const SkSched sc = sk_sched(a, x, W);
+    const int t = jx - sc.R * W;                           // index in the last round
+    if (jx >= sc.Jx || t < 0) return;
+    const int u0 = t * a.chunks;
+    const int w_first = u0 / sc.U, w_last = (u0 + a.chunks - 1) / sc.U;
+    if (w_first == w_last) return;                         // one workgroup did the whole item, epilogue included
+    const int kb = jx % a.kblocks, tblk = (jx / a.kblocks) * 8 + x;
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
+    for (int idx = threadIdx.x; idx < KB * TB; idx += 256) {
+        const int col = idx >> 5, tl = idx & 31;
+        const int co = kb * KB + col, T = tblk * TB + tl;
+        if (T >= a.NT || co >= a.M) continue;
+        float y[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) y[i][j] = 0.f;
+        for (int w = w_first; w <= w_last; ++w) {
+            // the item is workgroup w's first segment iff w's range starts inside it
+            const int slot = (w * sc.U) / a.chunks == t ? 0 : 1;
+            const f32x4* src = reinterpret_cast<const f32x4*>(
+                a.sk_ws + (((size_t)(w * 8 + x) * 2 + slot) * KB * TB + idx) * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v4 = src[i];
+                y[i][0] += v4.x; y[i][1] += v4.y; y[i][2] += v4.z; y[i][3] += v4.w;
+            }
+        }
+        const int n = T / (a.TY * a.TX);
+        const int rem = T - n * (a.TY * a.TX);
+        const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        emit_tile(a, rout, rres, n, ty, tx, co, y);
     }
 }
 
@@ -549,7 +659,7 @@ extern "C" int ct_conv2d_wino4_pool_fwd(const ct_conv_desc* d, const float* upac
         a.chunks_per_slice = a.chunks;
         a.Npix = nb * OHW;
         a.ws = nullptr;
-        if (d->ksplit_ws && nb == d->batch && !pool_out && (d->ksplit == -1 || d->ksplit > 1)) {
+        if (d->ksplit_ws && nb == d->batch && !pool_out && (d->ksplit == -1 || d->ksplit == -2 || d->ksplit > 1)) {
             static const int target = getenv("CTDET_W4_SPLIT_TARGET") ? atoi(getenv("CTDET_W4_SPLIT_TARGET")) : 256;
             const int wgs = a.tile_blocks * a.kblocks;
             int want = d->ksplit > 1 ? d->ksplit : target / std::max(wgs, 1);      // auto: at most one workgroup per CU in total
@@ -563,6 +673,32 @@ extern "C" int ct_conv2d_wino4_pool_fwd(const ct_conv_desc* d, const float* upac
         }
         // 8 XCD-local sequences of (tile block group, cout block); sequences past the last tile block exit at once
         const int groups = (a.tile_blocks + 7) / 8;
+        const int items = a.tile_blocks * a.kblocks;
+        // stream-K: the caller says the launch runs alone (ksplit -2) and the plain grid would end in a ragged round
+        constexpr int kCUs = 256, kWgsPerXcd = kCUs / 8;
+        const long long sk_floats = (long long)kCUs * 2 * KB * TB * 16;
+        a.streamk = 0;
+        a.sk_ws = nullptr;
+        if (d->ksplit == -2 && d->ksplit_ws && d->ksplit_ws_floats >= sk_floats && nb == d->batch && items > kCUs &&
+            a.chunks >= 8) {
+            const double rounds = (double)items / kCUs;
+            const double frac = rounds - std::floor(rounds);      // fill of the last round
+            const double max_frac = getenv("CTDET_W4_SK_FRAC") ? atof(getenv("CTDET_W4_SK_FRAC")) : 0.5;
+            if (frac > 0.0 && frac <= max_frac) {
+                a.streamk = 1;
+                a.sk_ws = d->ksplit_ws;
+                a.slices = 1;
+                a.chunks_per_slice = a.chunks;
+                a.ws = nullptr;
+            }
+        }
+        if (a.streamk) {
+            hipLaunchKernelGGL(wino_f4x4_3x3_f32, dim3(kCUs), dim3(512), W4_LDS_BYTES, st, a);
+            CT_LAUNCH_CHECK("wino_f4x4_3x3_f32 (stream-K)");
+            hipLaunchKernelGGL(wino4_streamk_fixup, dim3(8 * groups * a.kblocks), dim3(256), 0, st, a, kWgsPerXcd);
+            CT_LAUNCH_CHECK("wino4_streamk_fixup");
+            continue;
+        }
         hipLaunchKernelGGL(wino_f4x4_3x3_f32, dim3(8 * groups * a.kblocks, a.slices), dim3(512), W4_LDS_BYTES, st, a);
         CT_LAUNCH_CHECK("wino_f4x4_3x3_f32");
         if (a.slices > 1) {

@@ -682,6 +682,7 @@ class Runtime:
                 self.autotune(missing)
             self.tuned = not missing or mode != '0'
         self._fuse_pools()
+        self._mark_exclusive()
         self._build_schedule()
 
     def _fuse_pools(self):
@@ -705,6 +706,29 @@ class Runtime:
                                                               getattr(st, 'res', None) == ps.src)]
             prod[0].rt['pool'] = (self.bufs[ps.dst], ps.oh, ps.ow, bool(others))
             ps.fused_into = prod[0].name
+
+    def _mark_exclusive(self):
+        """Opt-in (CTDET_W4_STREAMK=1): F(4x4,3x3) launches of the trunk up to the first branch point (conv1_1 ..
+        conv4_3) have the device to themselves in every schedule -- nothing the side stream runs exists before the
+        first Norm / head source -- so they may use the kernel's stream-K form (desc.ksplit = -2: a persistent grid
+        whose last, partial round is cut by input-channel chunks; 67 MB of slab workspace shared by those launches,
+        they run one after another).  +1.3 .. 2.5 % images/s at bs 32 (three layers with 3.1 rounds of workgroups).
+        Off by default: the cut items are the LAST tiles of the batch, so an image's last bits would depend on its
+        position in the batch (tests/test_gpu_harness.py and test_full_size_pipeline_properties check that they do not).
+        The marking does not depend on CTDET_STREAMS or CTDET_FUSE_POOL."""
+        if os.environ.get('CTDET_W4_STREAMK', '0') != '1' or not hasattr(self.backend, 'lib'):
+            return
+        steps = self.plan.steps
+        first_side = next((i for i, st in enumerate(steps)
+                           if st.name.startswith(('Norm.', 'head.')) or st.kind == 'ctxpool'), len(steps))
+        ws = None
+        for st in steps[:first_side]:
+            if st.kind != 'conv' or st.rt.get('wino') != 4:
+                continue
+            if ws is None:
+                ws = self.bufs.setdefault('__streamk_ws', self.backend.alloc((256 * 2 * 64 * 32 * 16,)))
+            d = st.rt['desc']
+            d.ksplit, d.ksplit_ws, d.ksplit_ws_floats = -2, ws.data_ptr(), ws.numel()
 
     # ---- two-stream schedule: the Norm branch and the multibox heads are independent of the trunk that
     # follows their source (base.23.., extras..), and the small 19x19 .. 1x1 kernels of that trunk cannot fill

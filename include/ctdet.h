@@ -289,7 +289,12 @@ int ct_conv_pack_weights_wino_dgrad(const float* const* w, const int* cout, int 
  * desc->ksplit / ksplit_ws are honoured by ct_conv2d_wino4_fwd as a split over INPUT CHANNELS (ksplit -1: the library
  * decides, > 1: that many slices, else off): each slice stores its output-transformed partial sums in its slab
  * ws[slice][cout][batch*oh*ow] and a finishing kernel adds them in slice order -- for maps whose 32-tile x 64-cout
- * workgroup grid cannot fill the chip (small batches).  Not combined with the fused pooling. */
+ * workgroup grid cannot fill the chip (small batches).  Not combined with the fused pooling.
+ * ksplit -2 (with ksplit_ws >= 256*2*64*32*16 floats): stream-K -- the caller promises the launch runs alone on the
+ * device; a persistent grid of 256 workgroups does the full rounds of work items whole and cuts the last, partial round
+ * by input-channel chunks (partial sums in slabs, a fix-up kernel adds them in chunk order and applies the epilogue,
+ * fused pooling included).  Deterministic, but the cut items are the last tiles of the batch: an image's rounding then
+ * depends on its batch position, which is why ctdet/engine.py only uses it on request (CTDET_W4_STREAMK=1). */
 int ct_conv_wino4_supported(const ct_conv_desc* desc);
 size_t ct_conv_wino4_packed_floats(int cin, int cout);
 int ct_conv_pack_weights_wino4(const float* const* w, const int* cout, int nparts, int cin, float* upacked,

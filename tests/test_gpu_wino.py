@@ -222,3 +222,45 @@ def test_wino4_channel_split_matches_single_pass():
         assert rel_err(got, base) < 1e-5, ks
         again = _run_conv(x, [(w, None, bn, True)], 1, 1, 1, config=engine.WINO4, res=res, res_scale=0.7, ksplit=ks)
         assert torch.equal(got, again), ks
+
+
+@pytest.mark.parametrize('pool', [False, True], ids=['plain', 'fused_pool'])
+def test_wino4_streamk_matches_plain_grid(pool, monkeypatch):
+    """Stream-K form of the F(4x4,3x3) kernel (desc.ksplit = -2: persistent grid, last round cut by channel chunks,
+    slabs + wino4_streamk_fixup) against the plain grid: 3.1 rounds of workgroups (800 items), BN + ReLU epilogue,
+    optionally with the fused 2x2 max-pool -- the cut items' pooling happens in the fix-up kernel."""
+    import ctypes as C
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(41)
+    B, Cin, H, Wd, Cout = 8, 64, 76, 76, 256               # 19*19*8 = 2888 tiles -> 91 tile blocks x 4 cout blocks = 364
+    x = torch.randn(B, Cin, H, Wd, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.rand(Cout, generator=g) - 0.5
+    y = F.relu(F.conv2d(x, w, b, 1, 1))
+    want_pool = F.max_pool2d(y, 2, 2)
+    monkeypatch.setenv('CTDET_W4_SK_FRAC', '1')            # cut the last round whatever its fill (1.42 rounds here)
+    outs = []
+    for ks in (0, -2, -2):
+        be = engine.HipBackend('cuda:0')
+        st = engine.ConvStep('t', [engine.ConvPart(torch.nn.Parameter(w.cuda(), requires_grad=False),
+                                                   torch.nn.Parameter(b.cuda(), requires_grad=False), None, True)],
+                             Cin, 3, 3, 1, 1, 1, 1, 'x', 0, H, Wd, 'y', 0)
+        bufs = {'x': x.cuda(), 'y': torch.full((B, Cout, H, Wd), float('nan'), device='cuda')}
+        st.rt['config'] = engine.WINO4
+        be.prepare_conv(st, bufs, B)
+        ws = torch.full((256 * 2 * 64 * 32 * 16,), float('nan'), device='cuda')
+        d = st.rt['desc']
+        d.ksplit, d.ksplit_ws, d.ksplit_ws_floats = ks, ws.data_ptr(), ws.numel()
+        pooled = torch.full((B, Cout, H // 2, Wd // 2), float('nan'), device='cuda')
+        if pool:
+            st.rt['pool'] = (pooled, H // 2, Wd // 2, True)
+        be.run_conv(st)
+        torch.cuda.synchronize()
+        assert rel_err(bufs['y'].cpu(), y) < TOL
+        if pool:
+            assert rel_err(pooled.cpu(), want_pool) < TOL
+            assert torch.equal(F.max_pool2d(bufs['y'], 2, 2), pooled)
+        outs.append(bufs['y'].clone())
+    assert rel_err(outs[1].cpu(), outs[0].cpu()) < 1e-5         # other summation order in the cut items only
+    assert not torch.equal(outs[1], outs[0])                     # ... so the stream-K path really ran
+    assert torch.equal(outs[1], outs[2])                         # and is deterministic

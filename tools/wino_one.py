@@ -26,6 +26,10 @@ for name in names:
     st = engine.ConvStep(name, [engine.ConvPart(w, b, None, True)], Cin, 3, 3, 1, 1, 1, 1, 'x', 0, H, W, 'y', 0)
     bufs = {'x': torch.randn(B, Cin, H, W, device=DEV), 'y': torch.empty(B, Cout, H, W, device=DEV)}
     be.prepare_conv(st, bufs, B)
+    if os.environ.get('SK'):                  # stream-K: the launch has the device to itself
+        skws = torch.empty(256 * 2 * 64 * 32 * 16, device=DEV)
+        d = st.rt['desc']
+        d.ksplit, d.ksplit_ws, d.ksplit_ws_floats = -2, skws.data_ptr(), skws.numel()
     ref = None
     if os.environ.get('CHECK', '1') != '0' and B * Cin * H * W <= 64 << 20:
         ref = torch.relu(torch.nn.functional.conv2d(bufs['x'].double(), w.double(), b.double(), padding=1))
