@@ -160,7 +160,12 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[x][i][j][r] = 0.f;
 
-#define WINO_MFMA(XI, II, JJ, av, bv) acc[XI][II][JJ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[XI][II][JJ], 0, 0, 0)
+#define WINO_MFMA(XI, II, JJ, av, bv)                                                                   \
+    do {                                                                                                \
+        __builtin_amdgcn_s_setprio(1);                                                                  \
+        acc[XI][II][JJ] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[XI][II][JJ], 0, 0, 0);       \
+        __builtin_amdgcn_s_setprio(0);                                                                  \
+    } while (0)
 #define WINO_PIN() __builtin_amdgcn_sched_barrier(0)
     // ---- weights in registers.  The A fragments a wave needs for a chunk are 16 floats per lane, stored by
     // ct_conv_pack_weights_wino in exactly that order: four coalesced 16-byte loads per lane and chunk, no LDS
