@@ -108,6 +108,9 @@ SIGNATURES = {
     'ct_conv_wgrad_wino_supported': (_I, [C.POINTER(ConvDesc)]),
     'ct_conv_wgrad_wino_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'ct_conv2d_wgrad_wino': (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P, _P]),
+    'ct_conv_wgrad_wino4_supported': (_I, [C.POINTER(ConvDesc)]),
+    'ct_conv_wgrad_wino4_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
+    'ct_conv2d_wgrad_wino4': (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P, _P]),
     'ct_bn_train_stats': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     'ct_bn_train_apply': (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _I, _I, _F, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'ct_bn_train_backward': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _F, _I, _P, _F, _P, _I, _I, _I,

@@ -143,8 +143,15 @@ class TrainRuntime:
             # transform saves there); CTDET_WGRAD_WINO=0 keeps the direct kernel everywhere.
             s.wgrad_wino = bool(int(os.environ.get('CTDET_WGRAD_WINO', '1'))) and st.oh * st.ow >= 100 and \
                 bool(self.lib.ct_conv_wgrad_wino_supported(C.byref(w)))
+            # F(3x3, 4x4) from 19x19 maps up (15-20 % faster than F(3x3, 2x2) there, tools/wgrad_probe.py; slower on
+            # 10x10); CTDET_WGRAD_WINO4=0 keeps F(3x3, 2x2)
+            s.wgrad_tile = 4 if s.wgrad_wino and st.oh * st.ow >= 361 and \
+                os.environ.get('CTDET_WGRAD_WINO4', '1') != '0' else 2
             if s.wgrad_wino:
-                wino_ws = max(wino_ws, int(self.lib.ct_conv_wgrad_wino_workspace_bytes(C.byref(w))))
+                size = self.lib.ct_conv_wgrad_wino4_workspace_bytes if s.wgrad_tile == 4 else \
+                    self.lib.ct_conv_wgrad_wino_workspace_bytes
+                s.wgrad_ws_bytes = int(size(C.byref(w)))
+                wino_ws = max(wino_ws, s.wgrad_ws_bytes)
             for p in st.parts:
                 self._reg(p.weight)
                 if p.bn is not None:
@@ -166,8 +173,7 @@ class TrainRuntime:
                 for i, t in enumerate(getattr(s_, 'scratch', [])):
                     s_.scratch[i] = self.bn_scratch[o:o + t.numel()]
                     o += t.numel()
-            sizes = [(s_, int(self.lib.ct_conv_wgrad_wino_workspace_bytes(C.byref(s_.wgrad))) // 4)
-                     for s_ in self.state.values() if s_.wgrad_wino]
+            sizes = [(s_, s_.wgrad_ws_bytes // 4) for s_ in self.state.values() if s_.wgrad_wino]
             self.wgrad_ws_all = al((max(sum((n + 63) // 64 * 64 for _, n in sizes), 1),))
             o = 0
             for s_, n in sizes:
@@ -490,8 +496,9 @@ class TrainRuntime:
                 side.wait_event(s.ev_dz)
             with torch.cuda.stream(side if side is not None else main):
                 if s.wgrad_wino:
-                    _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
-                                                        (s.wgrad_ws if self.prezero else self.wgrad_ws).data_ptr(), self._s()),
+                    fn = lib.ct_conv2d_wgrad_wino4 if s.wgrad_tile == 4 else lib.ct_conv2d_wgrad_wino
+                    _lib.check(fn(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
+                                  (s.wgrad_ws if self.prezero else self.wgrad_ws).data_ptr(), self._s()),
                                st.name + ' wgrad (winograd)')
                 else:
                     _lib.check(lib.ct_conv2d_wgrad(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),

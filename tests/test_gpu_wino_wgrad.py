@@ -1,5 +1,5 @@
-"""Winograd F(3x3, 2x2) weight gradient (ct_conv2d_wgrad_wino) against autograd in float64 and against the direct
-weight-gradient kernel, through the C ABI.  What train.py:228 `losses.backward()` computes for the 3x3 / stride 1
+"""Winograd F(3x3, 2x2) and F(3x3, 4x4) weight gradients (ct_conv2d_wgrad_wino, ct_conv2d_wgrad_wino4) against
+autograd in float64 and against the direct weight-gradient kernel, through the C ABI.  What train.py:228 `losses.backward()` computes for the 3x3 / stride 1
 weights of models/RFB_Net_vgg.py."""
 import ctypes as C
 
@@ -12,6 +12,9 @@ from ctdet import _lib
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+# (supported, workspace_bytes, run, tolerance vs float64): the large tile's transforms round 10x coarser
+VARIANTS = {'f2': ('ct_conv_wgrad_wino_supported', 'ct_conv_wgrad_wino_workspace_bytes', 'ct_conv2d_wgrad_wino', 1e-5),
+            'f4': ('ct_conv_wgrad_wino4_supported', 'ct_conv_wgrad_wino4_workspace_bytes', 'ct_conv2d_wgrad_wino4', 5e-5)}
 
 
 def _s():
@@ -40,9 +43,11 @@ GEOMS = [  # B, Cin, H, W, Cout, x slice (ctot, coff), dz slice (ctot, coff)
 ]
 
 
+@pytest.mark.parametrize('variant', ['f2', 'f4'])
 @pytest.mark.parametrize('g', GEOMS, ids=[str(i) for i in range(len(GEOMS))])
-def test_wino_wgrad_vs_autograd(g):
+def test_wino_wgrad_vs_autograd(g, variant):
     B, Cin, H, W, Cout, xs, zs = g
+    sup, wsb, run, tol = VARIANTS[variant]
     gen = torch.Generator().manual_seed(11 + Cin + H)
     xctot, xcoff = xs or (Cin, 0)
     zctot, zcoff = zs or (Cout, 0)
@@ -54,37 +59,41 @@ def test_wino_wgrad_vs_autograd(g):
     lib = _lib.lib()
     xd, dzd = xfull.to(DEV), dzfull.to(DEV)
     d = _desc(xd, B, Cin, H, W, xctot, xcoff, Cout)
-    assert lib.ct_conv_wgrad_wino_supported(C.byref(d)) == 1
-    ws = torch.empty(lib.ct_conv_wgrad_wino_workspace_bytes(C.byref(d)) // 4, device=DEV)
+    assert getattr(lib, sup)(C.byref(d)) == 1
+    ws = torch.empty(getattr(lib, wsb)(C.byref(d)) // 4, device=DEV)
     dw = torch.full((Cout, Cin, 3, 3), float('nan'), device=DEV)
-    _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(d), dzd.data_ptr(), zctot, zcoff, dw.data_ptr(), ws.data_ptr(),
+    _lib.check(getattr(lib, run)(C.byref(d), dzd.data_ptr(), zctot, zcoff, dw.data_ptr(), ws.data_ptr(),
                                         _s()), 'wgrad wino')
     dw2 = torch.empty_like(dw)
     _lib.check(lib.ct_conv2d_wgrad(C.byref(d), dzd.data_ptr(), zctot, zcoff, dw2.data_ptr(), _s()), 'wgrad')
     torch.cuda.synchronize()
     e_w, e_d = rel_err(dw.cpu().double(), w.grad), rel_err(dw2.cpu().double(), w.grad)
-    assert e_w < 1e-5, (g, e_w, e_d)
+    assert e_w < tol, (g, e_w, e_d)
     # a second call reuses the workspace (zeroed inside) and overwrites dw
-    _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(d), dzd.data_ptr(), zctot, zcoff, dw2.data_ptr(), ws.data_ptr(),
+    _lib.check(getattr(lib, run)(C.byref(d), dzd.data_ptr(), zctot, zcoff, dw2.data_ptr(), ws.data_ptr(),
                                         _s()), 'wgrad wino again')
     torch.cuda.synchronize()
-    assert rel_err(dw2.cpu().double(), w.grad) < 1e-5
+    assert rel_err(dw2.cpu().double(), w.grad) < tol
 
 
-def test_wino_wgrad_rejects_other_geometries():
+@pytest.mark.parametrize('variant', ['f2', 'f4'])
+def test_wino_wgrad_rejects_other_geometries(variant):
+    sup, wsb, run, tol = VARIANTS[variant]
     lib = _lib.lib()
     x = torch.zeros(1, 8, 10, 10, device=DEV)
     for kw in (dict(stride=2), dict(dil=2, pad=2), dict(k=1, pad=0), dict(pad=0)):
         d = _desc(x, 1, 8, 10, 10, 8, 0, 8, **kw)
-        assert lib.ct_conv_wgrad_wino_supported(C.byref(d)) == 0
+        assert getattr(lib, sup)(C.byref(d)) == 0
         dw = torch.zeros(8 * 8 * 9, device=DEV)
-        rc = lib.ct_conv2d_wgrad_wino(C.byref(d), x.data_ptr(), 8, 0, dw.data_ptr(), dw.data_ptr(), _s())
+        rc = getattr(lib, run)(C.byref(d), x.data_ptr(), 8, 0, dw.data_ptr(), dw.data_ptr(), _s())
         assert rc != 0
 
 
-def test_wino_wgrad_above_2gib():
+@pytest.mark.parametrize('variant', ['f2', 'f4'])
+def test_wino_wgrad_above_2gib(variant):
     """An input buffer above 2 GiB (RFBNet-512 bs 32: conv1_1's output is exactly 2 GiB) goes through in batch
     chunks that accumulate into the same transform-domain workspace."""
+    sup, wsb, run, tol = VARIANTS[variant]
     B, ctot, coff, Cin, Cout, S = 3, 704, 301, 8, 8, 512          # 3 x 704 x 512 x 512 x 4 B = 2.2 GB
     gen = torch.Generator(device=DEV).manual_seed(3)
     xfull = torch.randn(B, ctot, S, S, device=DEV, generator=gen)
@@ -94,10 +103,10 @@ def test_wino_wgrad_above_2gib():
     F.conv2d(x, w, None, 1, 1).backward(dz.cpu().double())
     lib = _lib.lib()
     d = _desc(xfull, B, Cin, S, S, ctot, coff, Cout)
-    assert lib.ct_conv_wgrad_wino_supported(C.byref(d)) == 1
-    ws = torch.empty(lib.ct_conv_wgrad_wino_workspace_bytes(C.byref(d)) // 4, device=DEV)
+    assert getattr(lib, sup)(C.byref(d)) == 1
+    ws = torch.empty(getattr(lib, wsb)(C.byref(d)) // 4, device=DEV)
     dw = torch.empty(Cout, Cin, 3, 3, device=DEV)
-    _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(d), dz.data_ptr(), Cout, 0, dw.data_ptr(), ws.data_ptr(), _s()),
+    _lib.check(getattr(lib, run)(C.byref(d), dz.data_ptr(), Cout, 0, dw.data_ptr(), ws.data_ptr(), _s()),
                'wgrad wino > 2 GiB')
     torch.cuda.synchronize()
-    assert rel_err(dw.cpu().double(), w.grad) < 1e-5
+    assert rel_err(dw.cpu().double(), w.grad) < tol
