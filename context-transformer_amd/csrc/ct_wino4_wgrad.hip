@@ -21,7 +21,9 @@
 //   phase of one workgroup with the transform phase of the other (measured: 512 workgroups 762 us, 256 workgroups
 //   1027 us for 512->512 @38x38 bs 32; delaying the second workgroup of a CU by a transform phase changes nothing).
 //   The 32 x 32 block writes 72 KB of operands to LDS per 144 MFMAs -- at 64 B/clk that path alone is half the MFMA
-//   time, which is what keeps the matrix pipe at 0.45 here.
+//   time, which is what keeps the matrix pipe at 0.45 here.  A wave-specialised form (one workgroup of 8 waves per CU:
+//   four that only run MFMAs, four that only load and transform, double-buffered LDS, one barrier per chunk) was 45 %
+//   SLOWER (1109 us): the transform waves run at half speed beside an MFMA wave on their SIMD.
 // Tile ranges are split over blockIdx.y; partial sums meet in the workspace dU[36][cout][cin] through f32 atomics, and
 // wino4_wgrad_finish applies G^T . G per (k, c) into the dense dw[cout][cin][3][3].
 #include "ct_common.h"
