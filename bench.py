@@ -1,9 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of forward + NMS for RFBNet-300 (BASELINE.json metric).
 
-    python bench.py [--gpus N --steps K --warmup W]            (N=1)
+    python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --train [--gpus N]          data-parallel TRAINING step (BASELINE configs[3]), see below
+
+`--gpus N` with N > 1 and no torchrun environment (no WORLD_SIZE): bench.py launches its own N ranks through
+torch.distributed.run on 127.0.0.1, one per GPU, over RCCL (backend 'nccl'); it never prints a 1-GPU number for an
+N-GPU request: N > visible devices exits non-zero (unless --share-devices rehearses the N-rank path on fewer GPUs
+over gloo), and so does a process group whose size is not N.  The line carries `rccl_ranks`, the backend, and per
+rank the device index / PCI bus id and its own ms/step.
 
 One "step" = one pass of the whole hot path over one synthetic batch already resident in HBM:
 RFBNet engine (fused HIP convs) -> fused softmax/decode/score fusion -> per (image, class)
@@ -28,12 +35,21 @@ Extra objects on the JSON line (N=1, rank 0):
   cpu_baseline  the CPU oracle (port of the reference path: stock torch-CPU fp32 ops + C NMS) on a bounded
                 sample (BASELINE configs[0] shape), all physical cores and one thread, split by stage.
   other_configs the other single-GPU configurations BASELINE.json names (512, +Context-Transformer, the
-                bs-4 shard of a strong-scaled batch), a few steps each in the same process.
+                bs-4 shard of a strong-scaled batch, the per-GPU shape of configs[4]: bf16 512x512 bs 16 with its own
+                roofline block, the per-GPU training steps of configs[3]), a few steps each in the same process.
+
+--train: one step = forward (batch-statistics BatchNorm) + MultiBoxLoss_combined + HIP backward with the bucketed
+gradient all-reduce issued from inside it (ctdet.dist.GradBucketer, RCCL) + SGD update; default workload = the
+per-GPU share of BASELINE configs[3] (RFBNet-512 + Context-Transformer, phase 2 transfer, bs 8 per GPU).  For N > 1
+the line also reports the same step without the all-reduce, the all-reduce alone (bucket by bucket on the idle GPU)
+and overlap = 1 - (step_with - step_without) / allreduce_alone.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 import types
@@ -75,22 +91,31 @@ def physical_cores():
     return int(os.cpu_count() or 1), 'os.cpu_count() logical CPUs'
 
 
-def cpu_baseline(size, num_fg, images=4, reps=3):
+def cpu_baseline(size, num_fg, images=4, reps=2):
     """Oracle (port) timed on the host cores, SURVEY 8(d): forward / Detect / per-class NMS + top-200 timed
-    separately and end to end, with all physical cores and with one thread."""
+    separately and end to end.  torch-CPU convolutions do not scale to every core at 4 images, so the forward is
+    first timed over a small sweep of thread counts (1, 16, 32, 64, all physical cores; one run after one warm-up
+    each) and the whole pipeline is then timed at the BEST of them -- that is `value` / `cores`; the sweep and the
+    one-thread figure are reported next to it.  Bounded: about 15-25 s of host time."""
     from ctdet import synth
     from oracle import box_ref, nms_ref, rfbnet_ref
     nms_ref.build_c()
-    threads = int(os.environ.get('CTDET_CPU_THREADS', 0))
-    src = 'CTDET_CPU_THREADS'
-    if threads <= 0:
-        threads, src = physical_cores()
+    allc, src = physical_cores()
+    forced = int(os.environ.get('CTDET_CPU_THREADS', 0))
     sd = synth.fill_state_dict(rfbnet_ref.param_shapes(size, num_fg, 1))
     priors = box_ref.prior_box(box_ref.ANCHOR_CFGS['VOC_%d' % size])
+    x = synth.images(images, size, 'randn', 1234)
 
-    def run(n_img, n_threads, n_reps):
+    def forward_only(n_threads):
         torch.set_num_threads(n_threads)
-        x = synth.images(n_img, size, 'randn', 1234)
+        with torch.no_grad():
+            rfbnet_ref.forward(sd, x, size, num_fg)
+            t0 = time.perf_counter()
+            rfbnet_ref.forward(sd, x, size, num_fg)
+            return time.perf_counter() - t0
+
+    def run(n_threads, n_reps):
+        torch.set_num_threads(n_threads)
         rows = []
         with torch.no_grad():
             for r in range(n_reps + 1):
@@ -99,26 +124,32 @@ def cpu_baseline(size, num_fg, images=4, reps=3):
                 t1 = time.perf_counter()
                 boxes, scores = box_ref.detect(loc, conf, obj, priors)
                 t2 = time.perf_counter()
-                for i in range(n_img):
+                for i in range(images):
                     nms_ref.postprocess_image(boxes[i].numpy(), scores[i].numpy(), (500, 375), nms_fn=nms_ref.nms_c)
                 t3 = time.perf_counter()
                 if r > 0:
                     rows.append((t3 - t0, t1 - t0, t2 - t1, t3 - t2))
         med = np.median(np.array(rows), axis=0)
-        return {'images_per_s': round(n_img / float(med[0]), 3),
-                'ms_per_image': {'forward': round(float(med[1]) / n_img * 1e3, 2),
-                                 'detect': round(float(med[2]) / n_img * 1e3, 2),
-                                 'nms_top200': round(float(med[3]) / n_img * 1e3, 2)}}
-    full = run(images, threads, reps)
-    one = run(2, 1, 1)          # bounded: two images, one timed run after one warm-up
-    torch.set_num_threads(threads)
-    return {'value': full['images_per_s'], 'unit': 'images/s', 'cores': threads, 'cores_source': src, 'kind': 'port',
+        return {'images_per_s': round(images / float(med[0]), 3),
+                'ms_per_image': {'forward': round(float(med[1]) / images * 1e3, 2),
+                                 'detect': round(float(med[2]) / images * 1e3, 2),
+                                 'nms_top200': round(float(med[3]) / images * 1e3, 2)}}
+    before = torch.get_num_threads()
+    sweep = {}
+    for n in ([forced] if forced > 0 else sorted({1, 16, 32, 64, allc})):
+        if n <= allc or forced > 0:
+            sweep[n] = forward_only(n)
+    best = min(sweep, key=sweep.get)
+    full = run(best, reps)
+    torch.set_num_threads(before)
+    return {'value': full['images_per_s'], 'unit': 'images/s', 'cores': best, 'kind': 'port',
+            'cores_available': allc, 'cores_source': src if forced <= 0 else 'CTDET_CPU_THREADS',
             'stages_ms_per_image': full['ms_per_image'],
-            'one_thread': {'value': one['images_per_s'], 'unit': 'images/s', 'cores': 1,
-                           'stages_ms_per_image': one['ms_per_image'], 'sample': '2 images, 1 run after 1 warm-up'},
-            'sample': '%d synthetic %dx%d images (BASELINE configs[0] shape): torch-CPU fp32 forward + '
-                      'Detect + per-class C NMS + top-200, median of %d runs after 1 warm-up'
-                      % (images, size, size, reps)}
+            'thread_sweep_forward_ms_per_image': {str(n): round(t / images * 1e3, 1) for n, t in sorted(sweep.items())},
+            'sample': '%d synthetic %dx%d images (BASELINE configs[0] shape): torch-CPU fp32 forward + Detect + per-class '
+                      'C NMS + top-200; forward timed at %s threads (1 run after 1 warm-up each), the whole pipeline at '
+                      'the best of them (%d), median of %d runs after 1 warm-up'
+                      % (images, size, size, '/'.join(str(n) for n in sorted(sweep)), best, reps)}
 
 
 def load_pmc(workload):
@@ -288,8 +319,10 @@ def make_pipeline(size, num_fg, phase, setting, batch, dtype, dev):
     return pipe
 
 
-def quick_config(size, num_fg, phase, setting, batch, dtype, dev, steps=5, warmup=4):
-    """ms/step and images/s of another configuration, same step definition, in this process."""
+def quick_config(size, num_fg, phase, setting, batch, dtype, dev, steps=5, warmup=4, roofline=False):
+    """ms/step and images/s of another configuration, same step definition, in this process.  roofline=True adds the
+    conv roofline block of that configuration (HIP events around every conv launch of an eager pass + the committed
+    PMC traffic of that workload)."""
     from ctdet import synth
     pipe = make_pipeline(size, num_fg, phase, setting, batch, dtype, dev)
     x = synth.images(batch, size, 'randn', 4321).to(dev)
@@ -303,11 +336,121 @@ def quick_config(size, num_fg, phase, setting, batch, dtype, dev, steps=5, warmu
     dt = (time.perf_counter() - t0) / steps
     flops = pipe.rt.plan.conv_flops()
     res = {'ms_per_step': round(dt * 1e3, 3), 'images_per_s': round(batch / dt, 1), 'batch': batch, 'steps': steps,
+           'dtype': dtype, 'launch_mode': 'hipGraph replay' if pipe._graph is not None else 'eager launches',
            'conv_gflop_per_image': round(flops / batch / 1e9, 2),
            'conv_algorithmic_tflops': round(flops / dt / 1e12, 1)}
+    if roofline:
+        pipe.rt.event_log = []
+        for _ in range(steps):
+            pipe.run(x)
+        torch.cuda.synchronize(dev)
+        pmc = load_pmc({'size': size, 'batch': batch, 'phase': phase, 'classes': num_fg})    # kernel names tell the dtypes apart
+        res['roofline'] = conv_roofline(pipe.rt, batch, pmc)
+        res['roofline']['events_from'] = 'an eager pass of the same %d steps' % steps
+        res['roofline']['traffic_source'] = sorted({v[1] for v in pmc.values()}) or None
+        pipe.rt.event_log = None
     del pipe, x
     torch.cuda.empty_cache()
     return res
+
+
+def train_config(size, num_fg, phase, setting, batch, dev, steps=4, warmup=2, rank=0, world=1):
+    """One data-parallel training step (train.py:222-229 on this rank's image shard): forward with batch-statistics
+    BatchNorm, MultiBoxLoss_combined, HIP backward with the bucketed gradient all-reduce issued from inside it, SGD.
+    Returns local timings; for world > 1 also the step without the all-reduce and the all-reduce alone."""
+    import torch.distributed as tdist
+    from ctdet import synth, dist as cdist
+    from models.RFB_Net_vgg import build_net as bn
+    from layers.functions import PriorBox
+    from layers.modules.multibox_loss_combined import MultiBoxLoss_combined
+    import data as cfgs
+    net = bn(types.SimpleNamespace(method='ours', phase=phase, setting=setting), size, num_fg)
+    net.load_state_dict(synth.fill_state_dict(net.state_dict()))
+    net = net.to(dev).train()
+    net.device = dev
+    priors = PriorBox(getattr(cfgs, 'VOC_%d' % size)).forward().to(dev)
+    nout = num_fg if phase == 1 else net.OBJ_Target.weight.shape[0] + (num_fg if setting == 'incre' else 0)
+    crit = MultiBoxLoss_combined(nout + 1, 0.5, True, 0, True, 3, 0.5, False)
+    crit.sync_normalizer = world > 1
+    opt = torch.optim.SGD(net.parameters(), lr=1e-4, momentum=0.9, weight_decay=5e-4)
+    x = synth.images(batch, size, 'randn', 1234 + rank).to(dev)
+    tg = [t.to(dev) for t in synth.targets(batch, nout + 1, 99 + rank)]
+    trt = net.train_runtime(batch)
+    bucketer = trt.enable_grad_sync() if world > 1 else None
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def timed(n, split):
+        tf = tl = tb = 0.0
+        cdist.barrier(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            opt.zero_grad(set_to_none=True)
+            ev[0].record()
+            out = net(x)
+            ev[1].record()
+            loss = sum(crit(out, priors, tg).values())
+            ev[2].record()
+            loss.backward()
+            ev[3].record()
+            opt.step()
+            if split:
+                torch.cuda.synchronize(dev)
+                tf += ev[0].elapsed_time(ev[1])
+                tl += ev[1].elapsed_time(ev[2])
+                tb += ev[2].elapsed_time(ev[3])
+        cdist.barrier(dev)
+        return (time.perf_counter() - t0) / n, tf / n, tl / n, tb / n, float(loss)
+    timed(warmup, False)
+    dt, _, _, _, loss = timed(steps, False)              # the timed K steps: no host synchronisation inside
+    _, tf, tl, tb, _ = timed(max(2, steps // 2), True)   # stage split from HIP events, one sync per step
+    res = {'ms_per_step': dt * 1e3, 'fwd_ms': tf, 'loss_ms': tl, 'bwd_ms': tb, 'loss': loss, 'batch': batch,
+           'grad_bytes': int(trt.arena.numel()) * 4}
+    if world > 1:
+        trt.bucketer = None                              # the same step with every rank keeping its own gradients
+        timed(1, False)
+        res['ms_per_step_no_allreduce'] = timed(steps, False)[0] * 1e3
+        trt.bucketer = bucketer
+        spans = bucketer.bucket_span
+        cdist.barrier(dev)
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            hs = [tdist.all_reduce(bucketer.flat[a:b], async_op=True) for a, b in spans]
+            for h in hs:
+                h.wait()
+            torch.cuda.synchronize(dev)
+        cdist.barrier(dev)
+        res['allreduce_ms_alone'] = (time.perf_counter() - t0) / reps * 1e3
+        res['buckets'] = len(spans)
+    del net, trt, opt, x, tg
+    torch.cuda.empty_cache()
+    return res
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks ourselves (one per GPU, RCCL) and relay the
+    JSON line.  Never degrades to fewer ranks: refuses N > visible GPUs unless --share-devices was asked for."""
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev == 0:
+        raise SystemExit('bench.py needs a HIP device (the product has no CPU path)')
+    if a.gpus > ndev and not a.share_devices:
+        raise SystemExit('bench.py --gpus %d: only %d HIP device(s) visible on this node -- refusing to report a '
+                         'smaller run as %d GPUs (use --share-devices to REHEARSE the %d-rank path on %d device(s) '
+                         'over gloo; such a line is marked devices_shared)' % (a.gpus, ndev, a.gpus, a.gpus, ndev))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    env['CTDET_BENCH_SELF_LAUNCHED'] = '1'
+    rc = subprocess.call(cmd, env=env)
+    raise SystemExit(rc)
 
 
 def main():
@@ -317,37 +460,69 @@ def main():
         faulthandler.dump_traceback_later(int(os.environ['CTDET_BENCH_WATCHDOG']), exit=False)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--size', type=int, default=300)
-    ap.add_argument('--batch', type=int, default=32, help='images per GPU (weak scaling) / per job (strong scaling)')
-    ap.add_argument('--classes', type=int, default=20)
-    ap.add_argument('--phase', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=None, help='default 20 (inference) / 5 (--train)')
+    ap.add_argument('--warmup', type=int, default=None, help='default 5 (inference) / 2 (--train)')
+    ap.add_argument('--train', action='store_true',
+                    help='time the data-parallel TRAINING step (BASELINE configs[3]; default RFBNet-512 + '
+                         'Context-Transformer phase 2, 60 classes, bs 8 per GPU) instead of forward + NMS')
+    ap.add_argument('--size', type=int, default=None)
+    ap.add_argument('--batch', type=int, default=None, help='images per GPU (weak scaling) / per job (strong scaling)')
+    ap.add_argument('--classes', type=int, default=None)
+    ap.add_argument('--phase', type=int, default=None)
     ap.add_argument('--setting', default='transfer')
     ap.add_argument('--scaling', default=os.environ.get('CTDET_BENCH_SCALING', 'weak'), choices=['weak', 'strong'],
                     help='strong: ONE batch of --batch images split over the ranks (train.py:296-297 DataParallel scatter)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="bf16: NHWC bf16 activations + bf16 MFMA convolutions (BASELINE configs[4]); NOT the "
                          "headline metric, which is fp32")
+    ap.add_argument('--share-devices', action='store_true',
+                    help='allow more ranks than GPUs (rehearsal of the N-rank path on a smaller box; gloo, since RCCL '
+                         'refuses two ranks on one device); the line is marked devices_shared')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-other-configs', action='store_true')
     a = ap.parse_args()
+    dflt = (512, 8, 60, 2, 5, 2) if a.train else (300, 32, 20, 1, 20, 5)
+    explicit_workload = any(v is not None for v in (a.size, a.batch, a.classes, a.phase))
+    for name, v in zip(('size', 'batch', 'classes', 'phase', 'steps', 'warmup'), dflt):
+        if getattr(a, name) is None:
+            setattr(a, name, v)
 
     from ctdet import dist as cdist
     rank, local, world = cdist.env_world()
-    if world != a.gpus and world > 1:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (a.gpus, world))
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        self_launch(a)                      # does not return
+    if world != a.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: refusing to report a %d-rank run as %d GPUs'
+                         % (a.gpus, world, world, a.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a HIP device (the product has no CPU path)')
     ndev = torch.cuda.device_count()
-    if local >= ndev:            # more ranks than GPUs (a one-GPU box rehearsing the multi-rank path): share devices
-        local = local % ndev
+    shared = world > ndev
+    if shared and not a.share_devices:
+        raise SystemExit('%d ranks but %d HIP device(s): refusing to share devices without --share-devices' % (world, ndev))
+    local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    # RCCL (backend 'nccl'); only used for the timing barrier / max-over-ranks.  RCCL refuses two ranks on one device,
-    # so a rehearsal with more ranks than GPUs (or CTDET_DIST_BACKEND=gloo) uses gloo for those two scalars.
-    cdist.init(os.environ.get('CTDET_DIST_BACKEND') or ('nccl' if world <= ndev else 'gloo'))
+    # RCCL (backend 'nccl').  Inference uses it only for the timing barrier / max-over-ranks; --train all-reduces the
+    # gradients through it.  RCCL refuses two ranks on one device, so a --share-devices rehearsal uses gloo.
+    backend = os.environ.get('CTDET_DIST_BACKEND') or ('gloo' if shared else 'nccl')
+    cdist.init(backend)
+    ranks_info = [{'rank': rank, 'device': local, 'pci_bus_id': getattr(torch.cuda.get_device_properties(local), 'pci_bus_id', None),
+                   'name': torch.cuda.get_device_name(local)}]
+    if world > 1:
+        import torch.distributed as tdist
+        if tdist.get_world_size() != a.gpus:
+            raise SystemExit('process group has %d ranks, --gpus %d' % (tdist.get_world_size(), a.gpus))
+        probe = torch.ones(1, device=dev)
+        tdist.all_reduce(probe)             # every rank must answer through the data-path backend before anything is timed
+        if int(probe.item()) != a.gpus:
+            raise SystemExit('all-reduce over the process group saw %d ranks, --gpus %d' % (int(probe.item()), a.gpus))
+        gathered = [None] * world
+        tdist.all_gather_object(gathered, ranks_info[0])
+        ranks_info = gathered
+        if not shared and len({(r['device'], r['pci_bus_id']) for r in ranks_info}) != world:
+            raise SystemExit('ranks do not sit on %d distinct devices: %r' % (world, ranks_info))
 
     from ctdet import synth
     num_fg = a.classes
@@ -358,6 +533,59 @@ def main():
             raise SystemExit('--scaling strong: batch %d cannot be split over %d ranks' % (a.batch, world))
     else:
         batch, global_batch = a.batch, a.batch * world
+
+    def per_rank(value):
+        """value of every rank, in rank order (python floats)."""
+        if world == 1:
+            return [value]
+        import torch.distributed as tdist
+        out = [None] * world
+        tdist.all_gather_object(out, value)
+        return out
+
+    dist_info = {'backend': backend if world > 1 else None,
+                 'rccl_ranks': world if (world > 1 and backend == 'nccl') else (1 if world == 1 else 0),
+                 'devices_shared': shared, 'self_launched': os.environ.get('CTDET_BENCH_SELF_LAUNCHED') == '1',
+                 'ranks': ranks_info}
+
+    if a.train:
+        log('training step: building net + training runtime')
+        r = train_config(a.size, num_fg, a.phase, a.setting, batch, dev, a.steps, a.warmup, rank, world)
+        dt = cdist.max_over_ranks(r['ms_per_step'] * 1e-3, dev)
+        ms_rank = per_rank(round(r['ms_per_step'], 3))
+        if rank == 0:
+            line = {
+                'metric': 'images/sec training step (fwd + loss + bwd + grad all-reduce + SGD)',
+                'value': round(global_batch / dt, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': a.steps,
+                'warmup': a.warmup, 'ms_per_step': round(dt * 1e3, 3), 'higher_is_better': True, 'scaling': a.scaling,
+                'launch_mode': 'eager launches', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'config': {'workload': 'RFBNet-%d VGG16 TRAINING step, bs=%d per GPU, %d fg classes, phase %d%s: forward '
+                                       '(batch-stat BN) + MultiBoxLoss_combined + HIP backward + bucketed gradient '
+                                       'all-reduce + SGD; name-seeded random weights, randn images, synthetic targets'
+                                       % (a.size, batch, num_fg, a.phase, ' ' + a.setting if a.phase == 2 else ''),
+                           'global_batch': global_batch,
+                           'parallelism': 'dp%d (image shards, gradient all-reduce in 32 MiB buckets from inside the '
+                                          'backward pass, %s scaling)' % (world, a.scaling)},
+                'stages_ms': {'forward': round(r['fwd_ms'], 3), 'loss': round(r['loss_ms'], 3),
+                              'backward_incl_allreduce': round(r['bwd_ms'], 3)},
+                'loss': round(r['loss'], 5), 'grad_bytes': r['grad_bytes'],
+                'per_rank_ms_per_step': ms_rank, 'dist': dist_info,
+            }
+            if world > 1:
+                t_with, t_wo, t_ar = r['ms_per_step'], r['ms_per_step_no_allreduce'], r['allreduce_ms_alone']
+                line['allreduce'] = {
+                    'ms_alone': round(t_ar, 3), 'buckets': r['buckets'],
+                    'algbw_GBs': round(r['grad_bytes'] / t_ar / 1e6, 1),
+                    'busbw_GBs': round(r['grad_bytes'] / t_ar / 1e6 * 2 * (world - 1) / world, 1),
+                    'step_ms_without_allreduce': round(t_wo, 3), 'exposed_ms': round(max(0.0, t_with - t_wo), 3),
+                    'overlap_frac': round(min(1.0, max(0.0, 1.0 - (t_with - t_wo) / t_ar)), 3) if t_ar > 0 else None,
+                    'note': 'rank 0 timings; alone = the same buckets all-reduced back to back on the idle GPUs'}
+            print(json.dumps(line))
+        if world > 1:
+            import torch.distributed as tdist
+            tdist.destroy_process_group()
+        return
+
     log('building net + pipeline (plan, weight packing%s)' % (', conv autotune' if os.environ.get('CTDET_TUNE', '1') != '0' else ''))
     pipe = make_pipeline(a.size, num_fg, a.phase, a.setting, batch, a.dtype, dev)
     x = synth.images(global_batch if a.scaling == 'strong' else batch, a.size, 'randn', 1234 + (0 if a.scaling == 'strong' else rank))
@@ -381,9 +609,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         pipe.run(x)
+    torch.cuda.synchronize(dev)
+    dt_local = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
     dt = cdist.max_over_ranks(dt, dev)
+    ms_rank = per_rank(round(dt_local / a.steps * 1e3, 3))
 
     log('timed region done: %.2f ms/step' % (dt / a.steps * 1e3))
     graph_mode = pipe._graph is not None            # False if the capture failed and the steps were launched eagerly
@@ -412,8 +643,7 @@ def main():
     conv_gflop = round(pipe.rt.plan.conv_flops() / batch / 1e9, 2)
     tuned = bool(pipe.rt.tuned)
     other = None
-    if rank == 0 and world == 1 and not a.no_other_configs and a.dtype == 'f32' and \
-            (a.size, a.phase, a.classes, a.batch) == (300, 1, 20, 32):
+    if rank == 0 and world == 1 and not a.no_other_configs and a.dtype == 'f32' and not explicit_workload:
         del pipe
         torch.cuda.empty_cache()
         other = {}
@@ -425,6 +655,24 @@ def main():
             other[key] = quick_config(*cfg, 'f32', dev, steps=20 if cfg[4] == 4 else 5)
         other['rfb300_bs4_strong_shard']['note'] = \
             'the per-GPU shard when ONE bs-32 batch is split over 8 GPUs (--scaling strong); no collective on the path'
+        # BASELINE configs[4]: RFBNet-512 bf16 MFMA convs + fp32 NMS, bs 128 over 8 GPUs = bs 16 per GPU
+        log('other config bf16_rfb512_bs16')
+        other['bf16_rfb512_bs16'] = quick_config(512, 20, 1, 'transfer', 16, 'bf16', dev, steps=5, roofline=True)
+        other['bf16_rfb512_bs16']['note'] = 'per-GPU shape of BASELINE configs[4] (bs 128 over 8 GPUs); NHWC bf16 ' \
+                                            'activations, bf16 MFMA convs, fp32 softmax / decode / NMS'
+        # BASELINE configs[3]: the training step; its per-GPU shape (512 + Context-Transformer, bs 64 over 8 GPUs) and
+        # the RFBNet-300 bs-32 step
+        for key, cfg in (('train_rfb300_bs32', (300, 20, 1, 'transfer', 32)),
+                         ('train_rfb512ctx_bs8', (512, 60, 2, 'transfer', 8))):
+            log('other config %s' % key)
+            r = train_config(*cfg, dev, steps=4, warmup=2)
+            other[key] = {'ms_per_step': round(r['ms_per_step'], 3), 'images_per_s': round(cfg[4] / r['ms_per_step'] * 1e3, 1),
+                          'batch': cfg[4], 'steps': 4,
+                          'stages_ms': {'forward': round(r['fwd_ms'], 3), 'loss': round(r['loss_ms'], 3),
+                                        'backward': round(r['bwd_ms'], 3)},
+                          'grad_bytes': r['grad_bytes'],
+                          'step': 'forward (batch-stat BN) + MultiBoxLoss_combined + HIP backward + SGD, one GPU '
+                                  '(no all-reduce); `bench.py --train --gpus N` times the data-parallel form'}
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         log('cpu baseline (oracle on host cores)')
@@ -447,6 +695,7 @@ def main():
                        'parallelism': 'dp%d (image shards, no collective, %s scaling)' % (world, a.scaling),
                        'conv_gflop_per_image': conv_gflop,
                        'detections_per_batch': counts, 'conv_autotuned': tuned},
+            'per_rank_ms_per_step': ms_rank, 'dist': dist_info,
             'roofline': roof, 'cpu_baseline': cpu, 'other_configs': other,
         }
         print(json.dumps(line))

@@ -35,8 +35,13 @@ bool prof_enabled() { return g_prof_on.load(std::memory_order_relaxed); }
 void prof_start(const char* name, hipStream_t st, int* slot)
 {
     ProfRec r{name, nullptr, nullptr, false};
-    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
-    if (hipEventRecord(r.e0, st) != hipSuccess) return;
+    if (hipEventCreate(&r.e0) != hipSuccess) return;
+    if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); return; }
+    if (hipEventRecord(r.e0, st) != hipSuccess) {
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+        return;
+    }
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(r);
     *slot = (int)g_prof.size() - 1;

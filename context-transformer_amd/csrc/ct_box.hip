@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void match_pass1(const float* __restrict__ tru
     __shared__ float4 gtb[kMaxGT];
     __shared__ unsigned long long gbest[kMaxGT];
     const int b = blockIdx.y;
-    const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
+    const int g0 = gt_off[b], G = min(gt_off[b + 1] - g0, max_gt);    // the workspace holds max_gt slots per image
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const float4 pf = point_form(priors[p < P ? p : 0]);
     float bo = -INFINITY;
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void match_pass2(const float* __restrict__ tru
 {
     __shared__ int bprior[kMaxGT];
     const int b = blockIdx.y;
-    const int g0 = gt_off[b], G = gt_off[b + 1] - g0;
+    const int g0 = gt_off[b], G = min(gt_off[b + 1] - g0, max_gt);    // the workspace holds max_gt slots per image
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const size_t o = (size_t)b * P + (p < P ? p : 0);
     float ov = best_ov[o];

@@ -46,7 +46,9 @@ struct ProfScope {
     ProfScope(const char* name, hipStream_t s) : st(s) { if (prof_enabled()) prof_start(name, s, &slot); }
     ~ProfScope() { if (slot >= 0) prof_stop(st, slot); }
 };
-#define CT_PROF(name, stream) ::ctdet::ProfScope _ct_prof_scope_##__LINE__(name, stream)
+#define CT_PROF_CAT2(a, b) a##b
+#define CT_PROF_CAT(a, b) CT_PROF_CAT2(a, b)
+#define CT_PROF(name, stream) ::ctdet::ProfScope CT_PROF_CAT(_ct_prof_scope_, __LINE__)(name, stream)
 
 // Recording of weight-packing launches (ct_pack_record_begin / _end / ct_pack_run): while a recording is open on the
 // calling thread the pack entry points append their kernel arguments here instead of launching; the recorded table

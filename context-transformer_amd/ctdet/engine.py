@@ -570,7 +570,7 @@ class HipBackend:
         st.rt['config'] = best + 1
         if st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
             best_tile = 0
-            for tile in wino_tiles(self):
+            for tile in wino_tiles(self, st):
                 self.enable_wino(st, tile=tile)
                 self.run_conv(st)
                 torch.cuda.synchronize(self.device)
@@ -592,12 +592,18 @@ class HipBackend:
         return best, times
 
 
-def wino_tiles(backend=None):
+def wino_tiles(backend=None, st=None):
     """Winograd variants the tuner may pick: CTDET_WINO_TILES = '2', '4' or '2,4' (default), minus what the
-    runtime that owns `backend` excluded (wino4_allowed)."""
+    runtime that owns `backend` excluded (wino4_allowed / wino4_max_cin: F(4x4,3x3) only up to that many input
+    channels -- its rounding error grows with the length of the channel sum)."""
     tiles = tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4').split(',') if t)
     allowed = getattr(backend, 'wino_tile_set', None)
-    return tiles if allowed is None else tuple(t for t in tiles if t in allowed)
+    if allowed is not None:
+        tiles = tuple(t for t in tiles if t in allowed)
+    cap = getattr(backend, 'wino4_max_cin', None)
+    if cap is not None and st is not None and st.cin > cap:
+        tiles = tuple(t for t in tiles if t != 4)
+    return tiles
 
 
 def wino4_allowed(net):
@@ -608,7 +614,20 @@ def wino4_allowed(net):
     F(2x2,3x3) 0.6..1.1e-4, the CPU path itself 0.5e-4 from fp64 -- which is past the 1e-4 parity contract.  Those
     inference runtimes keep F(2x2,3x3) unless CTDET_WINO4_CTX=1."""
     ctx = getattr(net, 'method', None) == 'ours' and getattr(net, 'phase', 1) == 2
-    return not ctx or os.environ.get('CTDET_WINO4_CTX', '0') == '1'
+    return not ctx or os.environ.get('CTDET_WINO4_CTX', CTX_WINO4_DEFAULT) != '0'
+
+
+CTX_WINO4_DEFAULT = '0'
+
+
+def wino4_max_cin(net):
+    """Context-Transformer networks only: CTDET_WINO4_CTX = N > 1 allows F(4x4,3x3) on layers with at most N input
+    channels (its rounding error is that of a sequential fp32 channel sum in the transform domain and grows with
+    the number of channels, while most of its speed-up comes from the 64..256-channel layers); '1' = every layer,
+    '0' = none.  None = no cap."""
+    ctx = getattr(net, 'method', None) == 'ours' and getattr(net, 'phase', 1) == 2
+    v = os.environ.get('CTDET_WINO4_CTX', CTX_WINO4_DEFAULT)
+    return int(v) if ctx and v.isdigit() and int(v) > 1 else None
 
 
 def apply_tuned(backend, st, batch, wino4=True):
@@ -617,7 +636,7 @@ def apply_tuned(backend, st, batch, wino4=True):
     cfg = tune_table().get(st.tune_key(batch))
     names = [backend.lib.ct_conv_config_name(i).decode() for i in range(backend.lib.ct_conv_num_configs())]
     if cfg in ('wino', 'wino4') and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
-        tile = 4 if cfg == 'wino4' and wino4 and 4 in wino_tiles(backend) else 2
+        tile = 4 if cfg == 'wino4' and wino4 and 4 in wino_tiles(backend, st) else 2
         backend.enable_wino(st, tile=tile)
         return True
     if cfg in names:
@@ -674,6 +693,7 @@ class Runtime:
         mode = os.environ.get('CTDET_TUNE', '1') if tune is None else ('1' if tune else '0')
         if not wino4_allowed(net):
             backend.wino_tile_set = (2,)
+        backend.wino4_max_cin = wino4_max_cin(net)
         self.tuned = False
         self.event_log = None        # set to a list to collect (step, start_event, end_event) per conv
         if getattr(backend, 'tune_conv', None) is not None:

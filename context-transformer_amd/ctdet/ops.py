@@ -282,6 +282,11 @@ class Augmenter:
             raise ValueError('Augmenter: batch of %d images / %d plans (max %d)' % (n, len(plans), self.max_batch))
         if self.copied is not None:
             self.copied.synchronize()
+        need = sum(int(np.asarray(img).size) for img in images)
+        if need > self.cap:                 # any image size, like the reference (COCO is 640x480): grow, never refuse
+            self.cap = int(need * 1.25)
+            self.stage = torch.empty(self.cap, dtype=torch.uint8).pin_memory()
+            self.dev = torch.empty(self.cap, dtype=torch.uint8, device=self.device)
         recs = (AugPlan * n)()
         pos = 0
         for i, (img, p) in enumerate(zip(images, plans)):

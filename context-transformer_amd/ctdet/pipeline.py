@@ -60,6 +60,18 @@ class DetectionPipeline:
             self.scale = new.to(self.device)
             self._graph = None
 
+    def _net_key(self):
+        """Everything a captured step froze besides the packed conv weights (which are rewritten in place): whether the
+        Context-Transformer block runs, its 'incre' branch, the host-side value of `scale` and the raw pointers of the
+        block's parameters -- a load_state_dict that changes `scale`, a re-allocated parameter (net.to(), assign=True)
+        or a change of method / phase / setting re-captures instead of replaying stale arguments."""
+        net = self.net
+        key = (getattr(net, 'method', None), getattr(net, 'phase', None), getattr(net, 'setting', None))
+        if key[0] == 'ours' and key[1] == 2:
+            prm = net._ctx_params()
+            key += tuple(v.data_ptr() if isinstance(v, torch.Tensor) else v for _, v in sorted(prm.items()))
+        return key
+
     def _step(self):
         """The launches of one step on the current stream; reads rt.bufs['x'] (already filled)."""
         loc, conf, obj = self.net.forward_raw(None, _input_loaded=True, _batch=self.batch)
@@ -89,7 +101,7 @@ class DetectionPipeline:
             self.set_image_wh(image_wh)
         rt = self.rt
         rt.load_input(x)                            # shape check, weight refresh, copy into the plan's input buffer
-        key = (self.conf_thresh, self.nms_thresh, self.ge, self.max_per_image, rt.event_log is None)
+        key = (self.conf_thresh, self.nms_thresh, self.ge, self.max_per_image, rt.event_log is None) + self._net_key()
         if self.use_graph and rt.event_log is None:
             if self._graph is not None and self._graph_key == key:
                 self._graph.replay()

@@ -67,7 +67,11 @@ class MultiBoxLoss_combined(nn.Module):
         bg = obj_flat[:, :1] + torch.logsumexp(flat_conf, dim=1, keepdim=True)
         fg = obj_flat[:, 1:2].expand_as(flat_conf) + flat_conf
         logit = torch.cat((bg, fg), 1)
-        loss_c = (F.cross_entropy(logit, labels.long().view(-1), reduction='none') * w).sum()
+        # ignored boxes carry label -1 (data/voc0712.py:237-238, 263-264: 'incre' phase 2 / instance_shot); the reference
+        # never evaluates them (pos is False, their mining loss is zeroed so they are not drawn as negatives, :93) --
+        # here their row is evaluated against class 0 and multiplied by w = 0: a valid target index, the same sum
+        cls_t = labels.long().clamp_min(0).view(-1)
+        loss_c = (F.cross_entropy(logit, cls_t, reduction='none') * w).sum()
 
         n = num_pos.sum()
         if self.sync_normalizer:          # data-parallel: N over the global batch (see ctdet.dist)

@@ -150,7 +150,9 @@ int ct_jaccard(const float* a, int na, const float* b, int nb, int b_center_form
  *   truths dev [sum G,6] rows [x1,y1,x2,y2,label,weight]; gt_off dev [B+1]
  *   priors dev [P,4] center form
  *   -> loc_t [B,P,4], conf_t [B,P,2] (label, weight), obj_t uint8 [B,P], overlap [B,P] or NULL
- * Force-match collisions keep the reference's "later GT wins" order (:122-123). */
+ * Force-match collisions keep the reference's "later GT wins" order (:122-123).
+ * max_gt = the largest per-image box count in gt_off (any size); the workspace has max_gt slots per image, and an
+ * image with MORE boxes than max_gt is matched against its first max_gt boxes only (never an out-of-bounds write). */
 size_t ct_match_workspace_bytes(int batch, int num_priors, int max_gt);
 int ct_match_batched(const float* truths, const int* gt_off, int batch, int max_gt,
                      const float* priors, int num_priors, float threshold, float var0, float var1,

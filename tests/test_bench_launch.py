@@ -1,0 +1,91 @@
+"""bench.py's launch contract: `--gpus N` starts its own N ranks, never reports fewer ranks as N GPUs.
+CPU part: the refusals that need no device.  GPU part (one-GPU test box): the un-launched 2-rank rehearsal."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(REPO, 'bench.py')
+
+
+def _run(args, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def _line(stdout):
+    rows = [l for l in stdout.splitlines() if l.startswith('{')]
+    assert len(rows) == 1, stdout[-2000:]
+    return json.loads(rows[0])
+
+
+def test_world_size_mismatch_is_refused():
+    """A torchrun environment that disagrees with --gpus must not produce a number (WORLD_SIZE=1 with --gpus 8 used
+    to run one rank silently)."""
+    r = _run(['--gpus', '8', '--steps', '1', '--warmup', '0'], {'WORLD_SIZE': '1', 'RANK': '0', 'LOCAL_RANK': '0'})
+    assert r.returncode != 0
+    assert 'refusing' in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+def test_no_device_no_number():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('needs a box without a HIP device')
+    for args in (['--gpus', '2'], ['--gpus', '1'], ['--train']):
+        r = _run(args + ['--steps', '1', '--warmup', '0'])
+        assert r.returncode != 0, args
+        assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+@pytest.mark.gpu
+def test_self_launch_two_ranks_on_this_box():
+    """`python bench.py --gpus 2` outside torchrun: two ranks are started, both answer an all-reduce, the line says
+    n_gpus 2 with both ranks listed.  The test box has one GPU, so the rehearsal shares it (--share-devices, gloo)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    args = ['--gpus', '2', '--steps', '3', '--warmup', '2', '--batch', '4', '--no-cpu-baseline', '--no-other-configs']
+    r = _run(args + ([] if ndev >= 2 else ['--share-devices']), {'CTDET_TUNE': '0'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _line(r.stdout)
+    assert line['n_gpus'] == 2 and line['config']['global_batch'] == 8
+    assert len(line['per_rank_ms_per_step']) == 2 and all(v > 0 for v in line['per_rank_ms_per_step'])
+    d = line['dist']
+    assert d['self_launched'] and [x['rank'] for x in d['ranks']] == [0, 1]
+    if ndev >= 2:
+        assert d['backend'] == 'nccl' and d['rccl_ranks'] == 2 and not d['devices_shared']
+        assert len({x['device'] for x in d['ranks']}) == 2
+    else:
+        assert d['backend'] == 'gloo' and d['rccl_ranks'] == 0 and d['devices_shared']
+
+
+@pytest.mark.gpu
+def test_more_ranks_than_gpus_fails_loudly():
+    import torch
+    n = torch.cuda.device_count() + 7
+    r = _run(['--gpus', str(n), '--steps', '1', '--warmup', '0'])
+    assert r.returncode != 0
+    assert 'refusing' in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+@pytest.mark.gpu
+def test_train_mode_two_ranks_reports_allreduce_and_overlap():
+    """bench.py --train --gpus 2 (self-launched): a data-parallel training step with the all-reduce timed alone,
+    the step without it and the overlap fraction on the line (BASELINE configs[3], small shape here)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    args = ['--train', '--gpus', '2', '--steps', '2', '--warmup', '1', '--size', '300', '--batch', '2', '--classes', '20',
+            '--phase', '1']
+    r = _run(args + ([] if ndev >= 2 else ['--share-devices']), {'CTDET_TUNE': '0'})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _line(r.stdout)
+    assert line['n_gpus'] == 2 and line['metric'].startswith('images/sec training step')
+    ar = line['allreduce']
+    assert ar['ms_alone'] > 0 and ar['buckets'] >= 1 and 0.0 <= ar['overlap_frac'] <= 1.0
+    assert line['grad_bytes'] > 100e6 and len(line['per_rank_ms_per_step']) == 2

@@ -259,3 +259,34 @@ def test_training_reduces_the_loss_on_a_fixed_batch():
         losses.append(float(loss))
     assert all(math.isfinite(v) for v in losses), losses
     assert losses[-1] < 0.5 * losses[0], losses
+
+
+def test_loss_with_ignored_boxes_labelled_minus_one():
+    """data/voc0712.py:237-238,263-264 ('incre' phase 2, instance_shot) write label -1 for ignored boxes and match()
+    copies it into conf_t; the reference never evaluates those priors (multibox_loss_combined.py:76,93,99).  The
+    masked-sum form must give the gather form's losses and gradients, and a finite gradient on every row."""
+    from layers.functions import PriorBox
+    from layers.modules.multibox_loss_combined import MultiBoxLoss_combined
+    from data import VOC_300
+    priors = PriorBox(VOC_300).forward()
+    P, ncls, B = priors.shape[0], 21, 3
+    g = torch.Generator().manual_seed(5)
+    targets = synth.targets(B, ncls, 99)
+    for t in targets:                       # every second box (and one whole image) ignored
+        t[::2, 4] = -1
+    targets[1][:, 4] = -1
+    targets[0][0, 4] = 3                    # at least one positive in the batch
+    pred = [torch.randn(B, P, 4, generator=g), torch.randn(B, P, ncls - 1, generator=g) * 3,
+            torch.randn(B, P, 2, generator=g)]
+    dev = [p.clone().cuda().requires_grad_(True) for p in pred]
+    cpu = [p.clone().requires_grad_(True) for p in pred]
+    ld = MultiBoxLoss_combined(ncls, 0.5, True, 0, True, 3, 0.5, False)(dev, priors.cuda(), [t.cuda() for t in targets])
+    lo = loss_ref.multibox_loss_combined(cpu, priors, targets, ncls)
+    sum(ld.values()).backward()
+    sum(lo.values()).backward()
+    for k in lo:
+        assert abs(ld[k].item() - lo[k].item()) < 2e-5 * max(1.0, abs(lo[k].item())), (k, ld[k].item(), lo[k].item())
+    for a, b, n in zip(dev, cpu, ('loc', 'conf', 'obj')):
+        ga = a.grad.cpu()
+        assert torch.isfinite(ga).all(), n
+        assert float((ga - b.grad).abs().max()) <= 2e-5 * float(b.grad.abs().max()) + 1e-9, n

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Context-Transformer parity sweep + error budget on the MI355X (measurement tool; the oracle is the checker):
+    python tools/ctx_parity.py [--budget] [--sweep] [--policies 0,256,1] [--batches 2,8,32]
+Policies = values of CTDET_WINO4_CTX: 0 = F(2x2,3x3) only, N = F(4x4,3x3) up to N input channels, 1 = everywhere."""
+import argparse, os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(REPO, 'context-transformer_amd'), REPO, os.path.join(REPO, 'tests')):
+    sys.path.insert(0, p)
+os.environ.setdefault('CTDET_TUNE', '0')
+import torch  # noqa: E402
+import ctx_cases as cc  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--budget', action='store_true'); ap.add_argument('--sweep', action='store_true')
+ap.add_argument('--policies', default='0,256,1'); ap.add_argument('--batches', default='2,8,32')
+ap.add_argument('--seeds', default='1234,7,99'); ap.add_argument('--kinds', default='randn,u8')
+ap.add_argument('--size', type=int, default=300)
+a = ap.parse_args()
+names = {'0': 'F(2x2,3x3) on every Winograd layer', '1': 'F(4x4,3x3) wherever the table picks it'}
+for pol in a.policies.split(','):
+    os.environ['CTDET_WINO4_CTX'] = pol
+    net = cc.build(a.size, 60)
+    label = names.get(pol, 'F(4x4,3x3) up to %s input channels, F(2x2,3x3) above' % pol)
+    if a.budget:
+        for batch in (8,):
+            rt = net.runtime(batch)
+            tiles = [st.rt.get('wino') for st in rt.conv_steps() if st.rt.get('wino')]
+            print('== budget, RFBNet-%d phase 2 transfer, bs %d, policy CTDET_WINO4_CTX=%s: %s (%d layers F(4x4), %d F(2x2))'
+                  % (a.size, batch, pol, label, tiles.count(4), tiles.count(2)))
+            for lab, e in cc.budget(net, a.size, 60, batch):
+                print('   %-86s %s' % (lab, ('%.1f x' % e) if 'amplification' in lab else '%.2e' % e), flush=True)
+    if a.sweep:
+        print('== sweep, RFBNet-%d phase 2 transfer, policy CTDET_WINO4_CTX=%s: %s' % (a.size, pol, label))
+        print('   %5s %5s %6s | %-10s %-10s %-10s | %s' % ('batch', 'seed', 'input', 'GPU-CPU32', 'GPU-fp64', 'CPU32-fp64', 'verdict'))
+        sd32, sd64 = cc.state(net), cc.state(net, torch.float64)
+        bad = 0
+        for batch in [int(b) for b in a.batches.split(',')]:
+            for seed in [int(s) for s in a.seeds.split(',')]:
+                for kind in a.kinds.split(','):
+                    r = cc.sweep_case(net, a.size, 60, 'transfer', batch, seed, kind, sd32, sd64)
+                    v = cc.verdict(r)
+                    bad += v != 'ok'
+                    print('   %5d %5d %6s | %.2e   %.2e   %.2e   | %s' % (batch, seed, kind, r['gpu_cpu32'], r['gpu_fp64'],
+                                                                         r['cpu32_fp64'], v), flush=True)
+        print('   cases not within 1e-4 of the fp32 CPU path: %d' % bad)
+    del net
+    torch.cuda.empty_cache()
