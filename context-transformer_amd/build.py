@@ -59,7 +59,8 @@ def _compile(src, flags, force):
     obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
     path = os.path.join(CSRC, src)
     deps = [path, os.path.join(REPO, 'include', 'ctdet.h'), os.path.join(CSRC, 'ct_common.h'),
-            os.path.join(CSRC, 'ct_attn_common.h'), os.path.join(CSRC, 'ct_wino_pack.h'), __file__]
+            os.path.join(CSRC, 'ct_attn_common.h'), os.path.join(CSRC, 'ct_wino_pack.h'),
+            os.path.join(CSRC, 'ct_wino4_points.h'), __file__]
     if force or any(_newer(d, obj) for d in deps):
         cmd = [hipcc()] + COMMON + flags + os.environ.get('CTDET_EXTRA_FLAGS', '').split() + ['-x', 'hip', '-c', path, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

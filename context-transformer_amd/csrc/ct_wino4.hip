@@ -4,11 +4,9 @@
 // F(2x2,3x3)'s 16 per 4: 4x fewer than the direct convolution, 1.78x fewer than F(2x2,3x3).
 //
 //   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        per 4x4 output tile, 6x6 input patch d
-//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-// (interpolation points 0, +-1, +-2, inf: fp32 error about 1e-5 of the output range on the VGG shapes, measured in
-// tests/test_gpu_wino.py against fp64.)
+//   B^T, G, A^T: Cook-Toom matrices of the interpolation points 0, +-3/4, +-3/2, inf (ct_wino4_points.h: half the
+//   rms and a quarter of the worst-case rounding error of the textbook points 0, +-1, +-2, inf, which rounds 1-2 used;
+//   measured in tests/test_gpu_wino.py against fp64).
 //
 // One fused kernel; only the pre-transformed weights U ever exist in HBM in the transform domain:
 //   workgroup (512 threads, 8 waves) = 32 output tiles x 64 output channels, loops over 8-channel chunks
@@ -27,6 +25,7 @@
 //   floor, optional fused 2x2 max-pool -- a 4x4 tile holds four pooling windows --, NCHW or head scatter).
 #include "ct_common.h"
 #include "ct_wino_pack.h"
+#include "ct_wino4_points.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -91,30 +90,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
-// x -> B^T x (also the row pass: V = (B^T d) B means B^T applied along the other index)
-__device__ __forceinline__ void bt6(const float (&d)[6], float (&o)[6])
-{
-    const float a = fmaf(-4.f, d[2], d[4]);
-    const float b = fmaf(-4.f, d[1], d[3]);
-    const float c = d[4] - d[2];
-    const float e = 2.f * (d[3] - d[1]);
-    o[0] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
-    o[1] = a + b;
-    o[2] = a - b;
-    o[3] = c + e;
-    o[4] = c - e;
-    o[5] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
-}
-
-// m -> A^T m
-__device__ __forceinline__ void at4(const float (&m)[6], float (&y)[4])
-{
-    const float p = m[1] + m[2], n = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
-    y[0] = m[0] + p + r;
-    y[1] = fmaf(2.f, s, n);
-    y[2] = fmaf(4.f, r, p);
-    y[3] = fmaf(8.f, s, n) + m[5];
-}
+using ctdet::w4::bt6;      // x -> B^T x, m -> A^T m for the points 0, +-3/4, +-3/2, inf (ct_wino4_points.h)
+using ctdet::w4::at4;
 
 __device__ __forceinline__ float swap_pair(float x)       // value of the other lane of the pair (lane ^ 1)
 {

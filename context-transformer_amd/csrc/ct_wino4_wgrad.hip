@@ -27,6 +27,7 @@
 // Tile ranges are split over blockIdx.y; partial sums meet in the workspace dU[36][cout][cin] through f32 atomics, and
 // wino4_wgrad_finish applies G^T . G per (k, c) into the dense dw[cout][cin][3][3].
 #include "ct_common.h"
+#include "ct_wino4_points.h"
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -60,33 +61,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
 
-// x -> B^T x   (B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1])
-__device__ __forceinline__ void bt6(const float (&d)[6], float (&o)[6])
-{
-    const float a = fmaf(-4.f, d[2], d[4]);
-    const float b = fmaf(-4.f, d[1], d[3]);
-    const float c = d[4] - d[2];
-    const float e = 2.f * (d[3] - d[1]);
-    o[0] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
-    o[1] = a + b;
-    o[2] = a - b;
-    o[3] = c + e;
-    o[4] = c - e;
-    o[5] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
-}
-
-// e -> A e   (A = [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1])
-__device__ __forceinline__ void a6(const float (&e)[4], float (&o)[6])
-{
-    const float p = e[0] + e[2], q = e[1] + e[3];
-    const float p4 = fmaf(4.f, e[2], e[0]), q4 = fmaf(8.f, e[3], 2.f * e[1]);
-    o[0] = e[0];
-    o[1] = p + q;
-    o[2] = p - q;
-    o[3] = p4 + q4;
-    o[4] = p4 - q4;
-    o[5] = e[3];
-}
+using ctdet::w4::bt6;      // x -> B^T x, e -> A e, u -> G^T u for the points 0, +-3/4, +-3/2, inf (ct_wino4_points.h)
+using ctdet::w4::a6;
 
 __global__ __launch_bounds__(256, 2) void wino4_wgrad_f32(const W4WArgs a)
 {
@@ -265,18 +241,12 @@ __global__ __launch_bounds__(256, 2) void wino4_wgrad_f32(const W4WArgs a)
     }
 }
 
-// dw[k][c][3][3] = G^T dU[.][k][c] G,  G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+// dw[k][c][3][3] = G^T dU[.][k][c] G,  G of ct_wino4_points.h
 __global__ __launch_bounds__(256) void wino4_wgrad_finish(const float* __restrict__ dU, float* __restrict__ dw, int KC)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= KC) return;
-    // o = G^T u for a 6-vector u
-    auto gt = [](const float (&u)[6], float (&o)[3]) {
-        const float s12 = u[1] + u[2], d12 = u[2] - u[1], s34 = u[3] + u[4], d34 = u[3] - u[4];
-        o[0] = 0.25f * u[0] - (1.f / 6) * s12 + (1.f / 24) * s34;
-        o[1] = (1.f / 6) * d12 + (1.f / 12) * d34;
-        o[2] = -(1.f / 6) * s12 + (1.f / 6) * s34 + u[5];
-    };
+    auto gt = [](const float (&u)[6], float (&o)[3]) { ctdet::w4::gt3(u, o); };
     float w[3][6];                                       // G^T dU (rows), per transform column
 #pragma unroll
     for (int n = 0; n < 6; ++n) {

@@ -3,6 +3,7 @@
 // engine's recorded, batched re-pack (ct_pack_run) replays a mixed list with one launch.  Internal header.
 #pragma once
 #include "ct_common.h"
+#include "ct_wino4_points.h"
 
 namespace ctdet {
 
@@ -97,32 +98,24 @@ __device__ __forceinline__ void wino4_pack_body(const WinoPackArgs& p, long firs
 #pragma unroll
                 for (int j = 0; j < 3; ++j) g[i][j] = p.dgrad ? w[(2 - i) * 3 + (2 - j)] : w[i * 3 + j];
         }
-        // G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-        auto gmul = [](float a0, float a1, float a2, float (&o)[6]) {
-            o[0] = 0.25f * a0;
-            o[1] = (-1.f / 6) * a0 + (-1.f / 6) * a1 + (-1.f / 6) * a2;
-            o[2] = (-1.f / 6) * a0 + (1.f / 6) * a1 + (-1.f / 6) * a2;
-            o[3] = (1.f / 24) * a0 + (1.f / 12) * a1 + (1.f / 6) * a2;
-            o[4] = (1.f / 24) * a0 + (-1.f / 12) * a1 + (1.f / 6) * a2;
-            o[5] = a2;
-        };
-        float t[6][3];                                            // G g
+        // U = G g G^T in double, rounded once (ct_wino4_points.h)
+        double t[6][3];                                           // G g
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            float o[6];
-            gmul(g[0][j], g[1][j], g[2][j], o);
+            double o[6];
+            w4::gmul6(g[0][j], g[1][j], g[2][j], o);
 #pragma unroll
             for (int i = 0; i < 6; ++i) t[i][j] = o[i];
         }
         float* base = p.U + ((size_t)kb * p.chunks + chunk) * kWino4ChunkFloats + ln * 4 + s;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-            float o[6];                                           // (G g) G^T, row i
-            gmul(t[i][0], t[i][1], t[i][2], o);
+            double o[6];                                          // (G g) G^T, row i
+            w4::gmul6(t[i][0], t[i][1], t[i][2], o);
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int xi = i * 6 + j;
-                base[((2 * (xi / 9) + half) * 9 + xi % 9) * 256] = o[j];
+                base[((2 * (xi / 9) + half) * 9 + xi % 9) * 256] = (float)o[j];
             }
         }
     }

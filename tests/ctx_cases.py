@@ -47,19 +47,29 @@ def sweep_case(net, size, C, setting, batch, seed, kind, sd32=None, sd64=None):
     idx = subset(batch)
     with torch.no_grad():
         got = [t.cpu()[idx] for t in net.forward_raw(x.cuda())]
+        raw_gpu = net.forward_raw(x.cuda(), init=True).cpu()[idx]
+        raw32 = rfbnet_ref.forward(sd32, x[idx], size, C, 2, 'ours', setting, init=True)
         w32 = rfbnet_ref.forward(sd32, x[idx], size, C, 2, 'ours', setting, raw=True)
         w64 = rfbnet_ref.forward(sd64, x[idx].double(), size, C, 2, 'ours', setting, raw=True)
     return {'batch': batch, 'seed': seed, 'kind': kind, 'images': idx,
             'gpu_cpu32': rel(got[1], w32[1]), 'gpu_fp64': rel(got[1], w64[1]), 'cpu32_fp64': rel(w32[1], w64[1]),
-            'loc_gpu_cpu32': rel(got[0], w32[0]), 'obj_gpu_cpu32': rel(got[2], w32[2])}
+            'loc_gpu_cpu32': rel(got[0], w32[0]), 'obj_gpu_cpu32': rel(got[2], w32[2]),
+            'rawconf_gpu_cpu32': rel(raw_gpu, raw32)}
 
 
-def verdict(r, tol=1e-4, slack=1.5):
-    """'ok' (<= tol vs the reference's fp32 CPU arithmetic), 'exception' (above tol, but no further from the fp64
-    truth than slack x the CPU path itself), or 'FAIL'."""
+def verdict(r, tol=1e-4, slack=2.5, cap=2.5e-4):
+    """'ok': within tol of the reference's fp32 CPU arithmetic.  'exception': above tol, but (a) no further from the
+    fp64 truth than slack x the CPU fp32 path itself and (b) within `cap` of the CPU path.  Else 'FAIL'.
+
+    Why a slack at all: the block multiplies a perturbation of its input by ~1000 (budget below), so two correct
+    fp32 evaluations of the network differ by about sqrt(2) x 5..7e-5 at best, and the statistic is the MAXIMUM over
+    ~7e5 elements of a heavy-tailed error (near-ties of the arg-max softmax).  Measured over 27 randn cases
+    (profiles/r03_ctx_parity.txt): e(GPU,fp64) / e(CPU32,fp64) = 1.1 .. 1.7 with F(2x2,3x3) everywhere and 1.2 .. 2.0
+    with the shipped policy, at an input (raw conf) error ratio of 1.27 / 1.32 -- VERDICT r02 proposed 1.5, which the
+    F(2x2,3x3)-only path itself misses at (bs 32, seed 7)."""
     if r['gpu_cpu32'] <= tol:
         return 'ok'
-    return 'exception' if r['gpu_fp64'] <= slack * r['cpu32_fp64'] else 'FAIL'
+    return 'exception' if (r['gpu_fp64'] <= slack * r['cpu32_fp64'] and r['gpu_cpu32'] <= cap) else 'FAIL'
 
 
 def pool_from_conf(conf, size, C):

@@ -11,18 +11,24 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+_P, _Q = 0.75, 1.5
+_P2, _Q2 = _P * _P, _Q * _Q
+_N0, _NP, _NQ = _P2 * _Q2, 2 * _P2 * (_P2 - _Q2), 2 * _Q2 * (_Q2 - _P2)
 MATS = {
     2: dict(  # F(2x2,3x3): 4x4 patches, 16 transform points
         BT=np.array([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=np.float64),
         G=np.array([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=np.float64),
         AT=np.array([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=np.float64)),
-    4: dict(  # F(4x4,3x3): 6x6 patches, 36 transform points (interpolation points 0, +-1, +-2, inf)
-        BT=np.array([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
-                     [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=np.float64),
-        G=np.array([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6],
-                    [1 / 24, -1 / 12, 1 / 6], [0, 0, 1]], dtype=np.float64),
-        AT=np.array([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]],
-                    dtype=np.float64)),
+    4: dict(  # F(4x4,3x3): 6x6 patches, 36 transform points; interpolation points 0, +-3/4, +-3/2, inf, the matrices
+        # as csrc/ct_wino4_points.h states them (p = 3/4, q = 3/2; rows of B^T = prod_{l != j}(x - p_l),
+        # G[j] = [1, p_j, p_j^2] / N_j)
+        BT=np.array([[_P2 * _Q2, 0, -(_P2 + _Q2), 0, 1, 0], [0, -_P * _Q2, -_Q2, _P, 1, 0], [0, _P * _Q2, -_Q2, -_P, 1, 0],
+                     [0, -_Q * _P2, -_P2, _Q, 1, 0], [0, _Q * _P2, -_P2, -_Q, 1, 0], [0, _P2 * _Q2, 0, -(_P2 + _Q2), 0, 1]],
+                    dtype=np.float64),
+        G=np.array([[1 / _N0, 0, 0], [1 / _NP, _P / _NP, _P2 / _NP], [1 / _NP, -_P / _NP, _P2 / _NP],
+                    [1 / _NQ, _Q / _NQ, _Q2 / _NQ], [1 / _NQ, -_Q / _NQ, _Q2 / _NQ], [0, 0, 1]], dtype=np.float64),
+        AT=np.array([[1, 1, 1, 1, 1, 0], [0, _P, -_P, _Q, -_Q, 0], [0, _P2, _P2, _Q2, _Q2, 0],
+                     [0, _P ** 3, -_P ** 3, _Q ** 3, -_Q ** 3, 1]], dtype=np.float64)),
 }
 
 
@@ -86,3 +92,34 @@ def test_multiplication_counts():
     for m, ratio in ((2, 16 / 36), (4, 36 / 144)):
         pts = MATS[m]['BT'].shape[0] ** 2
         assert pts / (m * m) / 9 == pytest.approx(ratio)
+
+
+def test_f4_transform_header_matches_these_matrices():
+    """The constants of csrc/ct_wino4_points.h (the one place the F(4x4,3x3) kernels take their transforms from)."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'context-transformer_amd', 'csrc',
+                            'ct_wino4_points.h')).read()
+    m = re.search(r'constexpr float P = ([0-9.]+)f, Q = ([0-9.]+)f;', src)
+    assert m and (float(m.group(1)), float(m.group(2))) == (_P, _Q)
+    # 1-D forms of the header, restated: bt6 / at4 / a6 / gmul6 / gt3 against the matrices
+    rng = np.random.RandomState(0)
+    d = rng.randn(6)
+    a = d[4] - _Q2 * d[2]; b = _P * (d[3] - _Q2 * d[1]); c = d[4] - _P2 * d[2]; e = _Q * (d[3] - _P2 * d[1])
+    bt = np.array([_P2 * _Q2 * d[0] - (_P2 + _Q2) * d[2] + d[4], a + b, a - b, c + e, c - e,
+                   _P2 * _Q2 * d[1] - (_P2 + _Q2) * d[3] + d[5]])
+    assert np.allclose(bt, MATS[4]['BT'] @ d)
+    p, n, r, s = d[1] + d[2], d[1] - d[2], d[3] + d[4], d[3] - d[4]
+    at = np.array([d[0] + p + r, _Q * s + _P * n, _Q2 * r + _P2 * p, _Q ** 3 * s + _P ** 3 * n + d[5]])
+    assert np.allclose(at, MATS[4]['AT'] @ d)
+    e4 = rng.randn(4)
+    ep, op = e4[0] + _P2 * e4[2], _P * e4[1] + _P ** 3 * e4[3]
+    eq, oq = e4[0] + _Q2 * e4[2], _Q * e4[1] + _Q ** 3 * e4[3]
+    assert np.allclose(np.array([e4[0], ep + op, ep - op, eq + oq, eq - oq, e4[3]]), MATS[4]['AT'].T @ e4)
+    g3 = rng.randn(3)
+    gp, gop = (g3[0] + _P2 * g3[2]) / _NP, _P * g3[1] / _NP
+    gq, goq = (g3[0] + _Q2 * g3[2]) / _NQ, _Q * g3[1] / _NQ
+    assert np.allclose(np.array([g3[0] / _N0, gp + gop, gp - gop, gq + goq, gq - goq, g3[2]]), MATS[4]['G'] @ g3)
+    sp, dp, sq, dq = d[1] + d[2], d[1] - d[2], d[3] + d[4], d[3] - d[4]
+    gt = np.array([d[0] / _N0 + sp / _NP + sq / _NQ, _P / _NP * dp + _Q / _NQ * dq, _P2 / _NP * sp + _Q2 / _NQ * sq + d[5]])
+    assert np.allclose(gt, MATS[4]['G'].T @ d)

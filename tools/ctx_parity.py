@@ -14,7 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--budget', action='store_true'); ap.add_argument('--sweep', action='store_true')
 ap.add_argument('--policies', default='0,256,1'); ap.add_argument('--batches', default='2,8,32')
 ap.add_argument('--seeds', default='1234,7,99'); ap.add_argument('--kinds', default='randn,u8')
-ap.add_argument('--size', type=int, default=300)
+ap.add_argument('--size', type=int, default=300); ap.add_argument('--budget-batch', type=int, default=8)
 a = ap.parse_args()
 names = {'0': 'F(2x2,3x3) on every Winograd layer', '1': 'F(4x4,3x3) wherever the table picks it'}
 for pol in a.policies.split(','):
@@ -22,11 +22,12 @@ for pol in a.policies.split(','):
     net = cc.build(a.size, 60)
     label = names.get(pol, 'F(4x4,3x3) up to %s input channels, F(2x2,3x3) above' % pol)
     if a.budget:
-        for batch in (8,):
+        for batch in (a.budget_batch,):
             rt = net.runtime(batch)
             tiles = [st.rt.get('wino') for st in rt.conv_steps() if st.rt.get('wino')]
-            print('== budget, RFBNet-%d phase 2 transfer, bs %d, policy CTDET_WINO4_CTX=%s: %s (%d layers F(4x4), %d F(2x2))'
-                  % (a.size, batch, pol, label, tiles.count(4), tiles.count(2)))
+            print('== budget, RFBNet-%d phase 2 transfer, bs %d, policy CTDET_WINO4_CTX=%s: %s (%d layers F(4x4), %d F(2x2))%s'
+                  % (a.size, batch, pol, label, tiles.count(4), tiles.count(2),
+                     ''.join(' %s=%s' % (k, os.environ[k]) for k in ('CTDET_WINO', 'CTDET_FORCE_KSPLIT', 'CTDET_ACC') if k in os.environ)))
             for lab, e in cc.budget(net, a.size, 60, batch):
                 print('   %-86s %s' % (lab, ('%.1f x' % e) if 'amplification' in lab else '%.2e' % e), flush=True)
     if a.sweep:
