@@ -175,8 +175,14 @@ def pmc_lookup(pmc, name):
     """HBM bytes per launch of kernel `name` (bench naming) in the PMC table (rocprof naming)."""
     import re
     m = re.match(r'conv_igemm_f32<(\d+)x(\d+),(\d+)x(\d+)', name)
+    x = re.match(r'conv_x3_f32<\d+x\d+,(\d+)x(\d+)k(\d+)(d?)>', name)
     for k, (v, _) in pmc.items():
-        if m:
+        if x:       # rocprof: conv_x3_f32<BM, BN, BK, dual>; one instantiation serves every filter geometry
+            f = [t.strip() for t in k[k.find('<') + 1:k.find('>')].split(',')] if '<' in k else []
+            if k.startswith('conv_x3_f32') and len(f) >= 4 and tuple(f[:3]) == x.groups()[:3] and \
+                    (f[3] in ('true', '1')) == bool(x.group(4)):
+                return v
+        elif m:
             f = [x.strip() for x in k[k.find('<') + 1:k.find('>')].split(',')] if '<' in k else []
             if k.startswith('conv_igemm_f32') and len(f) >= 5 and (f[0], f[1], f[3], f[4]) == m.groups():
                 return v
@@ -192,23 +198,35 @@ def conv_roofline(rt, batch, pmc):
     lib = _lib.lib()
     agg = {}
     bf16 = getattr(rt.backend, 'load_input', None) is not None       # NHWC bf16 path (--dtype bf16, configs[4])
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_F32_MFMA_TFLOPS
+    x3_names = rt.backend.x3_names() if hasattr(rt.backend, 'x3_names') else []
     for st, e0, e1 in rt.event_log:
         cfg = st.rt['desc'].config
         wino = int(st.rt.get('wino') or 0)              # 0, 2 = F(2x2,3x3), 4 = F(4x4,3x3)
-        name = 'conv_bf16_nhwc' if bf16 else st.rt.get('kernel_name') or (WINOGRAD_KERNEL[wino] if wino else
-               'conv_igemm_f32<%dx%d,%s>' % (st.kh, st.kw, lib.ct_conv_config_name(cfg - 1).decode() if cfg > 0 else 'auto'))
-        a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
+        x3 = st.rt.get('x3')
+        if bf16:
+            name, mult, pk = 'conv_bf16_nhwc', 1.0, PEAK_BF16_MFMA_TFLOPS
+        elif wino:
+            name, mult, pk = WINOGRAD_KERNEL[wino], WINOGRAD_MULT_RATIO[wino], PEAK_F32_MFMA_TFLOPS
+        elif x3 is not None:
+            # bf16x3: six bf16 MFMA products per fp32 multiply-add, on the bf16 pipe
+            name, mult, pk = 'conv_x3_f32<%dx%d,%s>' % (st.kh, st.kw, x3_names[x3][3:]), 6.0, PEAK_BF16_MFMA_TFLOPS
+        else:
+            name = st.rt.get('kernel_name') or 'conv_igemm_f32<%dx%d,%s>' % (
+                st.kh, st.kw, lib.ct_conv_config_name(cfg - 1).decode() if cfg > 0 else 'auto')
+            mult, pk = 1.0, PEAK_F32_MFMA_TFLOPS
+        a = agg.setdefault(name, [0.0, 0.0, 0, 0.0, pk])
         a[0] += e0.elapsed_time(e1) * 1e-3
         a[1] += st.flops(batch)                # direct-convolution flops
         a[2] += 1
-        a[3] += st.flops(batch) * (WINOGRAD_MULT_RATIO[wino] if wino else 1.0)     # multiply-adds sent to the MFMA pipe
+        a[3] += st.flops(batch) * mult         # multiply-adds x2 sent to the matrix pipe the kernel uses
     tot_t = sum(a[0] for a in agg.values())
     tot_f = sum(a[1] for a in agg.values())
     tot_x = sum(a[3] for a in agg.values())
-    name, (t, f, n, fx) = max(agg.items(), key=lambda kv: kv[1][0])
+    tot_peak_s = sum(a[3] / (a[4] * 1e12) for a in agg.values())     # seconds the executed work needs at its pipe's peak
+    name, (t, f, n, fx, peak) = max(agg.items(), key=lambda kv: kv[1][0])
     wino = {v: k for k, v in WINOGRAD_KERNEL.items()}.get(name, 0)
     ach = fx / t / 1e12
+    nlog, nconv = max(1, len(rt.event_log)), len(rt.conv_steps())
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
         'frac': round(ach / peak, 4), 'traffic': pmc_lookup(pmc, name),
@@ -216,25 +234,31 @@ def conv_roofline(rt, batch, pmc):
         'flops_per_launch': round(fx / n),
         'flops_definition': 'multiply-adds x2 executed on the matrix pipe per launch' +
                             (' = direct-convolution flops x %s (Winograd F(%dx%d,3x3), output-tile padding not counted)'
-                             % ({2: '16/36', 4: '36/144'}[wino], wino, wino) if wino else ''),
+                             % ({2: '16/36', 4: '36/144'}[wino], wino, wino) if wino else
+                             ' = direct-convolution flops x 6 (bf16x3 split, bf16 MFMA pipe)' if name.startswith('conv_x3') else ''),
         'algorithmic_flops_per_launch': round(f / n),
         'algorithmic_achieved': round(f / t / 1e12, 2),
-        'algorithmic_frac': round(f / t / 1e12 / peak, 4),
+        'algorithmic_frac': round(f / t / 1e12 / PEAK_F32_MFMA_TFLOPS, 4) if not bf16 else round(f / t / 1e12 / peak, 4),
         'winograd_mult_ratio': round(WINOGRAD_MULT_RATIO[wino], 4) if wino else 1.0,
-        'by_kernel': {k: {'launches_per_step': round(v[2] / max(1, len(rt.event_log)) * len(rt.conv_steps()), 1),
-                          'ms_per_step': round(v[0] / max(1, len(rt.event_log)) * len(rt.conv_steps()) * 1e3, 3),
-                          'executed_frac': round(v[3] / v[0] / 1e12 / peak, 4),
-                          'algorithmic_frac': round(v[1] / v[0] / 1e12 / peak, 4)}
-                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:4]},
+        'peaks': {'f32_mfma_tflops': PEAK_F32_MFMA_TFLOPS, 'bf16_mfma_tflops': PEAK_BF16_MFMA_TFLOPS,
+                  'note': 'executed_frac of a kernel is against the pipe it runs on (conv_x3_f32: bf16 MFMA, six bf16 '
+                          'products per fp32 multiply-add; every other fp32 kernel: fp32 MFMA); algorithmic_frac is the '
+                          'direct-convolution flop rate over the fp32 MFMA peak (can exceed 1: Winograd / bf16x3 savings)'},
+        'by_kernel': {k: {'launches_per_step': round(v[2] / nlog * nconv, 1),
+                          'ms_per_step': round(v[0] / nlog * nconv * 1e3, 3),
+                          'executed_frac': round(v[3] / v[0] / 1e12 / v[4], 4),
+                          'algorithmic_frac': round(v[1] / v[0] / 1e12 / (v[4] if bf16 else PEAK_F32_MFMA_TFLOPS), 4)}
+                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:6]},
         'all_conv': {'achieved': round(tot_x / tot_t / 1e12, 2),
-                     'frac': round(tot_x / tot_t / 1e12 / peak, 4),
+                     # time the executed work would need at the peak of the pipe it runs on / measured launch time
+                     'frac': round(tot_peak_s / tot_t, 4),
                      'algorithmic_achieved': round(tot_f / tot_t / 1e12, 2),
-                     'algorithmic_frac': round(tot_f / tot_t / 1e12 / peak, 4),
+                     'algorithmic_frac': round(tot_f / tot_t / 1e12 / (peak if bf16 else PEAK_F32_MFMA_TFLOPS), 4),
                      'time_share_of_dominant': round(t / tot_t, 3),
                      # sum of the launch durations; with the two-stream schedule launches overlap, so this
                      # can exceed the wall time of a step (and every duration includes the contention)
-                     'sum_launch_ms_per_step': round(tot_t / max(1, len(rt.event_log)) * len(rt.conv_steps()) * 1e3, 3),
-                     'launches_per_step': len(rt.conv_steps()),
+                     'sum_launch_ms_per_step': round(tot_t / nlog * nconv * 1e3, 3),
+                     'launches_per_step': nconv,
                      'streams': 2 if getattr(rt, 'side', None) is not None else 1},
     }
 
@@ -640,6 +664,13 @@ def main():
         roof['stages'] = stage_rooflines(pipe, x, 5, pmc)
         roof['traffic_source'] = sorted({v[1] for v in pmc.values()}) or None
     counts = int(pipe.post.out_count.sum().item())
+    kinds = [('winograd' if st.rt.get('wino') else 'bf16x3' if st.rt.get('x3') is not None else 'fp32_mfma')
+             for st in pipe.rt.conv_steps()]
+    arith = ('bf16 MFMA, fp32 accumulate' if a.dtype == 'bf16' else
+             'fp32 results: %d launches Winograd F(4x4/2x2,3x3) on the fp32 MFMA, %d launches bf16x3 split (every fp32 '
+             'operand = 3 exact bf16 pieces, 6 products on the bf16 MFMA, fp32 accumulate in two accumulators; per-layer '
+             'error vs fp64 below the fp32 MFMA kernel\'s, tests/test_gpu_x3.py), %d launches fp32 MFMA direct'
+             % (kinds.count('winograd'), kinds.count('bf16x3'), kinds.count('fp32_mfma')))
     conv_gflop = round(pipe.rt.plan.conv_flops() / batch / 1e9, 2)
     tuned = bool(pipe.rt.tuned)
     other = None
@@ -687,6 +718,7 @@ def main():
             'ms_per_step': round(dt / a.steps * 1e3, 3), 'higher_is_better': True, 'scaling': a.scaling,
             'launch_mode': 'hipGraph replay' if graph_mode else 'eager launches',
             'vs_baseline': None, 'dtype': a.dtype, 'data': 'synthetic',
+            'arith': arith,
             'config': {'workload': 'RFBNet-%d VGG16 inference, bs=%d per GPU, %d fg classes, phase %d%s: '
                                    'fwd + softmax/decode + per-class NMS(0.45) + top-200; name-seeded random '
                                    'weights, randn images' % (a.size, batch, num_fg, a.phase,

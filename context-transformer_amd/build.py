@@ -30,6 +30,7 @@ SOURCES = {
     'ct_wino_wgrad.hip': [],
     'ct_wino4_wgrad.hip': [],
     'ct_conv_bf16.hip': [],
+    'ct_conv_x3.hip': [],
     'ct_pool.hip': [],
     'ct_preproc.hip': ['-ffp-contract=off'],
     'ct_attn.hip': [],

@@ -1,0 +1,618 @@
+// libctdet: fp32 convolution on the bf16 matrix pipe -- "bf16x3": every fp32 operand is split EXACTLY into three
+// bfloat16 pieces (x = hi + mid + lo, 3 x 8 significant bits, by truncation) and the product a.b is evaluated as the
+// six piece products of weight 2^0 .. 2^-16 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the three dropped products are below 2^-24 |a.b|.  Same layers,
+// descriptor and fused epilogue as ct_conv2d_fwd (models/RFB_Net_vgg.py:7-22 BasicConv, the plain Conv2d layers and the
+// multibox heads :238-248): NCHW fp32 in, NCHW fp32 / channels-last head scatter out.
+//
+// Why: the fp32-input MFMA runs at the vector rate (157 TFLOP/s); the bf16 MFMA at 16x that, so six bf16 MFMAs cost
+// 0.375 of one fp32 MFMA (MI355X_MICROARCH.md) -- for the layers that have no Winograd form (1x1, dilated, strided,
+// 1x3 / 3x1: ~40 % of the conv time of a step).  Accuracy: bf16 x bf16 products are exact in fp32 and a k-group of 16
+// is summed inside the MFMA before ONE rounding into the accumulator, so the accumulator sees 6 K / 16 roundings
+// where the fp32 MFMA kernel (v_mfma_f32_32x32x2_f32) sees K / 2; measured per layer against fp64 in
+// tests/test_gpu_x3.py (gate: no worse than ct_conv2d_fwd's error).
+//
+// GEMM view:  C[M = cout][N = batch*oh*ow] = W[M][K] * im2col(X)[K][N],  k ordered (channel group, tap, channel in group):
+// a k-step = BK (16 or 32) input channels of ONE filter tap, so filter geometry is a runtime loop (no template per
+// filter size) and a thread's gather of a k-step is 8 loads `buffer_load_dword voffset = its pixel at that tap,
+// soffset = wave-uniform channel` (adjacent lanes = adjacent pixels: coalesced; out-of-range offset = 0 = padding).
+//   workgroup 256 threads = 4 waves, tile BM x BN in {128x128, 64x128, 128x64, 64x64}, wave tile (BM/2) x (BN/2)
+//   B side: thread (pixel p = tid % BN, k-octet) loads 8 channels, splits them in registers (4 VALU per element + 3
+//     v_perm per pair) and writes three 16-byte rows into LDS [piece][k-octet][pixel][8 bf16]: linear in the lane
+//     index, so every ds_write_b128 / ds_read_b128 is conflict-free without padding;
+//   A side: the weights are split once per parameter version by ct_conv_pack_weights_x3 into
+//     [k-step][piece][k-octet][m_pad][8 bf16]; a tile is three contiguous runs per octet, copied with 16-byte loads;
+//   LDS double buffered, one barrier per k-step; the loads of step s+1 are issued before the MFMAs of step s.
+// Small maps use the same deterministic slab split-K as ct_conv2d_fwd (desc->ksplit).
+#include "ct_common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+#include <type_traits>
+#include <unordered_set>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kInvalidOff = 0x7FFFFFF0;
+constexpr long long kMaxBufBytes = 0x7FFFFF00LL;
+
+struct X3Args {
+    const float* in;
+    const unsigned char* wx3;       // [step][piece 3][octet BK/8][m_pad][8 bf16]
+    const float* scale;
+    const float* shift;
+    const float* res;
+    const float* lo;
+    float* out;
+    unsigned in_bytes, w_bytes;
+    int Cin, H, W, in_ctot, in_coff;
+    int M, M_pad, cgroups, KH, KW;
+    int stride, pad_h, pad_w, dil;
+    int OW, OHW, Npix;
+    int out_ctot, out_coff, res_ctot, res_coff;
+    float res_scale;
+    int relu;
+    int nseg;
+    ct_out_segment seg[3];
+    int tiles_m, tiles_n;
+    int ksplit, steps_per_split, nsteps;
+    float* ws;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// x = hi + mid + lo exactly (fp32 has 24 significant bits, every piece keeps the next 8 by truncation); returns
+// the three fp32 bit patterns whose upper halves are the bf16 pieces
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l)
+{
+    h = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+    const float r1 = x - __builtin_bit_cast(float, h);
+    m = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+    l = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, m));
+}
+
+// upper halves of (e0, e1) -> one dword [bf16 e0 | bf16 e1 << 16]
+__device__ __forceinline__ int pack_hi(unsigned e0, unsigned e1)
+{
+    return (int)__builtin_amdgcn_perm(e1, e0, 0x07060302u);
+}
+
+// DUAL: the hi.hi products accumulate in one register block, the five small products (2^-8 .. 2^-16 of it) in a second
+//   one, added at the end -- the large accumulator then sees K / 16 roundings instead of 6 K / 16 (measured: 2.5x less
+//   error against fp64 than ct_conv2d_fwd's v_mfma_f32_32x32x2_f32, which sees K / 2).
+// One k-step is ONE basic block: in source order a slice of the side work of the step (LDS write of tile s+1 from the
+// staging registers, the split of one gathered element, the re-issue of the same registers' loads for tile s+2) follows
+// every MFMA, and the compiler's scheduler keeps that interleaving (pinning the slots with sched_barrier measured
+// 10-40 % SLOWER here, as cdna_hip_programming.md warns for 32-cycle MFMAs); first / last steps are peeled (STORE /
+// LOAD flags) so no branch cuts the block.
+template <int BM, int BN, int BK, bool DUAL>
+__global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
+{
+    constexpr int OCT = BK / 8;                 // k-octets per k-step
+    constexpr int NH = BK / 16;                 // MFMA k-groups per k-step
+    constexpr int WM = BM / 2, WN = BN / 2;     // wave tile (2 x 2 waves)
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_PIECE = OCT * BM * 16;      // bytes of one piece of the A tile
+    constexpr int B_PIECE = OCT * BN * 16;
+    constexpr int A_BYTES = 3 * A_PIECE, B_BYTES = 3 * B_PIECE;
+    constexpr int NA = (3 * OCT * BM + 255) / 256;          // 16-byte rows of A per thread and k-step
+    constexpr int OSTR = 256 / BN;                          // octet stride between a thread's gathers
+    constexpr int GPT = OCT / OSTR;                         // k-octets gathered per thread and k-step
+    static_assert(256 % BN == 0 && OCT % OSTR == 0 && GPT >= 1, "B staging: every thread gathers GPT whole octets");
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];    // 2 x (A_BYTES + B_BYTES)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave & 1) * WM, wn0 = (wave >> 1) * WN;
+
+    int wg;
+    {   // XCD-aware tile order (cout-tile fastest): workgroups sharing an im2col tile share an L2
+        const int nwg = a.tiles_m * a.tiles_n;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, local = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int m0 = (wg % a.tiles_m) * BM;
+    const int n0 = (wg / a.tiles_m) * BN;
+
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wx3, a.w_bytes);
+
+    // ---- this thread's output pixel (B gather) ----
+    const int bp = tid % BN;
+    const int oct0 = __builtin_amdgcn_readfirstlane(tid / BN);       // first k-octet of this thread; next: + OSTR
+    const int HW = a.H * a.W;
+    int img_base, ih0, iw0;
+    bool pvalid;
+    {
+        const int P = n0 + bp;
+        pvalid = P < a.Npix;
+        const int Pc = pvalid ? P : 0;
+        const int n = Pc / a.OHW;
+        const int s = Pc - n * a.OHW;
+        const int oh = s / a.OW, ow = s - oh * a.OW;
+        ih0 = oh * a.stride - a.pad_h;
+        iw0 = ow * a.stride - a.pad_w;
+        img_base = (n * a.in_ctot + a.in_coff) * HW;
+    }
+
+    // ---- A staging constants ----
+    int a_voff[NA], a_lds[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        int f = tid + 256 * j;
+        if (f >= 3 * OCT * BM) f %= (3 * OCT * BM);      // surplus lanes duplicate an element (same data, same slot)
+        const int row = f % BM, po = f / BM;             // po = piece * OCT + octet
+        const int col = m0 + row;
+        a_voff[j] = col < a.M_pad ? (po * a.M_pad + col) * 16 : kInvalidOff;
+        a_lds[j] = po * (BM * 16) + row * 16;
+    }
+    const int a_step_bytes = 3 * OCT * a.M_pad * 16;
+    const int chan_bytes = HW * 4;
+
+    i32x4 areg[NA];
+    float breg[GPT][8];
+    unsigned sh[GPT][8], sm[GPT][8], sl[GPT][8];      // split pieces of the tile being stored
+
+    // ---- loader state: (channel group, tap) of the NEXT tile to load, advanced tap-fastest so the BK channels of a
+    // group stay in cache over the filter taps; everything wave-uniform lives in SGPRs
+    const int s0 = blockIdx.y * a.steps_per_split;
+    const int s1 = min(a.nsteps, s0 + a.steps_per_split);
+    int ld_kh, ld_kw, ld_cbase, ld_asoff;
+    {
+        const int khw = a.KH * a.KW;
+        const int cg = s0 / khw, tap = s0 - cg * khw;
+        ld_kh = tap / a.KW;
+        ld_kw = tap - ld_kh * a.KW;
+        ld_cbase = cg * BK;
+        ld_asoff = s0 * a_step_bytes;
+    }
+    int ld_voff = 0;
+    auto begin_load = [&]() {                      // per-tile part of the gather address: this lane's pixel at the tap
+        const int ih = ih0 + ld_kh * a.dil, iw = iw0 + ld_kw * a.dil;
+        const bool ok = pvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        ld_voff = ok ? (img_base + ih * a.W + iw) * 4 : kInvalidOff;
+    };
+    auto end_load = [&]() {                        // advance (tap, channel group)
+        ld_asoff += a_step_bytes;
+        ++ld_kw;
+        if (ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
+        if (ld_kh == a.KH) { ld_kh = 0; ld_cbase += BK; }
+    };
+    auto load_a = [&](int j) { areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, a_voff[j], ld_asoff, 0); };
+    int ld_soff = 0;                               // running channel offset of the gather (bytes, wave-uniform)
+    auto load_b = [&](int g, int e) {
+        // Cin is a multiple of BK (checked by the launcher): every channel of a group exists
+        if (e == 0) ld_soff = (ld_cbase + (oct0 + g * OSTR) * 8) * chan_bytes;
+        breg[g][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, ld_voff, ld_soff, 0));
+        ld_soff += chan_bytes;
+    };
+    auto store_a = [&](int j, int buf) {
+        *reinterpret_cast<i32x4*>(lds + buf * (A_BYTES + B_BYTES) + a_lds[j]) = areg[j];
+    };
+    auto store_b = [&](int g, int piece, int buf) {
+        const unsigned(&v)[8] = piece == 0 ? sh[g] : piece == 1 ? sm[g] : sl[g];
+        i32x4 pk;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pk[q] = pack_hi(v[2 * q], v[2 * q + 1]);
+        *reinterpret_cast<i32x4*>(lds + buf * (A_BYTES + B_BYTES) + A_BYTES + piece * B_PIECE +
+                                  ((oct0 + g * OSTR) * BN + bp) * 16) = pk;
+    };
+    // side work of a k-step as a list of items: A rows, then per gathered octet 8 x (split + reload) and 3 x (pack + write)
+    constexpr int NW = NA + GPT * 11;
+    auto side_item = [&](int w, int buf, auto store_c, auto load_c) {
+        constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
+        if (w < NA) {
+            if (STORE) store_a(w, buf);
+            if (LOAD) load_a(w);
+        } else {
+            const int g = (w - NA) / 11, r = (w - NA) % 11;
+            if (r < 8) {
+                if (STORE) split3(breg[g][r], sh[g][r], sm[g][r], sl[g][r]);
+                if (LOAD) load_b(g, r);
+            } else if (STORE) {
+                store_b(g, r - 8, buf);
+            }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+    f32x16 acs[DUAL ? TM : 1][DUAL ? TN : 1];     // DUAL: sum of the five small products
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc[i][j][r] = 0.f;
+                if (DUAL) acs[i][j][r] = 0.f;
+            }
+
+    constexpr int NMF = NH * 6 * TM * TN;                     // MFMAs per k-step and wave
+    constexpr int WPS = (NW + NMF - 2) / (NMF - 1);           // side items per MFMA slot (the last slot stays free)
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    auto k_step = [&](int buf, auto store_c, auto load_c) {
+        constexpr bool LOAD = decltype(load_c)::value;
+        const unsigned char* A = lds + buf * (A_BYTES + B_BYTES) + (wm0 + l31) * 16;
+        const unsigned char* B = lds + buf * (A_BYTES + B_BYTES) + A_BYTES + (wn0 + l31) * 16;
+        i32x4 fa[NH][3][TM], fb[NH][3][TN];
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[h][p][i] = *reinterpret_cast<const i32x4*>(A + p * A_PIECE + (2 * h + hsel) * (BM * 16) + i * 512);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[h][p][j] = *reinterpret_cast<const i32x4*>(B + p * B_PIECE + (2 * h + hsel) * (BN * 16) + j * 512);
+            }
+        if (LOAD) begin_load();
+        // smallest products first: (mid, mid), (lo, hi), (hi, lo), (mid, hi), (hi, mid), then (hi, hi)
+        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int s = 0; s < NMF; ++s) {
+            const int h = s / (6 * TM * TN), t = (s / (TM * TN)) % 6, i = (s / TN) % TM, j = s % TN;
+            if (DUAL && t < 5)
+                acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[h][PA[t]][i]),
+                                                                    __builtin_bit_cast(bf16x8, fb[h][PB[t]][j]),
+                                                                    acs[i][j], 0, 0, 0);
+            else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[h][PA[t]][i]),
+                                                                    __builtin_bit_cast(bf16x8, fb[h][PB[t]][j]),
+                                                                    acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < WPS; ++q) {
+                const int w = s * WPS + q;
+                if (w < NW) side_item(w, buf ^ 1, store_c, load_c);
+            }
+        }
+        if (LOAD) end_load();
+        __syncthreads();
+    };
+
+    // prologue: tile s0 -> LDS buffer 0, tile s0 + 1 -> staging registers
+    begin_load();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) side_item(w, 0, F_{}, T_{});
+    end_load();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) side_item(w, 0, T_{}, F_{});
+    if (s0 + 1 < s1) {
+        begin_load();
+#pragma unroll
+        for (int w = 0; w < NW; ++w) side_item(w, 0, F_{}, T_{});
+        end_load();
+    }
+    __syncthreads();
+    int step = s0;
+    for (; step + 2 < s1; ++step) k_step((step - s0) & 1, T_{}, T_{});
+    if (step + 1 < s1) { k_step((step - s0) & 1, T_{}, F_{}); ++step; }
+    k_step((step - s0) & 1, F_{}, F_{});
+    if (DUAL) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acs[i][j][r];
+    }
+
+    if (a.ksplit > 1) {
+        float* const slab = a.ws + (size_t)blockIdx.y * a.M * a.Npix;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int P = n0 + wn0 + j * 32 + l31;
+            if (P >= a.Npix) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                    if (co < a.M) slab[(size_t)co * a.Npix + P] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+
+    // ---- epilogue (the arithmetic of ct_conv2d_fwd) ----
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int P = n0 + wn0 + j * 32 + l31;
+        if (P >= a.Npix) continue;
+        const int n = P / a.OHW;
+        const int s = P - n * a.OHW;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                if (co >= a.M) continue;
+                float v = acc[i][j][r] * a.scale[co] + a.shift[co];
+                if (a.res) v = v * a.res_scale + a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
+                if (a.lo) v = fmaxf(v, a.lo[co]);
+                else if (a.relu) v = fmaxf(v, 0.f);
+                if (a.nseg == 0) {
+                    a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 3; ++g)
+                        if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
+                            a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                         (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
+                }
+            }
+        }
+    }
+}
+
+// sum of the split-K slabs in split order, then the fused epilogue
+__global__ __launch_bounds__(256) void conv_x3_splitk_epilogue(const X3Args a)
+{
+    const int total = a.M * a.Npix;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int co = idx / a.Npix, P = idx - co * a.Npix;
+        const int n = P / a.OHW, s = P - n * a.OHW;
+        float sum = a.ws[idx];
+        for (int k = 1; k < a.ksplit; ++k) sum += a.ws[(size_t)k * total + idx];
+        float v = sum * a.scale[co] + a.shift[co];
+        if (a.res) v = v * a.res_scale + a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
+        if (a.lo) v = fmaxf(v, a.lo[co]);
+        else if (a.relu) v = fmaxf(v, 0.f);
+        if (a.nseg == 0) {
+            a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
+        } else {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
+                    a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                 (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
+        }
+    }
+}
+
+// ---- weight split: [cout][cin][kh][kw] fp32 -> [step = (cgroup, tap)][piece][octet][m_pad][8 bf16] ----
+struct X3PackArgs {
+    const float* w[6];
+    int mbeg[7];
+    int nparts, cin, khw, bk, m_pad, cgroups;
+    unsigned short* out;
+};
+
+__global__ void x3_pack_kernel(const X3PackArgs p)
+{
+    const int oct = p.bk / 8;
+    const long rows = (long)p.cgroups * p.khw * oct * p.m_pad;            // 8-channel rows (all three pieces each)
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < rows; idx += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx % p.m_pad);
+        long t = idx / p.m_pad;
+        const int o = (int)(t % oct);
+        t /= oct;
+        const int tap = (int)(t % p.khw), cg = (int)(t / p.khw);
+        const float* src = nullptr;
+        int mm = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            if (i < p.nparts && m >= p.mbeg[i] && m < p.mbeg[i + 1]) { src = p.w[i]; mm = m - p.mbeg[i]; }
+        const long step = (long)cg * p.khw + tap;
+        unsigned short* base = p.out + (((step * 3) * oct + o) * (long)p.m_pad + m) * 8;
+        const long piece_stride = (long)oct * p.m_pad * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = cg * p.bk + o * 8 + e;
+            const float v = (src && ci < p.cin) ? src[((size_t)mm * p.cin + ci) * p.khw + tap] : 0.f;
+            unsigned h, mid, l;
+            split3(v, h, mid, l);
+            base[e] = (unsigned short)(h >> 16);
+            base[piece_stride + e] = (unsigned short)(mid >> 16);
+            base[2 * piece_stride + e] = (unsigned short)(l >> 16);
+        }
+    }
+}
+
+struct X3Cfg {
+    int bm, bn, bk, dual;
+    const char* name;
+};
+// name: x3:<BM>x<BN>k<BK>[d]   d = dual accumulators -- the configurations the engine may select (accuracy gate);
+// the single-accumulator forms are kept for the comparison in tests/test_gpu_x3.py and tools/x3_probe.py
+const X3Cfg kX3[] = {
+    {128, 128, 16, 1, "x3:128x128k16d"}, {64, 128, 16, 1, "x3:64x128k16d"}, {128, 64, 32, 1, "x3:128x64k32d"},
+    {64, 64, 32, 1, "x3:64x64k32d"},     {128, 128, 16, 0, "x3:128x128k16"}, {64, 128, 16, 0, "x3:64x128k16"},
+};
+constexpr int kNumX3 = sizeof(kX3) / sizeof(kX3[0]);
+
+template <typename K>
+hipError_t launch_x3(K kernel, size_t smem, const X3Args& a, hipStream_t st)
+{
+    if (smem > 64 * 1024) {
+        static std::mutex mu;
+        static std::unordered_set<const void*> raised;
+        const void* fn = reinterpret_cast<const void*>(kernel);
+        std::lock_guard<std::mutex> lock(mu);
+        if (!raised.count(fn)) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return e;
+            raised.insert(fn);
+        }
+    }
+    hipLaunchKernelGGL(kernel, dim3(a.tiles_m * a.tiles_n, a.ksplit > 1 ? a.ksplit : 1), dim3(256), smem, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_cfg(int cfg, const X3Args& a, hipStream_t st)
+{
+    switch (cfg) {
+#define X3_CASE(idx, BM, BN, BK, DU) \
+    case idx: return launch_x3(conv_x3_f32<BM, BN, BK, DU>, (size_t)2 * 3 * (BK / 8) * (BM + BN) * 16, a, st);
+        X3_CASE(0, 128, 128, 16, true)
+        X3_CASE(1, 64, 128, 16, true)
+        X3_CASE(2, 128, 64, 32, true)
+        X3_CASE(3, 64, 64, 32, true)
+        X3_CASE(4, 128, 128, 16, false)
+        X3_CASE(5, 64, 128, 16, false)
+#undef X3_CASE
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace
+
+extern "C" int ct_conv_x3_num_configs(void) { return kNumX3; }
+
+extern "C" const char* ct_conv_x3_config_name(int i) { return (i >= 0 && i < kNumX3) ? kX3[i].name : "?"; }
+
+extern "C" int ct_conv_x3_config_bk(int i) { return (i >= 0 && i < kNumX3) ? kX3[i].bk : -1; }
+
+// bytes of the split weights for k-steps of bk (16 or 32) channels
+extern "C" size_t ct_conv_x3_packed_bytes(int cin, int cout, int kh, int kw, int bk)
+{
+    if (bk != 16 && bk != 32) return 0;
+    const size_t cgroups = (size_t)(cin + bk - 1) / bk;
+    return cgroups * kh * kw * 3 * (size_t)bk * ct_conv_mpad(cout) * 2;
+}
+
+extern "C" int ct_conv_pack_weights_x3(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
+                                       int bk, void* wx3, ct_stream_t stream)
+{
+    CT_REQUIRE(w && cout && wx3, "ct_conv_pack_weights_x3: null pointer");
+    CT_REQUIRE(nparts >= 1 && nparts <= 6, "ct_conv_pack_weights_x3: nparts=%d (1..6)", nparts);
+    CT_REQUIRE(bk == 16 || bk == 32, "ct_conv_pack_weights_x3: bk=%d (16 or 32)", bk);
+    CT_REQUIRE(cin > 0 && kh > 0 && kw > 0, "ct_conv_pack_weights_x3: bad filter shape");
+    X3PackArgs p{};
+    int mtot = 0;
+    for (int i = 0; i < nparts; ++i) {
+        CT_REQUIRE(w[i] && cout[i] > 0, "ct_conv_pack_weights_x3: part %d", i);
+        p.w[i] = w[i];
+        p.mbeg[i] = mtot;
+        mtot += cout[i];
+    }
+    for (int i = nparts; i < 7; ++i) p.mbeg[i] = mtot;
+    p.nparts = nparts;
+    p.cin = cin;
+    p.khw = kh * kw;
+    p.bk = bk;
+    p.m_pad = ct_conv_mpad(mtot);
+    p.cgroups = (cin + bk - 1) / bk;
+    p.out = static_cast<unsigned short*>(wx3);
+    const long rows = (long)p.cgroups * p.khw * (bk / 8) * p.m_pad;
+    hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)std::min<long>((rows + 255) / 256, 4096)), dim3(256), 0,
+                       ctdet::as_stream(stream), p);
+    CT_LAUNCH_CHECK("x3_pack_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_conv2d_x3_fwd(const ct_conv_desc* d, const void* wx3, int config, ct_stream_t stream)
+{
+    CT_REQUIRE(d != nullptr && wx3 != nullptr, "ct_conv2d_x3_fwd: null pointer");
+    CT_REQUIRE(d->in && d->scale && d->shift, "ct_conv2d_x3_fwd: null tensor");
+    CT_REQUIRE(config >= 0 && config < kNumX3, "ct_conv2d_x3_fwd: config %d (0..%d)", config, kNumX3 - 1);
+    CT_REQUIRE(d->batch > 0 && d->cin > 0 && d->cout > 0 && d->h > 0 && d->w > 0, "ct_conv2d_x3_fwd: bad shape");
+    CT_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->dil >= 1, "ct_conv2d_x3_fwd: filter geometry");
+    if (d->transposed)
+        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_x3_fwd: the data-gradient form is not built");
+    const int eoh = (d->h + 2 * d->pad_h - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+    const int eow = (d->w + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+    CT_REQUIRE(eoh == d->oh && eow == d->ow, "ct_conv2d_x3_fwd: oh/ow %dx%d != expected %dx%d", d->oh, d->ow, eoh, eow);
+    CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "ct_conv2d_x3_fwd: input slice");
+    CT_REQUIRE(d->nseg >= 0 && d->nseg <= 3, "ct_conv2d_x3_fwd: nseg");
+    if (d->nseg == 0) {
+        CT_REQUIRE(d->out && d->out_coff >= 0 && d->out_coff + d->cout <= d->out_ctot, "ct_conv2d_x3_fwd: output slice");
+        CT_REQUIRE(!d->res || (d->res_coff >= 0 && d->res_coff + d->cout <= d->res_ctot), "ct_conv2d_x3_fwd: residual slice");
+    } else {
+        CT_REQUIRE(!d->res, "ct_conv2d_x3_fwd: residual with segmented output");
+        for (int g = 0; g < d->nseg; ++g) CT_REQUIRE(d->seg[g].ptr, "ct_conv2d_x3_fwd: null segment");
+    }
+    const int bm = kX3[config].bm, bn = kX3[config].bn, bk = kX3[config].bk;
+    if (d->cin % bk != 0)
+        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_x3_fwd: cin=%d is not a multiple of the k-step (%d channels)",
+                           d->cin, bk);
+    const int m_pad = ct_conv_mpad(d->cout);
+    const size_t wbytes = ct_conv_x3_packed_bytes(d->cin, d->cout, d->kh, d->kw, bk);
+    CT_REQUIRE((long long)wbytes < kMaxBufBytes, "ct_conv2d_x3_fwd: weights too large");
+    const long long img_in_bytes = (long long)d->in_ctot * d->h * d->w * 4;
+    CT_REQUIRE(img_in_bytes < kMaxBufBytes, "ct_conv2d_x3_fwd: one image exceeds 2 GiB");
+    const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / img_in_bytes);
+    hipStream_t st = ctdet::as_stream(stream);
+
+    for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
+        const int nb = std::min(max_chunk, d->batch - b0);
+        X3Args a{};
+        a.in = d->in + (size_t)b0 * d->in_ctot * d->h * d->w;
+        a.wx3 = static_cast<const unsigned char*>(wx3);
+        a.scale = d->scale;
+        a.shift = d->shift;
+        a.lo = d->lo;
+        a.OW = d->ow;
+        a.OHW = d->oh * d->ow;
+        a.res = d->res ? d->res + (size_t)b0 * d->res_ctot * a.OHW : nullptr;
+        a.out = d->nseg == 0 ? d->out + (size_t)b0 * d->out_ctot * a.OHW : nullptr;
+        a.in_bytes = (unsigned)(img_in_bytes * nb);
+        a.w_bytes = (unsigned)wbytes;
+        a.Cin = d->cin;
+        a.H = d->h;
+        a.W = d->w;
+        a.in_ctot = d->in_ctot;
+        a.in_coff = d->in_coff;
+        a.M = d->cout;
+        a.M_pad = m_pad;
+        a.cgroups = (d->cin + bk - 1) / bk;
+        a.KH = d->kh;
+        a.KW = d->kw;
+        a.nsteps = a.cgroups * d->kh * d->kw;
+        a.stride = d->stride;
+        a.pad_h = d->pad_h;
+        a.pad_w = d->pad_w;
+        a.dil = d->dil;
+        a.Npix = nb * a.OHW;
+        a.out_ctot = d->out_ctot;
+        a.out_coff = d->out_coff;
+        a.res_ctot = d->res_ctot;
+        a.res_coff = d->res_coff;
+        a.res_scale = d->res_scale;
+        a.relu = d->relu;
+        a.nseg = d->nseg;
+        for (int g = 0; g < d->nseg; ++g) {
+            a.seg[g] = d->seg[g];
+            a.seg[g].ptr += (size_t)b0 * d->seg[g].img_stride;
+        }
+        a.tiles_m = (d->cout + bm - 1) / bm;
+        a.tiles_n = (a.Npix + bn - 1) / bn;
+        a.ksplit = 1;
+        a.steps_per_split = a.nsteps;
+        int want = d->ksplit;
+        if (want < 0) {     // auto: ~3 workgroups per CU, at least two k-steps per split
+            const int tiles = a.tiles_m * a.tiles_n;
+            want = tiles * 2 > 768 ? 1 : std::min(a.nsteps / 2, 768 / tiles);
+        }
+        const long long slab = (long long)d->cout * a.Npix;
+        if (d->ksplit_ws && slab > 0) want = (int)std::min<long long>(want, d->ksplit_ws_floats / slab);
+        if (want > 1 && d->ksplit_ws && nb == d->batch && a.nsteps >= 2 && slab < 0x7FFFFFFFLL) {
+            const int ks = std::min(want, a.nsteps);
+            a.steps_per_split = (a.nsteps + ks - 1) / ks;
+            a.ksplit = (a.nsteps + a.steps_per_split - 1) / a.steps_per_split;
+            a.ws = d->ksplit_ws;
+        }
+        hipError_t e = launch_cfg(config, a, st);
+        if (e != hipSuccess) return ctdet::fail(CT_ERR_HIP, "conv_x3_f32 launch failed: %s", hipGetErrorString(e));
+        if (a.ksplit > 1) {
+            const int total = a.M * a.Npix;
+            hipLaunchKernelGGL(conv_x3_splitk_epilogue, dim3(std::min((total + 255) / 256, 2048)), dim3(256), 0, st, a);
+            CT_LAUNCH_CHECK("conv_x3_splitk_epilogue");
+        }
+    }
+    return CT_OK;
+}

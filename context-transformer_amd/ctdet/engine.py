@@ -443,6 +443,7 @@ class HipBackend:
             return
         if not rt.get('wino_ok'):
             raise _lib.CtdetError('%s: geometry has no Winograd path' % st.name)
+        rt['x3'] = None
         tile = int(tile or 2)
         if tile not in (2, 4):
             raise _lib.CtdetError('%s: Winograd tile %r (2 or 4)' % (st.name, tile))
@@ -479,6 +480,9 @@ class HipBackend:
             pass
         elif rt.get('wino'):                    # only the layout the launch reads; the other one is packed on demand
             self._pack_wino(st)
+            rt['wpk_stale'] = True
+        elif rt.get('x3') is not None:
+            self._pack_x3(st)
             rt['wpk_stale'] = True
         else:
             _lib.check(lib.ct_conv_pack_weights(ptrs, couts, n, st.cin, st.kh, st.kw, rt['wpk'].data_ptr(),
@@ -533,7 +537,46 @@ class HipBackend:
             fn = lib.ct_conv2d_wino4_fwd if tile == 4 else lib.ct_conv2d_wino_fwd
             _lib.check(fn(C.byref(st.rt['desc']), U, self._stream()), st.name)
             return
+        x3 = st.rt.get('x3')
+        if x3 is not None:               # fp32 convolution on the bf16 matrix pipe (bf16x3 split, csrc/ct_conv_x3.hip)
+            _lib.check(self.lib.ct_conv2d_x3_fwd(C.byref(st.rt['desc']), st.rt['wx3'][self.x3_bk(x3)].data_ptr(), x3,
+                                                 self._stream()), st.name)
+            return
         _lib.check(self.lib.ct_conv2d_fwd(C.byref(st.rt['desc']), self._stream()), st.name)
+
+    # ---- bf16x3 (ct_conv2d_x3_fwd): config index, or None for the fp32 MFMA kernel
+    def x3_bk(self, cfg):
+        return self.lib.ct_conv_x3_config_bk(cfg)
+
+    def x3_names(self):
+        return [self.lib.ct_conv_x3_config_name(i).decode() for i in range(self.lib.ct_conv_x3_num_configs())]
+
+    def enable_x3(self, st, cfg):
+        """Route this conv through the bf16x3 kernel with tile config `cfg` (None = back to ct_conv2d_fwd)."""
+        rt = st.rt
+        if cfg is None:
+            rt['x3'] = None
+            if rt.get('wpk_stale'):
+                self.pack_conv(st)
+            return
+        self.enable_wino(st, False)
+        bk = self.x3_bk(cfg)
+        if bk <= 0:
+            raise _lib.CtdetError('%s: bf16x3 config %r' % (st.name, cfg))
+        rt.setdefault('wx3', {})
+        if bk not in rt['wx3']:
+            nbytes = self.lib.ct_conv_x3_packed_bytes(st.cin, st.cout, st.kh, st.kw, bk)
+            rt['wx3'][bk] = self.alloc((nbytes,), torch.uint8)
+        rt['x3'] = cfg
+        self._pack_x3(st)
+
+    def _pack_x3(self, st):
+        n = len(st.parts)
+        ptrs = (C.c_void_p * n)(*[p.weight.detach().data_ptr() for p in st.parts])
+        couts = (C.c_int * n)(*[p.cout for p in st.parts])
+        bk = self.x3_bk(st.rt['x3'])
+        _lib.check(self.lib.ct_conv_pack_weights_x3(ptrs, couts, n, st.cin, st.kh, st.kw, bk,
+                                                    st.rt['wx3'][bk].data_ptr(), self._stream()), 'ct_conv_pack_weights_x3')
 
     def run_pool(self, st, bufs, batch):
         _lib.check(self.lib.ct_maxpool2d_fwd(bufs[st.src].data_ptr(), bufs[st.dst].data_ptr(), batch * st.ch,
@@ -572,6 +615,26 @@ class HipBackend:
                 best, best_t = cfg, t
         st.rt['desc'].config = best + 1
         st.rt['config'] = best + 1
+        best_x3 = None
+        if x3_allowed(st):
+            for cfg in range(self.lib.ct_conv_x3_num_configs()):
+                if st.cin % self.x3_bk(cfg) or not self.x3_names()[cfg].endswith('d'):
+                    times.append(float('inf'))      # k-step does not divide cin / single accumulator (accuracy gate)
+                    continue
+                self.enable_x3(st, cfg)
+                self.run_conv(st)
+                torch.cuda.synchronize(self.device)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    self.run_conv(st)
+                e1.record()
+                torch.cuda.synchronize(self.device)
+                t = e0.elapsed_time(e1) / iters
+                times.append(t)
+                if t < best_t:
+                    best_x3, best_t = cfg, t
+            self.enable_x3(st, best_x3)
         if st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
             best_tile = 0
             for tile in wino_tiles(self, st):
@@ -592,8 +655,16 @@ class HipBackend:
                 self.enable_wino(st, tile=best_tile)
             else:
                 self.enable_wino(st, False)
+                if best_x3 is not None:
+                    self.enable_x3(st, best_x3)
         st.rt['tune_ms'] = times
         return best, times
+
+
+def x3_allowed(st):
+    """bf16x3 (ct_conv2d_x3_fwd) is a candidate for every forward conv except the 3-channel image layer (K = 27:
+    nothing to gain); CTDET_X3=0 keeps the fp32 MFMA kernel everywhere."""
+    return os.environ.get('CTDET_X3', '1') != '0' and st.cin >= 16 and st.cin % 16 == 0
 
 
 def wino_tiles(backend=None, st=None):
@@ -647,6 +718,12 @@ def apply_tuned(backend, st, batch, wino4=True):
         tile = 4 if cfg == 'wino4' and wino4 and 4 in wino_tiles(backend, st) else 2
         backend.enable_wino(st, tile=tile)
         return True
+    if isinstance(cfg, str) and cfg.startswith('x3:'):
+        xn = backend.x3_names()
+        if cfg in xn and x3_allowed(st):
+            backend.enable_x3(st, xn.index(cfg))
+            return True
+        cfg = tune_table().get(st.tune_key(batch) + '|f32')       # the best fp32-MFMA tile, recorded next to it
     if cfg in names:
         st.rt['config'] = names.index(cfg) + 1
         st.rt['desc'].config = st.rt['config']
@@ -816,9 +893,22 @@ class Runtime:
 
     def tuned_configs(self):
         lib = self.backend.lib
-        return {st.tune_key(self.batch): ({2: 'wino', 4: 'wino4'}[st.rt['wino']] if st.rt.get('wino') else
-                                          lib.ct_conv_config_name(st.rt['desc'].config - 1).decode())
-                for st in self.conv_steps() if st.rt['desc'].config > 0 or st.rt.get('wino')}
+        out = {}
+        xn = self.backend.x3_names()
+        for st in self.conv_steps():
+            if not (st.rt['desc'].config > 0 or st.rt.get('wino') or st.rt.get('x3') is not None):
+                continue
+            key = st.tune_key(self.batch)
+            f32 = lib.ct_conv_config_name(st.rt['desc'].config - 1).decode() if st.rt['desc'].config > 0 else None
+            if st.rt.get('wino'):
+                out[key] = {2: 'wino', 4: 'wino4'}[st.rt['wino']]
+            elif st.rt.get('x3') is not None:
+                out[key] = xn[st.rt['x3']]
+                if f32:
+                    out[key + '|f32'] = f32        # fallback tile when CTDET_X3=0
+            else:
+                out[key] = f32
+        return out
 
     def refresh_weights(self):
         """Re-pack any fused conv whose parameters changed since the last pack."""

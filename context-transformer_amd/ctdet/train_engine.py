@@ -288,6 +288,11 @@ class TrainRuntime:
             self._pack_counts, self._pack_ptrs = (nd.value, nw.value), ptrs
         _lib.check(self.lib.ct_pack_run(self._pack_table.data_ptr(), self._pack_counts[0], self._pack_counts[1], self._s()),
                    'ct_pack_run')
+        # the bf16x3 split of a forward launch's weights (ct_conv_pack_weights_x3) is not a recordable pack kind: it ran
+        # once at record time and has to be re-issued from the current weights every step
+        for st in self.plan.steps:
+            if st.kind == 'conv' and self.state[st.name].fwd.rt.get('x3') is not None:
+                self.be._pack_x3(self.state[st.name].fwd)
 
     # ------------------------------------------------------------------ forward
     def _ctx_tensors(self):

@@ -307,6 +307,22 @@ int ct_conv2d_wino4_fwd(const ct_conv_desc* desc, const float* upacked, ct_strea
 int ct_conv2d_wino4_pool_fwd(const ct_conv_desc* desc, const float* upacked, float* pool_out, int pool_ctot,
                              int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
 
+/* ---- "bf16x3": the fp32 convolution of ct_conv2d_fwd on the bf16 matrix pipe (csrc/ct_conv_x3.hip) ----
+ * Same layers (models/RFB_Net_vgg.py:7-22 BasicConv, the plain Conv2d layers, the multibox heads :238-248), the same
+ * descriptor (NCHW fp32 in / out, channel slices, residual, per-channel floor, head scatter, ksplit slabs) and the
+ * same results to fp32 accuracy: every fp32 operand is split exactly into three bfloat16 pieces and the six leading
+ * piece products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (six bf16 MFMAs = 0.375 of one fp32 MFMA;
+ * per-layer error against fp64 no worse than ct_conv2d_fwd's, tests/test_gpu_x3.py).  Any filter size / stride /
+ * dilation; cin must be a multiple of the config's k-step (CT_ERR_UNSUPPORTED otherwise); `transposed` is not built.  desc->wpacked / m_pad / k_pad / config are ignored: the split weights come from
+ * ct_conv_pack_weights_x3 for the k-step length (16 or 32 channels) of the chosen tile config. */
+int ct_conv_x3_num_configs(void);
+const char* ct_conv_x3_config_name(int i);               /* e.g. "x3:128x128k16" */
+int ct_conv_x3_config_bk(int i);                         /* channels per k-step of config i */
+size_t ct_conv_x3_packed_bytes(int cin, int cout, int kh, int kw, int bk);
+int ct_conv_pack_weights_x3(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk,
+                            void* wx3, ct_stream_t stream);
+int ct_conv2d_x3_fwd(const ct_conv_desc* desc, const void* wx3, int config, ct_stream_t stream);
+
 /* ---- bf16 channels-last convolutions (BASELINE.json configs[4]: "bf16 MFMA convs + fp32 NMS") ----
  * Same layers and epilogue as ct_conv2d_fwd (models/RFB_Net_vgg.py:7-22,219-248), other storage: activations
  * are [batch][h][w][channels] bfloat16 (round-to-nearest-even of the fp32 value), accumulation and epilogue

@@ -36,7 +36,7 @@ class _Holder:
 
 
 def _run_conv(x, parts, stride, pad, dil, config=0, res=None, res_scale=1.0, cin_off=0, cin=None,
-              out_ctot=None, out_coff=0, ksplit=None):
+              out_ctot=None, out_coff=0, ksplit=None, x3=None):
     """parts: list of (weight, bias|None, bn_tuple|None, relu).  Returns the NCHW output tensor."""
     be = engine.HipBackend(DEV)
     cps = []
@@ -64,6 +64,8 @@ def _run_conv(x, parts, stride, pad, dil, config=0, res=None, res_scale=1.0, cin
     if ksplit is not None:                      # explicit split-K factor (0 = off) instead of the library's choice
         st.rt['desc'].ksplit = ksplit
         st.rt['ksws'].fill_(float('nan'))       # the workspace needs no initialisation
+    if x3 is not None:                          # bf16x3 tile config (ct_conv2d_x3_fwd)
+        be.enable_x3(st, x3)
     be.run_conv(st)
     torch.cuda.synchronize()
     return bufs['y'].cpu()
