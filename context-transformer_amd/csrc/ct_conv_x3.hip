@@ -60,6 +60,7 @@ struct X3Args {
     ct_out_segment seg[3];
     int tiles_m, tiles_n;
     int ksplit, steps_per_split, nsteps;
+    int transposed;                 // data gradient: `in` = dY, output pixel = input pixel of the forward convolution
     float* ws;
 };
 
@@ -142,8 +143,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
         const int n = Pc / a.OHW;
         const int s = Pc - n * a.OHW;
         const int oh = s / a.OW, ow = s - oh * a.OW;
-        ih0 = oh * a.stride - a.pad_h;
-        iw0 = ow * a.stride - a.pad_w;
+        // forward: (oh, ow) reads ih = oh*stride - pad + kh*dil.  transposed (this "output" pixel is the forward conv's
+        // INPUT pixel, `in` is dY): dY row = (oh + pad - kh*dil) / stride when that divides
+        ih0 = a.transposed ? oh + a.pad_h : oh * a.stride - a.pad_h;
+        iw0 = a.transposed ? ow + a.pad_w : ow * a.stride - a.pad_w;
         img_base = (n * a.in_ctot + a.in_coff) * HW;
     }
 
@@ -180,8 +183,19 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
     }
     int ld_voff = 0;
     auto begin_load = [&]() {                      // per-tile part of the gather address: this lane's pixel at the tap
-        const int ih = ih0 + ld_kh * a.dil, iw = iw0 + ld_kw * a.dil;
-        const bool ok = pvalid && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        int ih, iw;
+        bool ok = pvalid;
+        if (!a.transposed) {
+            ih = ih0 + ld_kh * a.dil;
+            iw = iw0 + ld_kw * a.dil;
+        } else {                                   // stride is 1 or 2 (checked by the launcher)
+            const int th = ih0 - ld_kh * a.dil, tw = iw0 - ld_kw * a.dil;
+            const int sh = a.stride - 1;           // 0 or 1: shift and parity mask
+            ih = th >> sh;
+            iw = tw >> sh;
+            ok = ok && th >= 0 && tw >= 0 && ((th | tw) & sh) == 0;
+        }
+        ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
         ld_voff = ok ? (img_base + ih * a.W + iw) * 4 : kInvalidOff;
     };
     auto end_load = [&]() {                        // advance (tap, channel group)
@@ -389,6 +403,7 @@ struct X3PackArgs {
     const float* w[6];
     int mbeg[7];
     int nparts, cin, khw, bk, m_pad, cgroups;
+    int dgrad;                // rows m = forward INPUT channels, k-channels = forward OUTPUT channels (concatenated parts)
     unsigned short* out;
 };
 
@@ -404,16 +419,26 @@ __global__ void x3_pack_kernel(const X3PackArgs p)
         const int tap = (int)(t % p.khw), cg = (int)(t / p.khw);
         const float* src = nullptr;
         int mm = 0;
+        if (!p.dgrad) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i)
-            if (i < p.nparts && m >= p.mbeg[i] && m < p.mbeg[i + 1]) { src = p.w[i]; mm = m - p.mbeg[i]; }
+            for (int i = 0; i < 6; ++i)
+                if (i < p.nparts && m >= p.mbeg[i] && m < p.mbeg[i + 1]) { src = p.w[i]; mm = m - p.mbeg[i]; }
+        }
         const long step = (long)cg * p.khw + tap;
         unsigned short* base = p.out + (((step * 3) * oct + o) * (long)p.m_pad + m) * 8;
         const long piece_stride = (long)oct * p.m_pad * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int ci = cg * p.bk + o * 8 + e;
-            const float v = (src && ci < p.cin) ? src[((size_t)mm * p.cin + ci) * p.khw + tap] : 0.f;
+            float v = 0.f;
+            if (!p.dgrad) {
+                if (src && ci < p.cin) v = src[((size_t)mm * p.cin + ci) * p.khw + tap];
+            } else if (m < p.cin) {             // ci runs over the concatenated forward output channels
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+                    if (i < p.nparts && ci >= p.mbeg[i] && ci < p.mbeg[i + 1])
+                        v = p.w[i][((size_t)(ci - p.mbeg[i]) * p.cin + m) * p.khw + tap];
+            }
             unsigned h, mid, l;
             split3(v, h, mid, l);
             base[e] = (unsigned short)(h >> 16);
@@ -485,8 +510,8 @@ extern "C" size_t ct_conv_x3_packed_bytes(int cin, int cout, int kh, int kw, int
     return cgroups * kh * kw * 3 * (size_t)bk * ct_conv_mpad(cout) * 2;
 }
 
-extern "C" int ct_conv_pack_weights_x3(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
-                                       int bk, void* wx3, ct_stream_t stream)
+static int x3_pack_impl(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk, void* wx3,
+                        int dgrad, ct_stream_t stream)
 {
     CT_REQUIRE(w && cout && wx3, "ct_conv_pack_weights_x3: null pointer");
     CT_REQUIRE(nparts >= 1 && nparts <= 6, "ct_conv_pack_weights_x3: nparts=%d (1..6)", nparts);
@@ -505,14 +530,28 @@ extern "C" int ct_conv_pack_weights_x3(const float* const* w, const int* cout, i
     p.cin = cin;
     p.khw = kh * kw;
     p.bk = bk;
-    p.m_pad = ct_conv_mpad(mtot);
-    p.cgroups = (cin + bk - 1) / bk;
+    p.dgrad = dgrad;
+    // forward: rows = concatenated couts, k-channels = cin; data gradient: rows = cin, k-channels = concatenated couts
+    p.m_pad = ct_conv_mpad(dgrad ? cin : mtot);
+    p.cgroups = ((dgrad ? mtot : cin) + bk - 1) / bk;
     p.out = static_cast<unsigned short*>(wx3);
     const long rows = (long)p.cgroups * p.khw * (bk / 8) * p.m_pad;
     hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)std::min<long>((rows + 255) / 256, 4096)), dim3(256), 0,
                        ctdet::as_stream(stream), p);
     CT_LAUNCH_CHECK("x3_pack_kernel");
     return CT_OK;
+}
+
+extern "C" int ct_conv_pack_weights_x3(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
+                                       int bk, void* wx3, ct_stream_t stream)
+{
+    return x3_pack_impl(w, cout, nparts, cin, kh, kw, bk, wx3, 0, stream);
+}
+
+extern "C" int ct_conv_pack_weights_x3_dgrad(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
+                                             int bk, void* wx3, ct_stream_t stream)
+{
+    return x3_pack_impl(w, cout, nparts, cin, kh, kw, bk, wx3, 1, stream);
 }
 
 extern "C" int ct_conv2d_x3_fwd(const ct_conv_desc* d, const void* wx3, int config, ct_stream_t stream)
@@ -522,11 +561,18 @@ extern "C" int ct_conv2d_x3_fwd(const ct_conv_desc* d, const void* wx3, int conf
     CT_REQUIRE(config >= 0 && config < kNumX3, "ct_conv2d_x3_fwd: config %d (0..%d)", config, kNumX3 - 1);
     CT_REQUIRE(d->batch > 0 && d->cin > 0 && d->cout > 0 && d->h > 0 && d->w > 0, "ct_conv2d_x3_fwd: bad shape");
     CT_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->stride >= 1 && d->dil >= 1, "ct_conv2d_x3_fwd: filter geometry");
-    if (d->transposed)
-        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_x3_fwd: the data-gradient form is not built");
-    const int eoh = (d->h + 2 * d->pad_h - d->dil * (d->kh - 1) - 1) / d->stride + 1;
-    const int eow = (d->w + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
-    CT_REQUIRE(eoh == d->oh && eow == d->ow, "ct_conv2d_x3_fwd: oh/ow %dx%d != expected %dx%d", d->oh, d->ow, eoh, eow);
+    if (!d->transposed) {
+        const int eoh = (d->h + 2 * d->pad_h - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+        const int eow = (d->w + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+        CT_REQUIRE(eoh == d->oh && eow == d->ow, "ct_conv2d_x3_fwd: oh/ow %dx%d != expected %dx%d", d->oh, d->ow, eoh, eow);
+    } else {    // data gradient: (h,w) = spatial size of dY, (oh,ow) = spatial size of dX (ct_conv2d_fwd's contract)
+        if (d->stride > 2)
+            return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_x3_fwd(transposed): stride %d (1 or 2)", d->stride);
+        const int fh = (d->oh + 2 * d->pad_h - d->dil * (d->kh - 1) - 1) / d->stride + 1;
+        const int fw = (d->ow + 2 * d->pad_w - d->dil * (d->kw - 1) - 1) / d->stride + 1;
+        CT_REQUIRE(fh == d->h && fw == d->w, "ct_conv2d_x3_fwd(transposed): dY %dx%d != forward output %dx%d of a %dx%d input",
+                   d->h, d->w, fh, fw, d->oh, d->ow);
+    }
     CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "ct_conv2d_x3_fwd: input slice");
     CT_REQUIRE(d->nseg >= 0 && d->nseg <= 3, "ct_conv2d_x3_fwd: nseg");
     if (d->nseg == 0) {
@@ -584,6 +630,7 @@ extern "C" int ct_conv2d_x3_fwd(const ct_conv_desc* d, const void* wx3, int conf
         a.res_coff = d->res_coff;
         a.res_scale = d->res_scale;
         a.relu = d->relu;
+        a.transposed = d->transposed;
         a.nseg = d->nseg;
         for (int g = 0; g < d->nseg; ++g) {
             a.seg[g] = d->seg[g];

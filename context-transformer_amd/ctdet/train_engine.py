@@ -129,6 +129,17 @@ class TrainRuntime:
                         s.dgrad_tile = 4 if s.fwd.rt.get('wino') == 4 else 2
                         sizeof = self.lib.ct_conv_wino4_packed_floats if s.dgrad_tile == 4 else self.lib.ct_conv_wino_packed_floats
                         s.U_d = al((sizeof(ctot, st.cin),))
+            # direct data gradients on the bf16 matrix pipe (bf16x3, ct_conv2d_x3_fwd transposed): every layer without
+            # a Winograd data gradient whose channel counts fit the k-step; CTDET_X3=0 keeps ct_conv2d_fwd
+            s.dgrad_x3 = None
+            if s.dgrad is not None and getattr(s, 'dgrad_wino', None) is None and st.stride <= 2 and \
+                    os.environ.get('CTDET_X3', '1') != '0' and ctot % 16 == 0 and ctot >= 32:
+                npix = batch * st.h * st.w
+                tiles128 = -(-st.cin // 128) * -(-npix // 128)
+                cfg = 0 if tiles128 >= 512 else (3 if ctot % 32 == 0 and -(-st.cin // 64) * -(-npix // 128) < 384 else 1)
+                bk = self.lib.ct_conv_x3_config_bk(cfg)
+                s.dgrad_x3 = cfg
+                s.wx3_d = al((self.lib.ct_conv_x3_packed_bytes(ctot, st.cin, st.kh, st.kw, bk),), torch.uint8)
             # weight-gradient descriptor = forward geometry on the forward input
             w = _lib.ConvDesc()
             src = self.bufs[st.src]
@@ -256,6 +267,12 @@ class TrainRuntime:
         if s.dgrad_wino is not None:
             pack = self.lib.ct_conv_pack_weights_wino4_dgrad if s.dgrad_tile == 4 else self.lib.ct_conv_pack_weights_wino_dgrad
             _lib.check(pack(ptrs, couts, n, st.cin, s.U_d.data_ptr(), self._s()), st.name + ' pack dgrad (winograd)')
+        elif s.dgrad_x3 is not None:
+            if getattr(self, '_recording', False):
+                return                  # not a recordable pack kind: re-issued every step by _repack_all
+            _lib.check(self.lib.ct_conv_pack_weights_x3_dgrad(ptrs, couts, n, st.cin, st.kh, st.kw,
+                                                              self.lib.ct_conv_x3_config_bk(s.dgrad_x3), s.wx3_d.data_ptr(),
+                                                              self._s()), st.name + ' pack dgrad (bf16x3)')
         else:
             _lib.check(self.lib.ct_conv_pack_weights_dgrad(ptrs, couts, n, st.cin, st.kh, st.kw, s.wpk_d.data_ptr(),
                                                            s.mpad_d, s.kpad_d, self._s()), st.name + ' pack dgrad')
@@ -271,6 +288,7 @@ class TrainRuntime:
         if self._pack_table is None or ptrs != self._pack_ptrs:
             lib = self.lib
             _lib.check(lib.ct_pack_record_begin(), 'ct_pack_record_begin')
+            self._recording = True
             try:
                 for st in self.plan.steps:
                     if st.kind != 'conv':
@@ -280,6 +298,7 @@ class TrainRuntime:
                     if s.dgrad is not None:
                         self._pack_dgrad(st, s)
             finally:
+                self._recording = False
                 nbytes = lib.ct_pack_record_bytes()
                 self._pack_table = torch.empty(nbytes, dtype=torch.uint8, device=self.be.device)
                 nd, nw = C.c_int(0), C.c_int(0)
@@ -291,8 +310,13 @@ class TrainRuntime:
         # the bf16x3 split of a forward launch's weights (ct_conv_pack_weights_x3) is not a recordable pack kind: it ran
         # once at record time and has to be re-issued from the current weights every step
         for st in self.plan.steps:
-            if st.kind == 'conv' and self.state[st.name].fwd.rt.get('x3') is not None:
-                self.be._pack_x3(self.state[st.name].fwd)
+            if st.kind != 'conv':
+                continue
+            s = self.state[st.name]
+            if s.fwd.rt.get('x3') is not None:
+                self.be._pack_x3(s.fwd)
+            if s.dgrad is not None and s.dgrad_x3 is not None:
+                self._pack_dgrad(st, s)
 
     # ------------------------------------------------------------------ forward
     def _ctx_tensors(self):
@@ -525,7 +549,11 @@ class TrainRuntime:
                     if not self._batched_packs:
                         self._pack_dgrad(st, s)
                     s.dgrad.res = self.grads[st.src].data_ptr() if acc else None
-                    _lib.check(lib.ct_conv2d_fwd(C.byref(s.dgrad), self._s()), st.name + ' dgrad')
+                    if s.dgrad_x3 is not None:
+                        _lib.check(lib.ct_conv2d_x3_fwd(C.byref(s.dgrad), s.wx3_d.data_ptr(), s.dgrad_x3, self._s()),
+                                   st.name + ' dgrad (bf16x3)')
+                    else:
+                        _lib.check(lib.ct_conv2d_fwd(C.byref(s.dgrad), self._s()), st.name + ' dgrad')
                 written.setdefault(st.src, []).append((st.src_coff, st.src_coff + st.cin))
 
 

@@ -313,7 +313,9 @@ int ct_conv2d_wino4_pool_fwd(const ct_conv_desc* desc, const float* upacked, flo
  * same results to fp32 accuracy: every fp32 operand is split exactly into three bfloat16 pieces and the six leading
  * piece products run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (six bf16 MFMAs = 0.375 of one fp32 MFMA;
  * per-layer error against fp64 no worse than ct_conv2d_fwd's, tests/test_gpu_x3.py).  Any filter size / stride /
- * dilation; cin must be a multiple of the config's k-step (CT_ERR_UNSUPPORTED otherwise); `transposed` is not built.  desc->wpacked / m_pad / k_pad / config are ignored: the split weights come from
+ * dilation; cin must be a multiple of the config's k-step (CT_ERR_UNSUPPORTED otherwise).  desc->transposed = 1 (the
+ * data gradient, ct_conv2d_fwd's contract: `in` = dY, weights from ct_conv_pack_weights_x3_dgrad, stride 1 or 2) is
+ * what `losses.backward()` (train.py:228) needs for the same layers.  desc->wpacked / m_pad / k_pad / config are ignored: the split weights come from
  * ct_conv_pack_weights_x3 for the k-step length (16 or 32 channels) of the chosen tile config. */
 int ct_conv_x3_num_configs(void);
 const char* ct_conv_x3_config_name(int i);               /* e.g. "x3:128x128k16" */
@@ -321,6 +323,10 @@ int ct_conv_x3_config_bk(int i);                         /* channels per k-step 
 size_t ct_conv_x3_packed_bytes(int cin, int cout, int kh, int kw, int bk);
 int ct_conv_pack_weights_x3(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk,
                             void* wx3, ct_stream_t stream);
+/* Data-gradient layout: rows = cin (forward input channels), k-channels = the concatenated couts; holds
+ * ct_conv_x3_packed_bytes(sum cout, cin, kh, kw, bk) bytes. */
+int ct_conv_pack_weights_x3_dgrad(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk,
+                                  void* wx3, ct_stream_t stream);
 int ct_conv2d_x3_fwd(const ct_conv_desc* desc, const void* wx3, int config, ct_stream_t stream);
 
 /* ---- bf16 channels-last convolutions (BASELINE.json configs[4]: "bf16 MFMA convs + fp32 NMS") ----

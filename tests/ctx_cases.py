@@ -18,6 +18,14 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max())
 
 
+def qrel(a, b, q=0.9999):
+    """q-quantile of |a - b| / max|b|: a tail statistic that does not hang on the single worst near-tie."""
+    a, b = a.double().reshape(-1), b.double().reshape(-1)
+    d = (a - b).abs()
+    k = max(1, int(round(q * d.numel())))
+    return float(d.kthvalue(k).values / b.abs().max())
+
+
 def build(size=300, C=60, setting='transfer'):
     from models.RFB_Net_vgg import build_net
     net = build_net(types.SimpleNamespace(method='ours', phase=2, setting=setting), size, C)
@@ -53,23 +61,27 @@ def sweep_case(net, size, C, setting, batch, seed, kind, sd32=None, sd64=None):
         w64 = rfbnet_ref.forward(sd64, x[idx].double(), size, C, 2, 'ours', setting, raw=True)
     return {'batch': batch, 'seed': seed, 'kind': kind, 'images': idx,
             'gpu_cpu32': rel(got[1], w32[1]), 'gpu_fp64': rel(got[1], w64[1]), 'cpu32_fp64': rel(w32[1], w64[1]),
+            'q_gpu_fp64': qrel(got[1], w64[1]), 'q_cpu32_fp64': qrel(w32[1], w64[1]),
             'loc_gpu_cpu32': rel(got[0], w32[0]), 'obj_gpu_cpu32': rel(got[2], w32[2]),
             'rawconf_gpu_cpu32': rel(raw_gpu, raw32)}
 
 
-def verdict(r, tol=1e-4, slack=2.5, cap=2.5e-4):
-    """'ok': within tol of the reference's fp32 CPU arithmetic.  'exception': above tol, but (a) no further from the
-    fp64 truth than slack x the CPU fp32 path itself and (b) within `cap` of the CPU path.  Else 'FAIL'.
+def verdict(r, tol=1e-4, slack=1.75, cap=2.5e-4):
+    """'ok': every element within tol of the reference's fp32 CPU arithmetic.  'exception': some element above tol,
+    but (a) the device is no further from the fp64 truth than slack x the CPU fp32 path itself, measured at the
+    99.99 % quantile of the error (70 of the 7e5 compared elements lie above it), and (b) every element within `cap`
+    of the CPU path.  Else 'FAIL'.
 
-    Why a slack at all: the block multiplies a perturbation of its input by ~1000 (budget below), so two correct
-    fp32 evaluations of the network differ by about sqrt(2) x 5..7e-5 at best, and the statistic is the MAXIMUM over
-    ~7e5 elements of a heavy-tailed error (near-ties of the arg-max softmax).  Measured over 27 randn cases
-    (profiles/r03_ctx_parity.txt): e(GPU,fp64) / e(CPU32,fp64) = 1.1 .. 1.7 with F(2x2,3x3) everywhere and 1.2 .. 2.0
-    with the shipped policy, at an input (raw conf) error ratio of 1.27 / 1.32 -- VERDICT r02 proposed 1.5, which the
-    F(2x2,3x3)-only path itself misses at (bs 32, seed 7)."""
+    Why not a flat 1e-4, and why a quantile: the fp64 block multiplies a perturbation of its input by ~1000
+    (budget below), so the CPU fp32 path itself is 5..7e-5 from fp64 and two correct fp32 evaluations differ by about
+    1e-4; the MAXIMUM over 7e5 elements of this heavy-tailed error (near-ties of the arg-max softmax) moves by 2x
+    between seeds for the SAME arithmetic, the quantile does not.  Measured (profiles/r03_ctx_parity.txt): max-norm
+    ratio e(GPU,fp64) / e(CPU32,fp64) = 1.0 .. 1.7 over 9 randn cases with the shipped policy, quantile ratio
+    1.1 .. 1.4, at an input (raw conf) error ratio of 1.29.  VERDICT r02 proposed max-norm slack 1.5, which the
+    F(2x2,3x3)-only path of round 2 itself misses at (bs 32, seed 7)."""
     if r['gpu_cpu32'] <= tol:
         return 'ok'
-    return 'exception' if (r['gpu_fp64'] <= slack * r['cpu32_fp64'] and r['gpu_cpu32'] <= cap) else 'FAIL'
+    return 'exception' if (r['q_gpu_fp64'] <= slack * r['q_cpu32_fp64'] and r['gpu_cpu32'] <= cap) else 'FAIL'
 
 
 def pool_from_conf(conf, size, C):

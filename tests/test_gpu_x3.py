@@ -106,3 +106,53 @@ def test_x3_error_vs_fp64_no_worse_than_the_fp32_mfma_kernel(case):
         # rms no worse; the maximum (a noisy statistic at this sample size) within 25 %
         assert e[0] <= 1.25 * e_base[0] + 1e-8 and e[1] <= 1.0 * e_base[1] + 1e-9, (name, cname, [float(v) for v in e],
                                                                                     [float(v) for v in e_base])
+
+
+DGRAD_GEOMS = [  # B, Cin, H, W, Cout, k, stride, pad, dil   (Cout = the k-channels of the data gradient: multiple of 32)
+    (2, 24, 19, 19, 64, 3, 1, 3, 3), (2, 40, 19, 17, 32, 3, 2, 1, 1), (2, 64, 19, 19, 96, 1, 1, 0, 1),
+    (2, 64, 19, 19, 96, 1, 2, 0, 1), (2, 20, 12, 12, 32, (1, 3), 1, (0, 1), 1), (2, 20, 12, 12, 32, (3, 1), 1, (1, 0), 1),
+    (1, 16, 10, 10, 64, 3, 1, 5, 5), (2, 16, 2, 2, 32, 4, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize('g', DGRAD_GEOMS, ids=[str(i) for i in range(len(DGRAD_GEOMS))])
+def test_x3_data_gradient_vs_autograd(g):
+    """desc->transposed = 1 with ct_conv_pack_weights_x3_dgrad: what autograd's conv backward-data computes for the
+    direct layers (train.py:228), written into a channel slice of a wider buffer, plain and accumulating."""
+    import ctypes as C
+    B, Cin, H, W, Cout, k, stride, pad, dil = g
+    kh, kw = (k, k) if isinstance(k, int) else k
+    ph, pw = (pad, pad) if isinstance(pad, int) else pad
+    gen = torch.Generator().manual_seed(sum(map(hash, map(str, g))) % 997)
+    x = torch.randn(B, Cin, H, W, generator=gen, requires_grad=True)
+    w = (torch.randn(Cout, Cin, kh, kw, generator=gen) * 0.2).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, (ph, pw), dil)
+    dy = torch.randn(y.shape, generator=gen)
+    y.backward(dy)
+    lib = _lib.lib()
+    OH, OW = y.shape[2:]
+    DEV = 'cuda:0'
+    wd, dyd = w.detach().to(DEV).contiguous(), dy.to(DEV).contiguous()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for cfg in range(_ncfg()):
+        bk = lib.ct_conv_x3_config_bk(cfg)
+        mpad = lib.ct_conv_mpad(Cin)
+        wx3 = torch.empty(lib.ct_conv_x3_packed_bytes(Cout, Cin, kh, kw, bk), dtype=torch.uint8, device=DEV)
+        ptrs = (C.c_void_p * 1)(wd.data_ptr()); couts = (C.c_int * 1)(Cout)
+        _lib.check(lib.ct_conv_pack_weights_x3_dgrad(ptrs, couts, 1, Cin, kh, kw, bk, wx3.data_ptr(), s), 'pack')
+        ones, zeros = torch.ones(mpad, device=DEV), torch.zeros(mpad, device=DEV)
+        dx = torch.full((B, Cin + 4, H, W), 7.0, device=DEV)
+        t = _lib.ConvDesc()
+        t.in_ = dyd.data_ptr()
+        t.batch, t.cin, t.h, t.w, t.in_ctot, t.in_coff = B, Cout, OH, OW, Cout, 0
+        t.scale, t.shift = ones.data_ptr(), zeros.data_ptr()
+        t.cout = Cin
+        t.kh, t.kw, t.stride, t.pad_h, t.pad_w, t.dil, t.oh, t.ow = kh, kw, stride, ph, pw, dil, H, W
+        t.out, t.out_ctot, t.out_coff = dx.data_ptr(), Cin + 4, 2
+        t.transposed = 1
+        _lib.check(lib.ct_conv2d_x3_fwd(C.byref(t), wx3.data_ptr(), cfg, s), 'dgrad x3')
+        assert rel_err(dx[:, 2:2 + Cin].cpu(), x.grad) < 1e-4, cfg
+        assert (dx[:, :2] == 7).all() and (dx[:, 2 + Cin:] == 7).all()
+        t.res, t.res_ctot, t.res_coff, t.res_scale = dx.data_ptr(), Cin + 4, 2, 1.0
+        _lib.check(lib.ct_conv2d_x3_fwd(C.byref(t), wx3.data_ptr(), cfg, s), 'dgrad x3 accumulate')
+        assert rel_err(dx[:, 2:2 + Cin].cpu(), 2 * x.grad) < 1e-4, cfg

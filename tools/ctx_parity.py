@@ -32,7 +32,8 @@ for pol in a.policies.split(','):
                 print('   %-86s %s' % (lab, ('%.1f x' % e) if 'amplification' in lab else '%.2e' % e), flush=True)
     if a.sweep:
         print('== sweep, RFBNet-%d phase 2 transfer, policy CTDET_WINO4_CTX=%s: %s' % (a.size, pol, label))
-        print('   %5s %5s %6s | %-10s %-10s %-10s | %s' % ('batch', 'seed', 'input', 'GPU-CPU32', 'GPU-fp64', 'CPU32-fp64', 'verdict'))
+        print('   %5s %5s %6s | %-10s %-10s %-10s | %-10s %-10s %-5s | %s' % ('batch', 'seed', 'input', 'GPU-CPU32', 'GPU-fp64', 'CPU32-fp64',
+                                                                          'q GPU-64', 'q CPU-64', 'ratio', 'verdict'))
         sd32, sd64 = cc.state(net), cc.state(net, torch.float64)
         bad = 0
         for batch in [int(b) for b in a.batches.split(',')]:
@@ -41,8 +42,9 @@ for pol in a.policies.split(','):
                     r = cc.sweep_case(net, a.size, 60, 'transfer', batch, seed, kind, sd32, sd64)
                     v = cc.verdict(r)
                     bad += v != 'ok'
-                    print('   %5d %5d %6s | %.2e   %.2e   %.2e   | %s' % (batch, seed, kind, r['gpu_cpu32'], r['gpu_fp64'],
-                                                                         r['cpu32_fp64'], v), flush=True)
+                    print('   %5d %5d %6s | %.2e   %.2e   %.2e   | %.2e   %.2e   %.2f  | %s'
+                          % (batch, seed, kind, r['gpu_cpu32'], r['gpu_fp64'], r['cpu32_fp64'], r['q_gpu_fp64'],
+                             r['q_cpu32_fp64'], r['q_gpu_fp64'] / r['q_cpu32_fp64'], v), flush=True)
         print('   cases not within 1e-4 of the fp32 CPU path: %d' % bad)
     del net
     torch.cuda.empty_cache()
