@@ -291,6 +291,34 @@ def test_full_size_pipeline_properties():
     assert total >= 32 * 150
 
 
+def test_full_size_pipeline_vs_oracle_on_first_and_last_image():
+    """BASELINE configs[1] at FULL size (RFBNet-300, bs 32) against the oracle: the CPU oracle evaluates images 0 and
+    31 of the same batch (the kernels are batch-position invariant, test above); raw loc / conf / obj within 1e-4,
+    and the detections of the batched device post-processing bit-exact against the reference's sequential per-class
+    loop (test.py:136-161, oracle/nms_ref.py with the C NMS) run on the device's own boxes / scores."""
+    from layers.functions import PriorBox
+    from data import VOC_300
+    net = _net(300, 20)
+    priors = PriorBox(VOC_300).forward()
+    pipe = DetectionPipeline(net, priors, 32, 20, image_wh=(500, 375))
+    x = synth.images(32, 300, 'randn', 2024)
+    pipe.run(x.cuda())
+    got = pipe.results()
+    idx = [0, 31]
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        want = rfbnet_ref.forward(sd, x[idx], 300, 20, raw=True)
+        raw = [t.cpu()[idx] for t in net.forward_raw(x.cuda())]
+    for a, b, name in zip(raw, want, ('loc', 'conf', 'obj')):
+        assert rel_err(a.reshape(b.shape), b) < TOL, (name, rel_err(a.reshape(b.shape), b))
+    boxes, scores = pipe.boxes.cpu().numpy(), pipe.scores.cpu().numpy()
+    nms_ref.build_c()
+    for i in idx:
+        ref = nms_ref.postprocess_image(boxes[i], scores[i], (1, 1), nms_fn=nms_ref.nms_c)
+        for j in range(1, 21):
+            assert np.array_equal(got[i][j], ref[j]), (i, j)
+
+
 def test_hipgraph_replay_equals_eager_launches(monkeypatch):
     """DetectionPipeline captures its step (two streams, ~100 launches) into a hipGraph after two eager steps; the
     replays give bit-identical detections, keep doing so after a weight update (re-packing happens outside the
