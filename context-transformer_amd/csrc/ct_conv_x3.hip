@@ -182,27 +182,25 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
         ld_asoff = s0 * a_step_bytes;
     }
     int ld_voff = 0;
+    const int tap_sgn = a.transposed ? -a.dil : a.dil, tap_sh = a.transposed ? a.stride - 1 : 0;
     auto begin_load = [&]() {                      // per-tile part of the gather address: this lane's pixel at the tap
-        int ih, iw;
-        bool ok = pvalid;
-        if (!a.transposed) {
-            ih = ih0 + ld_kh * a.dil;
-            iw = iw0 + ld_kw * a.dil;
-        } else {                                   // stride is 1 or 2 (checked by the launcher)
-            const int th = ih0 - ld_kh * a.dil, tw = iw0 - ld_kw * a.dil;
-            const int sh = a.stride - 1;           // 0 or 1: shift and parity mask
-            ih = th >> sh;
-            iw = tw >> sh;
-            ok = ok && th >= 0 && tw >= 0 && ((th | tw) & sh) == 0;
-        }
-        ok = ok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+        // forward: ih = ih0 + kh*dil.  transposed: th = ih0 - kh*dil must be >= 0 and divisible by the stride (1 or 2).
+        // One branch-free form for both (the k-step has to stay ONE basic block): tap_sgn = +-dil, tap_sh = 0 or 1; a
+        // negative th stays negative under the arithmetic shift and fails the unsigned range check.
+        const int th = ih0 + ld_kh * tap_sgn, tw = iw0 + ld_kw * tap_sgn;
+        const int ih = th >> tap_sh, iw = tw >> tap_sh;
+        const bool ok = pvalid & ((unsigned)ih < (unsigned)a.H) & ((unsigned)iw < (unsigned)a.W) & (((th | tw) & tap_sh) == 0);
         ld_voff = ok ? (img_base + ih * a.W + iw) * 4 : kInvalidOff;
     };
     auto end_load = [&]() {                        // advance (tap, channel group)
         ld_asoff += a_step_bytes;
         ++ld_kw;
-        if (ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
-        if (ld_kh == a.KH) { ld_kh = 0; ld_cbase += BK; }
+        const int wrap_w = ld_kw == a.KW;               // scalar selects, no branches
+        ld_kw = wrap_w ? 0 : ld_kw;
+        ld_kh += wrap_w;
+        const int wrap_h = ld_kh == a.KH;
+        ld_kh = wrap_h ? 0 : ld_kh;
+        ld_cbase += wrap_h ? BK : 0;
     };
     auto load_a = [&](int j) { areg[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, a_voff[j], ld_asoff, 0); };
     int ld_soff = 0;                               // running channel offset of the gather (bytes, wave-uniform)

@@ -41,6 +41,12 @@ for cfg in "--size 300 --batch 32" "--size 300 --batch 32 --phase 2 --classes 60
 done
 timeout 300 python tools/nms_probe.py > "$O/nms_probe.txt" 2>&1
 timeout 300 python tools/attn_probe.py > "$O/attn_probe.txt" 2>&1
+timeout 400 python tools/x3_probe.py > "$O/x3_probe.txt" 2>&1
+timeout 300 python tools/wino_accuracy.py > "$O/wino_accuracy.txt" 2>&1
+timeout 900 python tools/ctx_parity.py --budget --sweep --policies 0,256,1 > "$O/ctx_parity.txt" 2>&1
+timeout 300 python bench.py --train --steps 5 --warmup 2 > "$O/bench_train.json.log" 2> "$O/bench_train.err"
+timeout 300 python bench.py --gpus 2 --share-devices --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > "$O/bench_2rank_rehearsal.json.log" 2> "$O/bench_2rank_rehearsal.err"
+timeout 300 python bench.py --train --gpus 2 --share-devices --steps 3 --warmup 1 > "$O/bench_train_2rank_rehearsal.json.log" 2> "$O/bench_train_2rank_rehearsal.err"
 # keep what prof_summary.py needs, drop the bulky traces
 find "$O" -name '*kernel_trace.csv' -delete
 find "$O" -name '*agent_info.csv' -delete
