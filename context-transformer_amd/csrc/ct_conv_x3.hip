@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 #include <unordered_set>
@@ -420,11 +421,11 @@ struct X3PackArgs {
     unsigned short* out;
 };
 
-__global__ void x3_pack_kernel(const X3PackArgs p)
+__device__ __forceinline__ void x3_pack_body(const X3PackArgs& p, long first, long stride)
 {
     const int oct = p.bk / 8;
     const long rows = (long)p.cgroups * p.khw * oct * p.m_pad;            // 8-channel rows (all three pieces each)
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < rows; idx += (long)gridDim.x * blockDim.x) {
+    for (long idx = first; idx < rows; idx += stride) {
         const int m = (int)(idx % p.m_pad);
         long t = idx / p.m_pad;
         const int o = (int)(t % oct);
@@ -459,6 +460,18 @@ __global__ void x3_pack_kernel(const X3PackArgs p)
             base[2 * piece_stride + e] = (unsigned short)(l >> 16);
         }
     }
+}
+
+__global__ void x3_pack_kernel(const X3PackArgs p)
+{
+    x3_pack_body(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+}
+
+// every bf16x3 weight split of a training step in ONE launch: blockIdx.y = item of a device-resident list
+__global__ void x3_pack_batched_kernel(const X3PackArgs* __restrict__ items)
+{
+    const X3PackArgs p = items[blockIdx.y];
+    x3_pack_body(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 struct X3Cfg {
@@ -523,14 +536,29 @@ extern "C" size_t ct_conv_x3_packed_bytes(int cin, int cout, int kh, int kw, int
     return cgroups * kh * kw * 3 * (size_t)bk * ct_conv_mpad(cout) * 2;
 }
 
+static int x3_pack_fill(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk, void* wx3,
+                        int dgrad, X3PackArgs& p);
+
 static int x3_pack_impl(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk, void* wx3,
                         int dgrad, ct_stream_t stream)
+{
+    X3PackArgs p{};
+    if (int rc = x3_pack_fill(w, cout, nparts, cin, kh, kw, bk, wx3, dgrad, p)) return rc;
+    const long rows = (long)p.cgroups * p.khw * (bk / 8) * p.m_pad;
+    hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)std::min<long>((rows + 255) / 256, 4096)), dim3(256), 0,
+                       ctdet::as_stream(stream), p);
+    CT_LAUNCH_CHECK("x3_pack_kernel");
+    return CT_OK;
+}
+
+static int x3_pack_fill(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk, void* wx3,
+                        int dgrad, X3PackArgs& p)
 {
     CT_REQUIRE(w && cout && wx3, "ct_conv_pack_weights_x3: null pointer");
     CT_REQUIRE(nparts >= 1 && nparts <= 6, "ct_conv_pack_weights_x3: nparts=%d (1..6)", nparts);
     CT_REQUIRE(bk == 16 || bk == 32, "ct_conv_pack_weights_x3: bk=%d (16 or 32)", bk);
     CT_REQUIRE(cin > 0 && kh > 0 && kw > 0, "ct_conv_pack_weights_x3: bad filter shape");
-    X3PackArgs p{};
+    p = X3PackArgs{};
     int mtot = 0;
     for (int i = 0; i < nparts; ++i) {
         CT_REQUIRE(w[i] && cout[i] > 0, "ct_conv_pack_weights_x3: part %d", i);
@@ -548,10 +576,32 @@ static int x3_pack_impl(const float* const* w, const int* cout, int nparts, int 
     p.m_pad = ct_conv_mpad(dgrad ? cin : mtot);
     p.cgroups = ((dgrad ? mtot : cin) + bk - 1) / bk;
     p.out = static_cast<unsigned short*>(wx3);
-    const long rows = (long)p.cgroups * p.khw * (bk / 8) * p.m_pad;
-    hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)std::min<long>((rows + 255) / 256, 4096)), dim3(256), 0,
-                       ctdet::as_stream(stream), p);
-    CT_LAUNCH_CHECK("x3_pack_kernel");
+    return CT_OK;
+}
+
+// A training step re-splits the weights of every bf16x3 launch (forward and data gradient): ~80 small launches.  The
+// arguments never change between steps, so the caller builds the list once -- ct_conv_x3_pack_item fills ONE item of
+// ct_conv_x3_pack_item_bytes() bytes in HOST memory from the arguments of ct_conv_pack_weights_x3[_dgrad] --, copies
+// it to the device and replays it with ct_conv_x3_pack_run: one launch.
+extern "C" size_t ct_conv_x3_pack_item_bytes(void) { return sizeof(X3PackArgs); }
+
+extern "C" int ct_conv_x3_pack_item(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk,
+                                    void* wx3, int dgrad, void* host_item)
+{
+    CT_REQUIRE(host_item, "ct_conv_x3_pack_item: null item");
+    X3PackArgs p{};
+    if (int rc = x3_pack_fill(w, cout, nparts, cin, kh, kw, bk, wx3, dgrad, p)) return rc;
+    memcpy(host_item, &p, sizeof(p));
+    return CT_OK;
+}
+
+extern "C" int ct_conv_x3_pack_run(const void* items_dev, int n, ct_stream_t stream)
+{
+    CT_REQUIRE(items_dev || n == 0, "ct_conv_x3_pack_run: null list");
+    if (n <= 0) return CT_OK;
+    hipLaunchKernelGGL(x3_pack_batched_kernel, dim3(64, n), dim3(256), 0, ctdet::as_stream(stream),
+                       static_cast<const X3PackArgs*>(items_dev));
+    CT_LAUNCH_CHECK("x3_pack_batched_kernel");
     return CT_OK;
 }
 

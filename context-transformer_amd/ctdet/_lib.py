@@ -142,6 +142,9 @@ SIGNATURES = {
     'ct_conv_pack_weights_x3': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'ct_conv_pack_weights_x3_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'ct_conv2d_x3_fwd': (_I, [C.POINTER(ConvDesc), _P, _I, _P]),
+    'ct_conv_x3_pack_item_bytes': (_Z, []),
+    'ct_conv_x3_pack_item': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _I, _P]),
+    'ct_conv_x3_pack_run': (_I, [_P, _I, _P]),
     'ct_maxpool2d_fwd': (_I, [_P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _P]),
     'ct_preproc_resize': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     'ct_preproc_augment': (_I, [_P, _P, _I, _I, _P, _P, _P]),

@@ -307,16 +307,33 @@ class TrainRuntime:
             self._pack_counts, self._pack_ptrs = (nd.value, nw.value), ptrs
         _lib.check(self.lib.ct_pack_run(self._pack_table.data_ptr(), self._pack_counts[0], self._pack_counts[1], self._s()),
                    'ct_pack_run')
-        # the bf16x3 split of a forward launch's weights (ct_conv_pack_weights_x3) is not a recordable pack kind: it ran
-        # once at record time and has to be re-issued from the current weights every step
-        for st in self.plan.steps:
-            if st.kind != 'conv':
-                continue
-            s = self.state[st.name]
-            if s.fwd.rt.get('x3') is not None:
-                self.be._pack_x3(s.fwd)
-            if s.dgrad is not None and s.dgrad_x3 is not None:
-                self._pack_dgrad(st, s)
+        # the bf16x3 weight splits (forward + data-gradient launches) are their own list: built once (the arguments never
+        # change between steps), replayed as one launch
+        if getattr(self, '_x3_list', None) is None or self._x3_list[2] != ptrs:
+            items, nbytes = [], self.lib.ct_conv_x3_pack_item_bytes()
+
+            def item(parts, cin, kh, kw, bk, dst, dgrad):
+                n = len(parts)
+                wp = (C.c_void_p * n)(*[p.weight.data_ptr() for p in parts])
+                co = (C.c_int * n)(*[p.cout for p in parts])
+                buf = (C.c_ubyte * nbytes)()
+                _lib.check(self.lib.ct_conv_x3_pack_item(wp, co, n, cin, kh, kw, bk, dst.data_ptr(), dgrad, buf),
+                           'ct_conv_x3_pack_item')
+                items.append(bytes(buf))
+            for st in self.plan.steps:
+                if st.kind != 'conv':
+                    continue
+                s = self.state[st.name]
+                if s.fwd.rt.get('x3') is not None:
+                    bk = self.be.x3_bk(s.fwd.rt['x3'])
+                    item(s.fwd.parts, s.fwd.cin, s.fwd.kh, s.fwd.kw, bk, s.fwd.rt['wx3'][bk], 0)
+                if s.dgrad is not None and s.dgrad_x3 is not None:
+                    item(st.parts, st.cin, st.kh, st.kw, self.lib.ct_conv_x3_config_bk(s.dgrad_x3), s.wx3_d, 1)
+            table = torch.frombuffer(bytearray(b''.join(items)), dtype=torch.uint8).to(self.be.device) if items else None
+            self._x3_list = (table, len(items), ptrs)
+        if self._x3_list[1]:
+            _lib.check(self.lib.ct_conv_x3_pack_run(self._x3_list[0].data_ptr(), self._x3_list[1], self._s()),
+                       'ct_conv_x3_pack_run')
 
     # ------------------------------------------------------------------ forward
     def _ctx_tensors(self):

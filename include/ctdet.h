@@ -328,6 +328,15 @@ int ct_conv_pack_weights_x3(const float* const* w, const int* cout, int nparts, 
 int ct_conv_pack_weights_x3_dgrad(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk,
                                   void* wx3, ct_stream_t stream);
 int ct_conv2d_x3_fwd(const ct_conv_desc* desc, const void* wx3, int config, ct_stream_t stream);
+/* All weight splits of a training step (train.py:222-229 updates every weight every step) in ONE launch: the arguments
+ * never change between steps, so build the list once -- ct_conv_x3_pack_item fills one item of
+ * ct_conv_x3_pack_item_bytes() bytes in HOST memory from the arguments of ct_conv_pack_weights_x3 (dgrad = 0) or
+ * ct_conv_pack_weights_x3_dgrad (dgrad = 1) without launching --, copy the items to the device, and replay them with
+ * ct_conv_x3_pack_run(items_dev, n). */
+size_t ct_conv_x3_pack_item_bytes(void);
+int ct_conv_x3_pack_item(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk, void* wx3,
+                         int dgrad, void* host_item);
+int ct_conv_x3_pack_run(const void* items_dev, int n, ct_stream_t stream);
 
 /* ---- bf16 channels-last convolutions (BASELINE.json configs[4]: "bf16 MFMA convs + fp32 NMS") ----
  * Same layers and epilogue as ct_conv2d_fwd (models/RFB_Net_vgg.py:7-22,219-248), other storage: activations

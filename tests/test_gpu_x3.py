@@ -156,3 +156,34 @@ def test_x3_data_gradient_vs_autograd(g):
         t.res, t.res_ctot, t.res_coff, t.res_scale = dx.data_ptr(), Cin + 4, 2, 1.0
         _lib.check(lib.ct_conv2d_x3_fwd(C.byref(t), wx3.data_ptr(), cfg, s), 'dgrad x3 accumulate')
         assert rel_err(dx[:, 2:2 + Cin].cpu(), 2 * x.grad) < 1e-4, cfg
+
+
+def test_x3_batched_weight_split_equals_single_calls():
+    """ct_conv_x3_pack_item + ct_conv_x3_pack_run (one launch for a list of splits, what a training step replays)
+    writes the same bytes as ct_conv_pack_weights_x3 / _dgrad called one by one."""
+    import ctypes as C
+    lib = _lib.lib()
+    DEV = 'cuda:0'
+    g = torch.Generator().manual_seed(3)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    nbytes = lib.ct_conv_x3_pack_item_bytes()
+    items, outs, refs, keep = [], [], [], []
+    for (cout, cin, k, bk, dgrad) in [((40, 24), 64, 3, 32, 0), ((96,), 48, 1, 16, 0), ((64, 32), 20, (1, 3), 32, 1), ((32,), 16, 3, 16, 1)]:
+        kh, kw = (k, k) if isinstance(k, int) else k
+        ws = [(torch.randn(c, cin, kh, kw, generator=g) * 0.1).to(DEV) for c in cout]
+        keep.append(ws)
+        n = len(ws)
+        wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws]); co = (C.c_int * n)(*cout)
+        size = lib.ct_conv_x3_packed_bytes(sum(cout) if dgrad else cin, cin if dgrad else sum(cout), kh, kw, bk)
+        ref = torch.zeros(size, dtype=torch.uint8, device=DEV)
+        fn = lib.ct_conv_pack_weights_x3_dgrad if dgrad else lib.ct_conv_pack_weights_x3
+        _lib.check(fn(wp, co, n, cin, kh, kw, bk, ref.data_ptr(), s), 'single')
+        out = torch.zeros(size, dtype=torch.uint8, device=DEV)
+        buf = (C.c_ubyte * nbytes)()
+        _lib.check(lib.ct_conv_x3_pack_item(wp, co, n, cin, kh, kw, bk, out.data_ptr(), dgrad, buf), 'item')
+        items.append(bytes(buf)); outs.append(out); refs.append(ref)
+    table = torch.frombuffer(bytearray(b''.join(items)), dtype=torch.uint8).to(DEV)
+    _lib.check(lib.ct_conv_x3_pack_run(table.data_ptr(), len(items), s), 'run')
+    torch.cuda.synchronize()
+    for a, b in zip(outs, refs):
+        assert torch.equal(a, b)
