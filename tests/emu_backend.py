@@ -64,7 +64,7 @@ class EmuBackend:
         bufs[st.dst][:, st.dst_base:st.dst_base + y.shape[1]] = y
 
 
-def replay_plan_autograd(plan, leaf, x, relu_masks=None, dtype=torch.float64, pool_inputs=None):
+def replay_plan_autograd(plan, leaf, x, relu_masks=None, dtype=torch.float64, pool_inputs=None, batch_stats=False):
     """Differentiable replay of an inference/training Plan with eval-mode BatchNorm (TEST INFRASTRUCTURE).
 
     leaf: {id(parameter): tensor requiring grad} standing in for the network's parameters; buffers (running
@@ -76,6 +76,8 @@ def replay_plan_autograd(plan, leaf, x, relu_masks=None, dtype=torch.float64, po
     pool_inputs(step) -> the OTHER evaluation's input tensor of a max-pool step or None: when given, the window
     maximum is taken at that evaluation's arg-max position (first maximum in row-major order, torch's rule), for the
     same reason: two values within rounding of each other may swap places.
+    batch_stats=True: BatchNorm with the statistics of the batch (nn.BatchNorm2d in train mode, what train.py:222-229
+    runs), differentiated through mean and variance.
     -> (loc [B,P*4], conf [B,P*C], obj [B,P*2])"""
     pieces = {'x': [(0, x.to(dtype))]}
     flat = {}
@@ -109,8 +111,11 @@ def replay_plan_autograd(plan, leaf, x, relu_masks=None, dtype=torch.float64, po
             y = F.conv2d(xin, P(p.weight), None, st.stride, (st.ph, st.pw), st.dil)
             if p.bn is not None:
                 bn = p.bn
-                y = F.batch_norm(y, bn.running_mean.detach().to(x.device, dtype), bn.running_var.detach().to(x.device, dtype), P(bn.weight),
-                                 P(bn.bias), False, 0.0, bn.eps)
+                if batch_stats:
+                    y = F.batch_norm(y, None, None, P(bn.weight), P(bn.bias), True, 0.0, bn.eps)
+                else:
+                    y = F.batch_norm(y, bn.running_mean.detach().to(x.device, dtype), bn.running_var.detach().to(x.device, dtype), P(bn.weight),
+                                     P(bn.bias), False, 0.0, bn.eps)
             elif p.bias is not None:
                 y = y + P(p.bias).view(1, -1, 1, 1)
             if st.res is not None:
