@@ -120,25 +120,73 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
     const int nsteps = SMALL ? (taps + SPR - 1) / SPR : taps * csteps;
 
     i32x4 ra[NA], rb[NB];
-    auto load_step = [&](int step) {
-        int tap, c0;
-        if (SMALL) { tap = step * SPR + sseg; c0 = 0; }
-        else { tap = step / csteps; c0 = (step - tap * csteps) * BK + sseg * 8; }
-        const int kh = tap / a.KW, kw = tap - kh * a.KW;
-        const bool cok = c0 < a.Cin && tap < taps;
+    // Loader state (round 3).  Steps are visited in increasing order, so the (tap, channel step) pair advances
+    // incrementally: the per-lane part of every address (this lane's pixels at the current tap, its weight rows) lives in
+    // VGPRs that change only when the tap does, the channel step is a wave-uniform scalar offset.  The first version
+    // recomputed tap / pixel / bounds for every load (~120 VALU per 16 MFMAs; VALU never overlaps an MFMA on a SIMD,
+    // profiles/r03_mfma_valu_overlap.txt).
+    int ld_tap = 0, ld_kh = 0, ld_kw = 0, ld_cs = 0;       // non-SMALL: tap index, its (kh, kw), channel step within the tap
+    int va[NA], va_tail[NA], vb[NB];
+    const bool has_tail = !SMALL && (a.Cin % BK) != 0;      // last channel step: segments at or past Cin read zeros
+    auto tap_offsets = [&]() {
 #pragma unroll
         for (int q = 0; q < NA; ++q) {
-            const int ih = pix_h[q] + kh * a.dil, iw = pix_w[q] + kw * a.dil;
-            const bool ok = pix_ok[q] && cok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
-            const int off = ok ? (((pix_n[q] * a.H + ih) * a.W + iw) * a.in_ctot + a.in_coff + c0) * 2 : kInvalidOff;
-            ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+            const int ih = pix_h[q] + ld_kh * a.dil, iw = pix_w[q] + ld_kw * a.dil;
+            const bool ok = pix_ok[q] && ld_tap < taps && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+            const int off = (((pix_n[q] * a.H + ih) * a.W + iw) * a.in_ctot + a.in_coff + sseg * 8) * 2;
+            va[q] = ok ? off : kInvalidOff;
+            va_tail[q] = ok && (csteps - 1) * BK + sseg * 8 < a.Cin ? off : kInvalidOff;
         }
+    };
+    if (!SMALL) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int co = m0 + (tid + 256 * q) / SPR;
-            const int woff = (co < a.cout_pad && tap < taps) ? (((tap * cgroups + (c0 >> 3)) * a.cout_pad + co) * 8) * 2
-                                                             : kInvalidOff;
-            rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff, 0, 0);
+            vb[q] = co < a.cout_pad ? (sseg * a.cout_pad + co) * 16 : kInvalidOff;
+        }
+    }
+    auto seek_step = [&](int step) {                        // position the loader on `step` (once, before the first load)
+        ld_tap = step / csteps;
+        ld_cs = step - ld_tap * csteps;
+        ld_kh = ld_tap / a.KW;
+        ld_kw = ld_tap - ld_kh * a.KW;
+        tap_offsets();
+    };
+    auto load_step = [&](int step) {
+        if (SMALL) {
+            const int tap = step * SPR + sseg;
+            const int kh = tap / a.KW, kw = tap - kh * a.KW;
+            const bool cok = 0 < a.Cin && tap < taps;
+#pragma unroll
+            for (int q = 0; q < NA; ++q) {
+                const int ih = pix_h[q] + kh * a.dil, iw = pix_w[q] + kw * a.dil;
+                const bool ok = pix_ok[q] && cok && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                const int off = ok ? (((pix_n[q] * a.H + ih) * a.W + iw) * a.in_ctot + a.in_coff) * 2 : kInvalidOff;
+                ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int co = m0 + (tid + 256 * q) / SPR;
+                const int woff = (co < a.cout_pad && tap < taps) ? ((tap * cgroups * a.cout_pad + co) * 8) * 2 : kInvalidOff;
+                rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff, 0, 0);
+            }
+            return;
+        }
+        const int sa = ld_cs * BK * 2;                                      // bytes: channel step inside the pixel
+        const int sb = (ld_tap * cgroups + ld_cs * SPR) * a.cout_pad * 16;   // bytes: (tap, channel group) plane
+        const bool tail = has_tail && ld_cs == csteps - 1;
+#pragma unroll
+        for (int q = 0; q < NA; ++q) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rin, tail ? va_tail[q] : va[q], sa, 0);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, vb[q], sb, 0);
+        // advance to the next step
+        ++ld_cs;
+        if (ld_cs == csteps) {
+            ld_cs = 0;
+            ++ld_tap;
+            ++ld_kw;
+            if (ld_kw == a.KW) { ld_kw = 0; ++ld_kh; }
+            tap_offsets();
         }
     };
     auto store_step = [&](int buf) {
@@ -162,6 +210,7 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
 
     const int s0 = blockIdx.y * a.steps_per_split;
     const int s1 = min(nsteps, s0 + a.steps_per_split);
+    if (!SMALL) seek_step(s0);
     load_step(s0);
     store_step(0);
     if (s1 - s0 > 1) load_step(s0 + 1);
