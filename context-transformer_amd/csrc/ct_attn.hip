@@ -1,19 +1,25 @@
 // libctdet: the Context-Transformer block (models/RFB_Net_vgg.py:253-271) as two kernels.
 //
-//   ctx_project_kernel   theta/phi/g (and fc_base) = Linear(x) + x, written straight into the
-//                        operand layouts the attention kernel wants (zero padded d -> 64):
-//                          Qs [B][P_pad][2][32]   Qs[.][p][h][s] = theta[p][2s+h]
-//                          Kt [B][64][M_pad]      phi transposed (d-major, keys contiguous)
-//                          Vs [B][M_pad][64]      g rows
-//   ctx_attn_kernel      flash-style fused  softmax(theta phi^T) g  on the fp32 MFMA path
-//                        (v_mfma_f32_32x32x2_f32), the [P,M] affinity matrix (86 MB/image in
-//                        the reference) never exists.  One wave = 32 queries, workgroup = 128.
+//   ctx_project_x3_kernel  theta/phi/g = Linear(x) + x, split into three exact bfloat16 pieces and written straight
+//                        into the MFMA fragment order the attention kernel reads (zero padded d -> 64; layouts at the
+//                        kernel).  ctx_project_kernel (ct_attn_common.h) still writes fc_base for the 'incre' branch.
+//   ctx_attn_kernel      flash-style fused  softmax(theta phi^T) g; the [P,M] affinity matrix (86 MB/image in
+//                        the reference) never exists.  One wave = 32 queries, workgroup = 128.  Since round 3 both
+//                        contractions run as bf16x3 on v_mfma_f32_32x32x16_bf16 (every fp32 operand split exactly
+//                        into three bfloat16 pieces, six piece products per multiply, fp32 accumulation; the
+//                        theta.phi^T logits in two accumulators -- csrc/ct_conv_x3.hip has the arithmetic): 48 bf16
+//                        MFMAs per 32-key tile and wave instead of 64 fp32 ones at twice the issue time; measured on
+//                        the 512 train-mode logits (|S| ~ 370, d = 64) the log-sum-exp is 0.75x and the block output
+//                        0.56x the error of the fp32 chain against float64.  theta /
+//                        phi / g are split ONCE by ctx_project_x3_kernel, straight into the fragment order the MFMAs
+//                        read (keys of a V fragment in the order the S^T accumulator holds them), only the
+//                        probabilities are split in registers.
 //                        Per 32-key tile:
-//                          S^T = K Q^T   A = Kt tile from LDS (keys contiguous), B = Q registers
+//                          S^T = K Q^T   A = phi fragments from LDS, B = theta fragments in registers
 //                                        -> lane (q = l&31, h = l>>5) holds 16 keys of query q,
 //                                        so the softmax max / sum are in-lane + one lane^32 swap
-//                          O^T += V^T P^T  B operand = the S^T accumulator registers as they
-//                                        are (key pairing is free to choose), A = V tile rows
+//                          O^T += V^T P^T  B operand = the S^T accumulator registers split in place (the key order of
+//                                        a g fragment is chosen to match), A = g fragments from LDS
 //                        Epilogue in registers: (conf + O/l * Wz) -> L2 normalise -> cosine
 //                        classifier OBJ_Target * scale, written to out[B,P,(d)+T].
 #include "ct_common.h"
@@ -21,10 +27,87 @@
 
 namespace {
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int XT_BYTES = 3 * 8 * KT * 16;          // one 32-key tile of K or V as bf16x3 fragments: 12 KB
+constexpr int XQ_BYTES = 3 * 8 * 16;               // one query row: 384 B
+
+// x = hi + mid + lo exactly (three bfloat16 pieces by truncation); returns the fp32 bit patterns whose upper halves
+// are the pieces
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l)
+{
+    h = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+    const float r1 = x - __builtin_bit_cast(float, h);
+    m = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+    l = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, m));
+}
+__device__ __forceinline__ int pack_hi(unsigned e0, unsigned e1)
+{
+    return (int)__builtin_amdgcn_perm(e1, e0, 0x07060302u);
+}
+
+// y = Linear(x) + x (as ctx_project_kernel), written as bf16x3 pieces in MFMA fragment order:
+//   mode 0 (theta -> Q, B operand of S^T = K Q^T): Qx[b][row][piece 3][octet 8][8]      element d at octet d/8, slot d%8
+//   mode 1 (phi -> K, A operand of S^T):           Kx[b][tile][piece][octet 8][key 32][8]
+//   mode 2 (g -> V, A operand of O^T += V^T P^T):  Vx[b][tile][piece][kg 2][h 2][d 64][8]  slot j of (kg, h) = the key the
+//          S^T accumulator register 8 kg + j of lane half h holds (acc_row): P^T goes to the MFMA as it sits in registers
+__global__ __launch_bounds__(256) void ctx_project_x3_kernel(const float* __restrict__ x, int rows_valid, int rows_pad,
+                                                             int d, const float* __restrict__ W,
+                                                             const float* __restrict__ bias,
+                                                             unsigned short* __restrict__ out, int mode)
+{
+    __shared__ float Wt[DP * DP];      // Wt[i][o]
+    __shared__ float Xs[64 * DP];      // 64 rows
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < DP * DP; e += 256) {
+        const int i = e / DP, o = e % DP;
+        Wt[e] = (i < d && o < d) ? W[o * d + i] : 0.f;
+    }
+    for (int e = tid; e < 64 * DP; e += 256) {
+        const int r = e / DP, i = e % DP;
+        const int row = r0 + r;
+        Xs[e] = (row < rows_valid && i < d) ? x[((size_t)b * rows_valid + row) * d + i] : 0.f;
+    }
+    __syncthreads();
+    const int o = tid & 63, rg = tid >> 6;
+    const float bo = (o < d) ? bias[o] : 0.f;
+    for (int r = rg; r < 64; r += 4) {
+        const int row = r0 + r;
+        if (row >= rows_pad) break;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < DP; ++i) acc += Xs[r * DP + i] * Wt[i * DP + o];
+        const float y = (row < rows_valid && o < d) ? acc + bo + Xs[r * DP + o] : 0.f;
+        unsigned ph, pm, pl;
+        split3(y, ph, pm, pl);
+        size_t base;        // in bf16 elements, piece 0
+        size_t pstride;     // elements between pieces
+        if (mode == 0) {
+            base = ((size_t)b * rows_pad + row) * (XQ_BYTES / 2) + (o >> 3) * 8 + (o & 7);
+            pstride = 8 * 8;
+        } else {
+            const int tile = row / KT, kl = row % KT;
+            const size_t tb = ((size_t)b * (rows_pad / KT) + tile) * (XT_BYTES / 2);
+            if (mode == 1) {
+                base = tb + ((size_t)(o >> 3) * KT + kl) * 8 + (o & 7);
+            } else {
+                const int h = (kl >> 2) & 1, rr = (kl & 3) + 4 * (kl >> 3);     // kl = acc_row(rr, h)
+                base = tb + ((size_t)((rr >> 3) * 2 + h) * DP + o) * 8 + (rr & 7);
+            }
+            pstride = 8 * KT * 8;
+        }
+        out[base] = (unsigned short)(ph >> 16);
+        out[base + pstride] = (unsigned short)(pm >> 16);
+        out[base + 2 * pstride] = (unsigned short)(pl >> 16);
+    }
+}
+
 struct AttnArgs {
-    const float* Qs;
-    const float* Kt;
-    const float* Vs;
+    const unsigned char* Qx;
+    const unsigned char* Kx;
+    const unsigned char* Vx;
     const float* conf;
     const float* wz;
     const float* obj_w;
@@ -37,8 +120,7 @@ struct AttnArgs {
 
 __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float ks[2][DP * KT];   // [d][key]
-    __shared__ __attribute__((aligned(16))) float vs[2][KT * DP];   // [key][d]
+    __shared__ __attribute__((aligned(16))) unsigned char kv[2][2 * XT_BYTES];   // per buffer: K tile, V tile (fragments)
     __shared__ float objw[32 * DP];
     __shared__ float wzs[DP];
 
@@ -53,75 +135,73 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
     }
     if (tid < DP) wzs[tid] = tid < a.d ? a.wz[tid] : 0.f;
 
-    // Q fragment: B operand of step s is Qs[q][h][s]
-    float qreg[32];
+    // Q fragments (B operand of S^T): group g = 16 features, lane half h = octet 2g + h, three pieces
+    i32x4 qf[4][3];
     {
-        const float4* qp = reinterpret_cast<const float4*>(a.Qs + ((size_t)b * a.P_pad + q) * DP + h * 32);
+        const unsigned char* qp = a.Qx + ((size_t)b * a.P_pad + q) * XQ_BYTES;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 v = qp[i];
-            qreg[4 * i + 0] = v.x; qreg[4 * i + 1] = v.y; qreg[4 * i + 2] = v.z; qreg[4 * i + 3] = v.w;
-        }
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                qf[g][p] = *reinterpret_cast<const i32x4*>(qp + (p * 8 + 2 * g + h) * 16);
     }
 
-    const float* Ktb = a.Kt + (size_t)b * DP * a.M_pad;
-    const float* Vsb = a.Vs + (size_t)b * a.M_pad * DP;
     const int nt = a.M_pad / KT;
+    const unsigned char* Kxb = a.Kx + (size_t)b * nt * XT_BYTES;
+    const unsigned char* Vxb = a.Vx + (size_t)b * nt * XT_BYTES;
 
-    float4 kreg[2], vreg[2];
+    i32x4 treg[6];                                         // 24 KB per tile / 256 threads
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + 256 * i;                   // 512 float4 per tile
-            const int row = f >> 3, c4 = f & 7;
-            kreg[i] = *reinterpret_cast<const float4*>(Ktb + (size_t)row * a.M_pad + t * KT + c4 * 4);
-            vreg[i] = *reinterpret_cast<const float4*>(Vsb + (size_t)t * KT * DP + f * 4);
+        for (int i = 0; i < 3; ++i) {
+            treg[i] = *reinterpret_cast<const i32x4*>(Kxb + (size_t)t * XT_BYTES + (tid + 256 * i) * 16);
+            treg[3 + i] = *reinterpret_cast<const i32x4*>(Vxb + (size_t)t * XT_BYTES + (tid + 256 * i) * 16);
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + 256 * i;
-            *reinterpret_cast<float4*>(&ks[buf][f * 4]) = kreg[i];   // row*32 + c4*4 == f*4
-            *reinterpret_cast<float4*>(&vs[buf][f * 4]) = vreg[i];
+        for (int i = 0; i < 3; ++i) {
+            *reinterpret_cast<i32x4*>(&kv[buf][(tid + 256 * i) * 16]) = treg[i];
+            *reinterpret_cast<i32x4*>(&kv[buf][XT_BYTES + (tid + 256 * i) * 16]) = treg[3 + i];
         }
     };
 
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, mb_run = -INFINITY, l_run = 0.f;
 
     load_tile(0);
     store_tile(0);
     __syncthreads();
 
+    // piece pairs (A piece, B piece) of the six products, smallest first; the last one is hi.hi
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         const bool more = t + 1 < nt;
         if (more) load_tile(t + 1);
 
-        // ---- S^T = K Q^T ----  (A fragments read from LDS four steps ahead of their MFMAs)
-        f32x16 s;
+        // ---- S^T = K Q^T ----  hi.hi products in `s`, the five small ones in `ss`
+        f32x16 s, ss;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
-        const float* kb = &ks[buf][h * KT + l31];
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; ss[r] = 0.f; }
         {
-            float af[2][4];
+            const unsigned char* kb = &kv[buf][l31 * 16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) af[0][u] = kb[(2 * u) * KT];
+            for (int g = 0; g < 4; ++g) {
+                i32x4 kf[3];
 #pragma unroll
-            for (int g4 = 0; g4 < 8; ++g4) {
-                const int cur = g4 & 1;
-                if (g4 + 1 < 8) {
+                for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const i32x4*>(kb + ((p * 8 + 2 * g + h) * KT) * 16);
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) af[cur ^ 1][u] = kb[(2 * (4 * g4 + 4 + u)) * KT];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    s = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][u], qreg[4 * g4 + u], s, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int c = 0; c < 5; ++c)
+                    ss = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[PA[c]]),
+                                                                 __builtin_bit_cast(bf16x8, qf[g][PB[c]]), ss, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]),
+                                                            __builtin_bit_cast(bf16x8, qf[g][0]), s, 0, 0, 0);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] += ss[r];
         }
 
         // ---- online softmax over this tile's 32 keys (16 in-lane + partner lane^32) ----
@@ -135,11 +215,18 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
         const float m_new = fmaxf(m_run, mloc);
-        // exp(x) = 2^(x*log2 e) on the hardware exp2 (v_exp_f32): only keys within a few units of the
-        // row maximum carry weight, and there (s - m) is exact, so the result is good to ~2 ulp
+        // exp(x) = 2^(x*log2 e) on the hardware exp2 (v_exp_f32): only keys within a few units of the row maximum carry
+        // weight, and there fma(s, log2 e, -mb) is good to ~2 ulp.  `mb` is the ROUNDED product m * log2 e and every use
+        // must see that same value: the probabilities of all tiles that share a maximum are then scaled by one common
+        // factor 2^(m log2 e - mb), which the normalisation removes, and the rescale between two maxima is exactly
+        // 2^(mb_old - mb_new).  Left to -ffp-contract the compiler is free to fuse the multiply into one of the
+        // subtractions (it did: alpha = 2^(m_run log2 e - mb) != 1 with an unchanged maximum, 2e-5 per tile, compounding
+        // over 156 tiles), hence the opaque copy.
         constexpr float kLog2e = 1.4426950408889634f;
-        const float mb = m_new * kLog2e;
-        const float alpha = __builtin_amdgcn_exp2f(m_run * kLog2e - mb);
+        float mb = m_new * kLog2e;
+        asm volatile("" : "+v"(mb));
+        const float alpha = __builtin_amdgcn_exp2f(mb_run - mb);
+        mb_run = mb;
         float lsum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -152,31 +239,37 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 
-        // ---- O^T += V^T P^T ----  (V fragments two key-steps ahead)
-        const float* vb = &vs[buf][l31];
+        // ---- O^T += V^T P^T ----  B operand: this lane's own probabilities (registers 8 kg .. 8 kg + 7), split in place
         {
-            float vf[2][4];
+            i32x4 pf[2][3];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                vf[0][2 * u] = vb[acc_row(u, h) * DP];
-                vf[0][2 * u + 1] = vb[acc_row(u, h) * DP + 32];
+            for (int kg = 0; kg < 2; ++kg) {
+                unsigned ph[8], pm[8], pl[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) split3(s[8 * kg + j], ph[j], pm[j], pl[j]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    pf[kg][0][w] = pack_hi(ph[2 * w], ph[2 * w + 1]);
+                    pf[kg][1][w] = pack_hi(pm[2 * w], pm[2 * w + 1]);
+                    pf[kg][2][w] = pack_hi(pl[2 * w], pl[2 * w + 1]);
+                }
             }
+            const unsigned char* vb = &kv[buf][XT_BYTES + l31 * 16];
 #pragma unroll
-            for (int g2 = 0; g2 < 8; ++g2) {
-                const int cur = g2 & 1;
-                if (g2 + 1 < 8) {
+            for (int kg = 0; kg < 2; ++kg) {
+                i32x4 vf[3][2];
 #pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        vf[cur ^ 1][2 * u] = vb[acc_row(2 * g2 + 2 + u, h) * DP];
-                        vf[cur ^ 1][2 * u + 1] = vb[acc_row(2 * g2 + 2 + u, h) * DP + 32];
-                    }
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        vf[p][db] = *reinterpret_cast<const i32x4*>(vb + ((((p * 2 + kg) * 2 + h) * DP) + 32 * db) * 16);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[PA[c]][0]),
+                                                                 __builtin_bit_cast(bf16x8, pf[kg][PB[c]]), o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[PA[c]][1]),
+                                                                 __builtin_bit_cast(bf16x8, pf[kg][PB[c]]), o1, 0, 0, 0);
                 }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cur][2 * u], s[2 * g2 + u], o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[cur][2 * u + 1], s[2 * g2 + u], o1, 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
@@ -206,7 +299,7 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
             drow[8 + 2 * g + h] = make_float4(o1[4 * g] * inv_l, o1[4 * g + 1] * inv_l, o1[4 * g + 2] * inv_l,
                                               o1[4 * g + 3] * inv_l);
         }
-        if (h == 0) a.save_lse[(size_t)b * a.P_pad + q] = m_run * 1.4426950408889634f + log2f(l_run);
+        if (h == 0) a.save_lse[(size_t)b * a.P_pad + q] = mb_run + log2f(l_run);
     }
     const float* crow = a.conf + ((size_t)b * a.P + q) * a.d;
     float x[32];
@@ -238,7 +331,7 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
 }
 
 struct Ws {
-    float *Qs, *Kt, *Vs;
+    unsigned char *Qx, *Kx, *Vx;      // bf16x3 fragments (ctx_project_x3_kernel)
     int P_pad, M_pad;
     size_t total;
 };
@@ -252,11 +345,11 @@ Ws carve(char* base, int batch, int P, int M)
     auto take = [&](size_t bytes) {
         char* p = base ? base + off : nullptr;
         off += ctdet::align_up(bytes, 256);
-        return (float*)p;
+        return (unsigned char*)p;
     };
-    w.Qs = take((size_t)batch * w.P_pad * DP * 4);
-    w.Kt = take((size_t)batch * DP * w.M_pad * 4);
-    w.Vs = take((size_t)batch * w.M_pad * DP * 4);
+    w.Qx = take((size_t)batch * w.P_pad * XQ_BYTES);
+    w.Kx = take((size_t)batch * (w.M_pad / KT) * XT_BYTES);
+    w.Vx = take((size_t)batch * (w.M_pad / KT) * XT_BYTES);
     w.total = off;
     return w;
 }
@@ -283,22 +376,22 @@ int forward_impl(const float* conf, const float* pool, int batch, int num_priors
     const int ostride = (prm->fc_w ? d : 0) + prm->t;
     const dim3 blk(256);
     float* none = nullptr;
-    { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_kernel, dim3(w.P_pad / 64, batch), blk, 0, st, conf, num_priors,
-                       w.P_pad, d, prm->theta_w, prm->theta_b, w.Qs, none, none, none, 0); }
-    CT_LAUNCH_CHECK("ctx_project_kernel(theta)");
-    { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
-                       w.M_pad, d, prm->phi_w, prm->phi_b, none, w.Kt, none, none, 0); }
-    CT_LAUNCH_CHECK("ctx_project_kernel(phi)");
-    { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
-                       w.M_pad, d, prm->g_w, prm->g_b, none, none, w.Vs, none, 0); }
-    CT_LAUNCH_CHECK("ctx_project_kernel(g)");
+    { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_x3_kernel, dim3(w.P_pad / 64, batch), blk, 0, st, conf, num_priors,
+                       w.P_pad, d, prm->theta_w, prm->theta_b, (unsigned short*)w.Qx, 0); }
+    CT_LAUNCH_CHECK("ctx_project_x3_kernel(theta)");
+    { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_x3_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
+                       w.M_pad, d, prm->phi_w, prm->phi_b, (unsigned short*)w.Kx, 1); }
+    CT_LAUNCH_CHECK("ctx_project_x3_kernel(phi)");
+    { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_x3_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
+                       w.M_pad, d, prm->g_w, prm->g_b, (unsigned short*)w.Vx, 2); }
+    CT_LAUNCH_CHECK("ctx_project_x3_kernel(g)");
     if (prm->fc_w) {
         { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_kernel, dim3((num_priors + 63) / 64, batch), blk, 0, st, conf,
                            num_priors, num_priors, d, prm->fc_w, prm->fc_b, none, none, none, out, ostride); }
         CT_LAUNCH_CHECK("ctx_project_kernel(fc_base)");
     }
     AttnArgs a{};
-    a.Qs = w.Qs; a.Kt = w.Kt; a.Vs = w.Vs;
+    a.Qx = w.Qx; a.Kx = w.Kx; a.Vx = w.Vx;
     a.conf = conf; a.wz = prm->wz; a.obj_w = prm->obj_w; a.out = out;
     a.save_d = save_d; a.save_lse = save_lse;
     a.P = num_priors; a.P_pad = w.P_pad; a.M = num_ctx; a.M_pad = w.M_pad;
