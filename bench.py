@@ -211,9 +211,14 @@ def conv_roofline(rt, batch, pmc):
             # bf16x3: six bf16 MFMA products per fp32 multiply-add, on the bf16 pipe
             name, mult, pk = 'conv_x3_f32<%dx%d,%s>' % (st.kh, st.kw, x3_names[x3][3:]), 6.0, PEAK_BF16_MFMA_TFLOPS
         else:
-            name = st.rt.get('kernel_name') or 'conv_igemm_f32<%dx%d,%s>' % (
-                st.kh, st.kw, lib.ct_conv_config_name(cfg - 1).decode() if cfg > 0 else 'auto')
+            cname = lib.ct_conv_config_name(cfg - 1).decode() if cfg > 0 else 'auto'
+            name = st.rt.get('kernel_name') or 'conv_igemm_f32<%dx%d,%s>' % (st.kh, st.kw, cname)
             mult, pk = 1.0, PEAK_F32_MFMA_TFLOPS
+            if cname == 'valu' or (cfg == 0 and st.cin == 3 and (st.kh, st.kw) == (3, 3)):
+                # the 3-channel image layer on the vector ALU (v_pk_fma_f32): 256 CUs x 4 SIMDs x 16 lanes x 2 (packed)
+                # x 2 flop x 2.4 GHz = 157.3 TFLOP/s, numerically the fp32 MFMA peak; the kernel is bound by its
+                # 8 KB-per-pixel-row output stream, not by either pipe
+                name = 'conv_valu3x3_f32'
         a = agg.setdefault(name, [0.0, 0.0, 0, 0.0, pk])
         a[0] += e0.elapsed_time(e1) * 1e-3
         a[1] += st.flops(batch)                # direct-convolution flops

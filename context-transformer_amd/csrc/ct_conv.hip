@@ -340,6 +340,120 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
     }
 }
 
+// The 3-channel image layer (conv1_1: 3x3, 3 -> 64 at full resolution) on the vector ALU.  K = 27 is 14 MFMA steps of a
+// GEMM whose B operand is gathered one element per lane and step; its time goes into that gather and the LDS round trip,
+// not into the matrix pipe (measured 30 TFLOP/s, 335 us at 300x300 bs 32, against 737 MB of output = ~170 us of HBM
+// writes).  Here one lane owns one output pixel: its 27 inputs stay in registers, the weights of eight output channels
+// at a time arrive through the scalar cache (the packed [k][m_pad] layout makes them one s_load_dwordx8 per k) and feed
+// v_pk_fma_f32 straight from SGPR pairs; 864 packed FMAs per pixel, stores coalesced along the image row.
+template <int CIN, int PPT>
+__global__ __launch_bounds__(256) void conv_valu3x3_f32(const ConvArgs a)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int K = CIN * 9;
+    const int HW = a.H * a.W;
+    float x[PPT][K];
+    float* op[PPT];
+    bool live[PPT];
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) {          // pixels P, P + 256, ...: every store stays coalesced along the image row
+        const int P = (blockIdx.x * PPT + p) * 256 + threadIdx.x;
+        live[p] = P < a.Npix;
+        const int Pc = live[p] ? P : 0;
+        const int n = Pc / a.OHW, s = Pc - n * a.OHW;
+        const int oh = s / a.OW, ow = s - oh * a.OW;
+        const float* ip = a.in + ((size_t)n * a.in_ctot + a.in_coff) * HW;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * a.stride - a.pad_h + kh * a.dil;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * a.stride - a.pad_w + kw * a.dil;
+                const bool ok = live[p] && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
+                const int off = ok ? ih * a.W + iw : 0;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) {
+                    const float v = ip[ci * HW + off];
+                    x[p][ci * 9 + kh * 3 + kw] = ok ? v : 0.f;
+                }
+            }
+        }
+        op[p] = a.out + ((size_t)n * a.out_ctot + a.out_coff) * a.OHW + s;
+    }
+    // weights and epilogue vectors through the constant address space: wave-uniform, read-only for the whole launch,
+    // so they load through the scalar cache into SGPRs (as plain global pointers the stores below could alias them and
+    // the compiler keeps them on the vector memory path, 216 VGPRs of weights per eight output channels)
+    typedef const __attribute__((address_space(4))) float cfloat;
+    typedef const __attribute__((address_space(4))) f32x2 cf32x2;
+    cfloat* const wk = (cfloat*)a.wpk;
+    cfloat* const sc = (cfloat*)a.scale;
+    cfloat* const sh = (cfloat*)a.shift;
+    cfloat* const lo = (cfloat*)a.lo;
+    for (int co0 = 0; co0 < a.M; co0 += 8) {
+        f32x2 acc[PPT][4];
+#pragma unroll
+        for (int p = 0; p < PPT; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[p][j] = f32x2{0.f, 0.f};
+        cfloat* wp = wk + co0;
+        // groups of one filter row (3 k, 24 SGPRs of weights), double-buffered.  Scalar loads return out of order, so the
+        // only wait is lgkmcnt(0): the first FMA of a group takes that wait, THEN the next group's loads are issued and
+        // fly during the remaining FMAs.  (All 27 loads hoisted need 216 SGPRs: the compiler spills them to VGPR
+        // lanes, 4 v_readlane per FMA.)
+        f32x2 wc[3][4], wn[3][4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wc[i][j] = ((cf32x2*)(wp + (size_t)i * a.M_pad))[j];
+#pragma unroll
+        for (int g = 0; g < K / 3; ++g) {
+            {
+                const f32x2 xx = f32x2{x[0][3 * g], x[0][3 * g]};
+                acc[0][0] = __builtin_elementwise_fma(xx, wc[0][0], acc[0][0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < K / 3) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) wn[i][j] = ((cf32x2*)(wp + (size_t)(3 * g + 3 + i) * a.M_pad))[j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p = 0; p < PPT; ++p)
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const f32x2 xx = f32x2{x[p][3 * g + i], x[p][3 * g + i]};
+#pragma unroll
+                    for (int j = (p == 0 && i == 0 ? 1 : 0); j < 4; ++j)
+                        acc[p][j] = __builtin_elementwise_fma(xx, wc[i][j], acc[p][j]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wc[i][j] = wn[i][j];
+        }
+        // the sums are only used under `if (live)`: without this the compiler sinks most of the FMA chains into
+        // that branch, keeps all 27 weight rows alive until there and spills them
+#pragma unroll
+        for (int p = 0; p < PPT; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[p][j]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int co = co0 + j;
+            const float scv = sc[co], shv = sh[co];
+            const float lov = a.lo ? lo[co] : (a.relu ? 0.f : -INFINITY);
+#pragma unroll
+            for (int p = 0; p < PPT; ++p) {
+                const float v = fmaxf((j & 1 ? acc[p][j >> 1].y : acc[p][j >> 1].x) * scv + shv, lov);
+                if (live[p]) op[p][(size_t)co * a.OHW] = v;
+            }
+        }
+    }
+}
+
 // epilogue of a split-K convolution: sum of the slabs in split order, then the same arithmetic as the fused one
 __global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvArgs a)
 {
@@ -435,8 +549,10 @@ struct TileCfg {
 const TileCfg kCfgs[] = {
     {128, 128, 1, "128x128"}, {64, 128, 1, "64x128"}, {128, 64, 1, "128x64"}, {64, 64, 1, "64x64"},
     {32, 128, 1, "32x128"},   {160, 128, 1, "160x128"}, {128, 128, 2, "128x128k2"}, {96, 128, 1, "96x128"},
+    {0, 256, 0, "valu"},      // conv_valu3x3_f32: not an implicit-GEMM tile (3-channel 3x3 layers only)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+constexpr int kValuCfg = kNumCfgs - 1;
 
 // channels per k-step for (geometry, BN) at kmul = 1
 constexpr int cpb_for(int kh, int kw, int bn)
@@ -514,6 +630,7 @@ extern "C" int ct_conv_kpad(int cin, int kh, int kw)
     auto gcd = [](int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; };
     int l = 1;
     for (int i = 0; i < kNumCfgs; ++i) {
+        if (i == kValuCfg) continue;
         const int c = cpb_for(kh, kw, kCfgs[i].bn) * kCfgs[i].kmul;
         l = l / gcd(l, c) * c;
     }
@@ -645,8 +762,31 @@ extern "C" int ct_conv2d_fwd(const ct_conv_desc* d, ct_stream_t stream)
     CT_REQUIRE(img_in_bytes < kMaxBufBytes, "ct_conv2d_fwd: one image exceeds 2 GiB");
     const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / img_in_bytes);
 
-    int cfg = d->config > 0 ? d->config - 1 : pick_config(d->cout, (long)d->batch * d->oh * d->ow);
+    const bool valu_ok = d->kh == 3 && d->kw == 3 && d->cin == 3 && !d->transposed && d->nseg == 0 && !d->res &&
+                         d->cout % 8 == 0 && d->batch <= max_chunk && (long long)d->batch * d->oh * d->ow < 0x7FFFFFFFLL;
+    int cfg = d->config > 0 ? d->config - 1
+            : valu_ok       ? kValuCfg          // the image layer: 1.6-1.75x the best implicit-GEMM tile at every batch
+                            : pick_config(d->cout, (long)d->batch * d->oh * d->ow);
     CT_REQUIRE(cfg >= 0 && cfg < kNumCfgs, "ct_conv2d_fwd: config %d", d->config);
+    if (cfg == kValuCfg) {
+        if (!valu_ok)
+            return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_fwd: config 'valu' is for 3x3 convolutions of 3 input channels "
+                               "into a multiple of 8 output channels, NCHW output, no residual");
+        ConvArgs a{};
+        a.in = d->in; a.wpk = d->wpacked; a.scale = d->scale; a.shift = d->shift; a.lo = d->lo; a.out = d->out;
+        a.Cin = d->cin; a.H = d->h; a.W = d->w; a.in_ctot = d->in_ctot; a.in_coff = d->in_coff;
+        a.M = d->cout; a.M_pad = d->m_pad;
+        a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.dil = d->dil;
+        a.OW = d->ow; a.OHW = d->oh * d->ow; a.Npix = d->batch * a.OHW;
+        a.out_ctot = d->out_ctot; a.out_coff = d->out_coff; a.relu = d->relu;
+        static const int ppt = getenv("CTDET_VALU_PPT") ? atoi(getenv("CTDET_VALU_PPT")) : 2;
+        if (ppt == 1)
+            hipLaunchKernelGGL((conv_valu3x3_f32<3, 1>), dim3((a.Npix + 255) / 256), dim3(256), 0, ctdet::as_stream(stream), a);
+        else
+            hipLaunchKernelGGL((conv_valu3x3_f32<3, 2>), dim3((a.Npix + 511) / 512), dim3(256), 0, ctdet::as_stream(stream), a);
+        CT_LAUNCH_CHECK("conv_valu3x3_f32");
+        return CT_OK;
+    }
     const int bm = kCfgs[cfg].bm, bn = kCfgs[cfg].bn;
     const int cpb = cpb_for(d->kh, d->kw, bn) * kCfgs[cfg].kmul;
 

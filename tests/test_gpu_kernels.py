@@ -117,10 +117,41 @@ def test_conv_all_configs(case):
     want = _ref_conv(x, [(w, b, None, True)], stride, pad, dil)
     ncfg = _lib.lib().ct_conv_num_configs()
     errs = {}
+    names = [_lib.lib().ct_conv_config_name(i).decode() for i in range(ncfg)]
     for cfg in range(0, ncfg + 1):          # 0 = heuristic, 1.. = explicit tile configs
+        if cfg and names[cfg - 1] == 'valu' and not (Cin == 3 and (kh, kw) == (3, 3) and Cout % 8 == 0):
+            with pytest.raises(_lib.CtdetError):        # the vector-ALU kernel of the image layer refuses loudly
+                _run_conv(x, [(w, b, None, True)], stride, pad, dil, config=cfg)
+            continue
         got = _run_conv(x, [(w, b, None, True)], stride, pad, dil, config=cfg)
         errs[cfg] = rel_err(got, want)
     assert max(errs.values()) < TOL, errs
+    assert name != 'first_cin3' or len(errs) == ncfg + 1
+
+
+def test_conv_valu_image_layer():
+    """conv_valu3x3_f32 (config 'valu', the 3-channel image layer on the vector ALU): strides, dilation, a ragged
+    pixel count, BatchNorm scale + per-part ReLU floors, input / output channel slices -- against the torch reference
+    and against the implicit-GEMM kernel on the same descriptor."""
+    ncfg = _lib.lib().ct_conv_num_configs()
+    valu = 1 + [_lib.lib().ct_conv_config_name(i).decode() for i in range(ncfg)].index('valu')
+    g = torch.Generator().manual_seed(77)
+    for (B, H, W, Cout, stride, pad, dil) in ((2, 75, 75, 64, 1, 1, 1), (3, 37, 41, 24, 2, 1, 1), (1, 33, 29, 40, 1, 2, 2),
+                                              (1, 300, 300, 64, 1, 1, 1)):
+        x = torch.randn(B, 3, H, W, generator=g) * 60
+        w1 = torch.randn(Cout // 2, 3, 3, 3, generator=g) * 0.2
+        w2 = torch.randn(Cout - Cout // 2, 3, 3, 3, generator=g) * 0.2
+        parts = [(w1, None, _bn(Cout // 2, g), True), (w2, torch.rand(Cout - Cout // 2, generator=g), None, False)]
+        want = _ref_conv(x, parts, stride, pad, dil)
+        got = _run_conv(x, parts, stride, pad, dil, config=valu)
+        assert rel_err(got, want) < TOL, (B, H, W, Cout, stride, pad, dil)
+        assert rel_err(got, _run_conv(x, parts, stride, pad, dil, config=1)) < 2e-6
+    x5 = torch.randn(2, 5, 40, 40, generator=g)
+    w = torch.randn(16, 3, 3, 3, generator=g) * 0.2
+    bn = _bn(16, g)
+    got = _run_conv(x5, [(w, None, bn, True)], 1, 1, 1, cin_off=1, cin=3, out_ctot=30, out_coff=6, config=valu)
+    assert torch.isnan(got[:, :6]).all() and torch.isnan(got[:, 22:]).all()       # untouched slices
+    assert rel_err(got[:, 6:22], _ref_conv(x5[:, 1:4], [(w, None, bn, True)], 1, 1, 1)) < TOL
 
 
 def test_conv_fused_epilogues():
