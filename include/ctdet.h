@@ -244,7 +244,9 @@ typedef struct ct_conv_desc {
 int ct_conv_kpad(int cin, int kh, int kw);
 int ct_conv_mpad(int cout);
 int ct_conv_num_configs(void);
-/* Human-readable name of tile config i (0-based), e.g. "128x128". */
+/* Human-readable name of tile config i (0-based), e.g. "128x128".  The last one, "valu", is not an implicit-GEMM tile:
+ * conv_valu3x3_f32, the 3x3 / 3-input-channel image layer (models/RFB_Net_vgg.py:219, conv1_1) on the vector ALU; it
+ * is what config 0 picks for such a layer (cout % 8 == 0, NCHW output, no residual) and CT_ERR_UNSUPPORTED elsewhere. */
 const char* ct_conv_config_name(int i);
 /* Pack nparts (1..6) weight tensors w[i] dev [cout_i, cin, kh, kw] (concatenated along cout) into
  * wpacked dev [k_pad][m_pad] (k = ci*kh*kw + tap, zero padded). */
