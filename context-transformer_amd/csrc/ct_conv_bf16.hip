@@ -4,19 +4,23 @@
 // [batch][h][w][channels] bf16, so the 8 consecutive input channels an MFMA lane needs at one filter tap are ONE
 // 16-byte load, and the implicit-GEMM "im2col" gather degenerates to a row copy.  Accumulation and epilogue in fp32.
 //
-//   workgroup (256 threads, 4 waves) = 128 output pixels x 128 (or 64) output channels; a k-step = 64 input channels
-//   of one filter tap (for the 3-channel image, stored with 8 channels: 4 taps x 8 channels).  The A tile
-//   [128 px][64 ch] and the B tile [cout][64 ch] are staged through LDS with 16-byte accesses (144-byte rows:
-//   conflict-free), double buffered, one barrier per k-step, operand fragments of k-slice h+1 read while the
-//   v_mfma_f32_32x32x16_bf16 of slice h run; wave tile 64 x 64 (2 x 2 MFMA tiles).  XCD-aware tile order: the cout
+//   workgroup (256 threads, 4 waves) = 128 output pixels x 128 (or 64) output channels, or (512 threads, 8 waves) 256 x 256
+//   for layers with >= 256 output channels whose 256-pixel tiles still give every CU a workgroup; a k-step = 64 (or 32)
+//   input channels of one filter tap (for the 3-channel image, stored with 8 channels: 4 taps x 8 channels).  The A tile
+//   [pixels][k] and the B tile [cout][k] go global -> LDS by DMA (buffer_load_dwordx4 ... lds; round 3 -- the VGPR-staged
+//   form with ds_write_b128 remains for the image layer), XOR-swizzled 16-byte segments instead of padded rows, a ring of
+//   two (three for 32-channel steps) buffers, one barrier per k-step, operand fragments of k-slice h+1 read while the
+//   v_mfma_f32_32x32x16_bf16 of slice h run; wave tile 64 x 64 (128 x 64 in the big tile).  XCD-aware tile order: the cout
 //   tiles of one pixel tile share an L2.
 //   Epilogue: bf16 NHWC output goes through LDS once ([pixel][cout] fp32) so that a thread owns 8 consecutive
 //   channels of a pixel -- one 16-byte store and one 16-byte residual load (2-byte accesses made the 1x1 layers
 //   epilogue-bound: 270 -> 77 us for 512->512 @38x38); a channel slice of a wider buffer is torch.cat for free.
 //   Multibox heads write fp32 into the flattened head buffers, which ARE channels-last
 //   (models/RFB_Net_vgg.py:245-247).
-//   Measured (bs 32, tools/bf16_probe.py): 512->512 @38x38 292 us = 746 TFLOP/s (30 % of the 2.5 PFLOP/s dense bf16
-//   peak; LDS traffic per MFMA and the per-step barrier are the limiters of this 128x128 / 4-wave structure).
+//   Measured (bs 32, tools/bf16_probe.py): 512->512 @38x38 280-290 us = 750-780 TFLOP/s (30 % of the 2.5 PFLOP/s dense bf16
+//   peak), 256->256 @75x75 802 TFLOP/s on the 256 x 256 tile (740 on 128 x 128).  What bounds it (ablations, same layer):
+//   MFMAs + fragment reads alone 147 us (59 %); every KB a wave moves costs ~100 issue cycles whichever way it goes
+//   (DMA piece, or buffer_load + ds_write_b128), and a 128 x 128 tile moves 8 KB per wave per 512 MFMA cycles.
 #include "ct_common.h"
 #include <algorithm>
 #include <cstdlib>
@@ -31,7 +35,6 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kInvalidOff = 0x7FFFFFF0;
 constexpr long long kMaxBufBytes = 0x7FFFFF00LL;
-constexpr int BM = 128;                        // output pixels per workgroup
 constexpr int KSMALL = 8;                      // cin <= 8 (the image): one k-step = 4 taps x 8 channels
 
 struct Bf16Args {
@@ -72,15 +75,30 @@ __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float
 
 // BN: output channels per workgroup (128: 2x2 waves of 64x64; 64: 4x1 waves of 32 px x 64 couts)
 // BK: input channels (of one tap) per k-step / barrier;  SMALL: cin_pad == 8, a k-step is 4 taps x 8 channels
-template <int BN, int BK, bool SMALL>
-__global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
+// BM x BN = output pixels x output channels of a workgroup of NT threads: 128 x {64, 128} with four waves, 256 x 256
+// with eight (each wave 128 x 64: eight 32x32 accumulators; half the L2 -> LDS operand traffic per MFMA of 128 x 128,
+// which at 64 flop per byte asks for ~12 TB/s at the 0.75 PFLOP/s that tile tops out at)
+template <int BM, int BN, int BK, bool SMALL, int NT>
+__global__ __launch_bounds__(NT) void conv_bf16_nhwc(const Bf16Args a)
 {
     constexpr int SPR = BK / 8;                    // 16-byte segments per tile row
-    constexpr int ROWB = BK * 2 + 16;              // LDS row: payload + 16 bytes (conflict-free 16-byte accesses)
+    // DMA (every variant but the 8-channel image layer): the tiles go global -> LDS directly (buffer_load_dwordx4 ...
+    // lds, one KiB per wave instruction, lane i at M0 + 16 i), no VGPR staging and no ds_write_b128 -- ablation on
+    // 512 -> 512 @38x38 bs 32: 300 us with the staging, 231 without the global loads, 153 without the LDS stores (MFMAs +
+    // fragment reads alone: 147).  A DMA image is lane-contiguous, so rows are BK * 2 bytes without padding and the
+    // 16-byte segments are XOR swizzled instead: segment s of row r sits at s ^ ((r / RL) % SPR), RL = rows per
+    // 256-byte LDS line, which makes both the DMA write and the ds_read_b128 of a fragment (16 rows of one segment per
+    // lane group) conflict-free.  The swizzle is applied on the GLOBAL side: the lane that owns physical slot (r, p)
+    // fetches segment p ^ ((r / RL) % SPR).  The buffers form a ring of NBUF: step t lands in buffer t % NBUF while
+    // steps t - NBUF + 1 .. t - 1 compute (BK = 32: three 16 KB buffers, two steps in flight, three workgroups per CU).
+    constexpr bool DMA = !SMALL;
+    constexpr int NBUF = DMA && BK == 32 ? 3 : 2;
+    constexpr int ROWB = DMA ? BK * 2 : BK * 2 + 16;   // LDS row: padded by 16 bytes on the staged path (conflict-free 16-byte accesses)
+    constexpr int RL = 256 / (BK * 2);                // DMA: rows per 256-byte line (SPR * RL == 16)
     constexpr int A_B = BM * ROWB, B_B = BN * ROWB;
-    constexpr int NA = BM * SPR / 256, NB = BN * SPR / 256;
-    constexpr int WAVES_M = BN == 128 ? 2 : 4;     // waves along the pixel dimension
-    constexpr int WM = BM / WAVES_M, WN = BN / (4 / WAVES_M);
+    constexpr int NA = BM * SPR / NT, NB = BN * SPR / NT;
+    constexpr int WAVES_M = BN == 64 ? 4 : 2;      // waves along the pixel dimension
+    constexpr int WM = BM / WAVES_M, WN = BN / (NT / 64 / WAVES_M);
     constexpr int TM = WM / 32, TN = WN / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // A0 B0 A1 B1
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
@@ -103,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
     bool pix_ok[NA];
 #pragma unroll
     for (int q = 0; q < NA; ++q) {
-        const int P = n0 + (tid + 256 * q) / SPR;
+        const int P = n0 + (tid + NT * q) / SPR;
         pix_ok[q] = P < a.Npix;
         const int Pc = pix_ok[q] ? P : 0;
         pix_n[q] = Pc / a.OHW;
@@ -112,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
         pix_h[q] = oh * a.stride - a.pad_h;
         pix_w[q] = (s - oh * a.OW) * a.stride - a.pad_w;
     }
-    const int sseg = tid % SPR;
+    const int sseg = DMA ? (tid % SPR) ^ ((tid >> 4) % SPR) : tid % SPR;     // the segment this thread FETCHES (its LDS slot is tid % SPR)
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes), rw = make_rsrc(a.w, a.w_bytes);
     const int cgroups = a.cin_pad >> 3;                    // 8-channel groups per tap in the packed weights
     const int taps = a.KH * a.KW;
@@ -141,7 +159,7 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
     if (!SMALL) {
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-            const int co = m0 + (tid + 256 * q) / SPR;
+            const int co = m0 + (tid + NT * q) / SPR;
             vb[q] = co < a.cout_pad ? (sseg * a.cout_pad + co) * 16 : kInvalidOff;
         }
     }
@@ -152,6 +170,7 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
         ld_kw = ld_tap - ld_kh * a.KW;
         tap_offsets();
     };
+    int dma_buf = 0;                                       // DMA: the LDS buffer the next load_step fills
     auto load_step = [&](int step) {
         if (SMALL) {
             const int tap = step * SPR + sseg;
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
             }
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
-                const int co = m0 + (tid + 256 * q) / SPR;
+                const int co = m0 + (tid + NT * q) / SPR;
                 const int woff = (co < a.cout_pad && tap < taps) ? ((tap * cgroups * a.cout_pad + co) * 8) * 2 : kInvalidOff;
                 rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, woff, 0, 0);
             }
@@ -175,10 +194,25 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
         const int sa = ld_cs * BK * 2;                                      // bytes: channel step inside the pixel
         const int sb = (ld_tap * cgroups + ld_cs * SPR) * a.cout_pad * 16;   // bytes: (tap, channel group) plane
         const bool tail = has_tail && ld_cs == csteps - 1;
+        if constexpr (DMA) {
+            typedef __attribute__((address_space(3))) void* lds_ptr;
+            unsigned char* Ad = lds + dma_buf * (A_B + B_B) + wave * 1024;
+            unsigned char* Bd = Ad + A_B;
+            (void)Ad; (void)Bd;
+#if defined(__HIP_DEVICE_COMPILE__)         // the host pass of hipcc has no such builtin (and would drop the kernel's launch stub)
 #pragma unroll
-        for (int q = 0; q < NA; ++q) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rin, tail ? va_tail[q] : va[q], sa, 0);
+            for (int q = 0; q < NA; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(Ad + q * (NT * 16)), 16, tail ? va_tail[q] : va[q], sa, 0, 0);
 #pragma unroll
-        for (int q = 0; q < NB; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, vb[q], sb, 0);
+            for (int q = 0; q < NB; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(Bd + q * (NT * 16)), 16, vb[q], sb, 0, 0);
+#endif
+        } else {
+#pragma unroll
+            for (int q = 0; q < NA; ++q) ra[q] = __builtin_amdgcn_raw_buffer_load_b128(rin, tail ? va_tail[q] : va[q], sa, 0);
+#pragma unroll
+            for (int q = 0; q < NB; ++q) rb[q] = __builtin_amdgcn_raw_buffer_load_b128(rw, vb[q], sb, 0);
+        }
         // advance to the next step
         ++ld_cs;
         if (ld_cs == csteps) {
@@ -194,10 +228,10 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
         unsigned char* B = A + A_B;
 #pragma unroll
         for (int q = 0; q < NA; ++q)
-            *reinterpret_cast<i32x4*>(A + ((tid + 256 * q) / SPR) * ROWB + sseg * 16) = ra[q];
+            *reinterpret_cast<i32x4*>(A + ((tid + NT * q) / SPR) * ROWB + sseg * 16) = ra[q];
 #pragma unroll
         for (int q = 0; q < NB; ++q)
-            *reinterpret_cast<i32x4*>(B + ((tid + 256 * q) / SPR) * ROWB + sseg * 16) = rb[q];
+            *reinterpret_cast<i32x4*>(B + ((tid + NT * q) / SPR) * ROWB + sseg * 16) = rb[q];
     };
 
     f32x16 acc[TM][TN];
@@ -211,42 +245,90 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
     const int s0 = blockIdx.y * a.steps_per_split;
     const int s1 = min(nsteps, s0 + a.steps_per_split);
     if (!SMALL) seek_step(s0);
-    load_step(s0);
-    store_step(0);
-    if (s1 - s0 > 1) load_step(s0 + 1);
-    __syncthreads();
-    for (int step = s0; step < s1; ++step) {
-        const int buf = (step - s0) & 1;
-        const unsigned char* A = lds + buf * (A_B + B_B) + (wm0 + l31) * ROWB + kg * 16;
-        const unsigned char* B = lds + buf * (A_B + B_B) + A_B + (wn0 + l31) * ROWB + kg * 16;
-        // operand fragments of k-slice h+1 are read while the MFMAs of slice h run
-        i32x4 fa[2][TM], fb[2][TN];
-        auto read_frag = [&](int h, int slot) {
+    if constexpr (DMA) {
+        // a wave waits for its own pieces of the NEXT step (vmcnt: everything but the pieces of the steps after it) before
+        // the barrier that publishes that buffer
+        constexpr int PF = NBUF - 1;                       // steps in flight
+        constexpr int PIECES = NA + NB;                    // DMA instructions per step and wave
+        int nload = s0;                                    // next step to load, its buffer
 #pragma unroll
-            for (int t = 0; t < TM; ++t) fa[slot][t] = *reinterpret_cast<const i32x4*>(A + t * 32 * ROWB + h * 32);
-#pragma unroll
-            for (int t = 0; t < TN; ++t) fb[slot][t] = *reinterpret_cast<const i32x4*>(B + t * 32 * ROWB + h * 32);
-        };
-        read_frag(0, 0);
-        if (step + 1 < s1) store_step(buf ^ 1);
-        if (step + 2 < s1) load_step(step + 2);
-#pragma unroll
-        for (int h = 0; h < BK / 16; ++h) {
-            const int cur = h & 1;
-            if (h + 1 < BK / 16) read_frag(h + 1, cur ^ 1);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][i]),
-                                                                        __builtin_bit_cast(bf16x8, fb[cur][j]),
-                                                                        acc[i][j], 0, 0, 0);
-        }
+        for (int i = 0; i < PF; ++i)
+            if (nload < s1) { load_step(nload); ++nload; dma_buf = dma_buf + 1 == NBUF ? 0 : dma_buf + 1; }
+        if (PF == 2 && nload - s0 == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        const int xa = (((wm0 + l31) / RL) % SPR) * 16, xb = (((wn0 + l31) / RL) % SPR) * 16;
+        int buf = 0;
+        for (int step = s0; step < s1; ++step) {
+            const unsigned char* A = lds + buf * (A_B + B_B) + (wm0 + l31) * ROWB;
+            const unsigned char* B = lds + buf * (A_B + B_B) + A_B + (wn0 + l31) * ROWB;
+            i32x4 fa[2][TM], fb[2][TN];
+            auto read_frag = [&](int h, int slot) {
+                const int oa = (h * 32 + kg * 16) ^ xa, ob = (h * 32 + kg * 16) ^ xb;
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[slot][t] = *reinterpret_cast<const i32x4*>(A + t * 32 * ROWB + oa);
+#pragma unroll
+                for (int t = 0; t < TN; ++t) fb[slot][t] = *reinterpret_cast<const i32x4*>(B + t * 32 * ROWB + ob);
+            };
+            read_frag(0, 0);
+            const bool more = nload < s1;                  // buffer dma_buf held step - 1: every wave is past that barrier
+            if (more) { load_step(nload); ++nload; dma_buf = dma_buf + 1 == NBUF ? 0 : dma_buf + 1; }
+#pragma unroll
+            for (int h = 0; h < BK / 16; ++h) {
+                const int cur = h & 1;
+                if (h + 1 < BK / 16) read_frag(h + 1, cur ^ 1);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][i]),
+                                                                            __builtin_bit_cast(bf16x8, fb[cur][j]),
+                                                                            acc[i][j], 0, 0, 0);
+            }
+            // the next step's pieces must have landed; with two steps in flight the newest step's may still fly
+            if (PF == 2 && more && nload - step > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            buf = buf + 1 == NBUF ? 0 : buf + 1;
+        }
+    } else {
+        load_step(s0);
+        store_step(0);
+        if (s1 - s0 > 1) load_step(s0 + 1);
+        __syncthreads();
+        for (int step = s0; step < s1; ++step) {
+            const int buf = (step - s0) & 1;
+            const unsigned char* A = lds + buf * (A_B + B_B) + (wm0 + l31) * ROWB + kg * 16;
+            const unsigned char* B = lds + buf * (A_B + B_B) + A_B + (wn0 + l31) * ROWB + kg * 16;
+            // operand fragments of k-slice h+1 are read while the MFMAs of slice h run
+            i32x4 fa[2][TM], fb[2][TN];
+            auto read_frag = [&](int h, int slot) {
+    #pragma unroll
+                for (int t = 0; t < TM; ++t) fa[slot][t] = *reinterpret_cast<const i32x4*>(A + t * 32 * ROWB + h * 32);
+    #pragma unroll
+                for (int t = 0; t < TN; ++t) fb[slot][t] = *reinterpret_cast<const i32x4*>(B + t * 32 * ROWB + h * 32);
+            };
+            read_frag(0, 0);
+            if (step + 1 < s1) store_step(buf ^ 1);
+            if (step + 2 < s1) load_step(step + 2);
+    #pragma unroll
+            for (int h = 0; h < BK / 16; ++h) {
+                const int cur = h & 1;
+                if (h + 1 < BK / 16) read_frag(h + 1, cur ^ 1);
+    #pragma unroll
+                for (int i = 0; i < TM; ++i)
+    #pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[cur][i]),
+                                                                            __builtin_bit_cast(bf16x8, fb[cur][j]),
+                                                                            acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: acc[i][j][r] = pixel n0 + wm0 + 32 i + (r&3) + 8 (r>>2) + 4 kg, cout m0 + wn0 + 32 j + l31
-    if (a.ksplit > 1) {
+    if (BM != 256 && a.ksplit > 1) {        // (the 256 x 256 tile is only launched unsplit, with the bf16 NHWC output)
         // split-K (maps too small to fill the chip): raw partial sums to this split's slab, no atomics;
         // conv_bf16_splitk_epilogue adds the slabs in order and applies the epilogue
         float* const slab = a.ws + (size_t)blockIdx.y * a.Npix * a.M;
@@ -264,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
         }
         return;
     }
-    if (a.nseg > 0) {
+    if (BM != 256 && a.nseg > 0) {
         // multibox heads: fp32, channels-last per segment -> a lane's cout is already the fast index
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -293,26 +375,35 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
     // barrier) so that a thread owns 8 consecutive channels of a pixel: one 16-byte store (and one 16-byte residual
     // load) instead of eight 2-byte ones
     constexpr int SROW = BN * 4 + 16;                       // bytes per staged pixel row
+    // pixel rows staged per pass: all of them, or 64 at a time where that keeps the workgroup's LDS at its operand ring
+    // (BK = 32: 48 KB, three workgroups per CU)
+    constexpr int RP = BM * SROW <= NBUF * (A_B + B_B) || !(DMA && BK == 32) ? BM : 64;
+    static_assert(RP * SROW <= NBUF * (A_B + B_B) || RP == BM, "staging pass larger than the operand ring");
     float* const stage = reinterpret_cast<float*>(lds);
+    constexpr int GPR = BN / 8;                             // 8-channel groups per pixel row
+    const bool vec_ok = ((a.out_ctot | a.out_coff) & 7) == 0 && (!a.res || ((a.res_ctot | a.res_coff) & 7) == 0);
+#pragma unroll
+    for (int pass = 0; pass < BM / RP; ++pass) {
+    if (pass) __syncthreads();
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = wn0 + 32 * j + l31;
         const int co = m0 + col;
         const float sc = co < a.M ? a.scale[co] : 0.f, sh = co < a.M ? a.shift[co] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            if ((wm0 + 32 * i) / RP != pass) continue;      // wave-uniform
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                const int row = wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg - pass * RP;
                 stage[row * (SROW / 4) + col] = acc[i][j][r] * sc + sh;
             }
+        }
     }
     __syncthreads();
-    constexpr int GPR = BN / 8;                             // 8-channel groups per pixel row
-    const bool vec_ok = ((a.out_ctot | a.out_coff) & 7) == 0 && (!a.res || ((a.res_ctot | a.res_coff) & 7) == 0);
-    for (int e = tid; e < BM * GPR; e += 256) {
+    for (int e = tid; e < RP * GPR; e += NT) {
         const int row = e / GPR, g8 = e - row * GPR;
-        const int P = n0 + row, co = m0 + g8 * 8;
+        const int P = n0 + pass * RP + row, co = m0 + g8 * 8;
         if (P >= a.Npix || co >= a.M) continue;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(stage) + row * SROW + g8 * 32);
         const f32x4 v1 = *reinterpret_cast<const f32x4*>(reinterpret_cast<const unsigned char*>(stage) + row * SROW + g8 * 32 + 16);
@@ -352,6 +443,7 @@ __global__ __launch_bounds__(256) void conv_bf16_nhwc(const Bf16Args a)
             for (int q = 0; q < 8; ++q)
                 if (co + q < a.M) op[q] = f2bf(v[q]);
         }
+    }
     }
 }
 
@@ -595,9 +687,10 @@ extern "C" int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream)
     a.out_ctot = d->out_ctot; a.out_coff = d->out_coff; a.res_ctot = d->res_ctot; a.res_coff = d->res_coff;
     a.res_scale = d->res_scale; a.relu = d->relu; a.nseg = d->nseg;
     for (int g = 0; g < d->nseg; ++g) a.seg[g] = d->seg[g];
-    const int tiles_n = (a.Npix + BM - 1) / BM;
+    int tiles_n = 0;
     hipStream_t st = ctdet::as_stream(stream);
-    auto go = [&](auto kernel, int bn, int bk) {
+    auto go = [&](auto kernel, int bm, int bn, int bk, int nt) {
+        tiles_n = (a.Npix + bm - 1) / bm;
         a.tiles_m = (d->cout + bn - 1) / bn;
         const int taps = d->kh * d->kw;
         const int nsteps = a.cin_pad == KSMALL ? (taps + bk / 8 - 1) / (bk / 8) : taps * (a.cin_pad / bk);
@@ -606,6 +699,7 @@ extern "C" int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream)
         int want = d->ksplit;
         const int tiles = a.tiles_m * tiles_n;
         if (want < 0) want = tiles * 2 > 768 ? 1 : std::min(nsteps / 2, 768 / tiles);   // ~3 workgroups per CU
+        if (bm == 256) want = 1;
         const long long slab = (long long)d->cout * a.Npix;
         if (d->ksplit_ws && slab > 0) want = (int)std::min<long long>(want, d->ksplit_ws_floats / slab);
         if (want > 1 && d->ksplit_ws && nsteps >= 2 && slab < 0x7FFFFFFFLL) {
@@ -613,7 +707,10 @@ extern "C" int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream)
             a.ksplit = (nsteps + a.steps_per_split - 1) / a.steps_per_split;
             a.ws = d->ksplit_ws;
         }
-        const size_t smem = std::max((size_t)2 * (BM + bn) * (bk * 2 + 16), (size_t)BM * (bn * 4 + 16));   // operands | output staging
+        const bool dma = a.cin_pad != KSMALL;
+        const size_t ring = (size_t)(dma && bk == 32 ? 3 : 2) * (bm + bn) * (dma ? bk * 2 : bk * 2 + 16);
+        const size_t srow = (size_t)bn * 4 + 16;
+        const size_t smem = std::max(ring, (bm * srow <= ring || !(dma && bk == 32) ? bm : 64) * srow);   // operand ring | output staging
         static std::mutex mu;
         static std::unordered_set<const void*> raised;
         if (smem > 64 * 1024) {
@@ -624,17 +721,29 @@ extern "C" int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream)
                 raised.insert((const void*)kernel);
             }
         }
-        hipLaunchKernelGGL(kernel, dim3(a.tiles_m * tiles_n, a.ksplit), dim3(256), smem, st, a);
+        hipLaunchKernelGGL(kernel, dim3(a.tiles_m * tiles_n, a.ksplit), dim3(nt), smem, st, a);
     };
-    const bool narrow = d->cout <= 64 || (long long)((d->cout + 127) / 128) * tiles_n < 256;   // few tiles: finer ones
+    const int tn128 = (a.Npix + 127) / 128;
+    const bool narrow = d->cout <= 64 || (long long)((d->cout + 127) / 128) * tn128 < 256;   // few tiles: finer ones
+    // 256 x 256 (eight waves): layers with >= 256 output channels whose 256-pixel tiles still give every CU a workgroup
+    const char* big_env = getenv("CTDET_BF16_BIG_MIN");     // read per call: the tests force / forbid the variant
+    const int big_min = big_env ? atoi(big_env) : 200;
+    const bool big = a.cin_pad != KSMALL && d->cout >= 256 && a.cout_pad % 256 == 0 && d->nseg == 0 &&
+                     (long long)(a.cout_pad / 256) * ((a.Npix + 255) / 256) >= big_min;
+    static const int wide_bk = getenv("CTDET_BF16_BK") ? atoi(getenv("CTDET_BF16_BK")) : 64;   // 32: the three-buffer ring (faster on conv6 / conv7 / 1x1, slower on the 3x3 trunk)
     if (a.cin_pad == KSMALL) {
-        if (narrow) go(conv_bf16_nhwc<64, 32, true>, 64, 32); else go(conv_bf16_nhwc<128, 32, true>, 128, 32);
+        if (narrow) go(conv_bf16_nhwc<128, 64, 32, true, 256>, 128, 64, 32, 256);
+        else go(conv_bf16_nhwc<128, 128, 32, true, 256>, 128, 128, 32, 256);
+    } else if (big) {
+        go(conv_bf16_nhwc<256, 256, 32, false, 512>, 256, 256, 32, 512);
     } else if (narrow && d->cin <= 64 && !(getenv("CTDET_BF16_SHORTK") && atoi(getenv("CTDET_BF16_SHORTK")) == 0)) {
         // short reductions (conv1_2: 9 k-steps): the workgroup is prologue / epilogue bound, 32-channel steps halve
         // its LDS footprint so that four instead of two of them share a CU
-        go(conv_bf16_nhwc<64, 32, false>, 64, 32);
+        go(conv_bf16_nhwc<128, 64, 32, false, 256>, 128, 64, 32, 256);
     } else {
-        if (narrow) go(conv_bf16_nhwc<64, 64, false>, 64, 64); else go(conv_bf16_nhwc<128, 64, false>, 128, 64);
+        if (narrow) go(conv_bf16_nhwc<128, 64, 64, false, 256>, 128, 64, 64, 256);
+        else if (wide_bk == 32) go(conv_bf16_nhwc<128, 128, 32, false, 256>, 128, 128, 32, 256);
+        else go(conv_bf16_nhwc<128, 128, 64, false, 256>, 128, 128, 64, 256);
     }
     CT_LAUNCH_CHECK("conv_bf16_nhwc");
     if (a.ksplit > 1) {

@@ -105,6 +105,34 @@ def test_conv_bf16_slices_and_residual():
     assert (full[..., :16] == 0x7FC0).all() and (full[..., 80:] == 0x7FC0).all()      # untouched channel slices
 
 
+BIG_CASES = [  # B, ctot, H, W, cout, k, stride, pad, dil -- ragged pixel counts, several 256-wide cout tiles, a channel tail
+    (2, 128, 19, 19, 256, 3, 1, 1, 1), (1, 192, 27, 21, 512, 1, 1, 0, 1), (3, 72, 13, 13, 256, 3, 2, 1, 1),
+    (1, 256, 20, 20, 768, 3, 1, 6, 6),
+]
+
+
+@pytest.mark.parametrize('case', BIG_CASES, ids=[str(i) for i in range(len(BIG_CASES))])
+def test_conv_bf16_256x256_tile(case, monkeypatch):
+    """The 256 x 256 workgroup tile (eight waves of 128 x 64, epilogue staged in four row passes) forced on small
+    geometries (CTDET_BF16_BIG_MIN=1: the launch rule normally wants a workgroup per CU): against the torch reference,
+    and bit-identical to the 128-wide tiles on the same operands (same products, same k order per accumulator)."""
+    B, ctot, H, W, cout, k, stride, pad, dil = case
+    g = torch.Generator().manual_seed(11 + ctot + H)
+    x = torch.randn(B, ctot, H, W, generator=g)
+    w = torch.randn(cout, ctot, k, k, generator=g) * (2.0 / (ctot * k * k)) ** 0.5
+    OH = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    OW = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    res = torch.randn(B, cout, OH, OW, generator=g)
+    monkeypatch.setenv('CTDET_BF16_BIG_MIN', '1')
+    got, want, yb = _conv_bf16(x, [w], stride, pad, dil, True, res=res, res_scale=0.5, out_ctot=cout + 24, out_coff=8)
+    assert _close(got, want), (got - want).abs().max()
+    full = yb.view(B, OH, OW, cout + 24)
+    assert (full[..., :8] == 0x7FC0).all() and (full[..., 8 + cout:] == 0x7FC0).all()      # untouched channel slices
+    monkeypatch.setenv('CTDET_BF16_BIG_MIN', '1000000000')
+    small, _, _ = _conv_bf16(x, [w], stride, pad, dil, True, res=res, res_scale=0.5, out_ctot=cout + 24, out_coff=8)
+    assert torch.equal(got, small)
+
+
 def test_conv_bf16_split_k():
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 256, 5, 5, generator=g)
