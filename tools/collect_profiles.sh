@@ -47,6 +47,10 @@ timeout 900 python tools/ctx_parity.py --budget --sweep --policies 0,256,1 > "$O
 timeout 300 python bench.py --train --steps 5 --warmup 2 > "$O/bench_train.json.log" 2> "$O/bench_train.err"
 timeout 300 python bench.py --gpus 2 --share-devices --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > "$O/bench_2rank_rehearsal.json.log" 2> "$O/bench_2rank_rehearsal.err"
 timeout 300 python bench.py --train --gpus 2 --share-devices --steps 3 --warmup 1 > "$O/bench_train_2rank_rehearsal.json.log" 2> "$O/bench_train_2rank_rehearsal.err"
+timeout 300 python tools/ctx_attn_time.py > "$O/ctx_attn_time.txt" 2>&1
+bash tools/wino_pmc.sh base.19 ${TAG}_w4 > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_w4/summary.txt" "$O/wino4_pmc.txt"
+bash tools/bf16_pmc.sh ${TAG}_bf16 > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_bf16/summary.txt" "$O/bf16_pmc.txt"
+cd "$R"
 # keep what prof_summary.py needs, drop the bulky traces
 find "$O" -name '*kernel_trace.csv' -delete
 find "$O" -name '*agent_info.csv' -delete
