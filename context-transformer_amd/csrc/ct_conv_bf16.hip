@@ -728,8 +728,10 @@ extern "C" int ct_conv2d_bf16_fwd(const ct_conv_desc* d, ct_stream_t stream)
     // 256 x 256 (eight waves): layers with >= 256 output channels whose 256-pixel tiles still give every CU a workgroup
     const char* big_env = getenv("CTDET_BF16_BIG_MIN");     // read per call: the tests force / forbid the variant
     const int big_min = big_env ? atoi(big_env) : 200;
-    const bool big = a.cin_pad != KSMALL && d->cout >= 256 && a.cout_pad % 256 == 0 && d->nseg == 0 &&
-                     (long long)(a.cout_pad / 256) * ((a.Npix + 255) / 256) >= big_min;
+    const long long big_tiles = (long long)(a.cout_pad / 256) * ((a.Npix + 255) / 256);
+    // one workgroup per CU: the tile count must fill its last round of 256 (362 tiles = 1.41 rounds lose to the 128-wide tiles)
+    const bool big = a.cin_pad != KSMALL && d->cout >= 256 && a.cout_pad % 256 == 0 && d->nseg == 0 && big_tiles >= big_min &&
+                     (big_env || big_tiles * 5 >= (big_tiles + 255) / 256 * 256 * 4);
     static const int wide_bk = getenv("CTDET_BF16_BK") ? atoi(getenv("CTDET_BF16_BK")) : 64;   // 32: the three-buffer ring (faster on conv6 / conv7 / 1x1, slower on the 3x3 trunk)
     if (a.cin_pad == KSMALL) {
         if (narrow) go(conv_bf16_nhwc<128, 64, 32, true, 256>, 128, 64, 32, 256);
