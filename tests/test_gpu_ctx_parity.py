@@ -35,6 +35,20 @@ def test_phase2_parity_sweep(net300, batch, seed):
     assert cc.verdict(r) != 'FAIL', r
 
 
+def test_phase2_parity_512_at_the_per_gpu_batch_of_configs3():
+    """BASELINE configs[3] = RFBNet-512 + Context-Transformer at bs 64 over 8 GPUs: the per-GPU shape (bs 8; M = 4 964
+    context rows, 32 756 priors: the longest softmax rows of any configuration).  Everything up to the block's input
+    holds 1e-4 against the CPU fp32 path.  The block's output has no 1e-4 parity between ANY two fp32 evaluations here:
+    with the synthetic weights the un-scaled logits are ~400 and torch-CPU fp32 is itself 8e-4 from the fp64
+    evaluation (measured: CPU32-fp64 7.9e-4, GPU-fp64 8.1e-4, GPU-CPU32 9.1e-4), so the device is held to the truth
+    instead: no further from fp64 than 1.5 x the CPU path in the max norm and 1.75 x at the 99.99 % quantile."""
+    net = cc.build(512, 60)
+    r = cc.sweep_case(net, 512, 60, 'transfer', 8, 1234, 'randn')
+    assert r['loc_gpu_cpu32'] < 1e-4 and r['obj_gpu_cpu32'] < 1e-4 and r['rawconf_gpu_cpu32'] < 1e-4, r
+    assert r['gpu_fp64'] <= max(1e-4, 1.5 * r['cpu32_fp64']), r
+    assert r['q_gpu_fp64'] <= max(1e-4, 1.75 * r['q_cpu32_fp64']), r
+
+
 @pytest.mark.parametrize('batch', [2, 32])
 def test_phase2_image_like_input_block_input_parity(net300, batch):
     """SURVEY 8d (ii) inputs: everything up to the block's input holds 1e-4; the block's output has no fp32 parity
