@@ -27,25 +27,6 @@
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-constexpr int XT_BYTES = 3 * 8 * KT * 16;          // one 32-key tile of K or V as bf16x3 fragments: 12 KB
-constexpr int XQ_BYTES = 3 * 8 * 16;               // one query row: 384 B
-
-// x = hi + mid + lo exactly (three bfloat16 pieces by truncation); returns the fp32 bit patterns whose upper halves
-// are the pieces
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l)
-{
-    h = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
-    const float r1 = x - __builtin_bit_cast(float, h);
-    m = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-    l = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, m));
-}
-__device__ __forceinline__ int pack_hi(unsigned e0, unsigned e1)
-{
-    return (int)__builtin_amdgcn_perm(e1, e0, 0x07060302u);
-}
-
 // y = Linear(x) + x (as ctx_project_kernel), written as bf16x3 pieces in MFMA fragment order:
 //   mode 0 (theta -> Q, B operand of S^T = K Q^T): Qx[b][row][piece 3][octet 8][8]      element d at octet d/8, slot d%8
 //   mode 1 (phi -> K, A operand of S^T):           Kx[b][tile][piece][octet 8][key 32][8]
@@ -80,27 +61,7 @@ __global__ __launch_bounds__(256) void ctx_project_x3_kernel(const float* __rest
 #pragma unroll 8
         for (int i = 0; i < DP; ++i) acc += Xs[r * DP + i] * Wt[i * DP + o];
         const float y = (row < rows_valid && o < d) ? acc + bo + Xs[r * DP + o] : 0.f;
-        unsigned ph, pm, pl;
-        split3(y, ph, pm, pl);
-        size_t base;        // in bf16 elements, piece 0
-        size_t pstride;     // elements between pieces
-        if (mode == 0) {
-            base = ((size_t)b * rows_pad + row) * (XQ_BYTES / 2) + (o >> 3) * 8 + (o & 7);
-            pstride = 8 * 8;
-        } else {
-            const int tile = row / KT, kl = row % KT;
-            const size_t tb = ((size_t)b * (rows_pad / KT) + tile) * (XT_BYTES / 2);
-            if (mode == 1) {
-                base = tb + ((size_t)(o >> 3) * KT + kl) * 8 + (o & 7);
-            } else {
-                const int h = (kl >> 2) & 1, rr = (kl & 3) + 4 * (kl >> 3);     // kl = acc_row(rr, h)
-                base = tb + ((size_t)((rr >> 3) * 2 + h) * DP + o) * 8 + (rr & 7);
-            }
-            pstride = 8 * KT * 8;
-        }
-        out[base] = (unsigned short)(ph >> 16);
-        out[base + pstride] = (unsigned short)(pm >> 16);
-        out[base + 2 * pstride] = (unsigned short)(pl >> 16);
+        x3_emit(y, out, mode, b, row, rows_pad, o);
     }
 }
 

@@ -157,55 +157,76 @@ struct BwdArgs {
     int P, P_pad, M, M_pad, split;
 };
 
-__global__ __launch_bounds__(256) void ctx_attn_bwd_q(const BwdArgs a)
+// Rows of a "swizzled" fp32 operand ([B][rows_pad][2][32]: feature i at (i & 1) * 32 + (i >> 1), what ctx_project_kernel
+// and ctx_out_bwd_kernel write) split into bf16x3 fragments in one of the three orders of x3_emit (ct_attn_common.h).
+__global__ __launch_bounds__(256) void ctx_rows_to_x3_kernel(const float* __restrict__ src, int rows_pad,
+                                                            unsigned short* __restrict__ out, int mode)
 {
-    __shared__ __attribute__((aligned(16))) float kt[2][DP * KT];    // [d][key]
-    __shared__ __attribute__((aligned(16))) float vt[2][DP * KT];    // [d][key]
-    __shared__ __attribute__((aligned(16))) float kr[2][KT * RS];    // [key][d'] (swizzled features)
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int o = tid & 63, rg = tid >> 6;
+    const float* sb = src + (size_t)b * rows_pad * DP;
+    for (int r = rg; r < 64; r += 4) {
+        const int row = blockIdx.x * 64 + r;
+        if (row >= rows_pad) break;
+        x3_emit(sb[(size_t)row * DP + (o & 1) * 32 + (o >> 1)], out, mode, b, row, rows_pad, o);
+    }
+}
+
+// dQ on bf16x3 (round 3; the arithmetic of ctx_attn_kernel): per 32-key tile and wave 24 + 24 + 24
+// v_mfma_f32_32x32x16_bf16 instead of 32 + 32 + 32 fp32 MFMAs at twice the issue time.  S^T is recomputed with exactly the
+// forward kernel's products and summation order (hi.hi in one accumulator, the five small products in a second one), so
+// exp2(S log2 e - lse) reproduces the forward probabilities against the saved log-sum-exp.
+struct BwdQx3Args {
+    const unsigned char *Qx, *dDx;      // mode 0 rows of Q and dD
+    const unsigned char *Kx, *Vk, *Kv;  // 32-key tiles: K mode 1, V mode 1, K mode 2
+    const float *lse, *delta;
+    float* dQ;                          // [B][P_pad][64] natural feature order
+    int P_pad, M, M_pad;
+};
+
+__global__ __launch_bounds__(256) void ctx_attn_bwd_q(const BwdQx3Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char kv_raw[];       // 2 x 36 KB
+    unsigned char (*kv)[3 * XT_BYTES] = reinterpret_cast<unsigned char (*)[3 * XT_BYTES]>(kv_raw);   // per buffer: K (S), V (dA), K (dQ) tiles
 
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = blockIdx.x * QB + wave * QW + l31;
 
-    float qreg[32], dreg[32];
+    i32x4 qf[4][3], df[4][3];
     {
-        const float4* qp = reinterpret_cast<const float4*>(a.Qs + ((size_t)b * a.P_pad + q) * DP + h * 32);
-        const float4* dp = reinterpret_cast<const float4*>(a.dDs + ((size_t)b * a.P_pad + q) * DP + h * 32);
+        const unsigned char* qp = a.Qx + ((size_t)b * a.P_pad + q) * XQ_BYTES;
+        const unsigned char* dp = a.dDx + ((size_t)b * a.P_pad + q) * XQ_BYTES;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 v = qp[i], w = dp[i];
-            qreg[4 * i + 0] = v.x; qreg[4 * i + 1] = v.y; qreg[4 * i + 2] = v.z; qreg[4 * i + 3] = v.w;
-            dreg[4 * i + 0] = w.x; dreg[4 * i + 1] = w.y; dreg[4 * i + 2] = w.z; dreg[4 * i + 3] = w.w;
-        }
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                qf[g][p] = *reinterpret_cast<const i32x4*>(qp + (p * 8 + 2 * g + h) * 16);
+                df[g][p] = *reinterpret_cast<const i32x4*>(dp + (p * 8 + 2 * g + h) * 16);
+            }
     }
     const float lse2 = a.lse[(size_t)b * a.P_pad + q];
     const float dlt = a.delta[(size_t)b * a.P_pad + q];
 
-    const float* Ktb = a.Kt + (size_t)b * DP * a.M_pad;
-    const float* Vtb = a.Vt + (size_t)b * DP * a.M_pad;
-    const float* Krb = a.Ksw + (size_t)b * a.M_pad * DP;
     const int nt = a.M_pad / KT;
+    const unsigned char* Kxb = a.Kx + (size_t)b * nt * XT_BYTES;
+    const unsigned char* Vkb = a.Vk + (size_t)b * nt * XT_BYTES;
+    const unsigned char* Kvb = a.Kv + (size_t)b * nt * XT_BYTES;
 
-    float4 pk[2], pv[2], pr[2];
+    i32x4 treg[9];                                         // 36 KB per tile / 256 threads
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + 256 * i;
-            const int row = f >> 3, c4 = f & 7;
-            pk[i] = *reinterpret_cast<const float4*>(Ktb + (size_t)row * a.M_pad + t * KT + c4 * 4);
-            pv[i] = *reinterpret_cast<const float4*>(Vtb + (size_t)row * a.M_pad + t * KT + c4 * 4);
-            pr[i] = *reinterpret_cast<const float4*>(Krb + (size_t)t * KT * DP + f * 4);
+        for (int i = 0; i < 3; ++i) {
+            treg[i] = *reinterpret_cast<const i32x4*>(Kxb + (size_t)t * XT_BYTES + (tid + 256 * i) * 16);
+            treg[3 + i] = *reinterpret_cast<const i32x4*>(Vkb + (size_t)t * XT_BYTES + (tid + 256 * i) * 16);
+            treg[6 + i] = *reinterpret_cast<const i32x4*>(Kvb + (size_t)t * XT_BYTES + (tid + 256 * i) * 16);
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + 256 * i;
-            *reinterpret_cast<float4*>(&kt[buf][f * 4]) = pk[i];
-            *reinterpret_cast<float4*>(&vt[buf][f * 4]) = pv[i];
-            *reinterpret_cast<float4*>(&kr[buf][(f >> 4) * RS + (f & 15) * 4]) = pr[i];
-        }
+        for (int i = 0; i < 9; ++i)
+            *reinterpret_cast<i32x4*>(&kv[buf][(i / 3) * XT_BYTES + (tid + 256 * (i % 3)) * 16]) = treg[i];
     };
 
     f32x16 dq0, dq1;
@@ -216,29 +237,41 @@ __global__ __launch_bounds__(256) void ctx_attn_bwd_q(const BwdArgs a)
     store_tile(0);
     __syncthreads();
 
+    // piece pairs (A piece, B piece) of the six products, smallest first; the last one is hi.hi
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         const bool more = t + 1 < nt;
         if (more) load_tile(t + 1);
 
-        f32x16 s, da;
+        // ---- S^T = K Q^T (as the forward kernel) and dA^T = V dD^T ----
+        f32x16 s, ss, da;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; da[r] = 0.f; }
-        const float* kb = &kt[buf][h * KT + l31];
-        const float* vb = &vt[buf][h * KT + l31];
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; ss[r] = 0.f; da[r] = 0.f; }
+        {
+            const unsigned char* kb = &kv[buf][l31 * 16];
+            const unsigned char* vb = &kv[buf][XT_BYTES + l31 * 16];
 #pragma unroll
-        for (int g4 = 0; g4 < 8; ++g4) {
-            float ak[4], av[4];
+            for (int g = 0; g < 4; ++g) {
+                i32x4 kf[3], vf[3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                ak[u] = kb[(2 * (4 * g4 + u)) * KT];
-                av[u] = vb[(2 * (4 * g4 + u)) * KT];
+                for (int p = 0; p < 3; ++p) {
+                    kf[p] = *reinterpret_cast<const i32x4*>(kb + ((p * 8 + 2 * g + h) * KT) * 16);
+                    vf[p] = *reinterpret_cast<const i32x4*>(vb + ((p * 8 + 2 * g + h) * KT) * 16);
+                }
+#pragma unroll
+                for (int c = 0; c < 5; ++c)
+                    ss = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[PA[c]]),
+                                                                 __builtin_bit_cast(bf16x8, qf[g][PB[c]]), ss, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]),
+                                                            __builtin_bit_cast(bf16x8, qf[g][0]), s, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[PA[c]]),
+                                                                 __builtin_bit_cast(bf16x8, df[g][PB[c]]), da, 0, 0, 0);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[u], qreg[4 * g4 + u], s, 0, 0, 0);
-                da = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], dreg[4 * g4 + u], da, 0, 0, 0);
-            }
+            for (int r = 0; r < 16; ++r) s[r] += ss[r];
         }
         // dS^T = A^T * (dA^T - delta), A from the saved log-sum-exp
         const bool edge = (t + 1) * KT > a.M;
@@ -248,29 +281,49 @@ __global__ __launch_bounds__(256) void ctx_attn_bwd_q(const BwdArgs a)
             if (edge && t * KT + acc_row(r, h) >= a.M) p = 0.f;
             s[r] = p * (da[r] - dlt);
         }
-        // dQ^T += K^T dS^T
-        const float* rb = &kr[buf][l31];
+        // ---- dQ^T += K^T dS^T ----  B operand: this lane's own dS (registers 8 kg .. 8 kg + 7), split in place
+        {
+            i32x4 pf[2][3];
 #pragma unroll
-        for (int g2 = 0; g2 < 8; ++g2) {
-            float a0[2], a1[2];
+            for (int kg = 0; kg < 2; ++kg) {
+                unsigned ph[8], pm[8], pl[8];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                a0[u] = rb[acc_row(2 * g2 + u, h) * RS];
-                a1[u] = rb[acc_row(2 * g2 + u, h) * RS + 32];
+                for (int j = 0; j < 8; ++j) split3(s[8 * kg + j], ph[j], pm[j], pl[j]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    pf[kg][0][w] = pack_hi(ph[2 * w], ph[2 * w + 1]);
+                    pf[kg][1][w] = pack_hi(pm[2 * w], pm[2 * w + 1]);
+                    pf[kg][2][w] = pack_hi(pl[2 * w], pl[2 * w + 1]);
+                }
             }
+            const unsigned char* rb = &kv[buf][2 * XT_BYTES + l31 * 16];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], s[2 * g2 + u], dq0, 0, 0, 0);
-                dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], s[2 * g2 + u], dq1, 0, 0, 0);
+            for (int kg = 0; kg < 2; ++kg) {
+                i32x4 rf[3][2];
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int db = 0; db < 2; ++db)
+                        rf[p][db] = *reinterpret_cast<const i32x4*>(rb + ((((p * 2 + kg) * 2 + h) * DP) + 32 * db) * 16);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    dq0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[PA[c]][0]),
+                                                                  __builtin_bit_cast(bf16x8, pf[kg][PB[c]]), dq0, 0, 0, 0);
+                    dq1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[PA[c]][1]),
+                                                                  __builtin_bit_cast(bf16x8, pf[kg][PB[c]]), dq1, 0, 0, 0);
+                }
             }
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
     }
-    // dq0 row d' = acc_row(r,h) is feature 2d', dq1 is feature 2d'+1
-    float2* orow = reinterpret_cast<float2*>(a.dQ + ((size_t)b * a.P_pad + q) * DP);
+    // accumulator rows 4g .. 4g+3 are features 8g + 4h .. + 3 (dq0) and 32 + those (dq1)
+    float4* orow = reinterpret_cast<float4*>(a.dQ + ((size_t)b * a.P_pad + q) * DP);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) orow[acc_row(r, h)] = make_float2(dq0[r], dq1[r]);
+    for (int g = 0; g < 4; ++g) {
+        orow[2 * g + h] = make_float4(dq0[4 * g], dq0[4 * g + 1], dq0[4 * g + 2], dq0[4 * g + 3]);
+        orow[8 + 2 * g + h] = make_float4(dq1[4 * g], dq1[4 * g + 1], dq1[4 * g + 2], dq1[4 * g + 3]);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -537,6 +590,7 @@ __global__ __launch_bounds__(256) void ctx_pool_bwd_kernel(const float* __restri
 
 struct BwdWs {
     float *Qs, *Qt, *Ksw, *Kt, *Vsw, *Vt, *dDs, *dDt, *delta, *dQ, *dK, *dV;
+    unsigned char *Qx0, *dDx0, *Kx1, *Vx1, *Kx2;      // bf16x3 fragments for ctx_attn_bwd_q (x3_emit modes 0 / 1 / 2)
     int P_pad, M_pad;
     size_t total;
 };
@@ -557,6 +611,9 @@ BwdWs carve_bwd(char* base, int batch, int P, int M)
     w.delta = take((size_t)batch * w.P_pad);
     w.Ksw = take(mk); w.Kt = take(mk); w.Vsw = take(mk); w.Vt = take(mk);
     w.dK = take(mk); w.dV = take(mk);          // adjacent: zeroed with one memset
+    const size_t px = (size_t)batch * w.P_pad * XQ_BYTES / 4, mx = (size_t)batch * (w.M_pad / KT) * XT_BYTES / 4;
+    w.Qx0 = (unsigned char*)take(px); w.dDx0 = (unsigned char*)take(px);
+    w.Kx1 = (unsigned char*)take(mx); w.Vx1 = (unsigned char*)take(mx); w.Kx2 = (unsigned char*)take(mx);
     w.total = off;
     return w;
 }
@@ -636,8 +693,31 @@ extern "C" int ct_ctx_attention_bwd(const float* conf, const float* pool, int ba
     // enough workgroups to fill 256 CUs twice over
     const int kv_blocks = (w.M_pad / QB) * batch;
     ba.split = std::max(1, std::min(w.P_pad / (8 * KT), (1024 + kv_blocks - 1) / kv_blocks));
-    hipLaunchKernelGGL(ctx_attn_bwd_q, dim3(w.P_pad / QB, batch), blk, 0, st, ba);
-    CT_LAUNCH_CHECK("ctx_attn_bwd_q");
+    {
+        auto to_x3 = [&](const float* src, int rows_pad, unsigned char* dst, int mode) {
+            hipLaunchKernelGGL(ctx_rows_to_x3_kernel, dim3(rows_pad / 64, batch), blk, 0, st, src, rows_pad,
+                               (unsigned short*)dst, mode);
+        };
+        to_x3(w.Qs, w.P_pad, w.Qx0, 0);
+        to_x3(w.dDs, w.P_pad, w.dDx0, 0);
+        to_x3(w.Ksw, w.M_pad, w.Kx1, 1);
+        to_x3(w.Vsw, w.M_pad, w.Vx1, 1);
+        to_x3(w.Ksw, w.M_pad, w.Kx2, 2);
+        CT_LAUNCH_CHECK("ctx_rows_to_x3_kernel");
+        BwdQx3Args qa{};
+        qa.Qx = w.Qx0; qa.dDx = w.dDx0; qa.Kx = w.Kx1; qa.Vk = w.Vx1; qa.Kv = w.Kx2;
+        qa.lse = save_lse; qa.delta = w.delta; qa.dQ = w.dQ;
+        qa.P_pad = w.P_pad; qa.M = num_ctx; qa.M_pad = w.M_pad;
+        static std::once_flag once_q;
+        static hipError_t attr_q = hipSuccess;
+        std::call_once(once_q, [] {
+            attr_q = hipFuncSetAttribute((const void*)ctx_attn_bwd_q, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         2 * 3 * XT_BYTES);
+        });
+        CT_HIP(attr_q);
+        hipLaunchKernelGGL(ctx_attn_bwd_q, dim3(w.P_pad / QB, batch), blk, 2 * 3 * XT_BYTES, st, qa);
+        CT_LAUNCH_CHECK("ctx_attn_bwd_q");
+    }
     {
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;

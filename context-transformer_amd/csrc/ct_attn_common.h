@@ -13,6 +13,57 @@ constexpr int KT = 32;      // keys per tile
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// ---- bf16x3 operand fragments (csrc/ct_conv_x3.hip has the arithmetic) ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int XT_BYTES = 3 * 8 * KT * 16;          // one 32-row tile of a [rows][64] operand as bf16x3 fragments: 12 KB
+constexpr int XQ_BYTES = 3 * 8 * 16;               // one row in the register-operand layout: 384 B
+
+// x = hi + mid + lo exactly (three bfloat16 pieces by truncation); returns the fp32 bit patterns whose upper halves
+// are the pieces
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l)
+{
+    h = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+    const float r1 = x - __builtin_bit_cast(float, h);
+    m = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+    l = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, m));
+}
+__device__ __forceinline__ int pack_hi(unsigned e0, unsigned e1)
+{
+    return (int)__builtin_amdgcn_perm(e1, e0, 0x07060302u);
+}
+
+// element (row, feature o) of a [rows_pad][64] operand, split and stored in one of three fragment orders:
+//   mode 0  rows as the register (B) operand of a contraction over features:  [b][row][piece 3][octet 8][8]
+//   mode 1  32-row tiles as the LDS (A) operand of a contraction over features: [b][tile][piece][octet 8][row 32][8]
+//   mode 2  32-row tiles as the LDS (A) operand of a contraction over ROWS:    [b][tile][piece][kg 2][h 2][feature 64][8];
+//           slot j of (kg, h) = the row that accumulator register 8 kg + j of lane half h holds (acc_row), so a matrix
+//           held in accumulator registers goes to the MFMA as the other operand as it sits
+__device__ __forceinline__ void x3_emit(float y, unsigned short* __restrict__ out, int mode, int b, int row, int rows_pad,
+                                        int o)
+{
+    unsigned ph, pm, pl;
+    split3(y, ph, pm, pl);
+    size_t base, pstride;        // in bf16 elements
+    if (mode == 0) {
+        base = ((size_t)b * rows_pad + row) * (XQ_BYTES / 2) + (o >> 3) * 8 + (o & 7);
+        pstride = 8 * 8;
+    } else {
+        const int tile = row / KT, kl = row % KT;
+        const size_t tb = ((size_t)b * (rows_pad / KT) + tile) * (XT_BYTES / 2);
+        if (mode == 1) {
+            base = tb + ((size_t)(o >> 3) * KT + kl) * 8 + (o & 7);
+        } else {
+            const int h = (kl >> 2) & 1, rr = (kl & 3) + 4 * (kl >> 3);     // kl = acc_row(rr, h)
+            base = tb + ((size_t)((rr >> 3) * 2 + h) * DP + o) * 8 + (rr & 7);
+        }
+        pstride = 8 * KT * 8;
+    }
+    out[base] = (unsigned short)(ph >> 16);
+    out[base + pstride] = (unsigned short)(pm >> 16);
+    out[base + 2 * pstride] = (unsigned short)(pl >> 16);
+}
+
 // y = Linear(x) + x for 64 rows per block, written to any of four layouts (null = skip):
 //   o_sw    [B][rows_pad][2][32]  "swizzled" rows: o_sw[r][h][s] = y[r][2s+h]  (MFMA B-operand order)
 //   o_t     [B][64][rows_pad]     transposed (feature-major, rows contiguous)
