@@ -329,66 +329,67 @@ __global__ __launch_bounds__(256) void ctx_attn_bwd_q(const BwdQx3Args a)
 // ------------------------------------------------------------------------------------------------
 // key side: dK, dV
 // ------------------------------------------------------------------------------------------------
-constexpr int KV_TILE_FLOATS = 2 * DP * KT + 2 * KT * RS + 2 * KT;     // Qt, dDt, Qs rows, dDs rows, lse, delta
-constexpr int KV_LDS_BYTES = 2 * KV_TILE_FLOATS * 4;
+// dK, dV on bf16x3: per 32-query tile and wave 4 x 24 v_mfma_f32_32x32x16_bf16 (S, dA, dV, dK) instead of 4 x 32 fp32
+// MFMAs at twice the issue time.  S = Q K^T uses the forward kernel's products in the forward kernel's order (operand
+// roles swapped: the query tile is the LDS operand here, the wave's own keys sit in registers), so the probabilities
+// recomputed against the saved log-sum-exp are the forward's.  A and dS stay in the accumulator registers and go to the
+// two gradient contractions as the register operand (split in place); Q and dD tiles are staged in both fragment orders.
+struct BwdKVx3Args {
+    const unsigned char *Kx0, *Vx0;         // mode 0 rows of K and V (this wave's keys, register operands)
+    const unsigned char *Qx1, *dDx1;        // 32-query tiles, mode 1 (contraction over features: S, dA)
+    const unsigned char *Qx2, *dDx2;        // 32-query tiles, mode 2 (contraction over queries: dK, dV)
+    const float *lse, *delta;
+    float *dK, *dV;                         // [B][M_pad][64] natural feature order, accumulated with atomics
+    int P_pad, M, M_pad, split;
+};
+constexpr int KV_BUF_BYTES = 4 * XT_BYTES + 2 * KT * 4;      // Q1, dD1, Q2, dD2 tiles + lse, delta of the tile's queries
+constexpr int KV_LDS_BYTES = 2 * KV_BUF_BYTES;
 
-__global__ __launch_bounds__(256) void ctx_attn_bwd_kv(const BwdArgs a)
+__global__ __launch_bounds__(256) void ctx_attn_bwd_kv(const BwdKVx3Args a)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int key = blockIdx.x * QB + wave * QW + l31;           // < M_pad (M_pad % 128 == 0)
 
-    float kreg[32], vreg[32];
+    i32x4 kf[4][3], vf[4][3];
     {
-        const float4* kp = reinterpret_cast<const float4*>(a.Ksw + ((size_t)b * a.M_pad + key) * DP + h * 32);
-        const float4* vp = reinterpret_cast<const float4*>(a.Vsw + ((size_t)b * a.M_pad + key) * DP + h * 32);
+        const unsigned char* kp = a.Kx0 + ((size_t)b * a.M_pad + key) * XQ_BYTES;
+        const unsigned char* vp = a.Vx0 + ((size_t)b * a.M_pad + key) * XQ_BYTES;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 v = kp[i], w = vp[i];
-            kreg[4 * i + 0] = v.x; kreg[4 * i + 1] = v.y; kreg[4 * i + 2] = v.z; kreg[4 * i + 3] = v.w;
-            vreg[4 * i + 0] = w.x; vreg[4 * i + 1] = w.y; vreg[4 * i + 2] = w.z; vreg[4 * i + 3] = w.w;
-        }
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                kf[g][p] = *reinterpret_cast<const i32x4*>(kp + (p * 8 + 2 * g + h) * 16);
+                vf[g][p] = *reinterpret_cast<const i32x4*>(vp + (p * 8 + 2 * g + h) * 16);
+            }
     }
     const bool key_live = key < a.M;
 
-    const float* Qtb = a.Qt + (size_t)b * DP * a.P_pad;
-    const float* Dtb = a.dDt + (size_t)b * DP * a.P_pad;
-    const float* Qrb = a.Qs + (size_t)b * a.P_pad * DP;
-    const float* Drb = a.dDs + (size_t)b * a.P_pad * DP;
+    const int nt_all = a.P_pad / KT;
+    const unsigned char* src[4] = {a.Qx1 + (size_t)b * nt_all * XT_BYTES, a.dDx1 + (size_t)b * nt_all * XT_BYTES,
+                                   a.Qx2 + (size_t)b * nt_all * XT_BYTES, a.dDx2 + (size_t)b * nt_all * XT_BYTES};
     const float* lseb = a.lse + (size_t)b * a.P_pad;
     const float* delb = a.delta + (size_t)b * a.P_pad;
-    const int nt_all = a.P_pad / KT;
     const int t_begin = (int)((long)nt_all * blockIdx.z / a.split);
     const int t_end = (int)((long)nt_all * (blockIdx.z + 1) / a.split);
 
-    float4 pq[2], pd[2], prq[2], prd[2];
+    i32x4 treg[12];                                        // 48 KB per tile / 256 threads
     float pl = 0.f;
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + 256 * i;
-            const int row = f >> 3, c4 = f & 7;
-            pq[i] = *reinterpret_cast<const float4*>(Qtb + (size_t)row * a.P_pad + t * KT + c4 * 4);
-            pd[i] = *reinterpret_cast<const float4*>(Dtb + (size_t)row * a.P_pad + t * KT + c4 * 4);
-            prq[i] = *reinterpret_cast<const float4*>(Qrb + (size_t)t * KT * DP + f * 4);
-            prd[i] = *reinterpret_cast<const float4*>(Drb + (size_t)t * KT * DP + f * 4);
-        }
+        for (int i = 0; i < 12; ++i)
+            treg[i] = *reinterpret_cast<const i32x4*>(src[i / 3] + (size_t)t * XT_BYTES + (tid + 256 * (i % 3)) * 16);
         if (tid < 32) pl = lseb[t * KT + tid];
         else if (tid < 64) pl = delb[t * KT + tid - 32];
     };
     auto store_tile = [&](int buf) {
-        float* base = lds + buf * KV_TILE_FLOATS;
+        unsigned char* base = lds + buf * KV_BUF_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int f = tid + 256 * i;
-            *reinterpret_cast<float4*>(&base[f * 4]) = pq[i];
-            *reinterpret_cast<float4*>(&base[DP * KT + f * 4]) = pd[i];
-            *reinterpret_cast<float4*>(&base[2 * DP * KT + (f >> 4) * RS + (f & 15) * 4]) = prq[i];
-            *reinterpret_cast<float4*>(&base[2 * DP * KT + KT * RS + (f >> 4) * RS + (f & 15) * 4]) = prd[i];
-        }
-        if (tid < 64) base[2 * DP * KT + 2 * KT * RS + tid] = pl;
+        for (int i = 0; i < 12; ++i)
+            *reinterpret_cast<i32x4*>(base + (i / 3) * XT_BYTES + (tid + 256 * (i % 3)) * 16) = treg[i];
+        if (tid < 64) reinterpret_cast<float*>(base + 4 * XT_BYTES)[tid] = pl;
     };
 
     f32x16 dk0, dk1, dv0, dv1;
@@ -401,35 +402,46 @@ __global__ __launch_bounds__(256) void ctx_attn_bwd_kv(const BwdArgs a)
     }
     __syncthreads();
 
+    // piece pairs (LDS-operand piece, register-operand piece) of the six products, smallest first; the last one is hi.hi.
+    // For S the forward kernel pairs (K piece PA, Q piece PB): here the query tile is the LDS operand, so (Q PB, K PA).
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
         if (more) load_tile(t + 1);
-        const float* base = lds + buf * KV_TILE_FLOATS;
-        const float* qt = base + h * KT + l31;
-        const float* dt = base + DP * KT + h * KT + l31;
-        const float* qr = base + 2 * DP * KT + l31;
-        const float* dr = base + 2 * DP * KT + KT * RS + l31;
-        const float* ls = base + 2 * DP * KT + 2 * KT * RS;
+        const unsigned char* base = lds + buf * KV_BUF_BYTES;
+        const float* ls = reinterpret_cast<const float*>(base + 4 * XT_BYTES);
 
-        f32x16 s, da;
+        // ---- S = Q K^T and dA = dD V^T: rows = the tile's queries, column = this lane's key ----
+        f32x16 s, ss, da;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; da[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; ss[r] = 0.f; da[r] = 0.f; }
+        {
+            const unsigned char* qb = base + l31 * 16;
+            const unsigned char* db = base + XT_BYTES + l31 * 16;
 #pragma unroll
-        for (int g4 = 0; g4 < 8; ++g4) {
-            float aq[4], ad[4];
+            for (int g = 0; g < 4; ++g) {
+                i32x4 qa[3], dd[3];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                aq[u] = qt[(2 * (4 * g4 + u)) * KT];
-                ad[u] = dt[(2 * (4 * g4 + u)) * KT];
+                for (int p = 0; p < 3; ++p) {
+                    qa[p] = *reinterpret_cast<const i32x4*>(qb + ((p * 8 + 2 * g + h) * KT) * 16);
+                    dd[p] = *reinterpret_cast<const i32x4*>(db + ((p * 8 + 2 * g + h) * KT) * 16);
+                }
+#pragma unroll
+                for (int c = 0; c < 5; ++c)
+                    ss = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[PB[c]]),
+                                                                 __builtin_bit_cast(bf16x8, kf[g][PA[c]]), ss, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[0]),
+                                                            __builtin_bit_cast(bf16x8, kf[g][0]), s, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 6; ++c)
+                    da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dd[PA[c]]),
+                                                                 __builtin_bit_cast(bf16x8, vf[g][PB[c]]), da, 0, 0, 0);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(aq[u], kreg[4 * g4 + u], s, 0, 0, 0);
-                da = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[u], vreg[4 * g4 + u], da, 0, 0, 0);
-            }
+            for (int r = 0; r < 16; ++r) s[r] += ss[r];
         }
-        // A[q][key] and dS[q][key] for this lane's key; rows are the tile's queries acc_row(r,h)
+        // A[q][key] and dS[q][key] for this lane's key; rows are the tile's queries acc_row(r, h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qq = acc_row(r, h);
@@ -438,35 +450,64 @@ __global__ __launch_bounds__(256) void ctx_attn_bwd_kv(const BwdArgs a)
             s[r] = p;
             da[r] = p * (da[r] - ls[32 + qq]);
         }
+        // ---- dV^T += dD^T A, dK^T += Q^T dS: register operand = this lane's A / dS (registers 8 kg .. 8 kg + 7) ----
 #pragma unroll
-        for (int g2 = 0; g2 < 8; ++g2) {
-            float d0[2], d1[2], q0[2], q1[2];
+        for (int kg = 0; kg < 2; ++kg) {
+            i32x4 pp[3], ps[3];
+            {
+                unsigned ph[8], pm[8], pl8[8];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int ro = acc_row(2 * g2 + u, h) * RS;
-                d0[u] = dr[ro]; d1[u] = dr[ro + 32];
-                q0[u] = qr[ro]; q1[u] = qr[ro + 32];
+                for (int j = 0; j < 8; ++j) split3(s[8 * kg + j], ph[j], pm[j], pl8[j]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    pp[0][w] = pack_hi(ph[2 * w], ph[2 * w + 1]);
+                    pp[1][w] = pack_hi(pm[2 * w], pm[2 * w + 1]);
+                    pp[2][w] = pack_hi(pl8[2 * w], pl8[2 * w + 1]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) split3(da[8 * kg + j], ph[j], pm[j], pl8[j]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    ps[0][w] = pack_hi(ph[2 * w], ph[2 * w + 1]);
+                    ps[1][w] = pack_hi(pm[2 * w], pm[2 * w + 1]);
+                    ps[2][w] = pack_hi(pl8[2 * w], pl8[2 * w + 1]);
+                }
             }
+            const unsigned char* qr = base + 2 * XT_BYTES + l31 * 16;
+            const unsigned char* dr = base + 3 * XT_BYTES + l31 * 16;
+            i32x4 df2[3][2], qf2[3][2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(d0[u], s[2 * g2 + u], dv0, 0, 0, 0);
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(d1[u], s[2 * g2 + u], dv1, 0, 0, 0);
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0[u], da[2 * g2 + u], dk0, 0, 0, 0);
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1[u], da[2 * g2 + u], dk1, 0, 0, 0);
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    df2[p][hb] = *reinterpret_cast<const i32x4*>(dr + ((((p * 2 + kg) * 2 + h) * DP) + 32 * hb) * 16);
+                    qf2[p][hb] = *reinterpret_cast<const i32x4*>(qr + ((((p * 2 + kg) * 2 + h) * DP) + 32 * hb) * 16);
+                }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, df2[PA[c]][0]),
+                                                              __builtin_bit_cast(bf16x8, pp[PB[c]]), dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, df2[PA[c]][1]),
+                                                              __builtin_bit_cast(bf16x8, pp[PB[c]]), dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qf2[PA[c]][0]),
+                                                              __builtin_bit_cast(bf16x8, ps[PB[c]]), dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qf2[PA[c]][1]),
+                                                              __builtin_bit_cast(bf16x8, ps[PB[c]]), dk1, 0, 0, 0);
             }
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
     }
+    // accumulator row r = feature acc_row(r, h) (dk0 / dv0) and 32 + that (dk1 / dv1)
     float* krow = a.dK + ((size_t)b * a.M_pad + key) * DP;
     float* vrow = a.dV + ((size_t)b * a.M_pad + key) * DP;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int i = 2 * acc_row(r, h);
+        const int i = acc_row(r, h);
         atomic_add_f32(&krow[i], dk0[r]);
-        atomic_add_f32(&krow[i + 1], dk1[r]);
+        atomic_add_f32(&krow[32 + i], dk1[r]);
         atomic_add_f32(&vrow[i], dv0[r]);
-        atomic_add_f32(&vrow[i + 1], dv1[r]);
+        atomic_add_f32(&vrow[32 + i], dv1[r]);
     }
 }
 
@@ -591,6 +632,7 @@ __global__ __launch_bounds__(256) void ctx_pool_bwd_kernel(const float* __restri
 struct BwdWs {
     float *Qs, *Qt, *Ksw, *Kt, *Vsw, *Vt, *dDs, *dDt, *delta, *dQ, *dK, *dV;
     unsigned char *Qx0, *dDx0, *Kx1, *Vx1, *Kx2;      // bf16x3 fragments for ctx_attn_bwd_q (x3_emit modes 0 / 1 / 2)
+    unsigned char *Kx0, *Vx0, *Qx1, *dDx1, *Qx2, *dDx2;   // ... and for ctx_attn_bwd_kv
     int P_pad, M_pad;
     size_t total;
 };
@@ -614,6 +656,10 @@ BwdWs carve_bwd(char* base, int batch, int P, int M)
     const size_t px = (size_t)batch * w.P_pad * XQ_BYTES / 4, mx = (size_t)batch * (w.M_pad / KT) * XT_BYTES / 4;
     w.Qx0 = (unsigned char*)take(px); w.dDx0 = (unsigned char*)take(px);
     w.Kx1 = (unsigned char*)take(mx); w.Vx1 = (unsigned char*)take(mx); w.Kx2 = (unsigned char*)take(mx);
+    const size_t mx0 = (size_t)batch * w.M_pad * XQ_BYTES / 4, px1 = (size_t)batch * (w.P_pad / KT) * XT_BYTES / 4;
+    w.Kx0 = (unsigned char*)take(mx0); w.Vx0 = (unsigned char*)take(mx0);
+    w.Qx1 = (unsigned char*)take(px1); w.dDx1 = (unsigned char*)take(px1);
+    w.Qx2 = (unsigned char*)take(px1); w.dDx2 = (unsigned char*)take(px1);
     w.total = off;
     return w;
 }
@@ -703,6 +749,12 @@ extern "C" int ct_ctx_attention_bwd(const float* conf, const float* pool, int ba
         to_x3(w.Ksw, w.M_pad, w.Kx1, 1);
         to_x3(w.Vsw, w.M_pad, w.Vx1, 1);
         to_x3(w.Ksw, w.M_pad, w.Kx2, 2);
+        to_x3(w.Ksw, w.M_pad, w.Kx0, 0);
+        to_x3(w.Vsw, w.M_pad, w.Vx0, 0);
+        to_x3(w.Qs, w.P_pad, w.Qx1, 1);
+        to_x3(w.dDs, w.P_pad, w.dDx1, 1);
+        to_x3(w.Qs, w.P_pad, w.Qx2, 2);
+        to_x3(w.dDs, w.P_pad, w.dDx2, 2);
         CT_LAUNCH_CHECK("ctx_rows_to_x3_kernel");
         BwdQx3Args qa{};
         qa.Qx = w.Qx0; qa.dDx = w.dDx0; qa.Kx = w.Kx1; qa.Vk = w.Vx1; qa.Kv = w.Kx2;
@@ -727,8 +779,14 @@ extern "C" int ct_ctx_attention_bwd(const float* conf, const float* pool, int ba
         });
         CT_HIP(attr_err);
     }
-    hipLaunchKernelGGL(ctx_attn_bwd_kv, dim3(w.M_pad / QB, batch, ba.split), blk, KV_LDS_BYTES, st, ba);
-    CT_LAUNCH_CHECK("ctx_attn_bwd_kv");
+    {
+        BwdKVx3Args ka{};
+        ka.Kx0 = w.Kx0; ka.Vx0 = w.Vx0; ka.Qx1 = w.Qx1; ka.dDx1 = w.dDx1; ka.Qx2 = w.Qx2; ka.dDx2 = w.dDx2;
+        ka.lse = save_lse; ka.delta = w.delta; ka.dK = w.dK; ka.dV = w.dV;
+        ka.P_pad = w.P_pad; ka.M = num_ctx; ka.M_pad = w.M_pad; ka.split = ba.split;
+        hipLaunchKernelGGL(ctx_attn_bwd_kv, dim3(w.M_pad / QB, batch, ba.split), blk, KV_LDS_BYTES, st, ka);
+        CT_LAUNCH_CHECK("ctx_attn_bwd_kv");
+    }
 
     // projections backward
     auto linear = [&](const float* dy, long long dy_bs, int dy_stride, const float* x, int rows, const float* W,
