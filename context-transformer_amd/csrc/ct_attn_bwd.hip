@@ -4,13 +4,15 @@
 //     Y = X + D*Wz     N = Y/|Y|        out = scale * N OBJ^T              (X = conf, Pl = pooled conf)
 // the gradient of `out` flows back as
 //   ctx_out_bwd_kernel   per query row: dN -> dY -> (dX direct, dD = dY*Wz, delta = dD.D), dWz, dOBJ
-//   ctx_attn_bwd_q       flash-style, one wave = 32 queries, loops over key tiles (fp32 MFMA):
+//   ctx_rows_to_x3_kernel  Q, K, V, dD rows split once into bf16x3 fragments (three exact bfloat16 pieces per fp32 value,
+//                        csrc/ct_conv_x3.hip has the arithmetic) in the orders the two kernels below read
+//   ctx_attn_bwd_q       flash-style, one wave = 32 queries, loops over key tiles (bf16x3 on v_mfma_f32_32x32x16_bf16):
 //                          S^T = K Q^T, dA^T = V dD^T, dS = A*(dA - delta), dQ^T += K^T dS^T
 //   ctx_attn_bwd_kv      one wave = 32 keys, loops over query tiles:
 //                          S = Q K^T, dA = dD V^T, dV^T += dD^T A, dK^T += Q^T dS
-//                        (the [P,M] affinity matrix is recomputed from the saved row log-sum-exp,
-//                         never stored; the query range is split over blockIdx.z, partial sums
-//                         meet in dK/dV through float atomics)
+//                        (the [P,M] affinity matrix is recomputed from the saved row log-sum-exp with the forward
+//                         kernel's products in the forward kernel's order, never stored; the query range is split
+//                         over blockIdx.z, partial sums meet in dK/dV through float atomics)
 //   ctx_linear_bwd_kernel  y = Lin(x)+x: dx (+)= dy + dy W, dW += dy^T x, db += sum dy
 //   ctx_pool_bwd_kernel    max-pool backward of the context pooling (first maximum per window)
 #include "ct_common.h"
@@ -19,8 +21,6 @@
 
 namespace {
 
-constexpr int RS = 72;            // LDS row stride of [row][feature] tiles: 4*RS % 64 == 32 keeps the
-                                  // two half-waves of an MFMA A-fragment read on disjoint banks
 constexpr float kLog2e = 1.4426950408889634f;
 
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
@@ -36,7 +36,6 @@ struct OutBwdArgs {
     const float* obj_w;     // [T][d]
     float* dconf;           // [B][P][d]   (written)
     float* dDs;             // [B][P_pad][64] swizzled
-    float* dDt;             // [B][64][P_pad]
     float* delta;           // [B][P_pad]
     float* dwz;             // [d]    (atomics)
     float* dobj;            // [T][d] (atomics)
@@ -118,7 +117,6 @@ __global__ __launch_bounds__(256) void ctx_out_bwd_kernel(const OutBwdArgs a)
                 const float dD = dY * wzs[i];
                 if (live && i < a.d) a.dconf[((size_t)b * a.P + row) * a.d + i] = dY;
                 dsw[(i & 1) * 32 + (i >> 1)] = dD;
-                a.dDt[((size_t)b * DP + i) * a.P_pad + row] = dD;
                 dl += dD * Dv[j];
                 dwz_acc[j] += dY * Dv[j];
             }
@@ -151,12 +149,6 @@ __global__ __launch_bounds__(256) void ctx_out_bwd_kernel(const OutBwdArgs a)
 // ------------------------------------------------------------------------------------------------
 // query side: dQ
 // ------------------------------------------------------------------------------------------------
-struct BwdArgs {
-    const float *Qs, *Qt, *Ksw, *Kt, *Vsw, *Vt, *dDs, *dDt, *lse, *delta;
-    float *dQ, *dK, *dV;
-    int P, P_pad, M, M_pad, split;
-};
-
 // Rows of a "swizzled" fp32 operand ([B][rows_pad][2][32]: feature i at (i & 1) * 32 + (i >> 1), what ctx_project_kernel
 // and ctx_out_bwd_kernel write) split into bf16x3 fragments in one of the three orders of x3_emit (ct_attn_common.h).
 __global__ __launch_bounds__(256) void ctx_rows_to_x3_kernel(const float* __restrict__ src, int rows_pad,
@@ -184,7 +176,7 @@ struct BwdQx3Args {
     int P_pad, M, M_pad;
 };
 
-__global__ __launch_bounds__(256) void ctx_attn_bwd_q(const BwdQx3Args a)
+__global__ __launch_bounds__(256, 2) void ctx_attn_bwd_q(const BwdQx3Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char kv_raw[];       // 2 x 36 KB
     unsigned char (*kv)[3 * XT_BYTES] = reinterpret_cast<unsigned char (*)[3 * XT_BYTES]>(kv_raw);   // per buffer: K (S), V (dA), K (dQ) tiles
@@ -630,7 +622,7 @@ __global__ __launch_bounds__(256) void ctx_pool_bwd_kernel(const float* __restri
 }
 
 struct BwdWs {
-    float *Qs, *Qt, *Ksw, *Kt, *Vsw, *Vt, *dDs, *dDt, *delta, *dQ, *dK, *dV;
+    float *Qs, *Ksw, *Vsw, *dDs, *delta, *dQ, *dK, *dV;
     unsigned char *Qx0, *dDx0, *Kx1, *Vx1, *Kx2;      // bf16x3 fragments for ctx_attn_bwd_q (x3_emit modes 0 / 1 / 2)
     unsigned char *Kx0, *Vx0, *Qx1, *dDx1, *Qx2, *dDx2;   // ... and for ctx_attn_bwd_kv
     int P_pad, M_pad;
@@ -649,9 +641,9 @@ BwdWs carve_bwd(char* base, int batch, int P, int M)
         return (float*)p;
     };
     const size_t pq = (size_t)batch * w.P_pad * DP, mk = (size_t)batch * w.M_pad * DP;
-    w.Qs = take(pq); w.Qt = take(pq); w.dDs = take(pq); w.dDt = take(pq); w.dQ = take(pq);
+    w.Qs = take(pq); w.dDs = take(pq); w.dQ = take(pq);
     w.delta = take((size_t)batch * w.P_pad);
-    w.Ksw = take(mk); w.Kt = take(mk); w.Vsw = take(mk); w.Vt = take(mk);
+    w.Ksw = take(mk); w.Vsw = take(mk);
     w.dK = take(mk); w.dV = take(mk);          // adjacent: zeroed with one memset
     const size_t px = (size_t)batch * w.P_pad * XQ_BYTES / 4, mx = (size_t)batch * (w.M_pad / KT) * XT_BYTES / 4;
     w.Qx0 = (unsigned char*)take(px); w.dDx0 = (unsigned char*)take(px);
@@ -713,32 +705,27 @@ extern "C" int ct_ctx_attention_bwd(const float* conf, const float* pool, int ba
 
     // recompute the projections in the operand layouts of the two MFMA kernels
     hipLaunchKernelGGL(ctx_project_kernel, dim3(w.P_pad / 64, batch), blk, 0, st, conf, num_priors, w.P_pad, d,
-                       prm->theta_w, prm->theta_b, w.Qs, w.Qt, none, none, 0);
+                       prm->theta_w, prm->theta_b, w.Qs, none, none, none, 0);
     CT_LAUNCH_CHECK("ctx_project_kernel(theta)");
     hipLaunchKernelGGL(ctx_project_kernel, dim3(w.M_pad / 64, batch), blk, 0, st, pool, num_ctx, w.M_pad, d,
-                       prm->phi_w, prm->phi_b, w.Ksw, w.Kt, none, none, 0);
+                       prm->phi_w, prm->phi_b, w.Ksw, none, none, none, 0);
     CT_LAUNCH_CHECK("ctx_project_kernel(phi)");
     hipLaunchKernelGGL(ctx_project_kernel, dim3(w.M_pad / 64, batch), blk, 0, st, pool, num_ctx, w.M_pad, d,
-                       prm->g_w, prm->g_b, w.Vsw, w.Vt, none, none, 0);
+                       prm->g_w, prm->g_b, w.Vsw, none, none, none, 0);
     CT_LAUNCH_CHECK("ctx_project_kernel(g)");
 
     OutBwdArgs oa{};
     oa.conf = conf; oa.D = save_d; oa.dout = dout; oa.wz = prm->wz; oa.obj_w = prm->obj_w;
-    oa.dconf = dconf; oa.dDs = w.dDs; oa.dDt = w.dDt; oa.delta = w.delta;
+    oa.dconf = dconf; oa.dDs = w.dDs; oa.delta = w.delta;
     oa.dwz = grads->wz; oa.dobj = grads->obj_w;
     oa.P = num_priors; oa.P_pad = w.P_pad; oa.d = d; oa.T = T; oa.ostride = ostride;
     oa.ooff = prm->fc_w ? d : 0; oa.chunks = 4; oa.scale = prm->scale;
     hipLaunchKernelGGL(ctx_out_bwd_kernel, dim3((w.P_pad / 64 + oa.chunks - 1) / oa.chunks, batch), blk, 0, st, oa);
     CT_LAUNCH_CHECK("ctx_out_bwd_kernel");
 
-    BwdArgs ba{};
-    ba.Qs = w.Qs; ba.Qt = w.Qt; ba.Ksw = w.Ksw; ba.Kt = w.Kt; ba.Vsw = w.Vsw; ba.Vt = w.Vt;
-    ba.dDs = w.dDs; ba.dDt = w.dDt; ba.lse = save_lse; ba.delta = w.delta;
-    ba.dQ = w.dQ; ba.dK = w.dK; ba.dV = w.dV;
-    ba.P = num_priors; ba.P_pad = w.P_pad; ba.M = num_ctx; ba.M_pad = w.M_pad;
     // enough workgroups to fill 256 CUs twice over
     const int kv_blocks = (w.M_pad / QB) * batch;
-    ba.split = std::max(1, std::min(w.P_pad / (8 * KT), (1024 + kv_blocks - 1) / kv_blocks));
+    const int kv_split = std::max(1, std::min(w.P_pad / (8 * KT), (1024 + kv_blocks - 1) / kv_blocks));
     {
         auto to_x3 = [&](const float* src, int rows_pad, unsigned char* dst, int mode) {
             hipLaunchKernelGGL(ctx_rows_to_x3_kernel, dim3(rows_pad / 64, batch), blk, 0, st, src, rows_pad,
@@ -783,8 +770,8 @@ extern "C" int ct_ctx_attention_bwd(const float* conf, const float* pool, int ba
         BwdKVx3Args ka{};
         ka.Kx0 = w.Kx0; ka.Vx0 = w.Vx0; ka.Qx1 = w.Qx1; ka.dDx1 = w.dDx1; ka.Qx2 = w.Qx2; ka.dDx2 = w.dDx2;
         ka.lse = save_lse; ka.delta = w.delta; ka.dK = w.dK; ka.dV = w.dV;
-        ka.P_pad = w.P_pad; ka.M = num_ctx; ka.M_pad = w.M_pad; ka.split = ba.split;
-        hipLaunchKernelGGL(ctx_attn_bwd_kv, dim3(w.M_pad / QB, batch, ba.split), blk, KV_LDS_BYTES, st, ka);
+        ka.P_pad = w.P_pad; ka.M = num_ctx; ka.M_pad = w.M_pad; ka.split = kv_split;
+        hipLaunchKernelGGL(ctx_attn_bwd_kv, dim3(w.M_pad / QB, batch, kv_split), blk, KV_LDS_BYTES, st, ka);
         CT_LAUNCH_CHECK("ctx_attn_bwd_kv");
     }
 
