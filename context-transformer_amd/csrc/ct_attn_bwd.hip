@@ -334,18 +334,27 @@ struct BwdKVx3Args {
     float *dK, *dV;                         // [B][M_pad][64] natural feature order, accumulated with atomics
     int P_pad, M, M_pad, split;
 };
-constexpr int KV_BUF_BYTES = 4 * XT_BYTES + 2 * KT * 4;      // Q1, dD1, Q2, dD2 tiles + lse, delta of the tile's queries
-constexpr int KV_LDS_BYTES = 2 * KV_BUF_BYTES;
+// One kernel for both gradients needs 351 registers and 96 KB of LDS (one wave per SIMD: 4.4 ms at 512 bs 8); as two
+// launches -- WANT_V: S and dV (query tiles Q1, dD2), WANT_K: S, dA and dK (Q1, dD1, Q2) -- each fits two waves per SIMD and two
+// workgroups per CU at the price of recomputing S (120 instead of 96 MFMAs per tile).
+template <bool WANT_K>
+struct KvCfg {
+    static constexpr int NTILE = WANT_K ? 3 : 2;                         // staged tiles per query tile
+    static constexpr int BUF_BYTES = NTILE * XT_BYTES + 2 * KT * 4;      // + lse, delta of the tile's queries
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;
+};
 
-__global__ __launch_bounds__(256) void ctx_attn_bwd_kv(const BwdKVx3Args a)
+template <bool WANT_K>
+__global__ __launch_bounds__(256, 2) void ctx_attn_bwd_kv(const BwdKVx3Args a)
 {
+    constexpr int NTILE = KvCfg<WANT_K>::NTILE, BUF_BYTES = KvCfg<WANT_K>::BUF_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int key = blockIdx.x * QB + wave * QW + l31;           // < M_pad (M_pad % 128 == 0)
 
-    i32x4 kf[4][3], vf[4][3];
+    i32x4 kf[4][3], vf[WANT_K ? 4 : 1][3];
     {
         const unsigned char* kp = a.Kx0 + ((size_t)b * a.M_pad + key) * XQ_BYTES;
         const unsigned char* vp = a.Vx0 + ((size_t)b * a.M_pad + key) * XQ_BYTES;
@@ -354,39 +363,40 @@ __global__ __launch_bounds__(256) void ctx_attn_bwd_kv(const BwdKVx3Args a)
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
                 kf[g][p] = *reinterpret_cast<const i32x4*>(kp + (p * 8 + 2 * g + h) * 16);
-                vf[g][p] = *reinterpret_cast<const i32x4*>(vp + (p * 8 + 2 * g + h) * 16);
+                if (WANT_K) vf[g][p] = *reinterpret_cast<const i32x4*>(vp + (p * 8 + 2 * g + h) * 16);
             }
     }
     const bool key_live = key < a.M;
 
     const int nt_all = a.P_pad / KT;
-    const unsigned char* src[4] = {a.Qx1 + (size_t)b * nt_all * XT_BYTES, a.dDx1 + (size_t)b * nt_all * XT_BYTES,
-                                   a.Qx2 + (size_t)b * nt_all * XT_BYTES, a.dDx2 + (size_t)b * nt_all * XT_BYTES};
+    const size_t boff = (size_t)b * nt_all * XT_BYTES;
+    // staged tiles: slot 0 = Q mode 1 (S); WANT_K: slot 1 = dD mode 1 (dA), slot 2 = Q mode 2 (dK); else slot 1 = dD mode 2 (dV)
+    const unsigned char* src[3] = {a.Qx1 + boff, (WANT_K ? a.dDx1 : a.dDx2) + boff, a.Qx2 + boff};
     const float* lseb = a.lse + (size_t)b * a.P_pad;
     const float* delb = a.delta + (size_t)b * a.P_pad;
     const int t_begin = (int)((long)nt_all * blockIdx.z / a.split);
     const int t_end = (int)((long)nt_all * (blockIdx.z + 1) / a.split);
 
-    i32x4 treg[12];                                        // 48 KB per tile / 256 threads
+    i32x4 treg[3 * NTILE];
     float pl = 0.f;
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i)
+        for (int i = 0; i < 3 * NTILE; ++i)
             treg[i] = *reinterpret_cast<const i32x4*>(src[i / 3] + (size_t)t * XT_BYTES + (tid + 256 * (i % 3)) * 16);
         if (tid < 32) pl = lseb[t * KT + tid];
         else if (tid < 64) pl = delb[t * KT + tid - 32];
     };
     auto store_tile = [&](int buf) {
-        unsigned char* base = lds + buf * KV_BUF_BYTES;
+        unsigned char* base = lds + buf * BUF_BYTES;
 #pragma unroll
-        for (int i = 0; i < 12; ++i)
+        for (int i = 0; i < 3 * NTILE; ++i)
             *reinterpret_cast<i32x4*>(base + (i / 3) * XT_BYTES + (tid + 256 * (i % 3)) * 16) = treg[i];
-        if (tid < 64) reinterpret_cast<float*>(base + 4 * XT_BYTES)[tid] = pl;
+        if (tid < 64) reinterpret_cast<float*>(base + NTILE * XT_BYTES)[tid] = pl;
     };
 
-    f32x16 dk0, dk1, dv0, dv1;
+    f32x16 g0, g1;                                         // dK or dV: features acc_row (g0) and 32 + acc_row (g1)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { g0[r] = 0.f; g1[r] = 0.f; }
 
     if (t_begin < t_end) {
         load_tile(t_begin);
@@ -401,10 +411,10 @@ __global__ __launch_bounds__(256) void ctx_attn_bwd_kv(const BwdKVx3Args a)
         const int buf = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
         if (more) load_tile(t + 1);
-        const unsigned char* base = lds + buf * KV_BUF_BYTES;
-        const float* ls = reinterpret_cast<const float*>(base + 4 * XT_BYTES);
+        const unsigned char* base = lds + buf * BUF_BYTES;
+        const float* ls = reinterpret_cast<const float*>(base + NTILE * XT_BYTES);
 
-        // ---- S = Q K^T and dA = dD V^T: rows = the tile's queries, column = this lane's key ----
+        // ---- S = Q K^T (and dA = dD V^T): rows = the tile's queries, column = this lane's key ----
         f32x16 s, ss, da;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; ss[r] = 0.f; da[r] = 0.f; }
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(256) void ctx_attn_bwd_kv(const BwdKVx3Args a)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
                     qa[p] = *reinterpret_cast<const i32x4*>(qb + ((p * 8 + 2 * g + h) * KT) * 16);
-                    dd[p] = *reinterpret_cast<const i32x4*>(db + ((p * 8 + 2 * g + h) * KT) * 16);
+                    if (WANT_K) dd[p] = *reinterpret_cast<const i32x4*>(db + ((p * 8 + 2 * g + h) * KT) * 16);
                 }
 #pragma unroll
                 for (int c = 0; c < 5; ++c)
@@ -425,27 +435,28 @@ __global__ __launch_bounds__(256) void ctx_attn_bwd_kv(const BwdKVx3Args a)
                                                                  __builtin_bit_cast(bf16x8, kf[g][PA[c]]), ss, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qa[0]),
                                                             __builtin_bit_cast(bf16x8, kf[g][0]), s, 0, 0, 0);
+                if (WANT_K) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c)
-                    da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dd[PA[c]]),
-                                                                 __builtin_bit_cast(bf16x8, vf[g][PB[c]]), da, 0, 0, 0);
+                    for (int c = 0; c < 6; ++c)
+                        da = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dd[PA[c]]),
+                                                                     __builtin_bit_cast(bf16x8, vf[g][PB[c]]), da, 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] += ss[r];
         }
-        // A[q][key] and dS[q][key] for this lane's key; rows are the tile's queries acc_row(r, h)
+        // A[q][key] (WANT_K: dS[q][key]) for this lane's key; rows are the tile's queries acc_row(r, h)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qq = acc_row(r, h);
             float p = __builtin_amdgcn_exp2f(s[r] * kLog2e - ls[qq]);
             if (!key_live) p = 0.f;
-            s[r] = p;
-            da[r] = p * (da[r] - ls[32 + qq]);
+            s[r] = WANT_K ? p * (da[r] - ls[32 + qq]) : p;
         }
-        // ---- dV^T += dD^T A, dK^T += Q^T dS: register operand = this lane's A / dS (registers 8 kg .. 8 kg + 7) ----
+        // ---- dV^T += dD^T A  /  dK^T += Q^T dS: register operand = this lane's A / dS (registers 8 kg .. 8 kg + 7) ----
 #pragma unroll
         for (int kg = 0; kg < 2; ++kg) {
-            i32x4 pp[3], ps[3];
+            i32x4 pp[3];
             {
                 unsigned ph[8], pm[8], pl8[8];
 #pragma unroll
@@ -456,50 +467,32 @@ __global__ __launch_bounds__(256) void ctx_attn_bwd_kv(const BwdKVx3Args a)
                     pp[1][w] = pack_hi(pm[2 * w], pm[2 * w + 1]);
                     pp[2][w] = pack_hi(pl8[2 * w], pl8[2 * w + 1]);
                 }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) split3(da[8 * kg + j], ph[j], pm[j], pl8[j]);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    ps[0][w] = pack_hi(ph[2 * w], ph[2 * w + 1]);
-                    ps[1][w] = pack_hi(pm[2 * w], pm[2 * w + 1]);
-                    ps[2][w] = pack_hi(pl8[2 * w], pl8[2 * w + 1]);
-                }
             }
-            const unsigned char* qr = base + 2 * XT_BYTES + l31 * 16;
-            const unsigned char* dr = base + 3 * XT_BYTES + l31 * 16;
-            i32x4 df2[3][2], qf2[3][2];
+            const unsigned char* rr = base + (WANT_K ? 2 : 1) * XT_BYTES + l31 * 16;      // Q mode 2 / dD mode 2
+            i32x4 rf[3][2];
 #pragma unroll
             for (int p = 0; p < 3; ++p)
 #pragma unroll
-                for (int hb = 0; hb < 2; ++hb) {
-                    df2[p][hb] = *reinterpret_cast<const i32x4*>(dr + ((((p * 2 + kg) * 2 + h) * DP) + 32 * hb) * 16);
-                    qf2[p][hb] = *reinterpret_cast<const i32x4*>(qr + ((((p * 2 + kg) * 2 + h) * DP) + 32 * hb) * 16);
-                }
+                for (int hb = 0; hb < 2; ++hb)
+                    rf[p][hb] = *reinterpret_cast<const i32x4*>(rr + ((((p * 2 + kg) * 2 + h) * DP) + 32 * hb) * 16);
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, df2[PA[c]][0]),
-                                                              __builtin_bit_cast(bf16x8, pp[PB[c]]), dv0, 0, 0, 0);
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, df2[PA[c]][1]),
-                                                              __builtin_bit_cast(bf16x8, pp[PB[c]]), dv1, 0, 0, 0);
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qf2[PA[c]][0]),
-                                                              __builtin_bit_cast(bf16x8, ps[PB[c]]), dk0, 0, 0, 0);
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qf2[PA[c]][1]),
-                                                              __builtin_bit_cast(bf16x8, ps[PB[c]]), dk1, 0, 0, 0);
+                g0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[PA[c]][0]),
+                                                             __builtin_bit_cast(bf16x8, pp[PB[c]]), g0, 0, 0, 0);
+                g1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rf[PA[c]][1]),
+                                                             __builtin_bit_cast(bf16x8, pp[PB[c]]), g1, 0, 0, 0);
             }
         }
         if (more) store_tile(buf ^ 1);
         __syncthreads();
     }
-    // accumulator row r = feature acc_row(r, h) (dk0 / dv0) and 32 + that (dk1 / dv1)
-    float* krow = a.dK + ((size_t)b * a.M_pad + key) * DP;
-    float* vrow = a.dV + ((size_t)b * a.M_pad + key) * DP;
+    // accumulator row r = feature acc_row(r, h) (g0) and 32 + that (g1)
+    float* orow = (WANT_K ? a.dK : a.dV) + ((size_t)b * a.M_pad + key) * DP;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = acc_row(r, h);
-        atomic_add_f32(&krow[i], dk0[r]);
-        atomic_add_f32(&krow[32 + i], dk1[r]);
-        atomic_add_f32(&vrow[i], dv0[r]);
-        atomic_add_f32(&vrow[32 + i], dv1[r]);
+        atomic_add_f32(&orow[i], g0[r]);
+        atomic_add_f32(&orow[32 + i], g1[r]);
     }
 }
 
@@ -761,18 +754,21 @@ extern "C" int ct_ctx_attention_bwd(const float* conf, const float* pool, int ba
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
         std::call_once(once, [] {
-            attr_err = hipFuncSetAttribute((const void*)ctx_attn_bwd_kv, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           KV_LDS_BYTES);
+            attr_err = hipFuncSetAttribute((const void*)ctx_attn_bwd_kv<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           KvCfg<true>::LDS_BYTES);
+            if (attr_err == hipSuccess)
+                attr_err = hipFuncSetAttribute((const void*)ctx_attn_bwd_kv<false>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, KvCfg<false>::LDS_BYTES);
         });
         CT_HIP(attr_err);
-    }
-    {
         BwdKVx3Args ka{};
         ka.Kx0 = w.Kx0; ka.Vx0 = w.Vx0; ka.Qx1 = w.Qx1; ka.dDx1 = w.dDx1; ka.Qx2 = w.Qx2; ka.dDx2 = w.dDx2;
         ka.lse = save_lse; ka.delta = w.delta; ka.dK = w.dK; ka.dV = w.dV;
         ka.P_pad = w.P_pad; ka.M = num_ctx; ka.M_pad = w.M_pad; ka.split = kv_split;
-        hipLaunchKernelGGL(ctx_attn_bwd_kv, dim3(w.M_pad / QB, batch, kv_split), blk, KV_LDS_BYTES, st, ka);
-        CT_LAUNCH_CHECK("ctx_attn_bwd_kv");
+        hipLaunchKernelGGL(ctx_attn_bwd_kv<false>, dim3(w.M_pad / QB, batch, kv_split), blk, KvCfg<false>::LDS_BYTES, st, ka);
+        CT_LAUNCH_CHECK("ctx_attn_bwd_kv<dV>");
+        hipLaunchKernelGGL(ctx_attn_bwd_kv<true>, dim3(w.M_pad / QB, batch, kv_split), blk, KvCfg<true>::LDS_BYTES, st, ka);
+        CT_LAUNCH_CHECK("ctx_attn_bwd_kv<dK>");
     }
 
     // projections backward
