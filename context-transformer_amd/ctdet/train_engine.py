@@ -68,7 +68,14 @@ class TrainRuntime:
             s.is_bn = st.parts[0].bn is not None
             assert all((p.bn is not None) == s.is_bn for p in st.parts), st.name
             ctot = st.cout
-            s.dz = al((batch, ctot, st.oh, st.ow))
+            # channel count of the dZ buffer.  A multibox head has 4 k + C k + k output channels (156 for six anchors and 20
+            # classes): not a multiple of 8 / 16, so its data gradient (a 3x3 convolution WITH dZ's channels as input) fitted
+            # neither the Winograd nor the bf16x3 kernel and ran on the fp32 implicit GEMM (2 x 450-770 us per step).  dZ
+            # is padded with zero channels instead (ct_head_grad_gather writes 0 outside its segments; the packed
+            # data-gradient weights get a zero part of as many rows).
+            s.zc = (ctot + 15) // 16 * 16 if (st.segs and st.src != 'x' and (st.kh, st.kw, st.stride, st.dil) == (3, 3, 1, 1)) else ctot
+            s.zero_w = torch.zeros(s.zc - ctot, st.cin, st.kh, st.kw, device=backend.device) if s.zc > ctot else None
+            s.dz = al((batch, s.zc, st.oh, st.ow))
             s.dw = al((ctot, st.cin, st.kh, st.kw))
             if s.is_bn:
                 # conv with identity epilogue into a dense Z buffer
@@ -93,14 +100,15 @@ class TrainRuntime:
             # data-gradient launch (not needed for the image itself)
             s.dgrad = None
             if st.src != 'x':
-                kpad = self.lib.ct_conv_kpad(ctot, st.kh, st.kw)
+                zc = s.zc
+                kpad = self.lib.ct_conv_kpad(zc, st.kh, st.kw)
                 mpad = self.lib.ct_conv_mpad(st.cin)
                 s.wpk_d = al((kpad, mpad))
                 s.ones = torch.ones(mpad, device=backend.device)
                 s.zeros = torch.zeros(mpad, device=backend.device)
                 d = _lib.ConvDesc()
                 d.in_ = s.dz.data_ptr()
-                d.batch, d.cin, d.h, d.w, d.in_ctot, d.in_coff = batch, ctot, st.oh, st.ow, ctot, 0
+                d.batch, d.cin, d.h, d.w, d.in_ctot, d.in_coff = batch, zc, st.oh, st.ow, zc, 0
                 d.wpacked, d.scale, d.shift = s.wpk_d.data_ptr(), s.ones.data_ptr(), s.zeros.data_ptr()
                 d.cout, d.m_pad, d.k_pad = st.cin, mpad, kpad
                 d.kh, d.kw, d.stride, d.pad_h, d.pad_w, d.dil = st.kh, st.kw, st.stride, st.ph, st.pw, st.dil
@@ -117,7 +125,7 @@ class TrainRuntime:
                 # 3x3 / stride 1 / pad 1 layers: the data gradient is itself such a convolution (channels
                 # swapped, taps rotated) -> Winograd kernel on dY with ct_conv_pack_weights_wino_dgrad
                 s.dgrad_wino = None
-                if (st.kh, st.kw, st.stride, st.dil, st.ph, st.pw) == (3, 3, 1, 1, 1, 1) and ctot % 8 == 0 \
+                if (st.kh, st.kw, st.stride, st.dil, st.ph, st.pw) == (3, 3, 1, 1, 1, 1) and zc % 8 == 0 \
                         and st.oh * st.ow >= 19 * 19:
                     w2 = _lib.ConvDesc()
                     C.memmove(C.byref(w2), C.byref(d), C.sizeof(d))
@@ -128,18 +136,18 @@ class TrainRuntime:
                         # same tile size as the forward launch of this layer (same map, channels swapped)
                         s.dgrad_tile = 4 if s.fwd.rt.get('wino') == 4 else 2
                         sizeof = self.lib.ct_conv_wino4_packed_floats if s.dgrad_tile == 4 else self.lib.ct_conv_wino_packed_floats
-                        s.U_d = al((sizeof(ctot, st.cin),))
+                        s.U_d = al((sizeof(zc, st.cin),))
             # direct data gradients on the bf16 matrix pipe (bf16x3, ct_conv2d_x3_fwd transposed): every layer without
             # a Winograd data gradient whose channel counts fit the k-step; CTDET_X3=0 keeps ct_conv2d_fwd
             s.dgrad_x3 = None
             if s.dgrad is not None and getattr(s, 'dgrad_wino', None) is None and st.stride <= 2 and \
-                    os.environ.get('CTDET_X3', '1') != '0' and ctot % 16 == 0 and ctot >= 32:
+                    os.environ.get('CTDET_X3', '1') != '0' and s.zc % 16 == 0 and s.zc >= 32:
                 npix = batch * st.h * st.w
                 tiles128 = -(-st.cin // 128) * -(-npix // 128)
-                cfg = 0 if tiles128 >= 512 else (3 if ctot % 32 == 0 and -(-st.cin // 64) * -(-npix // 128) < 384 else 1)
+                cfg = 0 if tiles128 >= 512 else (3 if s.zc % 32 == 0 and -(-st.cin // 64) * -(-npix // 128) < 384 else 1)
                 bk = self.lib.ct_conv_x3_config_bk(cfg)
                 s.dgrad_x3 = cfg
-                s.wx3_d = al((self.lib.ct_conv_x3_packed_bytes(ctot, st.cin, st.kh, st.kw, bk),), torch.uint8)
+                s.wx3_d = al((self.lib.ct_conv_x3_packed_bytes(s.zc, st.cin, st.kh, st.kw, bk),), torch.uint8)
             # weight-gradient descriptor = forward geometry on the forward input
             w = _lib.ConvDesc()
             src = self.bufs[st.src]
@@ -261,9 +269,12 @@ class TrainRuntime:
     # ------------------------------------------------------------------ weight packing
     def _pack_dgrad(self, st, s):
         """The data-gradient layout of one fused conv from the current weights."""
-        n = len(st.parts)
-        ptrs = (C.c_void_p * n)(*[p.weight.data_ptr() for p in st.parts])
-        couts = (C.c_int * n)(*[p.cout for p in st.parts])
+        wts = [(p.weight.data_ptr(), p.cout) for p in st.parts]
+        if s.zero_w is not None:                # the zero channels dZ is padded with (s.zc)
+            wts.append((s.zero_w.data_ptr(), s.zero_w.shape[0]))
+        n = len(wts)
+        ptrs = (C.c_void_p * n)(*[w for w, _ in wts])
+        couts = (C.c_int * n)(*[c for _, c in wts])
         if s.dgrad_wino is not None:
             pack = self.lib.ct_conv_pack_weights_wino4_dgrad if s.dgrad_tile == 4 else self.lib.ct_conv_pack_weights_wino_dgrad
             _lib.check(pack(ptrs, couts, n, st.cin, s.U_d.data_ptr(), self._s()), st.name + ' pack dgrad (winograd)')
@@ -312,10 +323,13 @@ class TrainRuntime:
         if getattr(self, '_x3_list', None) is None or self._x3_list[2] != ptrs:
             items, nbytes = [], self.lib.ct_conv_x3_pack_item_bytes()
 
-            def item(parts, cin, kh, kw, bk, dst, dgrad):
-                n = len(parts)
-                wp = (C.c_void_p * n)(*[p.weight.data_ptr() for p in parts])
-                co = (C.c_int * n)(*[p.cout for p in parts])
+            def item(parts, cin, kh, kw, bk, dst, dgrad, zero_w=None):
+                wts = [(p.weight.data_ptr(), p.cout) for p in parts]
+                if zero_w is not None:
+                    wts.append((zero_w.data_ptr(), zero_w.shape[0]))
+                n = len(wts)
+                wp = (C.c_void_p * n)(*[w for w, _ in wts])
+                co = (C.c_int * n)(*[c for _, c in wts])
                 buf = (C.c_ubyte * nbytes)()
                 _lib.check(self.lib.ct_conv_x3_pack_item(wp, co, n, cin, kh, kw, bk, dst.data_ptr(), dgrad, buf),
                            'ct_conv_x3_pack_item')
@@ -328,7 +342,7 @@ class TrainRuntime:
                     bk = self.be.x3_bk(s.fwd.rt['x3'])
                     item(s.fwd.parts, s.fwd.cin, s.fwd.kh, s.fwd.kw, bk, s.fwd.rt['wx3'][bk], 0)
                 if s.dgrad is not None and s.dgrad_x3 is not None:
-                    item(st.parts, st.cin, st.kh, st.kw, self.lib.ct_conv_x3_config_bk(s.dgrad_x3), s.wx3_d, 1)
+                    item(st.parts, st.cin, st.kh, st.kw, self.lib.ct_conv_x3_config_bk(s.dgrad_x3), s.wx3_d, 1, s.zero_w)
             table = torch.frombuffer(bytearray(b''.join(items)), dtype=torch.uint8).to(self.be.device) if items else None
             self._x3_list = (table, len(items), ptrs)
         if self._x3_list[1]:
@@ -488,7 +502,7 @@ class TrainRuntime:
                 written.setdefault(st.src, []).append((0, st.ch))
                 continue
             s = self.state[st.name]
-            hw, ctot = st.oh * st.ow, st.cout
+            hw, ctot = st.oh * st.ow, s.zc          # channel stride of dZ (st.cout, padded for the heads)
             if st.segs:                                   # heads: gather the flattened gradients
                 segs = (_lib.OutSegment * 3)()
                 for g, sg in enumerate(st.segs):
