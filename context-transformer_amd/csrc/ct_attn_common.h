@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void ctx_project_kernel(const float* __restric
                                                           float* __restrict__ o_rows,
                                                           float* __restrict__ o_plain, int ostride)
 {
-    __shared__ float Wt[DP * DP];      // Wt[i][o]
-    __shared__ float Xs[64 * DP];      // 64 rows
+    __shared__ float Wt[DP * DP];                                  // Wt[i][o]
+    __shared__ __attribute__((aligned(16))) float Xt[DP * 64];     // Xt[i][row]: four rows of a feature are one 16-byte broadcast
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * 64;
     const int tid = threadIdx.x;
@@ -89,22 +89,33 @@ __global__ __launch_bounds__(256) void ctx_project_kernel(const float* __restric
     for (int e = tid; e < 64 * DP; e += 256) {
         const int r = e / DP, i = e % DP;
         const int row = r0 + r;
-        Xs[e] = (row < rows_valid && i < d) ? x[((size_t)b * rows_valid + row) * d + i] : 0.f;
+        Xt[i * 64 + r] = (row < rows_valid && i < d) ? x[((size_t)b * rows_valid + row) * d + i] : 0.f;
     }
     __syncthreads();
+    // thread = output feature o of rows 16 rg .. 16 rg + 15, four rows at a time (one weight read and one 16-byte row read
+    // per four FMAs); every output sums its 64 products in the order i = 0 .. 63
     const int o = tid & 63, rg = tid >> 6;
     const float bo = (o < d) ? bias[o] : 0.f;
-    for (int r = rg; r < 64; r += 4) {
-        const int row = r0 + r;
-        if (row >= rows_pad) break;
-        float acc = 0.f;
+    for (int rq = 0; rq < 4; ++rq) {
+        const int rl = 16 * rg + 4 * rq;
+        if (r0 + rl >= rows_pad) break;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-        for (int i = 0; i < DP; ++i) acc += Xs[r * DP + i] * Wt[i * DP + o];
-        float y = (row < rows_valid && o < d) ? acc + bo + Xs[r * DP + o] : 0.f;
-        if (o_sw) o_sw[((size_t)b * rows_pad + row) * DP + (o & 1) * 32 + (o >> 1)] = y;
-        if (o_t) o_t[((size_t)b * DP + o) * rows_pad + row] = y;
-        if (o_rows) o_rows[((size_t)b * rows_pad + row) * DP + o] = y;
-        if (o_plain && row < rows_valid && o < d) o_plain[((size_t)b * rows_valid + row) * ostride + o] = y;
+        for (int i = 0; i < DP; ++i) {
+            const float w = Wt[i * DP + o];
+            const float4 xv = *reinterpret_cast<const float4*>(&Xt[i * 64 + rl]);
+            acc[0] += xv.x * w; acc[1] += xv.y * w; acc[2] += xv.z * w; acc[3] += xv.w * w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = r0 + rl + k;
+            if (row >= rows_pad) break;
+            const float y = (row < rows_valid && o < d) ? acc[k] + bo + Xt[o * 64 + rl + k] : 0.f;
+            if (o_sw) o_sw[((size_t)b * rows_pad + row) * DP + (o & 1) * 32 + (o >> 1)] = y;
+            if (o_t) o_t[((size_t)b * DP + o) * rows_pad + row] = y;
+            if (o_rows) o_rows[((size_t)b * rows_pad + row) * DP + o] = y;
+            if (o_plain && row < rows_valid && o < d) o_plain[((size_t)b * rows_valid + row) * ostride + o] = y;
+        }
     }
 }
 
