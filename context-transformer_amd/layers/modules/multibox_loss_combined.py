@@ -10,7 +10,12 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from collections import namedtuple
+
 from ctdet import ops
+
+# what match() assigns to every prior: encoded box [B,P,4], (label, mixup weight) [B,P,2], ignore mask [B,P] bool
+MatchedTargets = namedtuple('MatchedTargets', 'loc_t conf_t obj_t')
 
 
 class MultiBoxLoss_combined(nn.Module):
@@ -28,14 +33,28 @@ class MultiBoxLoss_combined(nn.Module):
         self.variance = [0.1, 0.2]
         self.sync_normalizer = False      # set True under multi-process data parallelism
 
+    @torch.no_grad()
+    def match(self, priors, targets, device=None, out=None):
+        """The target assignment of :60-76 alone (it depends on the ground truth and the priors only): -> MatchedTargets,
+        which forward() accepts in place of the raw target list.  `out`: a MatchedTargets of the same batch to overwrite
+        in place -- a training step captured as a hipGraph (bench.py --train) reads the same three tensors at every
+        replay, the matching itself (a host-built offset table, an H2D copy) stays outside the graph."""
+        dev = torch.device(device) if device is not None else priors.device
+        loc_t, conf_t, obj_t = ops.match_batched([t.to(dev) for t in targets], priors.to(dev).float().contiguous(),
+                                                 self.threshold, self.variance)
+        if out is None:
+            return MatchedTargets(loc_t, conf_t, obj_t)
+        out.loc_t.copy_(loc_t); out.conf_t.copy_(conf_t); out.obj_t.copy_(obj_t)
+        return out
+
     def forward(self, predictions, priors, targets):
         loc_data, conf_data, obj_data = predictions
         dev = loc_data.device
         num, num_priors = loc_data.size(0), priors.size(0)
-        with torch.no_grad():
-            loc_t, conf_t, obj_t = ops.match_batched([t.to(dev) for t in targets],
-                                                     priors.to(dev).float().contiguous(),
-                                                     self.threshold, self.variance)
+        if isinstance(targets, MatchedTargets):
+            loc_t, conf_t, obj_t = targets
+        else:
+            loc_t, conf_t, obj_t = self.match(priors, targets, dev)
         labels, weights = conf_t[:, :, 0], conf_t[:, :, 1]
         pos = labels > 0
         num_pos = (weights * pos.float()).sum(1, keepdim=True).long()

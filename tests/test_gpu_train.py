@@ -290,3 +290,25 @@ def test_loss_with_ignored_boxes_labelled_minus_one():
         ga = a.grad.cpu()
         assert torch.isfinite(ga).all(), n
         assert float((ga - b.grad).abs().max()) <= 2e-5 * float(b.grad.abs().max()) + 1e-9, n
+
+
+def test_loss_with_prematched_targets_equals_loss_with_raw_targets():
+    """MultiBoxLoss_combined.match (the target assignment alone) + forward(MatchedTargets) = forward(raw targets), and
+    match(out=...) overwrites a previous assignment in place."""
+    from layers.modules.multibox_loss_combined import MultiBoxLoss_combined, MatchedTargets
+    g = torch.Generator().manual_seed(3)
+    B, P, C = 3, 500, 21
+    pri = torch.rand(P, 4, generator=g) * 0.5 + 0.25
+    pri[:, 2:] = pri[:, 2:] * 0.4 + 0.05
+    priors = pri.to(DEV)
+    tg = [t.to(DEV) for t in synth.targets(B, C, 11)]
+    tg2 = [t.to(DEV) for t in synth.targets(B, C, 12)]
+    preds = tuple(torch.randn(B, P, k, generator=g).to(DEV).requires_grad_(True) for k in (4, C - 1, 2))
+    crit = MultiBoxLoss_combined(C, 0.5, True, 0, True, 3, 0.5, False)
+    want = crit(preds, priors, tg)
+    mt = crit.match(priors, tg2)
+    assert isinstance(mt, MatchedTargets)
+    assert crit.match(priors, tg, out=mt) is mt
+    got = crit(preds, priors, mt)
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
