@@ -13,7 +13,7 @@ struct WinoPackArgs {
     int nparts, cin, cout, chunks, kblocks;
     int dgrad;               // 1: weights of the data-gradient convolution (channels swapped, taps flipped)
     int cin_fwd;
-    int tile;                // 2: F(2x2,3x3) layout, 4: F(4x4,3x3) layout
+    int tile;                // 2: F(2x2,3x3) layout, 4: F(4x4,3x3) layout, 23: F(2x2,3x3) split into bf16x3 pieces
     float* U;
 };
 
@@ -21,6 +21,8 @@ constexpr int kWinoCC = 8;                          // input channels per chunk 
 constexpr int kWinoKB = 64;                         // output channels per workgroup (both kernels)
 constexpr int kWino2ChunkFloats = 16 * 4 * 64 * 2;  // F(2x2): [wave 8][piece 4][lane 64][4]
 constexpr int kWino4ChunkFloats = 8 * 9 * 64 * 4;   // F(4x4): [wave 8][point 9][lane 64][4]
+constexpr int kWinoX3CC = 16;                       // ct_wino_x3.hip: input channels per chunk (one bf16 MFMA k-group)
+constexpr int kWinoX3ChunkBytes = 8 * 2 * 2 * 3 * 64 * 16;   // [wave 8][point 2][cout half 2][piece 3][lane 64][8 bf16]
 
 // forward: g = w[co][ci];  data gradient: this conv's (co, ci) = forward (ci, co), taps rotated 180 degrees
 __device__ __forceinline__ const float* wino_taps(const WinoPackArgs& p, int co, int ci)
@@ -121,9 +123,52 @@ __device__ __forceinline__ void wino4_pack_body(const WinoPackArgs& p, long firs
     }
 }
 
+// ct_wino_x3.hip: U[kb][chunk 16 ch][wave 8][x 2][cout half 2][piece 3][lane 64][8 bf16] -- wave w owns the points 2w + x;
+// lane (l31, hh) holds, for cout = kb*64 + half*32 + l31, the channels chunk*16 + 8*hh .. +7 of one bf16 piece: the A
+// operand of v_mfma_f32_32x32x16_bf16.  One thread = one (point, cout, 8 channels): G g G^T in fp32 (the F(2x2) G has
+// entries 0, 1, +-1/2: the same values ct_wino.hip multiplies with), then the exact three-piece split.
+__device__ __forceinline__ void winox3_pack_body(const WinoPackArgs& p, long first, long stride)
+{
+    const long total = (long)p.kblocks * p.chunks * (8 * 2 * 2 * 64);
+    unsigned short* const out = reinterpret_cast<unsigned short*>(p.U);
+    for (long idx = first; idx < total; idx += stride) {
+        const int ln = (int)(idx & 63), half = (int)((idx >> 6) & 1), x = (int)((idx >> 7) & 1), wv = (int)((idx >> 8) & 7);
+        const long rest = idx >> 11;
+        const int chunk = (int)(rest % p.chunks);
+        const int kb = (int)(rest / p.chunks);
+        const int hh = ln >> 5;
+        const int co = kb * kWinoKB + half * 32 + (ln & 31);
+        const int xi = 2 * wv + x;
+        float Ga[3], Gb[3];
+        auto grow = [](int r, float (&o)[3]) {          // G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+            if (r == 0) { o[0] = 1.f; o[1] = 0.f; o[2] = 0.f; }
+            else if (r == 1) { o[0] = .5f; o[1] = .5f; o[2] = .5f; }
+            else if (r == 2) { o[0] = .5f; o[1] = -.5f; o[2] = .5f; }
+            else { o[0] = 0.f; o[1] = 0.f; o[2] = 1.f; }
+        };
+        grow(xi >> 2, Ga);
+        grow(xi & 3, Gb);
+        unsigned short* base = out + ((((((size_t)kb * p.chunks + chunk) * 8 + wv) * 2 + x) * 2 + half) * 3 * 64 + ln) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = chunk * kWinoX3CC + 8 * hh + e;
+            float val = 0.f;
+            if (co < p.cout) val = wino_ggt(p, wino_taps(p, co, ci), Ga, Gb);
+            const unsigned hb = __builtin_bit_cast(unsigned, val) & 0xFFFF0000u;
+            const float r1 = val - __builtin_bit_cast(float, hb);
+            const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+            const unsigned lb = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, mb));
+            base[e] = (unsigned short)(hb >> 16);
+            base[64 * 8 + e] = (unsigned short)(mb >> 16);
+            base[2 * 64 * 8 + e] = (unsigned short)(lb >> 16);
+        }
+    }
+}
+
 __device__ __forceinline__ void wino_pack_any(const WinoPackArgs& p, long first, long stride)
 {
-    if (p.tile == 4) wino4_pack_body(p, first, stride);
+    if (p.tile == 23) winox3_pack_body(p, first, stride);
+    else if (p.tile == 4) wino4_pack_body(p, first, stride);
     else wino2_pack_body(p, first, stride);
 }
 

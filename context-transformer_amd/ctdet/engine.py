@@ -345,6 +345,15 @@ class Plan:
 # ======================================================================================
 WINO = -1          # ConvStep.rt['config'] value selecting the Winograd F(2x2,3x3) kernel
 WINO4 = -2         # ... the Winograd F(4x4,3x3) kernel
+WINOX = -3         # ... F(2x2,3x3) on the bf16 matrix pipe (bf16x3), two accumulators (csrc/ct_wino_x3.hip)
+WINOXS = -4        # ... the same with one accumulator
+WINOXQ = -5        # ... one accumulator, four-wave workgroups (two per CU)
+# st.rt['wino'] values: 2, 4 = the fp32-MFMA kernels' tile sizes; F(2x2,3x3) on bf16x3: 23 = two accumulators, 22 = one,
+# 24 = one accumulator in the four-wave / two-workgroups-per-CU form
+WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXS: 22, WINOXQ: 24}
+WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 22: 'winoxs', 24: 'winoxq'}
+WINOX_TILES = (22, 23, 24)
+WINOX_VARIANT = {22: 0, 23: 1, 24: 2}        # the `dual` argument of ct_conv2d_wino_x3_fwd
 
 
 class HipBackend:
@@ -429,12 +438,14 @@ class HipBackend:
                     rt['ksws'].numel()
         rt['desc'] = d
         rt['wino_ok'] = bool(lib.ct_conv_wino_supported(C.byref(d)))
-        if rt.get('config', 0) in (WINO, WINO4):
-            self.enable_wino(st, tile=2 if rt['config'] == WINO else 4)
+        rt['winox_ok'] = bool(lib.ct_conv_wino_x3_supported(C.byref(d)))
+        if rt.get('config', 0) in WINO_TILE:
+            self.enable_wino(st, tile=WINO_TILE[rt['config']])
 
     def enable_wino(self, st, on=True, tile=None):
         """Route this conv through a Winograd kernel (3x3 s1 d1 p1 layers only): tile 2 = F(2x2,3x3),
-        tile 4 = F(4x4,3x3).  st.rt['wino'] holds the tile size in use."""
+        tile 4 = F(4x4,3x3), 23 / 22 = F(2x2,3x3) on the bf16 matrix pipe with two / one accumulators (cin % 16 == 0).
+        st.rt['wino'] holds the code in use."""
         rt = st.rt
         if not on:
             rt['wino'] = False
@@ -445,12 +456,18 @@ class HipBackend:
             raise _lib.CtdetError('%s: geometry has no Winograd path' % st.name)
         rt['x3'] = None
         tile = int(tile or 2)
-        if tile not in (2, 4):
-            raise _lib.CtdetError('%s: Winograd tile %r (2 or 4)' % (st.name, tile))
-        key = 'U' if tile == 2 else 'U4'
-        if key not in rt:
-            sizeof = self.lib.ct_conv_wino_packed_floats if tile == 2 else self.lib.ct_conv_wino4_packed_floats
-            rt[key] = self.alloc((sizeof(st.cin, st.cout),))
+        if tile not in (2, 4) + WINOX_TILES:
+            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 22, 23 or 24)' % (st.name, tile))
+        if tile in WINOX_TILES:
+            if not rt.get('winox_ok'):
+                raise _lib.CtdetError('%s: geometry has no Winograd bf16x3 path (cin %% 16)' % st.name)
+            if 'UX' not in rt:
+                rt['UX'] = self.alloc((self.lib.ct_conv_wino_x3_packed_bytes(st.cin, st.cout),), torch.uint8)
+        else:
+            key = 'U' if tile == 2 else 'U4'
+            if key not in rt:
+                sizeof = self.lib.ct_conv_wino_packed_floats if tile == 2 else self.lib.ct_conv_wino4_packed_floats
+                rt[key] = self.alloc((sizeof(st.cin, st.cout),))
         rt['wino'] = tile
         self._pack_wino(st)
 
@@ -461,6 +478,10 @@ class HipBackend:
         if st.rt['wino'] == 4:
             _lib.check(self.lib.ct_conv_pack_weights_wino4(ptrs, couts, n, st.cin, st.rt['U4'].data_ptr(), self._stream()),
                        'ct_conv_pack_weights_wino4')
+            return
+        if st.rt['wino'] in WINOX_TILES:
+            _lib.check(self.lib.ct_conv_pack_weights_wino_x3(ptrs, couts, n, st.cin, st.rt['UX'].data_ptr(), self._stream()),
+                       'ct_conv_pack_weights_wino_x3')
             return
         _lib.check(self.lib.ct_conv_pack_weights_wino(ptrs, couts, n, st.cin, st.rt['U'].data_ptr(), self._stream()),
                    'ct_conv_pack_weights_wino')
@@ -524,6 +545,16 @@ class HipBackend:
 
     def run_conv(self, st):
         tile = st.rt.get('wino')
+        if tile in WINOX_TILES:          # F(2x2,3x3) on the bf16 matrix pipe (csrc/ct_wino_x3.hip)
+            lib, U, dual = self.lib, st.rt['UX'].data_ptr(), WINOX_VARIANT[tile]
+            pool = st.rt.get('pool')
+            if pool is not None:
+                t, poh, pow_, full = pool
+                _lib.check(lib.ct_conv2d_wino_x3_pool_fwd(C.byref(st.rt['desc']), U, dual, t.data_ptr(), t.shape[1], 0, poh,
+                                                          pow_, int(full), self._stream()), st.name)
+                return
+            _lib.check(lib.ct_conv2d_wino_x3_fwd(C.byref(st.rt['desc']), U, dual, self._stream()), st.name)
+            return
         if tile:
             lib = self.lib
             U = st.rt['U4' if tile == 4 else 'U'].data_ptr()
@@ -663,10 +694,12 @@ def wino_tiles(backend=None, st=None):
     """Winograd variants the tuner may pick: CTDET_WINO_TILES = '2', '4' or '2,4' (default), minus what the
     runtime that owns `backend` excluded (wino4_allowed / wino4_max_cin: F(4x4,3x3) only up to that many input
     channels -- its rounding error grows with the length of the channel sum)."""
-    tiles = tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4').split(',') if t)
+    tiles = tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4,23,24').split(',') if t)
     allowed = getattr(backend, 'wino_tile_set', None)
     if allowed is not None:
         tiles = tuple(t for t in tiles if t in allowed)
+    if st is not None and not st.rt.get('winox_ok'):
+        tiles = tuple(t for t in tiles if t not in WINOX_TILES)
     cap = getattr(backend, 'wino4_max_cin', None)
     if cap is not None and st is not None and st.cin > cap:
         tiles = tuple(t for t in tiles if t != 4)
@@ -708,9 +741,15 @@ def apply_tuned(backend, st, batch, wino4=True):
     wino4=False maps a 'wino4' entry to 'wino' (F(2x2,3x3): a tenth of the rounding error)."""
     cfg = tune_table().get(st.tune_key(batch))
     names = [backend.lib.ct_conv_config_name(i).decode() for i in range(backend.lib.ct_conv_num_configs())]
-    if cfg in ('wino', 'wino4') and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
-        tile = 4 if cfg == 'wino4' and wino4 and 4 in wino_tiles(backend, st) else 2
-        backend.enable_wino(st, tile=tile)
+    codes = {v: k for k, v in WINO_NAME.items()}
+    if cfg in codes and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
+        allowed = wino_tiles(backend, st)
+        want = codes[cfg]
+        if want == 4 and not wino4:
+            want = 2
+        if want not in allowed:         # policy of this runtime: the most accurate allowed variant instead
+            want = 23 if 23 in allowed and st.rt.get('winox_ok') else 2
+        backend.enable_wino(st, tile=want)
         return True
     if isinstance(cfg, str) and cfg.startswith('x3:'):
         xn = backend.x3_names()
@@ -895,7 +934,7 @@ class Runtime:
             key = st.tune_key(self.batch)
             f32 = lib.ct_conv_config_name(st.rt['desc'].config - 1).decode() if st.rt['desc'].config > 0 else None
             if st.rt.get('wino'):
-                out[key] = {2: 'wino', 4: 'wino4'}[st.rt['wino']]
+                out[key] = WINO_NAME[st.rt['wino']]
             elif st.rt.get('x3') is not None:
                 out[key] = xn[st.rt['x3']]
                 if f32:

@@ -309,6 +309,23 @@ int ct_conv2d_wino4_fwd(const ct_conv_desc* desc, const float* upacked, ct_strea
 int ct_conv2d_wino4_pool_fwd(const ct_conv_desc* desc, const float* upacked, float* pool_out, int pool_ctot,
                              int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
 
+/* Winograd F(2x2,3x3) on the bf16 matrix pipe (csrc/ct_wino_x3.hip): the entry points of ct_conv2d_wino_fwd above with
+ * the transform-domain products evaluated as six bf16 piece products ("bf16x3", see below) on v_mfma_f32_32x32x16_bf16
+ * -- same layers (models/RFB_Net_vgg.py:7-22,219-227,238-248), descriptor, epilogue, pooling fusion and head scatter;
+ * cin % 16 == 0.  The weights come pre-transformed AND pre-split from ct_conv_pack_weights_wino_x3
+ * (ct_conv_wino_x3_packed_bytes bytes).  dual != 0: the hi.hi products accumulate in their own register block (the
+ * large sum sees cin / 16 roundings; error vs fp64 about a quarter of ct_conv2d_wino_fwd's); dual == 0: one
+ * accumulator (6 cin / 16 roundings). */
+int ct_conv_wino_x3_supported(const ct_conv_desc* desc);
+size_t ct_conv_wino_x3_packed_bytes(int cin, int cout);
+int ct_conv_pack_weights_wino_x3(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                 ct_stream_t stream);
+int ct_conv_pack_weights_wino_x3_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                       ct_stream_t stream);
+int ct_conv2d_wino_x3_fwd(const ct_conv_desc* desc, const void* upacked, int dual, ct_stream_t stream);
+int ct_conv2d_wino_x3_pool_fwd(const ct_conv_desc* desc, const void* upacked, int dual, float* pool_out, int pool_ctot,
+                               int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
+
 /* ---- "bf16x3": the fp32 convolution of ct_conv2d_fwd on the bf16 matrix pipe (csrc/ct_conv_x3.hip) ----
  * Same layers (models/RFB_Net_vgg.py:7-22 BasicConv, the plain Conv2d layers, the multibox heads :238-248), the same
  * descriptor (NCHW fp32 in / out, channel slices, residual, per-channel floor, head scatter, ksplit slabs) and the

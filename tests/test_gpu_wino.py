@@ -1,4 +1,5 @@
-"""Winograd F(2x2,3x3) and F(4x4,3x3) convolutions (ct_conv2d_wino_fwd, ct_conv2d_wino4_fwd) against torch-CPU conv2d
+"""Winograd F(2x2,3x3) and F(4x4,3x3) convolutions (ct_conv2d_wino_fwd, ct_conv2d_wino4_fwd, and F(2x2,3x3) on the
+bf16 matrix pipe: ct_conv2d_wino_x3_fwd with two / one accumulators) against torch-CPU conv2d
 and against the direct implicit-GEMM kernel: same descriptor, same fused epilogues, 1e-4 relative (north_star's fp32
 bar; F(4x4,3x3)'s own rounding is about 2e-5 of the output range at 512 input channels, checked below against fp64)."""
 import zlib
@@ -13,8 +14,15 @@ from test_gpu_kernels import _bn, _ref_conv, _run_conv
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 W = engine.WINO
-VARIANTS = [engine.WINO, engine.WINO4]
-VIDS = ['f2x2', 'f4x4']
+VARIANTS = [engine.WINO, engine.WINO4, engine.WINOX, engine.WINOXS, engine.WINOXQ]
+VIDS = ['f2x2', 'f4x4', 'f2x2_x3', 'f2x2_x3s', 'f2x2_x3q']
+X3V = (engine.WINOX, engine.WINOXS, engine.WINOXQ)         # cin must be a multiple of 16 (one bf16 MFMA k-group)
+
+
+def _cin(W, cin):
+    """Input channels of a test case for variant W: the bf16x3 kernel walks 16-channel chunks."""
+    return (cin + 15) // 16 * 16 if W in X3V else cin
+
 
 CASES = [  # name, B, Cin, H, W, Cout
     ('vgg', 2, 64, 38, 38, 128), ('odd_hw', 3, 16, 19, 17, 70), ('one_pixel', 2, 8, 1, 1, 5), ('tiny', 2, 24, 5, 5, 64),
@@ -27,6 +35,7 @@ CASES = [  # name, B, Cin, H, W, Cout
 @pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
 def test_wino_matches_reference(case, W):
     name, B, Cin, H, Wd, Cout = case
+    Cin = _cin(W, Cin)
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
     x = torch.randn(B, Cin, H, Wd, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
@@ -82,6 +91,7 @@ def test_wino_fused_maxpool(case, W):
     """MaxPool2d(2, 2[, ceil_mode]) behind the conv (models/RFB_Net_vgg.py:328-330) from the Winograd epilogue."""
     import torch.nn.functional as F
     B, Cin, H, Wd, Cout, ceil, full = case
+    Cin = _cin(W, Cin)
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cout)
     x = torch.randn(B, Cin, H, Wd, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
@@ -111,7 +121,7 @@ def test_wino_fused_maxpool(case, W):
         assert torch.isnan(bufs['y']).all()                                             # full-resolution map skipped
 
 
-@pytest.mark.parametrize('use_wino', [engine.WINO, engine.WINO4, 0], ids=VIDS + ['direct'])
+@pytest.mark.parametrize('use_wino', VARIANTS + [0], ids=VIDS + ['direct'])
 def test_head_scatter_output(use_wino):
     """Multibox head (models/RFB_Net_vgg.py:239-248): one fused loc|conf|obj conv writing channels-last into
     three flattened buffers at a prior offset -- Winograd and direct kernels against permute/view/cat."""
@@ -131,7 +141,7 @@ def test_head_scatter_output(use_wino):
             'conf': torch.full((B, P * Cc), float('nan'), device='cuda'), 'obj': torch.full((B, P * 2), float('nan'), device='cuda')}
     st.rt['config'] = use_wino
     be.prepare_conv(st, bufs, B)
-    assert (st.rt.get('wino') or 0) == {engine.WINO: 2, engine.WINO4: 4, 0: 0}[use_wino]
+    assert (st.rt.get('wino') or 0) == {**engine.WINO_TILE, 0: 0}[use_wino]
     be.run_conv(st)
     torch.cuda.synchronize()
     import torch.nn.functional as F
@@ -143,7 +153,7 @@ def test_head_scatter_output(use_wino):
         assert torch.isnan(got[:, :lo]).all() and torch.isnan(got[:, hi:]).all(), name
 
 
-@pytest.mark.parametrize('use_wino', [engine.WINO, engine.WINO4, 0], ids=VIDS + ['direct'])
+@pytest.mark.parametrize('use_wino', VARIANTS + [0], ids=VIDS + ['direct'])
 def test_conv_input_above_2gib_is_chunked(use_wino):
     """BASELINE configs[4] shapes put more than 2 GiB into one activation (32x64x512x512 fp32): the buffer
     descriptors are 32-bit, so both kernels split the batch -- the images on both sides of the split must be right."""
@@ -160,11 +170,14 @@ def test_conv_input_above_2gib_is_chunked(use_wino):
         assert rel_err(got[n:n + 1], want) < TOL, n
 
 
-@pytest.mark.parametrize('W,bound', [(engine.WINO, 3e-6), (engine.WINO4, 5e-5)], ids=VIDS)
+@pytest.mark.parametrize('W,bound', [(engine.WINO, 3e-6), (engine.WINO4, 5e-5), (engine.WINOX, 1e-6), (engine.WINOXS, 2e-6),
+                                     (engine.WINOXQ, 2e-6)],
+                         ids=VIDS)
 def test_wino_rounding_error_vs_fp64(W, bound):
     """The transform-domain rounding of each variant on the deepest VGG shape (512 input channels, post-ReLU input):
     max error over the output range against an fp64 convolution.  Measured 1e-6 for F(2x2,3x3) and 2e-5 for
-    F(4x4,3x3) (interpolation points 0, +-1, +-2, inf; transform entries up to 8)."""
+    F(4x4,3x3) (interpolation points 0, +-1, +-2, inf; transform entries up to 8).  The bf16x3 forms sum 16 channels
+    inside an MFMA before one rounding; with two accumulators the large sum sees cin / 16 roundings."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 512, 38, 38, generator=g).relu()
