@@ -348,11 +348,12 @@ WINO4 = -2         # ... the Winograd F(4x4,3x3) kernel
 WINOX = -3         # ... F(2x2,3x3) on the bf16 matrix pipe (bf16x3), two accumulators (csrc/ct_wino_x3.hip)
 WINOXS = -4        # ... the same with one accumulator
 WINOXQ = -5        # ... one accumulator, four-wave workgroups (two per CU)
+WINO4X = -6        # ... F(4x4,3x3) on the bf16 matrix pipe (one accumulator, four waves with the whole register file)
 # st.rt['wino'] values: 2, 4 = the fp32-MFMA kernels' tile sizes; F(2x2,3x3) on bf16x3: 23 = two accumulators, 22 = one,
 # 24 = one accumulator in the four-wave / two-workgroups-per-CU form
-WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXS: 22, WINOXQ: 24}
-WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 22: 'winoxs', 24: 'winoxq'}
-WINOX_TILES = (22, 23, 24)
+WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXS: 22, WINOXQ: 24, WINO4X: 43}
+WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 22: 'winoxs', 24: 'winoxq', 43: 'wino4x'}
+WINOX_TILES = (22, 23, 24, 43)
 WINOX_VARIANT = {22: 0, 23: 1, 24: 2}        # the `dual` argument of ct_conv2d_wino_x3_fwd
 
 
@@ -461,7 +462,9 @@ class HipBackend:
         if tile in WINOX_TILES:
             if not rt.get('winox_ok'):
                 raise _lib.CtdetError('%s: geometry has no Winograd bf16x3 path (cin %% 16)' % st.name)
-            if 'UX' not in rt:
+            if tile == 43 and 'UX4' not in rt:
+                rt['UX4'] = self.alloc((self.lib.ct_conv_wino4_x3_packed_bytes(st.cin, st.cout),), torch.uint8)
+            if tile != 43 and 'UX' not in rt:
                 rt['UX'] = self.alloc((self.lib.ct_conv_wino_x3_packed_bytes(st.cin, st.cout),), torch.uint8)
         else:
             key = 'U' if tile == 2 else 'U4'
@@ -478,6 +481,10 @@ class HipBackend:
         if st.rt['wino'] == 4:
             _lib.check(self.lib.ct_conv_pack_weights_wino4(ptrs, couts, n, st.cin, st.rt['U4'].data_ptr(), self._stream()),
                        'ct_conv_pack_weights_wino4')
+            return
+        if st.rt['wino'] == 43:
+            _lib.check(self.lib.ct_conv_pack_weights_wino4_x3(ptrs, couts, n, st.cin, st.rt['UX4'].data_ptr(), self._stream()),
+                       'ct_conv_pack_weights_wino4_x3')
             return
         if st.rt['wino'] in WINOX_TILES:
             _lib.check(self.lib.ct_conv_pack_weights_wino_x3(ptrs, couts, n, st.cin, st.rt['UX'].data_ptr(), self._stream()),
@@ -545,6 +552,16 @@ class HipBackend:
 
     def run_conv(self, st):
         tile = st.rt.get('wino')
+        if tile == 43:                   # F(4x4,3x3) on the bf16 matrix pipe (csrc/ct_wino_x3.hip)
+            lib, U = self.lib, st.rt['UX4'].data_ptr()
+            pool = st.rt.get('pool')
+            if pool is not None:
+                t, poh, pow_, full = pool
+                _lib.check(lib.ct_conv2d_wino4_x3_pool_fwd(C.byref(st.rt['desc']), U, t.data_ptr(), t.shape[1], 0, poh, pow_,
+                                                           int(full), self._stream()), st.name)
+                return
+            _lib.check(lib.ct_conv2d_wino4_x3_fwd(C.byref(st.rt['desc']), U, self._stream()), st.name)
+            return
         if tile in WINOX_TILES:          # F(2x2,3x3) on the bf16 matrix pipe (csrc/ct_wino_x3.hip)
             lib, U, dual = self.lib, st.rt['UX'].data_ptr(), WINOX_VARIANT[tile]
             pool = st.rt.get('pool')
@@ -694,7 +711,7 @@ def wino_tiles(backend=None, st=None):
     """Winograd variants the tuner may pick: CTDET_WINO_TILES = '2', '4' or '2,4' (default), minus what the
     runtime that owns `backend` excluded (wino4_allowed / wino4_max_cin: F(4x4,3x3) only up to that many input
     channels -- its rounding error grows with the length of the channel sum)."""
-    tiles = tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4,23,24').split(',') if t)
+    tiles = tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4,23,24,43').split(',') if t)
     allowed = getattr(backend, 'wino_tile_set', None)
     if allowed is not None:
         tiles = tuple(t for t in tiles if t in allowed)
@@ -819,6 +836,12 @@ class Runtime:
             if missing and mode != '0':
                 self.autotune(missing)
             self.tuned = not missing or mode != '0'
+            # CTDET_WINO_FORCE = tile code (experiments, tools/ctx_parity.py): every layer that runs on a Winograd kernel
+            # and has the geometry for it is moved to that variant
+            force = int(os.environ.get('CTDET_WINO_FORCE', '0') or 0)
+            for st in (self.conv_steps() if force else ()):
+                if st.rt.get('wino') and (st.rt.get('winox_ok') or force in (2, 4)):
+                    backend.enable_wino(st, tile=force)
         self._fuse_pools()
         self._mark_exclusive()
         self._build_schedule()

@@ -15,12 +15,17 @@ ap.add_argument('--budget', action='store_true'); ap.add_argument('--sweep', act
 ap.add_argument('--policies', default='0,256,1'); ap.add_argument('--batches', default='2,8,32')
 ap.add_argument('--seeds', default='1234,7,99'); ap.add_argument('--kinds', default='randn,u8')
 ap.add_argument('--size', type=int, default=300); ap.add_argument('--budget-batch', type=int, default=8)
+ap.add_argument('--force-tile', default='', help='CTDET_WINO_FORCE: 23 = F(2x2,3x3) on bf16x3 with two accumulators on every Winograd layer')
 a = ap.parse_args()
 names = {'0': 'F(2x2,3x3) on every Winograd layer', '1': 'F(4x4,3x3) wherever the table picks it'}
+if a.force_tile:
+    os.environ['CTDET_WINO_FORCE'] = a.force_tile
 for pol in a.policies.split(','):
     os.environ['CTDET_WINO4_CTX'] = pol
     net = cc.build(a.size, 60)
     label = names.get(pol, 'F(4x4,3x3) up to %s input channels, F(2x2,3x3) above' % pol)
+    if a.force_tile:
+        label += '; then every Winograd layer forced to tile code %s' % a.force_tile
     if a.budget:
         for batch in (a.budget_batch,):
             rt = net.runtime(batch)
