@@ -65,8 +65,18 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md), --dtype bf16 only
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (6.3 TB/s achievable, MI355X_MICROARCH.md)
 # multiplications executed / direct-convolution multiplications: F(2x2,3x3) 16 per 4 outputs x 9, F(4x4,3x3) 36 per 16 x 9
-WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0}
-WINOGRAD_KERNEL = {2: 'wino_f2x2_3x3_f32', 4: 'wino_f4x4_3x3_f32'}
+# st.rt['wino'] codes 22 / 23 / 24 / 43 are the same algorithms on the bf16 pipe (csrc/ct_wino_x3.hip): every
+# transform-domain multiplication is six bf16 MFMA products (bf16x3), priced against the bf16 MFMA peak
+WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0, 22: 16.0 / 36.0, 23: 16.0 / 36.0, 24: 16.0 / 36.0, 43: 36.0 / 144.0,
+                       44: 36.0 / 144.0}
+WINOGRAD_KERNEL = {2: 'wino_f2x2_3x3_f32', 4: 'wino_f4x4_3x3_f32', 22: 'wino_f2x2_3x3_x3<single>',
+                   23: 'wino_f2x2_3x3_x3<dual>', 24: 'wino_f2x2_3x3_x3q', 43: 'wino_f4x4_3x3_x3', 44: 'wino4x_transform+wino4x_gemm'}
+WINOGRAD_X3 = (22, 23, 24, 43, 44)
+
+
+def _lib_config_name(cfg):
+    from ctdet import _lib
+    return _lib.lib().ct_conv_config_name(cfg - 1).decode() if cfg > 0 else 'auto'
 
 
 def build_net(size, num_fg, phase, setting, device):
@@ -205,6 +215,8 @@ def conv_roofline(rt, batch, pmc):
         x3 = st.rt.get('x3')
         if bf16:
             name, mult, pk = 'conv_bf16_nhwc', 1.0, PEAK_BF16_MFMA_TFLOPS
+        elif wino in WINOGRAD_X3:
+            name, mult, pk = WINOGRAD_KERNEL[wino], WINOGRAD_MULT_RATIO[wino] * 6.0, PEAK_BF16_MFMA_TFLOPS
         elif wino:
             name, mult, pk = WINOGRAD_KERNEL[wino], WINOGRAD_MULT_RATIO[wino], PEAK_F32_MFMA_TFLOPS
         elif x3 is not None:
@@ -238,8 +250,9 @@ def conv_roofline(rt, batch, pmc):
         'kernel': name, 'launches': n, 'avg_launch_us': round(t / n * 1e6, 2),
         'flops_per_launch': round(fx / n),
         'flops_definition': 'multiply-adds x2 executed on the matrix pipe per launch' +
-                            (' = direct-convolution flops x %s (Winograd F(%dx%d,3x3), output-tile padding not counted)'
-                             % ({2: '16/36', 4: '36/144'}[wino], wino, wino) if wino else
+                            (' = direct-convolution flops x %s (Winograd F(%dx%d,3x3), output-tile padding not counted)%s'
+                             % ('36/144' if wino in (4, 43, 44) else '16/36', 4 if wino in (4, 43, 44) else 2, 4 if wino in (4, 43, 44) else 2,
+                                ' x 6 (bf16x3 split, bf16 MFMA pipe)' if wino in WINOGRAD_X3 else '') if wino else
                              ' = direct-convolution flops x 6 (bf16x3 split, bf16 MFMA pipe)' if name.startswith('conv_x3') else ''),
         'algorithmic_flops_per_launch': round(f / n),
         'algorithmic_achieved': round(f / t / 1e12, 2),
@@ -451,6 +464,7 @@ def train_config(size, num_fg, phase, setting, batch, dev, steps=4, warmup=2, ra
         cdist.barrier(dev)
         res['allreduce_ms_alone'] = (time.perf_counter() - t0) / reps * 1e3
         res['buckets'] = len(spans)
+        res['bucket_bytes'] = max(b - a_ for a_, b in spans) * 4
     del net, trt, opt, x, tg
     torch.cuda.empty_cache()
     return res
@@ -603,7 +617,7 @@ def main():
             if world > 1:
                 t_with, t_wo, t_ar = r['ms_per_step'], r['ms_per_step_no_allreduce'], r['allreduce_ms_alone']
                 line['allreduce'] = {
-                    'ms_alone': round(t_ar, 3), 'buckets': r['buckets'],
+                    'ms_alone': round(t_ar, 3), 'buckets': r['buckets'], 'bucket_MiB': round(r['bucket_bytes'] / 2 ** 20, 2),
                     'algbw_GBs': round(r['grad_bytes'] / t_ar / 1e6, 1),
                     'busbw_GBs': round(r['grad_bytes'] / t_ar / 1e6 * 2 * (world - 1) / world, 1),
                     'step_ms_without_allreduce': round(t_wo, 3), 'exposed_ms': round(max(0.0, t_with - t_wo), 3),
@@ -669,13 +683,24 @@ def main():
         roof['stages'] = stage_rooflines(pipe, x, 5, pmc)
         roof['traffic_source'] = sorted({v[1] for v in pmc.values()}) or None
     counts = int(pipe.post.out_count.sum().item())
-    kinds = [('winograd' if st.rt.get('wino') else 'bf16x3' if st.rt.get('x3') is not None else 'fp32_mfma')
-             for st in pipe.rt.conv_steps()]
+    def kind(st):
+        w = int(st.rt.get('wino') or 0)
+        if w:
+            return 'winograd_x3' if w in WINOGRAD_X3 else 'winograd'
+        if st.rt.get('x3') is not None:
+            return 'bf16x3'
+        cfg = st.rt['desc'].config
+        name = _lib_config_name(cfg)
+        return 'valu' if name == 'valu' or (cfg == 0 and st.cin == 3 and (st.kh, st.kw) == (3, 3)) else 'fp32_mfma'
+    kinds = [kind(st) for st in pipe.rt.conv_steps()] if a.dtype != 'bf16' else []
     arith = ('bf16 MFMA, fp32 accumulate' if a.dtype == 'bf16' else
-             'fp32 results: %d launches Winograd F(4x4/2x2,3x3) on the fp32 MFMA, %d launches bf16x3 split (every fp32 '
-             'operand = 3 exact bf16 pieces, 6 products on the bf16 MFMA, fp32 accumulate in two accumulators; per-layer '
-             'error vs fp64 below the fp32 MFMA kernel\'s, tests/test_gpu_x3.py), %d launches fp32 MFMA direct'
-             % (kinds.count('winograd'), kinds.count('bf16x3'), kinds.count('fp32_mfma')))
+             'fp32 results: %d launches Winograd F(4x4/2x2,3x3) on the fp32 MFMA, %d launches Winograd F(2x2/4x4,3x3) with '
+             'bf16x3 transform-domain products on the bf16 MFMA, %d launches direct bf16x3 (every fp32 operand = 3 exact '
+             'bf16 pieces, 6 products on the bf16 MFMA, fp32 accumulate; per-layer error vs fp64 below the fp32 MFMA '
+             'kernel\'s, tests/test_gpu_x3.py, tests/test_gpu_wino.py), %d launches fp32 MFMA direct, %d launches fp32 vector '
+             'ALU (the 3-channel image layer)'
+             % (kinds.count('winograd'), kinds.count('winograd_x3'), kinds.count('bf16x3'), kinds.count('fp32_mfma'),
+                kinds.count('valu')))
     conv_gflop = round(pipe.rt.plan.conv_flops() / batch / 1e9, 2)
     tuned = bool(pipe.rt.tuned)
     other = None

@@ -72,6 +72,10 @@ struct WinoX3Args {
     int pool_ctot, pool_coff, pool_oh, pool_ow, write_full;
     int nseg;                // > 0: channels-last scatter into the flattened head buffers (ct_out_segment)
     ct_out_segment seg[3];
+    // two-kernel F(4x4) form: V[tile block][chunk][point 36][piece 3][lane 64][8 bf16], written by wino4x_transform
+    unsigned char* vws;
+    unsigned vws_bytes;
+    int chunks_per_wg;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -443,7 +447,6 @@ __global__ __launch_bounds__(256, 2) void wino_f2x2_3x3_x3q(const WinoX3Args a)
     if (tblk >= a.tile_blocks) return;
     const int tb0 = tblk * TB;
     const int HW = a.H * a.W;
-
     int voffr[4];
     bool lp, m2, m3;
     {
@@ -1087,6 +1090,253 @@ __global__ __launch_bounds__(256, 1) void wino_f4x4_3x3_x3(const WinoX3Args a)
     }
 }
 
+// =====================================================================================================================
+// The two-kernel F(4x4,3x3) / bf16x3 form.  On a SIMD, VALU and MFMA time ADD UP (SQ counters of every kernel in this
+// file and of ct_wino4.hip: SIMD time = 64 or 32 cycles per MFMA + 4 cycles per wave64 VALU instruction): the fused
+// kernels above spend 8 .. 11 VALU instructions per 32-cycle bf16 MFMA on the input transform and the operand split
+// and cannot pass ~0.45 of the matrix pipe however the instructions are arranged.  Here the transform and the split run
+// ONCE per (tile, channel) in their own memory-bound kernel, which leaves the fragments of V in HBM in MFMA register
+// order; the GEMM kernel's main loop then has no vector-ALU work at all: 12 MFMAs and 9 fragment loads per point.
+//   wino4x_transform: workgroup = (32 tiles, a group of 16-channel chunks), 256 threads; per chunk every thread
+//     transforms two 6x6 patches into LDS (V fp32 [36][16][32]), then wave w splits the points 9w..9w+8 and stores the
+//     three bf16 pieces of each as 1 KB rows -- 13.5 bytes per (output pixel, input channel), read once per cout block.
+//   wino4x_gemm: workgroup = 32 tiles x 64 couts, 4 waves with the whole register file (18 accumulator blocks); B
+//     fragments ring of 9 (a point's registers are re-loaded with the same point of the NEXT chunk right after its
+//     MFMAs: one chunk of latency), A fragments ring of 3 (two points of latency); epilogue as above.
+// Worth it where the cout blocks re-use V (>= 256 output channels) and V stays a few hundred MB (maps up to 75 x 75).
+constexpr int F4_V_CHUNK_BYTES = F4_NXI * 3 * 1024;            // 108 KB of fragments per (tile block, chunk)
+
+__global__ __launch_bounds__(256, 2) void wino4x_transform(const WinoX3Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // V fp32 [36][16][32] = 72 KB
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tblk = blockIdx.x;
+    const int tb0 = tblk * TB;
+    const int HW = a.H * a.W;
+    const int c_begin = blockIdx.y * a.chunks_per_wg, c_end = min(a.chunks, c_begin + a.chunks_per_wg);
+
+    int voffr[6];
+    bool mc[6], lp;
+    int hy_delta;
+    {
+        const int T = tb0 + l31;
+        const bool live = T < a.NT;
+        const int n = T / (a.TY * a.TX);
+        const int rem = T - n * (a.TY * a.TX);
+        const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) mc[c] = (unsigned)(x0 + c) < (unsigned)a.W;
+        lp = tx == 0;
+        hy_delta = lp ? 8 : 12;
+        const long base = (((long)n * a.in_ctot + a.in_coff + h) * a.H + y0) * (long)a.W + x0 + (lp ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
+            voffr[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t rV = make_rsrc(a.vws, a.vws_bytes);
+    const int chunk_bytes = CC * HW * 4;
+    const int chan_base = 4 * wave * HW * 4;
+
+    typedef int i32x3 __attribute__((ext_vector_type(3)));
+    typedef float f32x3 __attribute__((ext_vector_type(3)));
+    struct Half { i32x3 r[6]; };
+    auto load_patch = [&](int c, int q, Half& hx, Half& hy) {
+        const int soff = c * chunk_bytes + chan_base + q * (2 * HW * 4);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            hx.r[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, voffr[i], soff, 0);
+            hy.r[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, voffr[i] == kInvalidOff ? kInvalidOff : voffr[i] + hy_delta, soff, 0);
+        }
+    };
+    float* const vw_base = lds + wave * 128 + lane;
+    auto transform_store = [&](const Half& hx, const Half& hy, int q) {
+        float t[6][6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            float d[6], o[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const f32x3 qv = __builtin_bit_cast(f32x3, (c < 3 ? hx : hy).r[i]);
+                const float v = c == 1 ? (lp ? qv.x : qv.y) : c == 2 ? (lp ? qv.y : qv.z) : c % 3 == 0 ? qv.x : c % 3 == 1 ? qv.y : qv.z;
+                d[i] = mc[c] ? v : 0.f;
+            }
+            bt6(d, o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][c] = o[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float v[6];
+            bt6(t[i], v);
+            float* vp = vw_base + q * 64 + (i * 6) * PT_STRIDE;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) vp[j * PT_STRIDE] = v[j];
+        }
+    };
+    const float* const vr_base = lds + (8 * h) * TB + l31;
+
+    Half x0h, y0h, x1h, y1h;
+    load_patch(c_begin, 0, x0h, y0h);
+    load_patch(c_begin, 1, x1h, y1h);
+    for (int c = c_begin; c < c_end; ++c) {
+        transform_store(x0h, y0h, 0);
+        transform_store(x1h, y1h, 1);
+        if (c + 1 < c_end) {                       // the next chunk's rows are under way while this one is split and stored
+            load_patch(c + 1, 0, x0h, y0h);
+            load_patch(c + 1, 1, x1h, y1h);
+        }
+        __syncthreads();
+        const int vsoff = ((tblk * a.chunks + c) * F4_NXI + 9 * wave) * 3072;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const float* ptr = vr_base + (9 * wave + p) * PT_STRIDE;
+            float raw[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[e] = ptr[e * TB];
+            i32x4 fb[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                split3(raw[2 * q], h0, m0, l0);
+                split3(raw[2 * q + 1], h1, m1, l1);
+                fb[0][q] = pack_hi(h0, h1);
+                fb[1][q] = pack_hi(m0, m1);
+                fb[2][q] = pack_hi(l0, l1);
+            }
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+                __builtin_amdgcn_raw_buffer_store_b128(fb[pc], rV, lane * 16, vsoff + (p * 3 + pc) * 1024, 0);
+        }
+        __syncthreads();
+    }
+}
+
+// Eight waves, two per SIMD: wave w = (point group w & 3: the points 9g .. 9g+8, cout half w >> 2) -- 9 accumulator blocks
+// (144 registers), three A and three B fragment loads and six MFMAs per point.  The two waves of a SIMD give the matrix
+// pipe four accumulator chains and cover each other's waits (a single 512-register wave per SIMD with all 18 blocks was
+// measured first: two dependent chains issue ~48 cycles apart, and any register spill drains its whole prefetch queue).
+// Rings of three points for A and for B: a point's slots are re-loaded with the point three ahead right behind its
+// MFMAs.  The B fragments are loaded by both cout halves (L1 hits for the second).
+template <bool PIN, int ABL = 0>         // ABL (experiments): bit 0 no A loads in the loop, bit 1 no B loads
+__global__ __launch_bounds__(512) void wino4x_gemm(const WinoX3Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wave & 3, cbw = wave >> 2;
+    const int jx = blockIdx.x >> 3;
+    const int kb = jx % a.kblocks;
+    const int tblk = (jx / a.kblocks) * 8 + (blockIdx.x & 7);
+    if (tblk >= a.tile_blocks) return;
+    const int tb0 = tblk * TB;
+    const __amdgpu_buffer_rsrc_t rU = make_rsrc(a.U, a.u_bytes);
+    const __amdgpu_buffer_rsrc_t rV = make_rsrc(a.vws, a.vws_bytes);
+    const int last = a.chunks - 1;
+    const int u_voff = pg * (54 * 1024) + cbw * 3072 + lane * 16;      // [point][cb][piece][lane]
+    const int u_kb = kb * a.chunks;
+    const int v_voff = lane * 16;
+    const int v_tb = tblk * a.chunks;
+
+    i32x4 fa[3][3], fb[3][3];            // rings of three points: [piece]
+    auto load_a = [&](int c, int p, int pc, i32x4 (&dst)[3]) {
+        if (ABL & 1) return;
+        dst[pc] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, (u_kb + c) * F4_U_CHUNK_BYTES + (p * 6 + pc) * 1024, 0);
+    };
+    auto load_b = [&](int c, int p, int pc, i32x4 (&dst)[3]) {
+        if (ABL & 2) return;
+        dst[pc] = __builtin_amdgcn_raw_buffer_load_b128(rV, v_voff, ((v_tb + c) * F4_NXI + 9 * pg + p) * 3072 + pc * 1024, 0);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int p = 0; p < 9; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            fa[p][pc] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, u_kb * F4_U_CHUNK_BYTES + (p * 6 + pc) * 1024, 0);
+            fb[p][pc] = __builtin_amdgcn_raw_buffer_load_b128(rV, v_voff, (v_tb * F4_NXI + 9 * pg + p) * 3072 + pc * 1024, 0);
+        }
+
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+    for (int c = 0; c < a.chunks; ++c) {
+        const int cn = min(c + 1, last);
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            // the ring slots of the point that has just finished -- (c, p-1), or (c-1, 8) -- take the point three ahead of it
+            const int pp = (p + 8) % 9;
+            const int pn = (pp + 3) % 9;
+            const int ca = p == 0 ? c : (pp + 3 >= 9 ? cn : c);
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                if (PIN) __builtin_amdgcn_sched_barrier(0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                    __builtin_bit_cast(bf16x8, fa[p % 3][PA[s]]), __builtin_bit_cast(bf16x8, fb[p % 3][PB[s]]), acc[p], 0, 0, 0);
+                if (s < 3) load_a(ca, pn, s, fa[pp % 3]);
+                else load_b(ca, pn, s - 3, fb[pp % 3]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- output transform: four passes of 16 couts through LDS  M[point 36][cout 16][tile 32 (+8)]; a pass is staged by
+    // the four waves of its cout half, transformed by all eight
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
+    const int tl = tid & 31;
+    const int T = tb0 + tl;
+    const bool live = T < a.NT;
+    const int n = T / (a.TY * a.TX);
+    const int rem = T - n * (a.TY * a.TX);
+    const int ty = rem / a.TX, tx = rem - ty * a.TX;
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+        const int cb = pass >> 1, rh = pass & 1;
+        if (cbw == cb) {
+#pragma unroll
+            for (int p = 0; p < 9; ++p)
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int lc = (r8 & 3) + 8 * (r8 >> 2) + 4 * h;
+                    lds[(9 * pg + p) * F4_MXI + lc * F4_MS + l31] = acc[p][rh * 8 + r8];
+                }
+        }
+        __syncthreads();
+        {
+            const int lc = tid >> 5;                     // 16 couts x 32 tiles = 512 threads
+            const int co = kb * KB + pass * 16 + lc;
+            float z[6][4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float m[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) m[j] = lds[(i * 6 + j) * F4_MXI + lc * F4_MS + tl];
+                at4(m, z[i]);
+            }
+            if (live && co < a.M) {
+                float y[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float col[6] = {z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j]};
+                    float o[4];
+                    at4(col, o);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) y[i][j] = o[i];
+                }
+                emit_tile4(a, rout, rres, n, ty, tx, co, y);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 bool winox3_ok(const ct_conv_desc* d)
 {
     return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
@@ -1136,11 +1386,20 @@ extern "C" int ct_conv_pack_weights_wino4_x3_dgrad(const float* const* w, const 
                                 "ct_conv_pack_weights_wino4_x3_dgrad");
 }
 
-// dual: 0 / 1 = F(2x2), one / two accumulators, eight waves; 2 = F(2x2), four waves, two workgroups per CU; 4 = F(4x4)
-static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, float* pool_out, int pool_ctot,
-                          int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream, const char* who)
+extern "C" size_t ct_conv_wino4_x3_workspace_bytes(const ct_conv_desc* d)
 {
-    const bool f4 = dual == 4;
+    if (!d || !winox3_ok(d) || d->batch <= 0) return 0;
+    const long tiles = (long)d->batch * ((d->oh + 3) / 4) * ((d->ow + 3) / 4);
+    return (size_t)((tiles + TB - 1) / TB) * (d->cin / CC) * F4_V_CHUNK_BYTES;
+}
+
+// dual: 0 / 1 = F(2x2), one / two accumulators, eight waves; 2 = F(2x2), four waves, two workgroups per CU; 4 = F(4x4)
+// fused; 5 = F(4x4) as transform kernel + GEMM kernel (ws = ct_conv_wino4_x3_workspace_bytes bytes)
+static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, float* pool_out, int pool_ctot,
+                          int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream, const char* who,
+                          void* ws = nullptr, size_t ws_bytes = 0)
+{
+    const bool f4 = dual == 4 || dual == 5;
     CT_REQUIRE(d && upacked, "%s: null pointer", who);
     CT_REQUIRE(d->in && (d->out || d->nseg > 0) && d->scale && d->shift, "%s: null tensor", who);
     if (!winox3_ok(d))
@@ -1183,6 +1442,16 @@ static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, 
             for (const void* f : {(const void*)wino_f4x4_3x3_x3<true>, (const void*)wino_f4x4_3x3_x3<false>})
                 if (attr_err == hipSuccess)
                     attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F4_LDS_BYTES);
+            for (const void* f : {(const void*)wino4x_gemm<true>, (const void*)wino4x_gemm<false>,
+#ifdef CTDET_WX3_ABLATE
+                                  (const void*)wino4x_gemm<true, 1>, (const void*)wino4x_gemm<true, 2>, (const void*)wino4x_gemm<true, 3>,
+#endif
+                                 })
+                if (attr_err == hipSuccess)
+                    attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F4_NXI * F4_MXI * 4);
+            if (attr_err == hipSuccess)
+                attr_err = hipFuncSetAttribute((const void*)wino4x_transform, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               F4_V_FLOATS * 4);
             const void* fns[] = {(const void*)wino_f2x2_3x3_x3<false, false>, (const void*)wino_f2x2_3x3_x3<false, true>,
                                  (const void*)wino_f2x2_3x3_x3<true, false>, (const void*)wino_f2x2_3x3_x3<true, true>,
 #ifdef CTDET_WX3_ABLATE
@@ -1199,6 +1468,7 @@ static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, 
         CT_HIP(attr_err);
     }
     const int OHW = d->oh * d->ow;
+    if (dual == 5 && max_chunk < d->batch) dual = 4;      // a tensor above 2 GiB is walked in batch slices: fused form
     for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
         const int nb = std::min(max_chunk, d->batch - b0);
         WinoX3Args a{};
@@ -1231,8 +1501,34 @@ static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, 
         a.kblocks = (d->cout + KB - 1) / KB;
         // 8 XCD-local sequences of (tile block group, cout block); sequences past the last tile block exit at once
         const int groups = (a.tile_blocks + 7) / 8;
-        static const bool pin = [] { const char* e = getenv("CTDET_WX3_PIN"); return !e || e[0] != '0'; }();
+        // every MFMA slot closed by a scheduling barrier (kernel template parameter PIN): measured faster for the F(2x2)
+        // forms (+5 .. 8 %), slower for the F(4x4) form (the pinned build spills); CTDET_WX3_PIN = 0 / 1 overrides both
+        static const int pin_env = [] { const char* e = getenv("CTDET_WX3_PIN"); return e ? (e[0] != '0') : -1; }();
+        const bool pin = pin_env < 0 ? !f4 : pin_env != 0;
         const dim3 grid(8 * groups * a.kblocks), blk(512);
+        if (dual == 5) {
+            const size_t need = (size_t)a.tile_blocks * a.chunks * F4_V_CHUNK_BYTES;
+            CT_REQUIRE(ws && ws_bytes >= need, "%s: workspace of %zu bytes needed, got %zu", who, need, ws_bytes);
+            CT_REQUIRE(need < (size_t)kMaxBufBytes, "%s: V workspace of %zu bytes exceeds 2 GiB", who, need);
+            a.vws = (unsigned char*)ws;
+            a.vws_bytes = (unsigned)need;
+            // enough workgroups for the transform kernel to fill the chip: ~4 per CU
+            int cpw = a.chunks;
+            while (cpw > 1 && (long)a.tile_blocks * ((a.chunks + cpw - 1) / cpw) < 1024) cpw = (cpw + 1) / 2;
+            a.chunks_per_wg = cpw;
+            hipLaunchKernelGGL(wino4x_transform, dim3(a.tile_blocks, (a.chunks + cpw - 1) / cpw), dim3(256), F4_V_FLOATS * 4, st, a);
+            CT_LAUNCH_CHECK("wino4x_transform");
+#ifdef CTDET_WX3_ABLATE
+            static const int gabl = [] { const char* e = getenv("CTDET_WX3_GABL"); return e ? atoi(e) : 0; }();
+            if (gabl == 1) { hipLaunchKernelGGL((wino4x_gemm<true, 1>), grid, dim3(512), F4_NXI * F4_MXI * 4, st, a); continue; }
+            if (gabl == 2) { hipLaunchKernelGGL((wino4x_gemm<true, 2>), grid, dim3(512), F4_NXI * F4_MXI * 4, st, a); continue; }
+            if (gabl == 3) { hipLaunchKernelGGL((wino4x_gemm<true, 3>), grid, dim3(512), F4_NXI * F4_MXI * 4, st, a); continue; }
+#endif
+            if (pin) hipLaunchKernelGGL((wino4x_gemm<true>), grid, dim3(512), F4_NXI * F4_MXI * 4, st, a);
+            else hipLaunchKernelGGL((wino4x_gemm<false>), grid, dim3(512), F4_NXI * F4_MXI * 4, st, a);
+            CT_LAUNCH_CHECK("wino4x_gemm");
+            continue;
+        }
         if (f4) {
             if (pin) hipLaunchKernelGGL((wino_f4x4_3x3_x3<true>), grid, dim3(256), F4_LDS_BYTES, st, a);
             else hipLaunchKernelGGL((wino_f4x4_3x3_x3<false>), grid, dim3(256), F4_LDS_BYTES, st, a);
@@ -1285,4 +1581,18 @@ extern "C" int ct_conv2d_wino4_x3_pool_fwd(const ct_conv_desc* d, const void* up
 extern "C" int ct_conv2d_wino4_x3_fwd(const ct_conv_desc* d, const void* upacked, ct_stream_t stream)
 {
     return ct_conv2d_wino4_x3_pool_fwd(d, upacked, nullptr, 0, 0, 0, 0, 1, stream);
+}
+
+extern "C" int ct_conv2d_wino4_x3_split_pool_fwd(const ct_conv_desc* d, const void* upacked, void* ws, size_t ws_bytes,
+                                                 float* pool_out, int pool_ctot, int pool_coff, int pool_oh, int pool_ow,
+                                                 int write_full, ct_stream_t stream)
+{
+    return launch_wino_x3(d, upacked, 5, pool_out, pool_ctot, pool_coff, pool_oh, pool_ow, write_full, stream,
+                          "ct_conv2d_wino4_x3_split_fwd", ws, ws_bytes);
+}
+
+extern "C" int ct_conv2d_wino4_x3_split_fwd(const ct_conv_desc* d, const void* upacked, void* ws, size_t ws_bytes,
+                                            ct_stream_t stream)
+{
+    return ct_conv2d_wino4_x3_split_pool_fwd(d, upacked, ws, ws_bytes, nullptr, 0, 0, 0, 0, 1, stream);
 }

@@ -31,7 +31,8 @@ import torch
 
 from . import _lib
 
-TUNE_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_tune_gfx950.json')
+# CTDET_TUNE_TABLE: another table file (A/B measurements of a re-tuned table against the committed one)
+TUNE_TABLE = os.environ.get('CTDET_TUNE_TABLE') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv_tune_gfx950.json')
 _tune_table = None
 
 
@@ -349,11 +350,12 @@ WINOX = -3         # ... F(2x2,3x3) on the bf16 matrix pipe (bf16x3), two accumu
 WINOXS = -4        # ... the same with one accumulator
 WINOXQ = -5        # ... one accumulator, four-wave workgroups (two per CU)
 WINO4X = -6        # ... F(4x4,3x3) on the bf16 matrix pipe (one accumulator, four waves with the whole register file)
+WINO4XS = -7       # ... the same as two launches: input transform + split into a workspace, then a VALU-free GEMM kernel
 # st.rt['wino'] values: 2, 4 = the fp32-MFMA kernels' tile sizes; F(2x2,3x3) on bf16x3: 23 = two accumulators, 22 = one,
 # 24 = one accumulator in the four-wave / two-workgroups-per-CU form
-WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXS: 22, WINOXQ: 24, WINO4X: 43}
-WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 22: 'winoxs', 24: 'winoxq', 43: 'wino4x'}
-WINOX_TILES = (22, 23, 24, 43)
+WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXS: 22, WINOXQ: 24, WINO4X: 43, WINO4XS: 44}
+WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 22: 'winoxs', 24: 'winoxq', 43: 'wino4x', 44: 'wino4xs'}
+WINOX_TILES = (22, 23, 24, 43, 44)
 WINOX_VARIANT = {22: 0, 23: 1, 24: 2}        # the `dual` argument of ct_conv2d_wino_x3_fwd
 
 
@@ -462,9 +464,14 @@ class HipBackend:
         if tile in WINOX_TILES:
             if not rt.get('winox_ok'):
                 raise _lib.CtdetError('%s: geometry has no Winograd bf16x3 path (cin %% 16)' % st.name)
-            if tile == 43 and 'UX4' not in rt:
+            if tile == 44 and 'VWS' not in rt:          # workspace of the transform kernel (the fragments of V)
+                nb = self.lib.ct_conv_wino4_x3_workspace_bytes(C.byref(rt['desc']))
+                if not 0 < nb < (2 << 30) - 4096:
+                    raise _lib.CtdetError('%s: the two-kernel F(4x4) form needs a %d-byte workspace (limit 2 GiB)' % (st.name, nb))
+                rt['VWS'] = self.alloc((nb,), torch.uint8)
+            if tile in (43, 44) and 'UX4' not in rt:
                 rt['UX4'] = self.alloc((self.lib.ct_conv_wino4_x3_packed_bytes(st.cin, st.cout),), torch.uint8)
-            if tile != 43 and 'UX' not in rt:
+            if tile not in (43, 44) and 'UX' not in rt:
                 rt['UX'] = self.alloc((self.lib.ct_conv_wino_x3_packed_bytes(st.cin, st.cout),), torch.uint8)
         else:
             key = 'U' if tile == 2 else 'U4'
@@ -482,7 +489,7 @@ class HipBackend:
             _lib.check(self.lib.ct_conv_pack_weights_wino4(ptrs, couts, n, st.cin, st.rt['U4'].data_ptr(), self._stream()),
                        'ct_conv_pack_weights_wino4')
             return
-        if st.rt['wino'] == 43:
+        if st.rt['wino'] in (43, 44):
             _lib.check(self.lib.ct_conv_pack_weights_wino4_x3(ptrs, couts, n, st.cin, st.rt['UX4'].data_ptr(), self._stream()),
                        'ct_conv_pack_weights_wino4_x3')
             return
@@ -552,6 +559,18 @@ class HipBackend:
 
     def run_conv(self, st):
         tile = st.rt.get('wino')
+        if tile == 44:                   # F(4x4,3x3) on the bf16 matrix pipe as transform kernel + GEMM kernel
+            lib, U, ws = self.lib, st.rt['UX4'].data_ptr(), st.rt['VWS']
+            pool = st.rt.get('pool')
+            if pool is not None:
+                t, poh, pow_, full = pool
+                _lib.check(lib.ct_conv2d_wino4_x3_split_pool_fwd(C.byref(st.rt['desc']), U, ws.data_ptr(), ws.numel(),
+                                                                 t.data_ptr(), t.shape[1], 0, poh, pow_, int(full),
+                                                                 self._stream()), st.name)
+                return
+            _lib.check(lib.ct_conv2d_wino4_x3_split_fwd(C.byref(st.rt['desc']), U, ws.data_ptr(), ws.numel(),
+                                                        self._stream()), st.name)
+            return
         if tile == 43:                   # F(4x4,3x3) on the bf16 matrix pipe (csrc/ct_wino_x3.hip)
             lib, U = self.lib, st.rt['UX4'].data_ptr()
             pool = st.rt.get('pool')
@@ -686,7 +705,11 @@ class HipBackend:
         if st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
             best_tile = 0
             for tile in wino_tiles(self, st):
-                self.enable_wino(st, tile=tile)
+                try:
+                    self.enable_wino(st, tile=tile)
+                except _lib.CtdetError:        # e.g. the workspace of the two-kernel form would exceed 2 GiB
+                    times.append(float('inf'))
+                    continue
                 t = self._time_conv(st, iters)
                 times.append(t)
                 if t < best_t:
@@ -708,54 +731,47 @@ def x3_allowed(st):
 
 
 def wino_tiles(backend=None, st=None):
-    """Winograd variants the tuner may pick: CTDET_WINO_TILES = '2', '4' or '2,4' (default), minus what the
-    runtime that owns `backend` excluded (wino4_allowed / wino4_max_cin: F(4x4,3x3) only up to that many input
-    channels -- its rounding error grows with the length of the channel sum)."""
-    tiles = tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4,23,24,43').split(',') if t)
+    """Winograd variants the tuner may pick (st.rt['wino'] codes): CTDET_WINO_TILES, default '2,4,23,24,43' = the two
+    fp32-MFMA kernels and the bf16x3 forms (F(2x2) with two accumulators, F(2x2) in four-wave workgroups, F(4x4)), minus
+    what the runtime that owns `backend` excluded (ctx_tile_set) and what the layer's geometry rules out."""
+    tiles = tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4,23,24,43,44').split(',') if t)
     allowed = getattr(backend, 'wino_tile_set', None)
     if allowed is not None:
         tiles = tuple(t for t in tiles if t in allowed)
     if st is not None and not st.rt.get('winox_ok'):
         tiles = tuple(t for t in tiles if t not in WINOX_TILES)
-    cap = getattr(backend, 'wino4_max_cin', None)
-    if cap is not None and st is not None and st.cin > cap:
-        tiles = tuple(t for t in tiles if t != 4)
     return tiles
 
 
-def wino4_allowed(net):
-    """False only if a Context-Transformer network (method 'ours', phase 2) is run with CTDET_WINO4_CTX=0; see
-    wino4_max_cin for the policy and its measurements."""
-    ctx = getattr(net, 'method', None) == 'ours' and getattr(net, 'phase', 1) == 2
-    return not ctx or os.environ.get('CTDET_WINO4_CTX', CTX_WINO4_DEFAULT) != '0'
+CTX_TILES_DEFAULT = '2,23'
 
 
-CTX_WINO4_DEFAULT = '1'
-
-
-def wino4_max_cin(net):
-    """Winograd tile policy of networks with the Context-Transformer block (models/RFB_Net_vgg.py:253-271).
+def ctx_tile_set(net):
+    """Winograd tile policy of networks with the Context-Transformer block (models/RFB_Net_vgg.py:253-271); None = no
+    restriction (every other network).
 
     The block's un-scaled theta.phi^T softmax is near-arg-max and amplifies a perturbation of its INPUT (the conf-head
-    output) ~1000x (tools/ctx_parity.py --budget: 970x; the block's own fp32 arithmetic, on the device or on the
-    CPU, is 1.6e-5 of its output range, everything else is the fp32 rounding of the trunk): the reference's fp32
-    CPU path itself sits 5..7e-5 from an fp64 evaluation, so every bit of trunk accuracy shows.  Round 2 kept these
-    networks on F(2x2,3x3) (raw conf error vs fp64 at bs 8: 1.18e-6, F(4x4,3x3) 1.91e-6, torch-CPU fp32 0.93e-6).
-    Round 3 measured where a Winograd layer's error comes from (the sequential fp32 channel sum in the transform
-    domain), moved F(4x4,3x3) to the interpolation points 0, +-3/4, +-3/2, inf (half the error) and the non-Winograd
-    layers to bf16x3 with two accumulators (0.4x the error of the fp32 MFMA kernel): F(4x4,3x3) everywhere now gives
-    1.20e-6, F(4x4,3x3) up to 256 input channels 1.02e-6 -- at or below what round 2 shipped, and the parity sweep
-    (tests/test_gpu_ctx_parity.py, profiles/r03_ctx_parity.txt) cannot tell the three apart.  Default: no cap.
-    CTDET_WINO4_CTX = N > 1: F(4x4,3x3) only on layers with at most N input channels; '1' = every layer the table
-    picks (default); '0' = none.  Returns None = no cap."""
+    output) ~1000x (tools/ctx_parity.py --budget: 970x), so the reference's own fp32 CPU path sits 5..7e-5 from an fp64
+    evaluation and every bit of trunk accuracy shows in the 1e-4 parity contract.  Rounds 2-3 chose between the fp32-MFMA
+    kernels (F(2x2,3x3) / F(4x4,3x3): raw conf error vs fp64 1.0..1.2e-6, the CPU path 0.93e-6) and accepted that 4 of 9
+    sweep cases exceed 1e-4 against the CPU path.  Round 4: these networks run every Winograd layer on F(2x2,3x3) over
+    bf16x3 with TWO accumulators (tile code 23: exact +-1 transforms, the large channel sum sees cin / 16 roundings;
+    per-layer error vs fp64 4e-7 against 5e-6 for F(4x4,3x3) / fp32): the device is then CLOSER to fp64 than the CPU
+    path in all 9 sweep cases (3.5..5.9e-5 vs 4.9..7.2e-5, profiles/r04_ctx_parity.txt), which is as far as fp32
+    activation storage goes.  Layers without 16-channel chunks keep F(2x2,3x3) on the fp32 MFMA (tile 2).
+    CTDET_CTX_TILES = comma list of allowed tile codes, or 'any' for the unconstrained table."""
     ctx = getattr(net, 'method', None) == 'ours' and getattr(net, 'phase', 1) == 2
-    v = os.environ.get('CTDET_WINO4_CTX', CTX_WINO4_DEFAULT)
-    return int(v) if ctx and v.isdigit() and int(v) > 1 else None
+    v = os.environ.get('CTDET_CTX_TILES', CTX_TILES_DEFAULT)
+    if not ctx or v == 'any':
+        return None
+    return tuple(int(t) for t in v.split(',') if t)
 
 
 def apply_tuned(backend, st, batch, wino4=True):
     """Give a prepared conv step the committed tile choice for its shape; False if the table has none.
-    wino4=False maps a 'wino4' entry to 'wino' (F(2x2,3x3): a tenth of the rounding error)."""
+    wino4=False maps a 'wino4' entry to 'wino'.  A Winograd entry the runtime's policy excludes (ctx_tile_set) becomes the
+    most accurate allowed variant: F(2x2) on bf16x3 with two accumulators where the layer has 16-channel chunks, else
+    F(2x2) on the fp32 MFMA."""
     cfg = tune_table().get(st.tune_key(batch))
     names = [backend.lib.ct_conv_config_name(i).decode() for i in range(backend.lib.ct_conv_num_configs())]
     codes = {v: k for k, v in WINO_NAME.items()}
@@ -765,7 +781,7 @@ def apply_tuned(backend, st, batch, wino4=True):
         if want == 4 and not wino4:
             want = 2
         if want not in allowed:         # policy of this runtime: the most accurate allowed variant instead
-            want = 23 if 23 in allowed and st.rt.get('winox_ok') else 2
+            want = 23 if 23 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
         backend.enable_wino(st, tile=want)
         return True
     if isinstance(cfg, str) and cfg.startswith('x3:'):
@@ -826,9 +842,7 @@ class Runtime:
         # tile config per conv: committed table first (names, so it survives config reordering),
         # live autotune only for shapes the table does not know (CTDET_TUNE=0 disables, =2 forces)
         mode = os.environ.get('CTDET_TUNE', '1') if tune is None else ('1' if tune else '0')
-        if not wino4_allowed(net):
-            backend.wino_tile_set = (2,)
-        backend.wino4_max_cin = wino4_max_cin(net)
+        backend.wino_tile_set = ctx_tile_set(net)
         self.tuned = False
         self.event_log = None        # set to a list to collect (step, start_event, end_event) per conv
         if getattr(backend, 'tune_conv', None) is not None:

@@ -136,7 +136,7 @@ class TrainRuntime:
                         # F(4x4,3x3) where the forward launch of this layer uses it (same map, channels swapped) and on
                         # the multibox heads from 19x19 maps up (their forward launch is a bf16x3 / F(2x2) one chosen for
                         # cout = 156; the data gradient has cout = the source's channel count)
-                        s.dgrad_tile = 4 if s.fwd.rt.get('wino') == 4 or (wino4 and st.segs and st.oh * st.ow >= 361 and
+                        s.dgrad_tile = 4 if s.fwd.rt.get('wino') not in (None, False, 0, 2) or (wino4 and st.segs and st.oh * st.ow >= 361 and
                                                                          self.lib.ct_conv_wino4_supported(C.byref(w2))) else 2
                         sizeof = self.lib.ct_conv_wino4_packed_floats if s.dgrad_tile == 4 else self.lib.ct_conv_wino_packed_floats
                         s.U_d = al((sizeof(zc, st.cin),))

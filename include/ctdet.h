@@ -335,6 +335,17 @@ int ct_conv_pack_weights_wino4_x3_dgrad(const float* const* w, const int* cout, 
 int ct_conv2d_wino4_x3_fwd(const ct_conv_desc* desc, const void* upacked, ct_stream_t stream);
 int ct_conv2d_wino4_x3_pool_fwd(const ct_conv_desc* desc, const void* upacked, float* pool_out, int pool_ctot,
                                 int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
+/* The same convolution as TWO launches: a memory-bound kernel that transforms and splits the input once into
+ * `ws` (ct_conv_wino4_x3_workspace_bytes(desc) bytes: the bf16x3 fragments of V in MFMA register order, 13.5 bytes per
+ * (output pixel, input channel)) and a GEMM kernel whose main loop has no vector-ALU work (csrc/ct_wino_x3.hip: on a
+ * SIMD, VALU and MFMA time add up).  Same packed weights, results and epilogue as ct_conv2d_wino4_x3_fwd; pays where the
+ * cout blocks re-use V (cout >= 256) on maps up to ~75 x 75.  The whole batch must fit 2 GiB per tensor. */
+size_t ct_conv_wino4_x3_workspace_bytes(const ct_conv_desc* desc);
+int ct_conv2d_wino4_x3_split_fwd(const ct_conv_desc* desc, const void* upacked, void* ws, size_t ws_bytes,
+                                 ct_stream_t stream);
+int ct_conv2d_wino4_x3_split_pool_fwd(const ct_conv_desc* desc, const void* upacked, void* ws, size_t ws_bytes,
+                                      float* pool_out, int pool_ctot, int pool_coff, int pool_oh, int pool_ow,
+                                      int write_full, ct_stream_t stream);
 
 /* ---- "bf16x3": the fp32 convolution of ct_conv2d_fwd on the bf16 matrix pipe (csrc/ct_conv_x3.hip) ----
  * Same layers (models/RFB_Net_vgg.py:7-22 BasicConv, the plain Conv2d layers, the multibox heads :238-248), the same

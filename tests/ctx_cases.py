@@ -66,22 +66,22 @@ def sweep_case(net, size, C, setting, batch, seed, kind, sd32=None, sd64=None):
             'rawconf_gpu_cpu32': rel(raw_gpu, raw32)}
 
 
-def verdict(r, tol=1e-4, slack=1.75, cap=2.5e-4):
-    """'ok': every element within tol of the reference's fp32 CPU arithmetic.  'exception': some element above tol,
-    but (a) the device is no further from the fp64 truth than slack x the CPU fp32 path itself, measured at the
-    99.99 % quantile of the error (70 of the 7e5 compared elements lie above it), and (b) every element within `cap`
-    of the CPU path.  Else 'FAIL'.
+def verdict(r, tol=1e-4, cap=1.25e-4):
+    """'ok': every element of the block's output within tol of the reference's fp32 CPU arithmetic.
+    'closer': some element above tol, but the device is at least as close to the fp64 truth as the CPU fp32 path
+    itself IN THE MAX NORM (no quantile, no slack), and every element within `cap` of the CPU path.  Else 'FAIL'.
 
-    Why not a flat 1e-4, and why a quantile: the fp64 block multiplies a perturbation of its input by ~1000
-    (budget below), so the CPU fp32 path itself is 5..7e-5 from fp64 and two correct fp32 evaluations differ by about
-    1e-4; the MAXIMUM over 7e5 elements of this heavy-tailed error (near-ties of the arg-max softmax) moves by 2x
-    between seeds for the SAME arithmetic, the quantile does not.  Measured (profiles/r03_ctx_parity.txt): max-norm
-    ratio e(GPU,fp64) / e(CPU32,fp64) = 1.0 .. 1.7 over 9 randn cases with the shipped policy, quantile ratio
-    1.1 .. 1.4, at an input (raw conf) error ratio of 1.29.  VERDICT r02 proposed max-norm slack 1.5, which the
-    F(2x2,3x3)-only path of round 2 itself misses at (bs 32, seed 7)."""
+    Why the second clause exists at all: the fp64 block multiplies a perturbation of its input by ~1000 (budget below),
+    so the reference's own fp32 CPU path sits 4.9..7.2e-5 from fp64, and fp32 STORAGE of the trunk's activations alone
+    leaves any implementation ~4e-5 from fp64 -- two correct fp32 evaluations land about 1e-4 apart and which side of
+    1e-4 the worst of 7e5 elements falls on depends on the seed.  With the round-4 policy (every Winograd layer on
+    F(2x2,3x3) / bf16x3 with two accumulators, engine.ctx_tile_set) the device is closer to fp64 than the CPU path in
+    all 9 sweep cases (3.5..5.9e-5 vs 4.9..7.2e-5) and within 1e-4 of the CPU path in 8 of them, 1.0003e-4 in the ninth
+    (profiles/r04_ctx_parity.txt).  Rounds 2-3 accepted 'no further from fp64 than 1.75 x the CPU path at the 99.99 %
+    quantile and within 2.5e-4': that waiver is gone."""
     if r['gpu_cpu32'] <= tol:
         return 'ok'
-    return 'exception' if (r['q_gpu_fp64'] <= slack * r['q_cpu32_fp64'] and r['gpu_cpu32'] <= cap) else 'FAIL'
+    return 'closer' if (r['gpu_fp64'] <= r['cpu32_fp64'] and r['gpu_cpu32'] <= cap) else 'FAIL'
 
 
 def pool_from_conf(conf, size, C):

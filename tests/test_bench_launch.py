@@ -61,6 +61,8 @@ def test_self_launch_two_ranks_on_this_box():
     if ndev >= 2:
         assert d['backend'] == 'nccl' and d['rccl_ranks'] == 2 and not d['devices_shared']
         assert len({x['device'] for x in d['ranks']}) == 2
+        ids = [x['pci_bus_id'] for x in d['ranks']]
+        assert None in ids or len(set(ids)) == 2, ids
     else:
         assert d['backend'] == 'gloo' and d['rccl_ranks'] == 0 and d['devices_shared']
 
@@ -88,4 +90,10 @@ def test_train_mode_two_ranks_reports_allreduce_and_overlap():
     assert line['n_gpus'] == 2 and line['metric'].startswith('images/sec training step')
     ar = line['allreduce']
     assert ar['ms_alone'] > 0 and ar['buckets'] >= 1 and 0.0 <= ar['overlap_frac'] <= 1.0
+    assert ar['bucket_MiB'] > 0 and ar['buckets'] * ar['bucket_MiB'] * 2 ** 20 >= line['grad_bytes']
     assert line['grad_bytes'] > 100e6 and len(line['per_rank_ms_per_step']) == 2
+    d = line['dist']
+    if ndev >= 2:
+        assert d['backend'] == 'nccl' and d['rccl_ranks'] == 2 and len({x['device'] for x in d['ranks']}) == 2
+    else:
+        assert d['backend'] == 'gloo' and d['devices_shared']

@@ -2,16 +2,16 @@
 bs {2, 8, 32} x seeds {1234, 7, 99}, EVERY element of the block's output on the oracle's image subset, against the
 reference's fp32 CPU arithmetic AND an fp64 evaluation (models/RFB_Net_vgg.py:253-271).
 
-What is asserted, and why it is not a flat 1e-4 (tools/ctx_parity.py --budget, profiles/r03_ctx_parity.txt):
+What is asserted (tools/ctx_parity.py --budget, profiles/r04_ctx_parity.txt):
   * the block's INPUT (raw conf-head output) and loc / obj: 1e-4 vs the CPU fp32 path (measured: 2e-6);
-  * the block's own arithmetic on an identical input: 1e-4 (measured 1.6e-5, the same as torch-CPU fp32's);
-  * the composite: the fp64 block amplifies a 1e-6 perturbation of its input ~1000x, so the CPU fp32 path itself is
-    5..7e-5 from fp64 and two independent fp32 evaluations differ by ~1e-4 -- ctx_cases.verdict: <= 1e-4 vs CPU fp32,
-    else no further from fp64 than 2.5 x the CPU path and within 2.5e-4 of it.
+  * the block's own arithmetic on an identical input: 1e-4 (measured 1.0e-5; torch-CPU fp32's is 1.6e-5);
+  * the composite: 1e-4 vs the CPU fp32 path; where the worst of the 7e5 elements exceeds it, the device must be CLOSER
+    to an fp64 evaluation than the CPU fp32 path itself (max norm) and within 1.25e-4 of the CPU path (ctx_cases.verdict:
+    the fp64 block amplifies a perturbation of its input ~1000x, the CPU path itself is 4.9..7.2e-5 from fp64).
 Inputs are 'randn' (SURVEY 8d (i)).  On image-like 'u8' inputs (8d (ii), |x| ~ 128) the logits are ~1e4 and the
 block is chaotic in fp32: torch-CPU fp32 itself is 1e-3 .. 1e-1 away from fp64 there, so no fp32 implementation has a
-parity to meet; that case only checks the block's input.  The shipped Winograd tile policy (engine.wino4_max_cin)
-runs here."""
+parity to meet; that case only checks the block's input.  The shipped Winograd tile policy (engine.ctx_tile_set:
+F(2x2,3x3) on bf16x3 with two accumulators) runs here."""
 import pytest
 import torch
 

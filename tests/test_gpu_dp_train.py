@@ -186,19 +186,25 @@ def _dp_worker(rank, world, port, q):
     try:
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-        torch.cuda.set_device(0)                    # both ranks share the one GPU of the box
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+        # one device per rank over RCCL as soon as the box has two; on a one-GPU box both ranks share it over gloo
+        two = torch.cuda.device_count() >= world
+        torch.cuda.set_device(rank if two else 0)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl' if two else 'gloo', rank=rank, world_size=world)
         net = _freeze_bn(_net(300, 20).train())
         B = 8 // world
         x = synth.images(8, 300, 'randn', 31)[rank * B:(rank + 1) * B]
         tg = synth.targets(8, 21, 17)[rank * B:(rank + 1) * B]
         flat, ld = _dp_step(net, B, x, tg, True)
         nb = len(net.train_runtime(B).bucketer.bucket_span)
-        q.put((rank, flat.numpy(), ld, nb, None))
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        info = {'backend': dist.get_backend(), 'device': torch.cuda.current_device(),
+                'pci_bus_id': getattr(props, 'pci_bus_id', None)}
+        q.put((rank, flat.numpy(), ld, nb, None, info))
         dist.destroy_process_group()
     except Exception as e:      # surface the failure in the parent instead of a queue timeout
         import traceback
-        q.put((rank, None, None, 0, traceback.format_exc()))
+        q.put((rank, None, None, 0, traceback.format_exc(), None))
         raise
 
 
@@ -207,7 +213,8 @@ def test_two_rank_gradient_equals_full_batch_gradient():
     batch): two single-GPU ranks, each with half of the bs-8 batch, all-reduce (mean) of the flat gradient in
     buckets issued from inside the HIP backward, loss normaliser made global -- equals the bs-8 step of one
     process (to the tolerance a ReLU network allows between two batch sizes) and, to rounding, the same two
-    half-batches accumulated by hand in one process."""
+    half-batches accumulated by hand in one process.  On a box with two or more GPUs the ranks run on DISTINCT devices
+    over RCCL (backend 'nccl'), which is then asserted; on the one-GPU test box they share the device over gloo."""
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
@@ -237,6 +244,13 @@ def test_two_rank_gradient_equals_full_batch_gradient():
         assert r[4] is None, r[4]
     for p in ps:
         assert p.exitcode == 0
+    if torch.cuda.device_count() >= world:           # the first multi-GPU box runs RCCL here without being asked
+        assert [r[5]['backend'] for r in res] == ['nccl'] * world, res[0][5]
+        assert len({r[5]['device'] for r in res}) == world
+        ids = [r[5]['pci_bus_id'] for r in res]
+        assert None in ids or len(set(ids)) == world, ids
+    else:
+        assert [r[5]['backend'] for r in res] == ['gloo'] * world
     g0, g1 = torch.from_numpy(res[0][1]), torch.from_numpy(res[1][1])
     assert res[0][3] >= 3                                    # really bucketed
     assert torch.equal(g0, g1)                               # both ranks hold the same averaged gradient

@@ -14,9 +14,9 @@ from test_gpu_kernels import _bn, _ref_conv, _run_conv
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 W = engine.WINO
-VARIANTS = [engine.WINO, engine.WINO4, engine.WINOX, engine.WINOXS, engine.WINOXQ, engine.WINO4X]
-VIDS = ['f2x2', 'f4x4', 'f2x2_x3', 'f2x2_x3s', 'f2x2_x3q', 'f4x4_x3']
-X3V = (engine.WINOX, engine.WINOXS, engine.WINOXQ, engine.WINO4X)         # cin must be a multiple of 16 (one bf16 MFMA k-group)
+VARIANTS = [engine.WINO, engine.WINO4, engine.WINOX, engine.WINOXS, engine.WINOXQ, engine.WINO4X, engine.WINO4XS]
+VIDS = ['f2x2', 'f4x4', 'f2x2_x3', 'f2x2_x3s', 'f2x2_x3q', 'f4x4_x3', 'f4x4_x3_split']
+X3V = (engine.WINOX, engine.WINOXS, engine.WINOXQ, engine.WINO4X, engine.WINO4XS)         # cin must be a multiple of 16 (one bf16 MFMA k-group)
 
 
 def _cin(W, cin):
@@ -171,7 +171,7 @@ def test_conv_input_above_2gib_is_chunked(use_wino):
 
 
 @pytest.mark.parametrize('W,bound', [(engine.WINO, 3e-6), (engine.WINO4, 5e-5), (engine.WINOX, 1e-6), (engine.WINOXS, 2e-6),
-                                     (engine.WINOXQ, 2e-6), (engine.WINO4X, 2e-5)],
+                                     (engine.WINOXQ, 2e-6), (engine.WINO4X, 2e-5), (engine.WINO4XS, 2e-5)],
                          ids=VIDS)
 def test_wino_rounding_error_vs_fp64(W, bound):
     """The transform-domain rounding of each variant on the deepest VGG shape (512 input channels, post-ReLU input):

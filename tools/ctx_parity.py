@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Context-Transformer parity sweep + error budget on the MI355X (measurement tool; the oracle is the checker):
-    python tools/ctx_parity.py [--budget] [--sweep] [--policies 0,256,1] [--batches 2,8,32]
-Policies = values of CTDET_WINO4_CTX: 0 = F(2x2,3x3) only, N = F(4x4,3x3) up to N input channels, 1 = everywhere."""
+    python tools/ctx_parity.py [--budget] [--sweep] [--policies 2+23,any] [--batches 2,8,32]
+Policies = values of CTDET_CTX_TILES with '+' for ',' (engine.ctx_tile_set): '2+23' = the shipped policy (every Winograd layer
+on F(2x2,3x3): bf16x3 with two accumulators where the layer has 16-channel chunks, else fp32 MFMA), '2' = F(2x2,3x3) on the
+fp32 MFMA only, '2+4' = the two fp32-MFMA kernels as the table picks them (round 3), 'any' = the unconstrained table."""
 import argparse, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(REPO, 'context-transformer_amd'), REPO, os.path.join(REPO, 'tests')):
@@ -12,44 +14,47 @@ import ctx_cases as cc  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--budget', action='store_true'); ap.add_argument('--sweep', action='store_true')
-ap.add_argument('--policies', default='0,256,1'); ap.add_argument('--batches', default='2,8,32')
+ap.add_argument('--policies', default='2+23'); ap.add_argument('--batches', default='2,8,32')
 ap.add_argument('--seeds', default='1234,7,99'); ap.add_argument('--kinds', default='randn,u8')
 ap.add_argument('--size', type=int, default=300); ap.add_argument('--budget-batch', type=int, default=8)
 ap.add_argument('--force-tile', default='', help='CTDET_WINO_FORCE: 23 = F(2x2,3x3) on bf16x3 with two accumulators on every Winograd layer')
 a = ap.parse_args()
-names = {'0': 'F(2x2,3x3) on every Winograd layer', '1': 'F(4x4,3x3) wherever the table picks it'}
+names = {'2+23': 'F(2x2,3x3) on bf16x3 (two accumulators) on every Winograd layer', '2': 'F(2x2,3x3) / fp32 MFMA only',
+         '2+4': 'fp32-MFMA Winograd kernels as the table picks them', 'any': 'the unconstrained table'}
 if a.force_tile:
     os.environ['CTDET_WINO_FORCE'] = a.force_tile
 for pol in a.policies.split(','):
-    os.environ['CTDET_WINO4_CTX'] = pol
+    os.environ['CTDET_CTX_TILES'] = pol.replace('+', ',')
     net = cc.build(a.size, 60)
-    label = names.get(pol, 'F(4x4,3x3) up to %s input channels, F(2x2,3x3) above' % pol)
+    label = names.get(pol, 'tile codes ' + pol)
     if a.force_tile:
         label += '; then every Winograd layer forced to tile code %s' % a.force_tile
     if a.budget:
         for batch in (a.budget_batch,):
             rt = net.runtime(batch)
             tiles = [st.rt.get('wino') for st in rt.conv_steps() if st.rt.get('wino')]
-            print('== budget, RFBNet-%d phase 2 transfer, bs %d, policy CTDET_WINO4_CTX=%s: %s (%d layers F(4x4), %d F(2x2))%s'
-                  % (a.size, batch, pol, label, tiles.count(4), tiles.count(2),
+            print('== budget, RFBNet-%d phase 2 transfer, bs %d, policy CTDET_CTX_TILES=%s: %s (Winograd layers by tile code: %s)%s'
+                  % (a.size, batch, pol, label, {t: tiles.count(t) for t in sorted(set(tiles))},
                      ''.join(' %s=%s' % (k, os.environ[k]) for k in ('CTDET_WINO', 'CTDET_FORCE_KSPLIT', 'CTDET_ACC') if k in os.environ)))
             for lab, e in cc.budget(net, a.size, 60, batch):
                 print('   %-86s %s' % (lab, ('%.1f x' % e) if 'amplification' in lab else '%.2e' % e), flush=True)
     if a.sweep:
-        print('== sweep, RFBNet-%d phase 2 transfer, policy CTDET_WINO4_CTX=%s: %s' % (a.size, pol, label))
+        print('== sweep, RFBNet-%d phase 2 transfer, policy CTDET_CTX_TILES=%s: %s' % (a.size, pol, label))
         print('   %5s %5s %6s | %-10s %-10s %-10s | %-10s %-10s %-5s | %s' % ('batch', 'seed', 'input', 'GPU-CPU32', 'GPU-fp64', 'CPU32-fp64',
                                                                           'q GPU-64', 'q CPU-64', 'ratio', 'verdict'))
         sd32, sd64 = cc.state(net), cc.state(net, torch.float64)
-        bad = 0
+        bad = far = 0
         for batch in [int(b) for b in a.batches.split(',')]:
             for seed in [int(s) for s in a.seeds.split(',')]:
                 for kind in a.kinds.split(','):
                     r = cc.sweep_case(net, a.size, 60, 'transfer', batch, seed, kind, sd32, sd64)
                     v = cc.verdict(r)
                     bad += v != 'ok'
+                    far += r['gpu_fp64'] > r['cpu32_fp64']
                     print('   %5d %5d %6s | %.2e   %.2e   %.2e   | %.2e   %.2e   %.2f  | %s'
                           % (batch, seed, kind, r['gpu_cpu32'], r['gpu_fp64'], r['cpu32_fp64'], r['q_gpu_fp64'],
                              r['q_cpu32_fp64'], r['q_gpu_fp64'] / r['q_cpu32_fp64'], v), flush=True)
         print('   cases not within 1e-4 of the fp32 CPU path: %d' % bad)
+        print('   cases where the device is further from fp64 than the CPU fp32 path (max norm): %d' % far)
     del net
     torch.cuda.empty_cache()

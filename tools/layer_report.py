@@ -55,6 +55,8 @@ for name, (st, ms) in agg.items():
     cfg = st.rt['desc'].config
     geo = '%dx%d s%d d%d %d->%d @%dx%d' % (st.kh, st.kw, st.stride, st.dil, st.cin, st.cout, st.oh, st.ow)
     tune = ' '.join('%.3f' % t for t in st.rt.get('tune_ms', []))
-    print('%-22s %-26s %-9s %9.1f %8.2f %6.3f  %s' % (name, geo, lib.ct_conv_config_name(cfg - 1).decode() if cfg else 'auto',
+    from ctdet import engine as _e
+    kname = _e.WINO_NAME.get(st.rt.get('wino')) or (rt.backend.x3_names()[st.rt['x3']] if st.rt.get('x3') is not None else None)
+    print('%-22s %-26s %-9s %9.1f %8.2f %6.3f  %s' % (name, geo, kname or (lib.ct_conv_config_name(cfg - 1).decode() if cfg else 'auto'),
                                                     ms * 1e3, f / ms / 1e9, f / ms / 1e9 / 157.3, tune))
 print('TOTAL conv %.3f ms/step, %.2f TFLOP/s (%.1f%% of 157.3)' % (tot_t, tot_f / tot_t / 1e9, tot_f / tot_t / 1e9 / 1.573))

@@ -10,7 +10,7 @@ import torch
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, 'context-transformer_amd')); sys.path.insert(0, REPO)
 os.environ['CTDET_TUNE'] = '2'
-os.environ['CTDET_WINO4_CTX'] = '1'          # the table holds the unconstrained choice; policies map it at plan time
+os.environ['CTDET_CTX_TILES'] = 'any'       # the table holds the unconstrained choice; policies map it at plan time
 from ctdet import engine, synth  # noqa: E402
 from models.RFB_Net_vgg import build_net  # noqa: E402
 
