@@ -65,13 +65,11 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md), --dtype bf16 only
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (6.3 TB/s achievable, MI355X_MICROARCH.md)
 # multiplications executed / direct-convolution multiplications: F(2x2,3x3) 16 per 4 outputs x 9, F(4x4,3x3) 36 per 16 x 9
-# st.rt['wino'] codes 22 / 23 / 24 / 43 are the same algorithms on the bf16 pipe (csrc/ct_wino_x3.hip): every
+# st.rt['wino'] codes 23 / 24 are F(2x2,3x3) on the bf16 pipe (csrc/ct_wino_x3.hip): every
 # transform-domain multiplication is six bf16 MFMA products (bf16x3), priced against the bf16 MFMA peak
-WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0, 22: 16.0 / 36.0, 23: 16.0 / 36.0, 24: 16.0 / 36.0, 43: 36.0 / 144.0,
-                       44: 36.0 / 144.0}
-WINOGRAD_KERNEL = {2: 'wino_f2x2_3x3_f32', 4: 'wino_f4x4_3x3_f32', 22: 'wino_f2x2_3x3_x3<single>',
-                   23: 'wino_f2x2_3x3_x3<dual>', 24: 'wino_f2x2_3x3_x3q', 43: 'wino_f4x4_3x3_x3', 44: 'wino4x_transform+wino4x_gemm'}
-WINOGRAD_X3 = (22, 23, 24, 43, 44)
+WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0, 23: 16.0 / 36.0, 24: 16.0 / 36.0}
+WINOGRAD_KERNEL = {2: 'wino_f2x2_3x3_f32', 4: 'wino_f4x4_3x3_f32', 23: 'wino_f2x2_3x3_x3', 24: 'wino_f2x2_3x3_x3q'}
+WINOGRAD_X3 = (23, 24)
 
 
 def _lib_config_name(cfg):
@@ -251,7 +249,7 @@ def conv_roofline(rt, batch, pmc):
         'flops_per_launch': round(fx / n),
         'flops_definition': 'multiply-adds x2 executed on the matrix pipe per launch' +
                             (' = direct-convolution flops x %s (Winograd F(%dx%d,3x3), output-tile padding not counted)%s'
-                             % ('36/144' if wino in (4, 43, 44) else '16/36', 4 if wino in (4, 43, 44) else 2, 4 if wino in (4, 43, 44) else 2,
+                             % ('36/144' if wino == 4 else '16/36', 4 if wino == 4 else 2, 4 if wino == 4 else 2,
                                 ' x 6 (bf16x3 split, bf16 MFMA pipe)' if wino in WINOGRAD_X3 else '') if wino else
                              ' = direct-convolution flops x 6 (bf16x3 split, bf16 MFMA pipe)' if name.startswith('conv_x3') else ''),
         'algorithmic_flops_per_launch': round(f / n),

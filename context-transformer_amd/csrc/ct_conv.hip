@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
                 if (a.res)
                     v = v * a.res_scale +
                         a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
-                v = fmaxf(v, ev[2 * BM + cl]);
+                { const float fl = ev[2 * BM + cl]; v = v < fl ? fl : v; }      // NaN propagates (torch.relu / no clamp)
                 if (a.nseg == 0) {
                     a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
                 } else {
@@ -447,7 +447,8 @@ __global__ __launch_bounds__(256) void conv_valu3x3_f32(const ConvArgs a)
             const float lov = a.lo ? lo[co] : (a.relu ? 0.f : -INFINITY);
 #pragma unroll
             for (int p = 0; p < PPT; ++p) {
-                const float v = fmaxf((j & 1 ? acc[p][j >> 1].y : acc[p][j >> 1].x) * scv + shv, lov);
+                float v = (j & 1 ? acc[p][j >> 1].y : acc[p][j >> 1].x) * scv + shv;
+                v = v < lov ? lov : v;                  // NaN propagates
                 if (live[p]) op[p][(size_t)co * a.OHW] = v;
             }
         }
@@ -465,8 +466,8 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvArgs a)
         for (int k = 1; k < a.ksplit; ++k) sum += a.ws[(size_t)k * total + idx];
         float v = sum * a.scale[co] + a.shift[co];
         if (a.res) v = v * a.res_scale + a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
-        if (a.lo) v = fmaxf(v, a.lo[co]);
-        else if (a.relu) v = fmaxf(v, 0.f);
+        if (a.lo) { const float fl = a.lo[co]; v = v < fl ? fl : v; }      // NaN propagates
+        else if (a.relu) v = v < 0.f ? 0.f : v;
         if (a.nseg == 0) {
             a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
         } else {

@@ -360,7 +360,8 @@ __global__ __launch_bounds__(NT) void conv_bf16_nhwc(const Bf16Args a)
                 for (int r = 0; r < 16; ++r) {
                     const int P = n0 + wm0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * kg;
                     if (P >= a.Npix) continue;
-                    const float v = fmaxf(acc[i][j][r] * sc + sh, lo);
+                    float v = acc[i][j][r] * sc + sh;
+                    v = v < lo ? lo : v;            // NaN propagates
                     const int n = P / a.OHW, s = P - n * a.OHW;
 #pragma unroll
                     for (int g = 0; g < 3; ++g)
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(NT) void conv_bf16_nhwc(const Bf16Args a)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const float lo = a.lo ? (co + q < a.M ? a.lo[co + q] : 0.f) : (a.relu ? 0.f : -INFINITY);
-            v[q] = fmaxf(v[q], lo);
+            v[q] = v[q] < lo ? lo : v[q];
         }
         unsigned short* op = reinterpret_cast<unsigned short*>(a.out) + (size_t)P * a.out_ctot + a.out_coff + co;
         if (full) {
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256) void conv_bf16_splitk_epilogue(const Bf16Args 
         if (a.res)
             v = v * a.res_scale +
                 bf2f(reinterpret_cast<const unsigned short*>(a.res)[(size_t)P * a.res_ctot + a.res_coff + co]);
-        v = fmaxf(v, a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY));
+        { const float fl = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY); v = v < fl ? fl : v; }
         if (a.nseg == 0) {
             reinterpret_cast<unsigned short*>(a.out)[(size_t)P * a.out_ctot + a.out_coff + co] = f2bf(v);
         } else {

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
                 if (co >= a.M) continue;
                 float v = acc[i][j][r] * ev[cl] + ev[BM + cl];
                 if (rrow) v = v * a.res_scale + rrow[(size_t)co * a.OHW];
-                v = fmaxf(v, ev[2 * BM + cl]);
+                { const float fl = ev[2 * BM + cl]; v = v < fl ? fl : v; }      // NaN propagates (torch.relu / no clamp)
                 if (a.nseg == 0) {
                     orow[(size_t)co * a.OHW] = v;
                 } else {
@@ -398,8 +398,8 @@ __global__ __launch_bounds__(256) void conv_x3_splitk_epilogue(const X3Args a)
         for (int k = 1; k < a.ksplit; ++k) sum += a.ws[(size_t)k * total + idx];
         float v = sum * a.scale[co] + a.shift[co];
         if (a.res) v = v * a.res_scale + a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
-        if (a.lo) v = fmaxf(v, a.lo[co]);
-        else if (a.relu) v = fmaxf(v, 0.f);
+        if (a.lo) { const float fl = a.lo[co]; v = v < fl ? fl : v; }      // NaN propagates
+        else if (a.relu) v = v < 0.f ? 0.f : v;
         if (a.nseg == 0) {
             a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
         } else {

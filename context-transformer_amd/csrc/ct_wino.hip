@@ -341,8 +341,8 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_f32(const WinoArgs a)
                     v0 = v0 * a.res_scale + r0;
                     v1 = v1 * a.res_scale + r1;
                 }
-                v0 = fmaxf(v0, lo);
-                v1 = fmaxf(v1, lo);
+                v0 = v0 < lo ? lo : v0;                 // NaN propagates (fmaxf would turn it into the floor)
+                v1 = v1 < lo ? lo : v1;
                 pooled = fmaxf(pooled, two ? fmaxf(v0, v1) : v0);
                 if (!a.write_full) continue;
                 if (a.nseg > 0) {          // heads: permute(0,2,3,1) + view + cat of models/RFB_Net_vgg.py:239-248
@@ -422,7 +422,7 @@ int ctdet::pack_wino_any(const float* const* w, const int* cout, int nparts, int
     p.cin_fwd = cin;
     p.cin = dgrad ? tot : cin;          // input channels of THIS convolution
     p.cout = dgrad ? cin : tot;
-    const int cc = tile == 23 || tile == 43 ? ctdet::kWinoX3CC : CC;          // 23, 43: the bf16x3 layouts of ct_wino_x3.hip
+    const int cc = tile == 23 ? ctdet::kWinoX3CC : CC;          // 23: the bf16x3 layout of ct_wino_x3.hip
     CT_REQUIRE(p.cin > 0 && p.cin % cc == 0, "%s: %d input channels, must be a multiple of %d", who, p.cin, cc);
     p.chunks = p.cin / cc;
     p.kblocks = (p.cout + KB - 1) / KB;
@@ -431,7 +431,7 @@ int ctdet::pack_wino_any(const float* const* w, const int* cout, int nparts, int
         ctdet::pack_record(1, &p, sizeof(p));
         return CT_OK;
     }
-    const long total = (long)p.kblocks * p.chunks * (tile == 4 ? 512 : tile == 23 ? 2048 : tile == 43 ? 36 * 128 : ctdet::kWino2ChunkFloats);      // threads
+    const long total = (long)p.kblocks * p.chunks * (tile == 4 ? 512 : tile == 23 ? 2048 : ctdet::kWino2ChunkFloats);      // threads
     hipLaunchKernelGGL(wino_pack_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
                        ctdet::as_stream(stream), p);
     CT_LAUNCH_CHECK("wino_pack_kernel");

@@ -142,7 +142,7 @@ __device__ __forceinline__ void emit_tile(const Wino4Args& a, const __amdgpu_buf
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], lo);
+        for (int j = 0; j < 4; ++j) v[j] = v[j] < lo ? lo : v[j];      // NaN propagates
         pl[i >> 1][0] = fmaxf(pl[i >> 1][0], c1 ? fmaxf(v[0], v[1]) : v[0]);
         if (c2) pl[i >> 1][1] = fmaxf(pl[i >> 1][1], c3 ? fmaxf(v[2], v[3]) : v[2]);
         if (!a.write_full) continue;
@@ -518,8 +518,8 @@ __global__ __launch_bounds__(256) void wino4_slab_epilogue(const Wino4Args a)
         for (int k = 1; k < a.slices; ++k) sum += a.ws[(size_t)k * total + idx];
         float v = sum * a.scale[co] + a.shift[co];
         if (a.res) v = v * a.res_scale + a.res[((size_t)n * a.res_ctot + a.res_coff + co) * OHW + sp];
-        if (a.lo) v = fmaxf(v, a.lo[co]);
-        else if (a.relu) v = fmaxf(v, 0.f);
+        if (a.lo) { const float fl = a.lo[co]; v = v < fl ? fl : v; }      // NaN propagates
+        else if (a.relu) v = v < 0.f ? 0.f : v;
         if (a.nseg == 0) {
             a.out[((size_t)n * a.out_ctot + a.out_coff + co) * OHW + sp] = v;
         } else {

@@ -13,7 +13,7 @@ struct WinoPackArgs {
     int nparts, cin, cout, chunks, kblocks;
     int dgrad;               // 1: weights of the data-gradient convolution (channels swapped, taps flipped)
     int cin_fwd;
-    int tile;                // 2: F(2x2,3x3) layout, 4: F(4x4,3x3) layout, 23 / 43: F(2x2,3x3) / F(4x4,3x3) split into bf16x3 pieces
+    int tile;                // 2: F(2x2,3x3) layout, 4: F(4x4,3x3) layout, 23: F(2x2,3x3) split into bf16x3 pieces
     float* U;
 };
 
@@ -23,7 +23,6 @@ constexpr int kWino2ChunkFloats = 16 * 4 * 64 * 2;  // F(2x2): [wave 8][piece 4]
 constexpr int kWino4ChunkFloats = 8 * 9 * 64 * 4;   // F(4x4): [wave 8][point 9][lane 64][4]
 constexpr int kWinoX3CC = 16;                       // ct_wino_x3.hip: input channels per chunk (one bf16 MFMA k-group)
 constexpr int kWinoX3ChunkBytes = 8 * 2 * 2 * 3 * 64 * 16;   // [wave 8][point 2][cout half 2][piece 3][lane 64][8 bf16]
-constexpr int kWino4X3ChunkBytes = 36 * 2 * 3 * 64 * 16;     // F(4x4) on bf16x3: [point 36][cout half 2][piece 3][lane 64][8 bf16]
 
 // forward: g = w[co][ci];  data gradient: this conv's (co, ci) = forward (ci, co), taps rotated 180 degrees
 __device__ __forceinline__ const float* wino_taps(const WinoPackArgs& p, int co, int ci)
@@ -166,61 +165,9 @@ __device__ __forceinline__ void winox3_pack_body(const WinoPackArgs& p, long fir
     }
 }
 
-// ct_wino_x3.hip, F(4x4,3x3): U[kb][chunk 16 ch][point 36][cout half 2][piece 3][lane 64][8 bf16].  One thread = one
-// (point, cout, 8 channels): G g G^T in double (ct_wino4_points.h, the values ct_wino4.hip multiplies with), rounded
-// once to fp32, then the exact three-piece split.
-__device__ __forceinline__ void wino4x3_pack_body(const WinoPackArgs& p, long first, long stride)
-{
-    const long total = (long)p.kblocks * p.chunks * (36 * 2 * 64);
-    unsigned short* const out = reinterpret_cast<unsigned short*>(p.U);
-    for (long idx = first; idx < total; idx += stride) {
-        const int ln = (int)(idx & 63), half = (int)((idx >> 6) & 1);
-        long rest = idx >> 7;
-        const int xi = (int)(rest % 36);
-        rest /= 36;
-        const int chunk = (int)(rest % p.chunks);
-        const int kb = (int)(rest / p.chunks);
-        const int hh = ln >> 5;
-        const int co = kb * kWinoKB + half * 32 + (ln & 31);
-        const int pi = xi / 6, pj = xi % 6;
-        unsigned short* base = out + (((((size_t)kb * p.chunks + chunk) * 36 + xi) * 2 + half) * 3 * 64 + ln) * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ci = chunk * kWinoX3CC + 8 * hh + e;
-            float val = 0.f;
-            if (co < p.cout) {
-                const float* w = wino_taps(p, co, ci);
-                float g[3][3];
-#pragma unroll
-                for (int i = 0; i < 3; ++i)
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) g[i][j] = p.dgrad ? w[(2 - i) * 3 + (2 - j)] : w[i * 3 + j];
-                double trow[3];                               // row pi of G g
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    double o[6];
-                    w4::gmul6(g[0][j], g[1][j], g[2][j], o);
-                    trow[j] = o[pi];
-                }
-                double o[6];
-                w4::gmul6(trow[0], trow[1], trow[2], o);
-                val = (float)o[pj];
-            }
-            const unsigned hb = __builtin_bit_cast(unsigned, val) & 0xFFFF0000u;
-            const float r1 = val - __builtin_bit_cast(float, hb);
-            const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-            const unsigned lb = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, mb));
-            base[e] = (unsigned short)(hb >> 16);
-            base[64 * 8 + e] = (unsigned short)(mb >> 16);
-            base[2 * 64 * 8 + e] = (unsigned short)(lb >> 16);
-        }
-    }
-}
-
 __device__ __forceinline__ void wino_pack_any(const WinoPackArgs& p, long first, long stride)
 {
-    if (p.tile == 43) wino4x3_pack_body(p, first, stride);
-    else if (p.tile == 23) winox3_pack_body(p, first, stride);
+    if (p.tile == 23) winox3_pack_body(p, first, stride);
     else if (p.tile == 4) wino4_pack_body(p, first, stride);
     else wino2_pack_body(p, first, stride);
 }

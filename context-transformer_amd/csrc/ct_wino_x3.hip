@@ -9,9 +9,12 @@
 // at 16x the fp32 MFMA rate that is 4 * 6 / 16 = 1.5 fp32-MFMA multiplication times, against 2.25 for F(4x4,3x3) on the
 // fp32 MFMA (ct_wino4.hip) and 3.4 for the direct bf16x3 kernel.  F(4x4,3x3) on bf16x3 would be 0.84, but its 36
 // accumulator blocks fill the register file at 32 tiles x 64 couts, its split V does not fit LDS twice and a workgroup
-// needs 221 KB of U per 16 channels.  Accuracy: the transforms are exact up to the usual fp32 adds,
-// bf16 x bf16 products are exact in fp32, a k-group of 16 channels is summed inside the MFMA before ONE rounding, and
-// with DUAL the hi.hi products have their own accumulator (K / 16 roundings of the large sum; the fp32 MFMA sees K).
+// needs 221 KB of U per 16 channels; two F(4x4) / bf16x3 forms were built and measured in round 4 (git history: a fused
+// four-wave kernel with the whole register file, 700 .. 800 us on 512 -> 512 @38x38 bs 32; a transform kernel + a
+// VALU-free GEMM kernel, 85 + 780 us) and removed again.  Accuracy: the transforms are exact up to
+// the usual fp32 adds, bf16 x bf16 products are exact in fp32, a k-group of 16 channels is summed inside the MFMA before
+// ONE rounding, and the eight-wave form keeps the hi.hi products in their own accumulator (K / 16 roundings of the large
+// sum; the fp32 MFMA sees K).
 //
 // One fused kernel, only the pre-transformed, pre-split weights U exist in HBM in the transform domain:
 //   workgroup (512 threads, 8 waves) = 32 output tiles x 64 output channels, loops over 16-channel chunks
@@ -72,10 +75,6 @@ struct WinoX3Args {
     int pool_ctot, pool_coff, pool_oh, pool_ow, write_full;
     int nseg;                // > 0: channels-last scatter into the flattened head buffers (ct_out_segment)
     ct_out_segment seg[3];
-    // two-kernel F(4x4) form: V[tile block][chunk][point 36][piece 3][lane 64][8 bf16], written by wino4x_transform
-    unsigned char* vws;
-    unsigned vws_bytes;
-    int chunks_per_wg;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -154,9 +153,9 @@ __device__ __forceinline__ void emit_tile(const WinoX3Args& a, const __amdgpu_bu
 
 // PIN: every MFMA slot (one MFMA + its slice of side work) is closed with a scheduling barrier, so the instruction
 // stream is the source order below; without it the compiler is free to regroup the side work.
-// ABL (development builds, -DCTDET_WX3_ABLATE): bit 0 no U loads in the loop, 1 no patch loads, 2 no split (raw bits as
-// fragments), 3 no V stores, 4 no V reads -- wrong results, used to price the parts of the main loop.
-template <bool DUAL, bool PIN, int ABL = 0>
+// Two accumulators per output block (DUAL): the hi.hi products in acc, the five small ones in acs.  A one-accumulator
+// build of this kernel runs at the same speed (measured), so only the accurate one exists.
+template <bool PIN>
 __global__ __launch_bounds__(512) void wino_f2x2_3x3_x3(const WinoX3Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -222,7 +221,6 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_x3(const WinoX3Args a)
     float* const vw_base = lds + wave * 64 + lane;
     auto row_pass_store = [&](const float* t, int i, int buf) {
         float* vp = vw_base + buf * V_FLOATS + (i * 4) * PT_STRIDE;
-        if (ABL & 8) return;
         vp[0 * PT_STRIDE] = t[i * 4 + 0] - t[i * 4 + 2];
         vp[1 * PT_STRIDE] = t[i * 4 + 1] + t[i * 4 + 2];
         vp[2 * PT_STRIDE] = t[i * 4 + 2] - t[i * 4 + 1];
@@ -242,17 +240,10 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_x3(const WinoX3Args a)
     const float* const vr_base = lds + (8 * h) * TB + l31;
     auto read_raw = [&](int buf, int x, float (&raw)[8]) {
         const float* p = vr_base + buf * V_FLOATS + (2 * wave + x) * PT_STRIDE;
-        if (ABL & 16) return;
 #pragma unroll
         for (int e = 0; e < 8; ++e) raw[e] = p[e * TB];
     };
     auto split_pair = [&](const float (&raw)[8], int q, i32x4 (&fb)[3]) {
-        if (ABL & 4) {
-            fb[0][q] = __builtin_bit_cast(int, raw[2 * q]);
-            fb[1][q] = __builtin_bit_cast(int, raw[2 * q + 1]);
-            fb[2][q] = __builtin_bit_cast(int, raw[2 * q]) ^ 0x5555;
-            return;
-        }
         unsigned h0, m0, l0, h1, m1, l1;
         split3(raw[2 * q], h0, m0, l0);
         split3(raw[2 * q + 1], h1, m1, l1);
@@ -266,11 +257,11 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_x3(const WinoX3Args a)
     const int u_kb = kb * a.chunks;
     auto load_u = [&](int c, int x, int j, i32x4 (&ua)[6]) {           // j = cb * 3 + piece
         const int soff = (u_kb + c) * U_CHUNK_BYTES + (x * 6 + j) * 1024;
-        if (!(ABL & 1) || c < 0) ua[j] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, soff, 0);
+        ua[j] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, soff, 0);
     };
 
-    f32x16 acc[2][2];                              // [point][cout half]
-    f32x16 acs[DUAL ? 2 : 1][DUAL ? 2 : 1];        // DUAL: sum of the five small products
+    f32x16 acc[2][2];                              // [point][cout half]: the hi.hi products
+    f32x16 acs[2][2];                              // the sum of the five small products
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
@@ -278,7 +269,7 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_x3(const WinoX3Args a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 acc[x][i][r] = 0.f;
-                if (DUAL) acs[x][i][r] = 0.f;
+                acs[x][i][r] = 0.f;
             }
 
     // smallest products first: (mid, mid), (lo, hi), (hi, lo), (mid, hi), (hi, mid), then (hi, hi)   [A piece, B piece]
@@ -286,10 +277,10 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_x3(const WinoX3Args a)
 #define WX3_MFMA(X, S, UA, FB)                                                                                     \
     do {                                                                                                           \
         constexpr int t_ = (S) >> 1, cb_ = (S) & 1;                                                                \
-        if (DUAL && t_ < 5)                                                                                        \
-            acs[DUAL ? X : 0][DUAL ? cb_ : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                           \
+        if (t_ < 5)                                                                                                \
+            acs[X][cb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                 \
                 __builtin_bit_cast(bf16x8, UA[cb_ * 3 + PA[t_]]), __builtin_bit_cast(bf16x8, FB[PB[t_]]),          \
-                acs[DUAL ? X : 0][DUAL ? cb_ : 0], 0, 0, 0);                                                       \
+                acs[X][cb_], 0, 0, 0);                                                                             \
         else                                                                                                       \
             acc[X][cb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                 \
                 __builtin_bit_cast(bf16x8, UA[cb_ * 3 + PA[t_]]), __builtin_bit_cast(bf16x8, FB[PB[t_]]),          \
@@ -307,10 +298,7 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_x3(const WinoX3Args a)
         load_patch(min(1, last), r1);
         load_patch(min(2, last), rw);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            ua0[j] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, u_kb * U_CHUNK_BYTES + j * 1024, 0);
-            if (ABL & 1) ua1[j] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, u_kb * U_CHUNK_BYTES + (6 + j) * 1024, 0);
-        }
+        for (int j = 0; j < 6; ++j) load_u(0, 0, j, ua0);
         transform_store(r0, 0);
         transform_store(r1, 1);
     }
@@ -329,7 +317,6 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_x3(const WinoX3Args a)
         const int cn = min(c + 1, last), cp3 = min(c + 3, last);
         float d[16], t[16];
         float raw[8];
-        if (ABL & 16) for (int e = 0; e < 8; ++e) raw[e] = (float)(e + c);
         // ---- point 0 of chunk c.  Behind the MFMAs: fragments of point 1 (V(c)), its U, B^T d of patch(c+2),
         // the loads of patch(c+3)
         read_raw(b0, 1, raw);
@@ -345,11 +332,11 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_x3(const WinoX3Args a)
         WX3_PIN(); WX3_MFMA(0, 9, ua0, fb0);
         {
             const int soff = cp3 * (CC * HW * 4) + chan_pair_bytes;
-            if (!(ABL & 2)) rw[0] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[0], soff, 0);
-            if (!(ABL & 2)) rw[1] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[1], soff, 0);
+            rw[0] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[0], soff, 0);
+            rw[1] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[1], soff, 0);
             WX3_PIN(); WX3_MFMA(0, 10, ua0, fb0);
-            if (!(ABL & 2)) rw[2] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[2], soff, 0);
-            if (!(ABL & 2)) rw[3] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[3], soff, 0);
+            rw[2] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[2], soff, 0);
+            rw[3] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[3], soff, 0);
         }
         WX3_PIN(); WX3_MFMA(0, 11, ua0, fb0);
         // ---- point 1 of chunk c.  Behind the MFMAs: fragments of (chunk c+1, point 0) from V(c+1), its U, the row
@@ -376,14 +363,12 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_x3(const WinoX3Args a)
 #undef WX3_PIN
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (DUAL) {
 #pragma unroll
-        for (int x = 0; x < 2; ++x)
+    for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[x][i][r] += acs[x][i][r];
-    }
+            for (int r = 0; r < 16; ++r) acc[x][i][r] += acs[x][i][r];
 
     // ---- output transform through LDS  M[point][cout 64][tile 32], row stride 40 floats: the two half-waves of an
     // accumulator store (k and k+4) and of a transform read land on disjoint banks (ct_wino.hip)
@@ -686,657 +671,6 @@ __global__ __launch_bounds__(256, 2) void wino_f2x2_3x3_x3q(const WinoX3Args a)
     }
 }
 
-// =====================================================================================================================
-// F(4x4,3x3) on the bf16 matrix pipe: 36 multiplications per 16 outputs -- 0.84 fp32-MFMA multiplication times per
-// (output, cin, cout) against 1.5 for the F(2x2) form above and 2.25 for ct_wino4.hip, and 13.5 bytes of U per output
-// against 24: the F(2x2) form is bound by what a CU can pull through its L1 (96 KB of U + the patches per 16 channels
-// and 32 tiles), this one moves 1.8x less per output.  Same transforms as ct_wino4.hip (ct_wino4_points.h: interpolation
-// points 0, +-3/4, +-3/2, inf); the transform-domain sums see 6 K / 16 roundings instead of K.
-//   workgroup = 256 threads = 4 waves, ONE per SIMD with the whole register file: wave w owns the points 9w .. 9w+8 for
-//   all 64 couts x 32 tiles -- 18 accumulator blocks = 288 registers -- and is the only reader of those points, so the
-//   bf16x3 split happens after the LDS read (V stays fp32 in LDS: 2 x 72 KB).  A thread transforms two full 6x6 patches
-//   per 16-channel chunk (tile = lane & 31, channels 4 wave + h and 4 wave + 2 + h); 108 MFMAs per wave and chunk, one
-//   barrier per chunk; the MFMAs of a chunk's last point run behind the barrier, covering the split of the next chunk's
-//   first point.  Output transform through LDS in four passes of 16 couts.
-constexpr int F4_NXI = 36;
-constexpr int F4_V_FLOATS = F4_NXI * PT_STRIDE;                 // 18432 floats = 72 KB: V[point 36][channel 16][tile 32]
-constexpr int F4_U_CHUNK_BYTES = ctdet::kWino4X3ChunkBytes;     // [wave 4][point 9][cb 2][piece 3][lane 64][16 B] = 216 KB
-constexpr int F4_MS = 40, F4_MXI = 16 * F4_MS;                  // output staging M[point 36][cout 16][tile 32 (+8)]
-constexpr int F4_LDS_BYTES = 2 * F4_V_FLOATS * 4;               // 144 KB (a staging pass uses 90 KB)
-static_assert(F4_NXI * F4_MXI * 4 <= F4_LDS_BYTES, "staging pass fits");
-
-using ctdet::w4::bt6;
-using ctdet::w4::at4;
-
-// Epilogue of one (cout, 4x4 output tile) (the arithmetic of ct_wino4.hip's emit_tile without the slab forms)
-__device__ __forceinline__ void emit_tile4(const WinoX3Args& a, const __amdgpu_buffer_rsrc_t rout,
-                                           const __amdgpu_buffer_rsrc_t rres, const int n, const int ty, const int tx,
-                                           const int co, const float (&y)[4][4])
-{
-    const int OH = a.H, OW = a.W;
-    const int oy = 4 * ty, ox = 4 * tx;
-    const bool c1 = ox + 1 < OW, c2 = ox + 2 < OW, c3 = ox + 3 < OW;
-    const float sc = a.scale[co], sh = a.shift[co];
-    const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
-    float pl[2][2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int yy = oy + i;
-        if (yy >= OH) continue;
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = y[i][j] * sc + sh;
-        if (a.res) {
-            const unsigned ro = (unsigned)(((((size_t)n * a.res_ctot + a.res_coff + co) * OH + yy) * OW + ox) * 4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = j == 0 || (j == 1 ? c1 : j == 2 ? c2 : c3);
-                const float r = __builtin_bit_cast(
-                    float, __builtin_amdgcn_raw_buffer_load_b32(rres, ok ? ro + 4 * j : (unsigned)kInvalidOff, 0, 0));
-                v[j] = v[j] * a.res_scale + r;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] < lo ? lo : v[j];
-        pl[i >> 1][0] = fmaxf(pl[i >> 1][0], c1 ? fmaxf(v[0], v[1]) : v[0]);
-        if (c2) pl[i >> 1][1] = fmaxf(pl[i >> 1][1], c3 ? fmaxf(v[2], v[3]) : v[2]);
-        if (!a.write_full) continue;
-        if (a.nseg > 0) {          // heads: permute(0,2,3,1) + view + cat of models/RFB_Net_vgg.py:239-248
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-                if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end) {
-                    float* dst = a.seg[g].ptr + (size_t)n * a.seg[g].img_stride + a.seg[g].base +
-                                 (size_t)(yy * OW + ox) * a.seg[g].pix_stride + (co - a.seg[g].co_begin);
-                    dst[0] = v[0];
-                    if (c1) dst[a.seg[g].pix_stride] = v[1];
-                    if (c2) dst[2 * a.seg[g].pix_stride] = v[2];
-                    if (c3) dst[3 * a.seg[g].pix_stride] = v[3];
-                }
-            continue;
-        }
-        const unsigned oo = (unsigned)(((((size_t)n * a.out_ctot + a.out_coff + co) * OH + yy) * OW + ox) * 4);
-        if (c3) {
-            i32x4 pk;
-            pk.x = __builtin_bit_cast(int, v[0]);
-            pk.y = __builtin_bit_cast(int, v[1]);
-            pk.z = __builtin_bit_cast(int, v[2]);
-            pk.w = __builtin_bit_cast(int, v[3]);
-            __builtin_amdgcn_raw_buffer_store_b128(pk, rout, oo, 0, 0);
-        } else {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[0]), rout, oo, 0, 0);
-            if (c1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[1]), rout, oo + 4, 0, 0);
-            if (c2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v[2]), rout, oo + 8, 0, 0);
-        }
-    }
-    // a 4x4 output tile holds the four windows (2ty + pi, 2tx + pj) of MaxPool2d(2, 2[, ceil_mode])
-    if (a.pool_out) {
-#pragma unroll
-        for (int pi = 0; pi < 2; ++pi)
-#pragma unroll
-            for (int pj = 0; pj < 2; ++pj) {
-                const int py = 2 * ty + pi, px = 2 * tx + pj;
-                if (py < a.pool_oh && px < a.pool_ow && oy + 2 * pi < OH && ox + 2 * pj < OW)
-                    a.pool_out[(((size_t)n * a.pool_ctot + a.pool_coff + co) * a.pool_oh + py) * a.pool_ow + px] = pl[pi][pj];
-            }
-    }
-}
-
-template <bool PIN>
-__global__ __launch_bounds__(256, 1) void wino_f4x4_3x3_x3(const WinoX3Args a)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int jx = blockIdx.x >> 3;
-    const int kb = jx % a.kblocks;
-    const int tblk = (jx / a.kblocks) * 8 + (blockIdx.x & 7);
-    if (tblk >= a.tile_blocks) return;
-    const int tb0 = tblk * TB;
-    const int HW = a.H * a.W;
-
-    // ---- patch loader: tile = l31, six rows of six pixels from (4ty - 1, 4tx - 1) as two 12-byte loads per row.  Rows
-    // outside the image use the out-of-range offset; the columns right of the image are masked; for the left padding
-    // column (tx == 0, x0 = -1) the first load starts at x = 0 and the gather shifts by one (a negative byte offset is
-    // out of range for the whole access, not only for its first dword).
-    int voffr[6];
-    bool mc[6], lp;
-    int hy_delta;
-    {
-        const int T = tb0 + l31;
-        const bool live = T < a.NT;
-        const int n = T / (a.TY * a.TX);
-        const int rem = T - n * (a.TY * a.TX);
-        const int ty = rem / a.TX, tx = rem - ty * a.TX;
-        const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) mc[c] = (unsigned)(x0 + c) < (unsigned)a.W;
-        lp = tx == 0;
-        hy_delta = lp ? 8 : 12;
-        const long base = (((long)n * a.in_ctot + a.in_coff + h) * a.H + y0) * (long)a.W + x0 + (lp ? 1 : 0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
-            voffr[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
-        }
-    }
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
-    const __amdgpu_buffer_rsrc_t rU = make_rsrc(a.U, a.u_bytes);
-    const int last = a.chunks - 1;
-    const int chunk_bytes = CC * HW * 4;
-    const int chan_base = 4 * wave * HW * 4;           // patch q of this thread: channel 4 wave + 2 q + h
-
-    // A register set holds three columns of the six rows (one 12-byte load per row): set X = columns 0..2, Y = columns
-    // 3..5, of patch 0 and then of patch 1 of a chunk -- each is re-loaded right after its column passes and not needed
-    // again for half a chunk.
-    typedef int i32x3 __attribute__((ext_vector_type(3)));
-    typedef float f32x3 __attribute__((ext_vector_type(3)));
-    struct Half { i32x3 r[6]; };
-    auto load_row = [&](int c, int q, int half, int i, Half& hv) {
-        const int soff = c * chunk_bytes + chan_base + q * (2 * HW * 4);
-        hv.r[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, voffr[i] == kInvalidOff ? kInvalidOff : voffr[i] + (half ? hy_delta : 0), soff, 0);
-    };
-    // bt6 (ct_wino4_points.h) in two halves of ~10 instructions, so that every MFMA slot carries an even share
-    auto bt6_a = [&](const float (&d)[6], float (&w)[4]) {
-        using namespace ctdet::w4;
-        w[0] = fmaf(-Q2, d[2], d[4]);
-        w[1] = P * fmaf(-Q2, d[1], d[3]);
-        w[2] = fmaf(-P2, d[2], d[4]);
-        w[3] = Q * fmaf(-P2, d[1], d[3]);
-    };
-    auto bt6_b = [&](const float (&d)[6], const float (&w)[4], float (&o)[6]) {
-        using namespace ctdet::w4;
-        o[0] = fmaf(P2Q2, d[0], fmaf(-SPQ, d[2], d[4]));
-        o[1] = w[0] + w[1];
-        o[2] = w[0] - w[1];
-        o[3] = w[2] + w[3];
-        o[4] = w[2] - w[3];
-        o[5] = fmaf(P2Q2, d[1], fmaf(-SPQ, d[3], d[5]));
-    };
-    // column c of the patch (masked): d[r] = patch[r][c]
-    auto gather_col = [&](const Half& hv, int c, float (&d)[6]) {          // c = column of the patch, 0..5
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const f32x3 qv = __builtin_bit_cast(f32x3, hv.r[i]);
-            // set X of a left-edge tile holds x = 0, 1, 2 = columns 1, 2, 3 (column 0 is padding: mc[0] is false)
-            const float v = c == 1 ? (lp ? qv.x : qv.y) : c == 2 ? (lp ? qv.y : qv.z) : c % 3 == 0 ? qv.x : c % 3 == 1 ? qv.y : qv.z;
-            d[i] = mc[c] ? v : 0.f;
-        }
-    };
-    // V[6 i + j] of patch q is stored lane-linearly: (4 wave + 2 q + h) * 32 + l31
-    float* const vw_base = lds + wave * 128 + lane;
-    auto store_row = [&](const float (&v)[6], int i, int q, int buf) {
-        float* vp = vw_base + buf * F4_V_FLOATS + q * 64 + (i * 6) * PT_STRIDE;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) vp[j * PT_STRIDE] = v[j];
-    };
-    // the whole patch at once (prologue): t = B^T d, V = t B
-    auto transform_store = [&](const Half& hx, const Half& hy, int q, int buf) {
-        float t[6][6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            float d[6], w[4], o[6];
-            gather_col(c < 3 ? hx : hy, c, d);
-            bt6_a(d, w);
-            bt6_b(d, w, o);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) t[i][c] = o[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            float w[4], v[6];
-            bt6_a(t[i], w);
-            bt6_b(t[i], w, v);
-            store_row(v, i, q, buf);
-        }
-    };
-    const float* const vr_base = lds + (8 * h) * TB + l31;
-    auto read_raw = [&](int buf, int p, float (&raw)[8]) {
-        const float* ptr = vr_base + buf * F4_V_FLOATS + (9 * wave + p) * PT_STRIDE;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) raw[e] = ptr[e * TB];
-    };
-    auto split_pair = [&](const float (&raw)[8], int q, i32x4 (&fb)[3]) {
-        unsigned h0, m0, l0, h1, m1, l1;
-        split3(raw[2 * q], h0, m0, l0);
-        split3(raw[2 * q + 1], h1, m1, l1);
-        fb[0][q] = pack_hi(h0, h1);
-        fb[1][q] = pack_hi(m0, m1);
-        fb[2][q] = pack_hi(l0, l1);
-    };
-    const int u_voff = wave * (54 * 1024) + lane * 16;
-    const int u_kb = kb * a.chunks;
-    auto load_u = [&](int c, int p, int j, i32x4 (&ua)[6]) {           // j = cb * 3 + piece
-        const int soff = (u_kb + c) * F4_U_CHUNK_BYTES + (p * 6 + j) * 1024;
-        ua[j] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, soff, 0);
-    };
-
-    f32x16 acc[9][2];
-#pragma unroll
-    for (int p = 0; p < 9; ++p)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][i][r] = 0.f;
-
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-#define W4X_MFMA(P_, S, UA, FB)                                                                                    \
-    do {                                                                                                           \
-        constexpr int t_ = (S) >> 1, cb_ = (S) & 1;                                                                \
-        acc[P_][cb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                    \
-            __builtin_bit_cast(bf16x8, UA[cb_ * 3 + PA[t_]]), __builtin_bit_cast(bf16x8, FB[PB[t_]]), acc[P_][cb_], 0, 0, 0); \
-    } while (0)
-#define W4X_PIN() do { if (PIN) __builtin_amdgcn_sched_barrier(0); } while (0)
-
-    // ---- prologue: V(0) in LDS, patch 0 of chunk 1 in the two register sets, U of (chunk 0, point 0)
-    Half hX, hY;
-    i32x4 ua[2][6];
-    i32x4 fb[2][3];
-    {
-        Half a0, a1, b0, b1;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            load_row(0, 0, 0, i, a0); load_row(0, 0, 1, i, a1);
-            load_row(0, 1, 0, i, b0); load_row(0, 1, 1, i, b1);
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) { load_row(min(1, last), 0, 0, i, hX); load_row(min(1, last), 0, 1, i, hY); }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) load_u(0, 0, j, ua[0]);
-        transform_store(a0, a1, 0, 0);
-        transform_store(b0, b1, 1, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    {
-        float raw[8];
-        read_raw(0, 0, raw);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) split_pair(raw, q, fb[0]);
-    }
-
-    // One chunk = 9 points x 12 MFMA slots; every slot is followed by ~10 instructions of side work (a single wave per
-    // SIMD hides what fits between two MFMAs and nothing else):
-    //   s == 0: the 8 V reads of point p+1;  s in 0..5: one U load of point p+1;  s in 3..6: the split of point p+1;
-    //   s in {1, 2, 7, 8, 9, 10} of points 0..7: item k = 6 p + .. of the patch transform list (48 half-bt6 items per
-    //   chunk: per patch 6 column passes, then 6 row passes with their stores into V(c+1); the row loads of the patch
-    //   two chunks ahead re-fill a patch's registers behind its row-pass items).
-    // The fragments of (chunk c+1, point 0) are prepared after the barrier, behind the MFMAs of this chunk's point 8.
-    // Nine points per chunk: the fragment double buffer changes parity from chunk to chunk, so the body exists twice
-    // (par = c & 1 is then a compile-time constant and the register arrays are never indexed dynamically).
-    auto chunk_body = [&](const int c, auto par_c) {
-        constexpr int par = decltype(par_c)::value;
-        const int b0 = par, b1 = par ^ 1;
-        const int cn = min(c + 1, last), cp2 = min(c + 2, last);
-        float t[6][6];
-        float raw[8];
-        float dcol[6], wk[4];
-#pragma unroll
-        for (int p = 0; p < 9; ++p) {
-            const int cur = (p + par) & 1, nxt = cur ^ 1;
-            if (p == 8) {                           // V(c+1) is complete once every wave is here
-                W4X_PIN();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-            }
-            // side work that refers to point p+1: within the chunk for p < 8, (chunk c+1, point 0) for p == 8
-            const int rb = p < 8 ? b0 : b1;
-            const int rp = p < 8 ? p + 1 : 0;
-            const int uc = p < 8 ? c : cn;
-            read_raw(rb, rp, raw);
-#pragma unroll
-            for (int s = 0; s < 12; ++s) {
-                W4X_PIN();
-                {
-                    const int t_ = s >> 1, cb_ = s & 1;
-                    acc[p][cb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                        __builtin_bit_cast(bf16x8, ua[cur][cb_ * 3 + PA[t_]]), __builtin_bit_cast(bf16x8, fb[cur][PB[t_]]),
-                        acc[p][cb_], 0, 0, 0);
-                }
-                if (s < 6) load_u(uc, rp, s, ua[nxt]);
-                if (s >= 3 && s <= 6) split_pair(raw, s - 3, fb[nxt]);
-                const int slot_item = s == 1 ? 0 : s == 2 ? 1 : (s >= 7 && s <= 10) ? s - 5 : -1;
-                if (p < 8 && slot_item >= 0) {
-                    const int k = p * 6 + slot_item;        // 0 .. 47
-                    const int q = k / 24, kk = k % 24;      // patch; kk < 12: column passes, else row passes
-                    const int idx = (kk % 12) >> 1, half = kk & 1;
-                    if (kk < 12) {
-                        Half& hv = idx < 3 ? hX : hY;
-                        if (half == 0) {
-                            gather_col(hv, idx, dcol);
-                            bt6_a(dcol, wk);
-                        } else {
-                            float o[6];
-                            bt6_b(dcol, wk, o);
-#pragma unroll
-                            for (int i = 0; i < 6; ++i) t[i][idx] = o[i];
-                            // the set's third column is done: re-fill it with the same columns of the next patch in turn
-                            // (patch 1 of chunk c+1 after patch 0; patch 0 of chunk c+2 after patch 1)
-                            if (idx % 3 == 2) {
-#pragma unroll
-                                for (int i = 0; i < 6; ++i) load_row(q == 0 ? cn : cp2, q ^ 1, idx / 3, i, hv);
-                            }
-                        }
-                    } else {
-                        if (half == 0) {
-                            bt6_a(t[idx], wk);
-                        } else {
-                            float v[6];
-                            bt6_b(t[idx], wk, v);
-                            store_row(v, idx, q, b1);
-                        }
-                    }
-                }
-            }
-        }
-    };
-    {
-        int c = 0;
-        for (; c + 1 < a.chunks; c += 2) {
-            chunk_body(c, std::integral_constant<int, 0>{});
-            chunk_body(c + 1, std::integral_constant<int, 1>{});
-        }
-        if (c < a.chunks) chunk_body(c, std::integral_constant<int, 0>{});
-    }
-#undef W4X_MFMA
-#undef W4X_PIN
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    // ---- output transform: four passes of 16 couts through LDS  M[point 36][cout 16][tile 32 (+8)]
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
-    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
-    const int tl = tid & 31;
-    const int T = tb0 + tl;
-    const bool live = T < a.NT;
-    const int n = T / (a.TY * a.TX);
-    const int rem = T - n * (a.TY * a.TX);
-    const int ty = rem / a.TX, tx = rem - ty * a.TX;
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int cb = pass >> 1, rh = pass & 1;
-#pragma unroll
-        for (int p = 0; p < 9; ++p)
-#pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8) {
-                const int lc = (r8 & 3) + 8 * (r8 >> 2) + 4 * h;       // cout within the pass
-                lds[(9 * wave + p) * F4_MXI + lc * F4_MS + l31] = acc[p][cb][rh * 8 + r8];
-            }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int lc = (tid >> 5) + 8 * it;
-            const int co = kb * KB + pass * 16 + lc;
-            float z[6][4];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                float m[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) m[j] = lds[(i * 6 + j) * F4_MXI + lc * F4_MS + tl];
-                at4(m, z[i]);
-            }
-            if (!live || co >= a.M) continue;
-            float y[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float col[6] = {z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j]};
-                float o[4];
-                at4(col, o);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) y[i][j] = o[i];
-            }
-            emit_tile4(a, rout, rres, n, ty, tx, co, y);
-        }
-        __syncthreads();
-    }
-}
-
-// =====================================================================================================================
-// The two-kernel F(4x4,3x3) / bf16x3 form.  On a SIMD, VALU and MFMA time ADD UP (SQ counters of every kernel in this
-// file and of ct_wino4.hip: SIMD time = 64 or 32 cycles per MFMA + 4 cycles per wave64 VALU instruction): the fused
-// kernels above spend 8 .. 11 VALU instructions per 32-cycle bf16 MFMA on the input transform and the operand split
-// and cannot pass ~0.45 of the matrix pipe however the instructions are arranged.  Here the transform and the split run
-// ONCE per (tile, channel) in their own memory-bound kernel, which leaves the fragments of V in HBM in MFMA register
-// order; the GEMM kernel's main loop then has no vector-ALU work at all: 12 MFMAs and 9 fragment loads per point.
-//   wino4x_transform: workgroup = (32 tiles, a group of 16-channel chunks), 256 threads; per chunk every thread
-//     transforms two 6x6 patches into LDS (V fp32 [36][16][32]), then wave w splits the points 9w..9w+8 and stores the
-//     three bf16 pieces of each as 1 KB rows -- 13.5 bytes per (output pixel, input channel), read once per cout block.
-//   wino4x_gemm: workgroup = 32 tiles x 64 couts, 4 waves with the whole register file (18 accumulator blocks); B
-//     fragments ring of 9 (a point's registers are re-loaded with the same point of the NEXT chunk right after its
-//     MFMAs: one chunk of latency), A fragments ring of 3 (two points of latency); epilogue as above.
-// Worth it where the cout blocks re-use V (>= 256 output channels) and V stays a few hundred MB (maps up to 75 x 75).
-constexpr int F4_V_CHUNK_BYTES = F4_NXI * 3 * 1024;            // 108 KB of fragments per (tile block, chunk)
-
-__global__ __launch_bounds__(256, 2) void wino4x_transform(const WinoX3Args a)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];       // V fp32 [36][16][32] = 72 KB
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tblk = blockIdx.x;
-    const int tb0 = tblk * TB;
-    const int HW = a.H * a.W;
-    const int c_begin = blockIdx.y * a.chunks_per_wg, c_end = min(a.chunks, c_begin + a.chunks_per_wg);
-
-    int voffr[6];
-    bool mc[6], lp;
-    int hy_delta;
-    {
-        const int T = tb0 + l31;
-        const bool live = T < a.NT;
-        const int n = T / (a.TY * a.TX);
-        const int rem = T - n * (a.TY * a.TX);
-        const int ty = rem / a.TX, tx = rem - ty * a.TX;
-        const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) mc[c] = (unsigned)(x0 + c) < (unsigned)a.W;
-        lp = tx == 0;
-        hy_delta = lp ? 8 : 12;
-        const long base = (((long)n * a.in_ctot + a.in_coff + h) * a.H + y0) * (long)a.W + x0 + (lp ? 1 : 0);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
-            voffr[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
-        }
-    }
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
-    const __amdgpu_buffer_rsrc_t rV = make_rsrc(a.vws, a.vws_bytes);
-    const int chunk_bytes = CC * HW * 4;
-    const int chan_base = 4 * wave * HW * 4;
-
-    typedef int i32x3 __attribute__((ext_vector_type(3)));
-    typedef float f32x3 __attribute__((ext_vector_type(3)));
-    struct Half { i32x3 r[6]; };
-    auto load_patch = [&](int c, int q, Half& hx, Half& hy) {
-        const int soff = c * chunk_bytes + chan_base + q * (2 * HW * 4);
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            hx.r[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, voffr[i], soff, 0);
-            hy.r[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, voffr[i] == kInvalidOff ? kInvalidOff : voffr[i] + hy_delta, soff, 0);
-        }
-    };
-    float* const vw_base = lds + wave * 128 + lane;
-    auto transform_store = [&](const Half& hx, const Half& hy, int q) {
-        float t[6][6];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            float d[6], o[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const f32x3 qv = __builtin_bit_cast(f32x3, (c < 3 ? hx : hy).r[i]);
-                const float v = c == 1 ? (lp ? qv.x : qv.y) : c == 2 ? (lp ? qv.y : qv.z) : c % 3 == 0 ? qv.x : c % 3 == 1 ? qv.y : qv.z;
-                d[i] = mc[c] ? v : 0.f;
-            }
-            bt6(d, o);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) t[i][c] = o[i];
-        }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            float v[6];
-            bt6(t[i], v);
-            float* vp = vw_base + q * 64 + (i * 6) * PT_STRIDE;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) vp[j * PT_STRIDE] = v[j];
-        }
-    };
-    const float* const vr_base = lds + (8 * h) * TB + l31;
-
-    Half x0h, y0h, x1h, y1h;
-    load_patch(c_begin, 0, x0h, y0h);
-    load_patch(c_begin, 1, x1h, y1h);
-    for (int c = c_begin; c < c_end; ++c) {
-        transform_store(x0h, y0h, 0);
-        transform_store(x1h, y1h, 1);
-        if (c + 1 < c_end) {                       // the next chunk's rows are under way while this one is split and stored
-            load_patch(c + 1, 0, x0h, y0h);
-            load_patch(c + 1, 1, x1h, y1h);
-        }
-        __syncthreads();
-        const int vsoff = ((tblk * a.chunks + c) * F4_NXI + 9 * wave) * 3072;
-#pragma unroll
-        for (int p = 0; p < 9; ++p) {
-            const float* ptr = vr_base + (9 * wave + p) * PT_STRIDE;
-            float raw[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) raw[e] = ptr[e * TB];
-            i32x4 fb[3];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned h0, m0, l0, h1, m1, l1;
-                split3(raw[2 * q], h0, m0, l0);
-                split3(raw[2 * q + 1], h1, m1, l1);
-                fb[0][q] = pack_hi(h0, h1);
-                fb[1][q] = pack_hi(m0, m1);
-                fb[2][q] = pack_hi(l0, l1);
-            }
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
-                __builtin_amdgcn_raw_buffer_store_b128(fb[pc], rV, lane * 16, vsoff + (p * 3 + pc) * 1024, 0);
-        }
-        __syncthreads();
-    }
-}
-
-// Eight waves, two per SIMD: wave w = (point group w & 3: the points 9g .. 9g+8, cout half w >> 2) -- 9 accumulator blocks
-// (144 registers), three A and three B fragment loads and six MFMAs per point.  The two waves of a SIMD give the matrix
-// pipe four accumulator chains and cover each other's waits (a single 512-register wave per SIMD with all 18 blocks was
-// measured first: two dependent chains issue ~48 cycles apart, and any register spill drains its whole prefetch queue).
-// Rings of three points for A and for B: a point's slots are re-loaded with the point three ahead right behind its
-// MFMAs.  The B fragments are loaded by both cout halves (L1 hits for the second).
-template <bool PIN, int ABL = 0>         // ABL (experiments): bit 0 no A loads in the loop, bit 1 no B loads
-__global__ __launch_bounds__(512) void wino4x_gemm(const WinoX3Args a)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pg = wave & 3, cbw = wave >> 2;
-    const int jx = blockIdx.x >> 3;
-    const int kb = jx % a.kblocks;
-    const int tblk = (jx / a.kblocks) * 8 + (blockIdx.x & 7);
-    if (tblk >= a.tile_blocks) return;
-    const int tb0 = tblk * TB;
-    const __amdgpu_buffer_rsrc_t rU = make_rsrc(a.U, a.u_bytes);
-    const __amdgpu_buffer_rsrc_t rV = make_rsrc(a.vws, a.vws_bytes);
-    const int last = a.chunks - 1;
-    const int u_voff = pg * (54 * 1024) + cbw * 3072 + lane * 16;      // [point][cb][piece][lane]
-    const int u_kb = kb * a.chunks;
-    const int v_voff = lane * 16;
-    const int v_tb = tblk * a.chunks;
-
-    i32x4 fa[3][3], fb[3][3];            // rings of three points: [piece]
-    auto load_a = [&](int c, int p, int pc, i32x4 (&dst)[3]) {
-        if (ABL & 1) return;
-        dst[pc] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, (u_kb + c) * F4_U_CHUNK_BYTES + (p * 6 + pc) * 1024, 0);
-    };
-    auto load_b = [&](int c, int p, int pc, i32x4 (&dst)[3]) {
-        if (ABL & 2) return;
-        dst[pc] = __builtin_amdgcn_raw_buffer_load_b128(rV, v_voff, ((v_tb + c) * F4_NXI + 9 * pg + p) * 3072 + pc * 1024, 0);
-    };
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int p = 0; p < 9; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) {
-            fa[p][pc] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, u_kb * F4_U_CHUNK_BYTES + (p * 6 + pc) * 1024, 0);
-            fb[p][pc] = __builtin_amdgcn_raw_buffer_load_b128(rV, v_voff, (v_tb * F4_NXI + 9 * pg + p) * 3072 + pc * 1024, 0);
-        }
-
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-    for (int c = 0; c < a.chunks; ++c) {
-        const int cn = min(c + 1, last);
-#pragma unroll
-        for (int p = 0; p < 9; ++p) {
-            // the ring slots of the point that has just finished -- (c, p-1), or (c-1, 8) -- take the point three ahead of it
-            const int pp = (p + 8) % 9;
-            const int pn = (pp + 3) % 9;
-            const int ca = p == 0 ? c : (pp + 3 >= 9 ? cn : c);
-#pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                if (PIN) __builtin_amdgcn_sched_barrier(0);
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-                    __builtin_bit_cast(bf16x8, fa[p % 3][PA[s]]), __builtin_bit_cast(bf16x8, fb[p % 3][PB[s]]), acc[p], 0, 0, 0);
-                if (s < 3) load_a(ca, pn, s, fa[pp % 3]);
-                else load_b(ca, pn, s - 3, fb[pp % 3]);
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // ---- output transform: four passes of 16 couts through LDS  M[point 36][cout 16][tile 32 (+8)]; a pass is staged by
-    // the four waves of its cout half, transformed by all eight
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
-    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
-    const int tl = tid & 31;
-    const int T = tb0 + tl;
-    const bool live = T < a.NT;
-    const int n = T / (a.TY * a.TX);
-    const int rem = T - n * (a.TY * a.TX);
-    const int ty = rem / a.TX, tx = rem - ty * a.TX;
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int cb = pass >> 1, rh = pass & 1;
-        if (cbw == cb) {
-#pragma unroll
-            for (int p = 0; p < 9; ++p)
-#pragma unroll
-                for (int r8 = 0; r8 < 8; ++r8) {
-                    const int lc = (r8 & 3) + 8 * (r8 >> 2) + 4 * h;
-                    lds[(9 * pg + p) * F4_MXI + lc * F4_MS + l31] = acc[p][rh * 8 + r8];
-                }
-        }
-        __syncthreads();
-        {
-            const int lc = tid >> 5;                     // 16 couts x 32 tiles = 512 threads
-            const int co = kb * KB + pass * 16 + lc;
-            float z[6][4];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                float m[6];
-#pragma unroll
-                for (int j = 0; j < 6; ++j) m[j] = lds[(i * 6 + j) * F4_MXI + lc * F4_MS + tl];
-                at4(m, z[i]);
-            }
-            if (live && co < a.M) {
-                float y[4][4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float col[6] = {z[0][j], z[1][j], z[2][j], z[3][j], z[4][j], z[5][j]};
-                    float o[4];
-                    at4(col, o);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) y[i][j] = o[i];
-                }
-                emit_tile4(a, rout, rres, n, ty, tx, co, y);
-            }
-        }
-        __syncthreads();
-    }
-}
-
 bool winox3_ok(const ct_conv_desc* d)
 {
     return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
@@ -1367,39 +701,10 @@ extern "C" int ct_conv_pack_weights_wino_x3_dgrad(const float* const* w, const i
                                 "ct_conv_pack_weights_wino_x3_dgrad");
 }
 
-extern "C" size_t ct_conv_wino4_x3_packed_bytes(int cin, int cout)
-{
-    if (cin <= 0 || cout <= 0 || cin % CC) return 0;
-    return (size_t)((cout + KB - 1) / KB) * (cin / CC) * F4_U_CHUNK_BYTES;
-}
-
-extern "C" int ct_conv_pack_weights_wino4_x3(const float* const* w, const int* cout, int nparts, int cin,
-                                             void* upacked, ct_stream_t stream)
-{
-    return ctdet::pack_wino_any(w, cout, nparts, cin, 0, 43, (float*)upacked, stream, "ct_conv_pack_weights_wino4_x3");
-}
-
-extern "C" int ct_conv_pack_weights_wino4_x3_dgrad(const float* const* w, const int* cout, int nparts, int cin,
-                                                   void* upacked, ct_stream_t stream)
-{
-    return ctdet::pack_wino_any(w, cout, nparts, cin, 1, 43, (float*)upacked, stream,
-                                "ct_conv_pack_weights_wino4_x3_dgrad");
-}
-
-extern "C" size_t ct_conv_wino4_x3_workspace_bytes(const ct_conv_desc* d)
-{
-    if (!d || !winox3_ok(d) || d->batch <= 0) return 0;
-    const long tiles = (long)d->batch * ((d->oh + 3) / 4) * ((d->ow + 3) / 4);
-    return (size_t)((tiles + TB - 1) / TB) * (d->cin / CC) * F4_V_CHUNK_BYTES;
-}
-
-// dual: 0 / 1 = F(2x2), one / two accumulators, eight waves; 2 = F(2x2), four waves, two workgroups per CU; 4 = F(4x4)
-// fused; 5 = F(4x4) as transform kernel + GEMM kernel (ws = ct_conv_wino4_x3_workspace_bytes bytes)
+// variant 1: two accumulators, eight waves; 2: one accumulator, four-wave workgroups (two per CU)
 static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, float* pool_out, int pool_ctot,
-                          int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream, const char* who,
-                          void* ws = nullptr, size_t ws_bytes = 0)
+                          int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream, const char* who)
 {
-    const bool f4 = dual == 4 || dual == 5;
     CT_REQUIRE(d && upacked, "%s: null pointer", who);
     CT_REQUIRE(d->in && (d->out || d->nseg > 0) && d->scale && d->shift, "%s: null tensor", who);
     if (!winox3_ok(d))
@@ -1426,7 +731,7 @@ static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, 
     const long long img_out_bytes = d->nseg ? 4 : (long long)d->out_ctot * d->oh * d->ow * 4;
     const long long img_res_bytes = d->res ? (long long)d->res_ctot * d->oh * d->ow * 4 : 0;
     CT_REQUIRE(img_out_bytes < kMaxBufBytes && img_res_bytes < kMaxBufBytes, "%s: one image exceeds 2 GiB", who);
-    const size_t u_bytes = f4 ? ct_conv_wino4_x3_packed_bytes(d->cin, d->cout) : ct_conv_wino_x3_packed_bytes(d->cin, d->cout);
+    const size_t u_bytes = ct_conv_wino_x3_packed_bytes(d->cin, d->cout);
     CT_REQUIRE(u_bytes < (size_t)kMaxBufBytes, "%s: packed weights exceed 2 GiB", who);
     const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / std::max(img_in_bytes, std::max(img_out_bytes, img_res_bytes)));
     hipStream_t st = ctdet::as_stream(stream);
@@ -1434,41 +739,18 @@ static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, 
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
         std::call_once(once, [] {
-            attr_err = hipFuncSetAttribute((const void*)wino_f2x2_3x3_x3q<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-            if (attr_err == hipSuccess)
-                attr_err = hipFuncSetAttribute((const void*)wino_f2x2_3x3_x3q<false>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            for (const void* f : {(const void*)wino_f4x4_3x3_x3<true>, (const void*)wino_f4x4_3x3_x3<false>})
-                if (attr_err == hipSuccess)
-                    attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F4_LDS_BYTES);
-            for (const void* f : {(const void*)wino4x_gemm<true>, (const void*)wino4x_gemm<false>,
-#ifdef CTDET_WX3_ABLATE
-                                  (const void*)wino4x_gemm<true, 1>, (const void*)wino4x_gemm<true, 2>, (const void*)wino4x_gemm<true, 3>,
-#endif
-                                 })
-                if (attr_err == hipSuccess)
-                    attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, F4_NXI * F4_MXI * 4);
-            if (attr_err == hipSuccess)
-                attr_err = hipFuncSetAttribute((const void*)wino4x_transform, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               F4_V_FLOATS * 4);
-            const void* fns[] = {(const void*)wino_f2x2_3x3_x3<false, false>, (const void*)wino_f2x2_3x3_x3<false, true>,
-                                 (const void*)wino_f2x2_3x3_x3<true, false>, (const void*)wino_f2x2_3x3_x3<true, true>,
-#ifdef CTDET_WX3_ABLATE
-                                 (const void*)wino_f2x2_3x3_x3<true, true, 1>, (const void*)wino_f2x2_3x3_x3<true, true, 2>,
-                                 (const void*)wino_f2x2_3x3_x3<true, true, 4>, (const void*)wino_f2x2_3x3_x3<true, true, 8>,
-                                 (const void*)wino_f2x2_3x3_x3<true, true, 16>, (const void*)wino_f2x2_3x3_x3<true, true, 3>,
-                                 (const void*)wino_f2x2_3x3_x3<true, true, 28>, (const void*)wino_f2x2_3x3_x3<true, true, 31>,
-#endif
-            };
-            for (const void* f : fns)
+            const void* f8[] = {(const void*)wino_f2x2_3x3_x3<false>, (const void*)wino_f2x2_3x3_x3<true>};
+            const void* f4w[] = {(const void*)wino_f2x2_3x3_x3q<false>, (const void*)wino_f2x2_3x3_x3q<true>};
+            for (const void* f : f8)
                 if (attr_err == hipSuccess)
                     attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WX3_LDS_BYTES);
+            for (const void* f : f4w)
+                if (attr_err == hipSuccess)
+                    attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS_BYTES);
         });
         CT_HIP(attr_err);
     }
     const int OHW = d->oh * d->ow;
-    if (dual == 5 && max_chunk < d->batch) dual = 4;      // a tensor above 2 GiB is walked in batch slices: fused form
     for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
         const int nb = std::min(max_chunk, d->batch - b0);
         WinoX3Args a{};
@@ -1488,8 +770,7 @@ static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, 
         a.res_bytes = (unsigned)(img_res_bytes * nb);
         a.Cin = d->cin; a.H = d->h; a.W = d->w; a.in_ctot = d->in_ctot; a.in_coff = d->in_coff;
         a.M = d->cout; a.chunks = d->cin / CC;
-        a.TY = f4 ? (d->oh + 3) / 4 : (d->oh + 1) / 2;
-        a.TX = f4 ? (d->ow + 3) / 4 : (d->ow + 1) / 2;
+        a.TY = (d->oh + 1) / 2; a.TX = (d->ow + 1) / 2;
         a.NT = nb * a.TY * a.TX;
         a.tile_blocks = (a.NT + TB - 1) / TB;
         a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
@@ -1501,57 +782,18 @@ static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, 
         a.kblocks = (d->cout + KB - 1) / KB;
         // 8 XCD-local sequences of (tile block group, cout block); sequences past the last tile block exit at once
         const int groups = (a.tile_blocks + 7) / 8;
-        // every MFMA slot closed by a scheduling barrier (kernel template parameter PIN): measured faster for the F(2x2)
-        // forms (+5 .. 8 %), slower for the F(4x4) form (the pinned build spills); CTDET_WX3_PIN = 0 / 1 overrides both
-        static const int pin_env = [] { const char* e = getenv("CTDET_WX3_PIN"); return e ? (e[0] != '0') : -1; }();
-        const bool pin = pin_env < 0 ? !f4 : pin_env != 0;
-        const dim3 grid(8 * groups * a.kblocks), blk(512);
-        if (dual == 5) {
-            const size_t need = (size_t)a.tile_blocks * a.chunks * F4_V_CHUNK_BYTES;
-            CT_REQUIRE(ws && ws_bytes >= need, "%s: workspace of %zu bytes needed, got %zu", who, need, ws_bytes);
-            CT_REQUIRE(need < (size_t)kMaxBufBytes, "%s: V workspace of %zu bytes exceeds 2 GiB", who, need);
-            a.vws = (unsigned char*)ws;
-            a.vws_bytes = (unsigned)need;
-            // enough workgroups for the transform kernel to fill the chip: ~4 per CU
-            int cpw = a.chunks;
-            while (cpw > 1 && (long)a.tile_blocks * ((a.chunks + cpw - 1) / cpw) < 1024) cpw = (cpw + 1) / 2;
-            a.chunks_per_wg = cpw;
-            hipLaunchKernelGGL(wino4x_transform, dim3(a.tile_blocks, (a.chunks + cpw - 1) / cpw), dim3(256), F4_V_FLOATS * 4, st, a);
-            CT_LAUNCH_CHECK("wino4x_transform");
-#ifdef CTDET_WX3_ABLATE
-            static const int gabl = [] { const char* e = getenv("CTDET_WX3_GABL"); return e ? atoi(e) : 0; }();
-            if (gabl == 1) { hipLaunchKernelGGL((wino4x_gemm<true, 1>), grid, dim3(512), F4_NXI * F4_MXI * 4, st, a); continue; }
-            if (gabl == 2) { hipLaunchKernelGGL((wino4x_gemm<true, 2>), grid, dim3(512), F4_NXI * F4_MXI * 4, st, a); continue; }
-            if (gabl == 3) { hipLaunchKernelGGL((wino4x_gemm<true, 3>), grid, dim3(512), F4_NXI * F4_MXI * 4, st, a); continue; }
-#endif
-            if (pin) hipLaunchKernelGGL((wino4x_gemm<true>), grid, dim3(512), F4_NXI * F4_MXI * 4, st, a);
-            else hipLaunchKernelGGL((wino4x_gemm<false>), grid, dim3(512), F4_NXI * F4_MXI * 4, st, a);
-            CT_LAUNCH_CHECK("wino4x_gemm");
-            continue;
-        }
-        if (f4) {
-            if (pin) hipLaunchKernelGGL((wino_f4x4_3x3_x3<true>), grid, dim3(256), F4_LDS_BYTES, st, a);
-            else hipLaunchKernelGGL((wino_f4x4_3x3_x3<false>), grid, dim3(256), F4_LDS_BYTES, st, a);
-            CT_LAUNCH_CHECK("wino_f4x4_3x3_x3");
-            continue;
-        }
+        // every MFMA slot closed by a scheduling barrier (kernel template parameter PIN): measured +5 .. 8 % on both forms;
+        // CTDET_WX3_PIN=0 selects the unpinned builds (A/B measurements)
+        static const bool pin = [] { const char* e = getenv("CTDET_WX3_PIN"); return !e || e[0] != '0'; }();
+        const dim3 grid(8 * groups * a.kblocks);
         if (dual == 2) {            // the four-wave, two-workgroups-per-CU form (single accumulator)
-            // CTDET_WX3_Q1 (experiments): ask for all of the LDS so that ONE workgroup runs per CU (one wave per SIMD)
-            static const int qlds = getenv("CTDET_WX3_Q1") ? 160 * 1024 : Q_LDS_BYTES;
-            if (pin) hipLaunchKernelGGL((wino_f2x2_3x3_x3q<true>), grid, dim3(256), qlds, st, a);
-            else hipLaunchKernelGGL((wino_f2x2_3x3_x3q<false>), grid, dim3(256), qlds, st, a);
+            if (pin) hipLaunchKernelGGL((wino_f2x2_3x3_x3q<true>), grid, dim3(256), Q_LDS_BYTES, st, a);
+            else hipLaunchKernelGGL((wino_f2x2_3x3_x3q<false>), grid, dim3(256), Q_LDS_BYTES, st, a);
             CT_LAUNCH_CHECK("wino_f2x2_3x3_x3q");
             continue;
         }
-#ifdef CTDET_WX3_ABLATE
-        static const int abl = [] { const char* e = getenv("CTDET_WX3_ABL"); return e ? atoi(e) : 0; }();
-#define WX3_ABL_CASE(N) if (abl == N) { hipLaunchKernelGGL((wino_f2x2_3x3_x3<true, true, N>), grid, blk, WX3_LDS_BYTES, st, a); CT_LAUNCH_CHECK("abl"); continue; }
-        WX3_ABL_CASE(1) WX3_ABL_CASE(2) WX3_ABL_CASE(4) WX3_ABL_CASE(8) WX3_ABL_CASE(16) WX3_ABL_CASE(3) WX3_ABL_CASE(28) WX3_ABL_CASE(31)
-#endif
-        if (dual && pin) hipLaunchKernelGGL((wino_f2x2_3x3_x3<true, true>), grid, blk, WX3_LDS_BYTES, st, a);
-        else if (dual) hipLaunchKernelGGL((wino_f2x2_3x3_x3<true, false>), grid, blk, WX3_LDS_BYTES, st, a);
-        else if (pin) hipLaunchKernelGGL((wino_f2x2_3x3_x3<false, true>), grid, blk, WX3_LDS_BYTES, st, a);
-        else hipLaunchKernelGGL((wino_f2x2_3x3_x3<false, false>), grid, blk, WX3_LDS_BYTES, st, a);
+        if (pin) hipLaunchKernelGGL((wino_f2x2_3x3_x3<true>), grid, dim3(512), WX3_LDS_BYTES, st, a);
+        else hipLaunchKernelGGL((wino_f2x2_3x3_x3<false>), grid, dim3(512), WX3_LDS_BYTES, st, a);
         CT_LAUNCH_CHECK("wino_f2x2_3x3_x3");
     }
     return CT_OK;
@@ -1561,7 +803,7 @@ extern "C" int ct_conv2d_wino_x3_pool_fwd(const ct_conv_desc* d, const void* upa
                                           int pool_ctot, int pool_coff, int pool_oh, int pool_ow, int write_full,
                                           ct_stream_t stream)
 {
-    if (dual < 0 || dual > 2) return ctdet::fail(CT_ERR_INVALID, "ct_conv2d_wino_x3_fwd: variant %d (0, 1 or 2)", dual);
+    if (dual != 1 && dual != 2) return ctdet::fail(CT_ERR_INVALID, "ct_conv2d_wino_x3_fwd: variant %d (1 or 2)", dual);
     return launch_wino_x3(d, upacked, dual, pool_out, pool_ctot, pool_coff, pool_oh, pool_ow, write_full, stream,
                           "ct_conv2d_wino_x3_fwd");
 }
@@ -1569,30 +811,4 @@ extern "C" int ct_conv2d_wino_x3_pool_fwd(const ct_conv_desc* d, const void* upa
 extern "C" int ct_conv2d_wino_x3_fwd(const ct_conv_desc* d, const void* upacked, int dual, ct_stream_t stream)
 {
     return ct_conv2d_wino_x3_pool_fwd(d, upacked, dual, nullptr, 0, 0, 0, 0, 1, stream);
-}
-
-extern "C" int ct_conv2d_wino4_x3_pool_fwd(const ct_conv_desc* d, const void* upacked, float* pool_out, int pool_ctot,
-                                           int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream)
-{
-    return launch_wino_x3(d, upacked, 4, pool_out, pool_ctot, pool_coff, pool_oh, pool_ow, write_full, stream,
-                          "ct_conv2d_wino4_x3_fwd");
-}
-
-extern "C" int ct_conv2d_wino4_x3_fwd(const ct_conv_desc* d, const void* upacked, ct_stream_t stream)
-{
-    return ct_conv2d_wino4_x3_pool_fwd(d, upacked, nullptr, 0, 0, 0, 0, 1, stream);
-}
-
-extern "C" int ct_conv2d_wino4_x3_split_pool_fwd(const ct_conv_desc* d, const void* upacked, void* ws, size_t ws_bytes,
-                                                 float* pool_out, int pool_ctot, int pool_coff, int pool_oh, int pool_ow,
-                                                 int write_full, ct_stream_t stream)
-{
-    return launch_wino_x3(d, upacked, 5, pool_out, pool_ctot, pool_coff, pool_oh, pool_ow, write_full, stream,
-                          "ct_conv2d_wino4_x3_split_fwd", ws, ws_bytes);
-}
-
-extern "C" int ct_conv2d_wino4_x3_split_fwd(const ct_conv_desc* d, const void* upacked, void* ws, size_t ws_bytes,
-                                            ct_stream_t stream)
-{
-    return ct_conv2d_wino4_x3_split_pool_fwd(d, upacked, ws, ws_bytes, nullptr, 0, 0, 0, 0, 1, stream);
 }

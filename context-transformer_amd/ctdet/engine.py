@@ -347,16 +347,13 @@ class Plan:
 WINO = -1          # ConvStep.rt['config'] value selecting the Winograd F(2x2,3x3) kernel
 WINO4 = -2         # ... the Winograd F(4x4,3x3) kernel
 WINOX = -3         # ... F(2x2,3x3) on the bf16 matrix pipe (bf16x3), two accumulators (csrc/ct_wino_x3.hip)
-WINOXS = -4        # ... the same with one accumulator
 WINOXQ = -5        # ... one accumulator, four-wave workgroups (two per CU)
-WINO4X = -6        # ... F(4x4,3x3) on the bf16 matrix pipe (one accumulator, four waves with the whole register file)
-WINO4XS = -7       # ... the same as two launches: input transform + split into a workspace, then a VALU-free GEMM kernel
-# st.rt['wino'] values: 2, 4 = the fp32-MFMA kernels' tile sizes; F(2x2,3x3) on bf16x3: 23 = two accumulators, 22 = one,
-# 24 = one accumulator in the four-wave / two-workgroups-per-CU form
-WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXS: 22, WINOXQ: 24, WINO4X: 43, WINO4XS: 44}
-WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 22: 'winoxs', 24: 'winoxq', 43: 'wino4x', 44: 'wino4xs'}
-WINOX_TILES = (22, 23, 24, 43, 44)
-WINOX_VARIANT = {22: 0, 23: 1, 24: 2}        # the `dual` argument of ct_conv2d_wino_x3_fwd
+# st.rt['wino'] values: 2, 4 = the fp32-MFMA kernels' tile sizes; F(2x2,3x3) on bf16x3: 23 = two accumulators (eight
+# waves), 24 = one accumulator in the four-wave / two-workgroups-per-CU form
+WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXQ: 24}
+WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 24: 'winoxq'}
+WINOX_TILES = (23, 24)
+WINOX_VARIANT = {23: 1, 24: 2}               # the `variant` argument of ct_conv2d_wino_x3_fwd
 
 
 class HipBackend:
@@ -447,8 +444,8 @@ class HipBackend:
 
     def enable_wino(self, st, on=True, tile=None):
         """Route this conv through a Winograd kernel (3x3 s1 d1 p1 layers only): tile 2 = F(2x2,3x3),
-        tile 4 = F(4x4,3x3), 23 / 22 = F(2x2,3x3) on the bf16 matrix pipe with two / one accumulators (cin % 16 == 0).
-        st.rt['wino'] holds the code in use."""
+        tile 4 = F(4x4,3x3), 23 / 24 = F(2x2,3x3) on the bf16 matrix pipe (cin % 16 == 0) with two accumulators / in the
+        four-wave form.  st.rt['wino'] holds the code in use."""
         rt = st.rt
         if not on:
             rt['wino'] = False
@@ -460,18 +457,11 @@ class HipBackend:
         rt['x3'] = None
         tile = int(tile or 2)
         if tile not in (2, 4) + WINOX_TILES:
-            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 22, 23 or 24)' % (st.name, tile))
+            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23 or 24)' % (st.name, tile))
         if tile in WINOX_TILES:
             if not rt.get('winox_ok'):
                 raise _lib.CtdetError('%s: geometry has no Winograd bf16x3 path (cin %% 16)' % st.name)
-            if tile == 44 and 'VWS' not in rt:          # workspace of the transform kernel (the fragments of V)
-                nb = self.lib.ct_conv_wino4_x3_workspace_bytes(C.byref(rt['desc']))
-                if not 0 < nb < (2 << 30) - 4096:
-                    raise _lib.CtdetError('%s: the two-kernel F(4x4) form needs a %d-byte workspace (limit 2 GiB)' % (st.name, nb))
-                rt['VWS'] = self.alloc((nb,), torch.uint8)
-            if tile in (43, 44) and 'UX4' not in rt:
-                rt['UX4'] = self.alloc((self.lib.ct_conv_wino4_x3_packed_bytes(st.cin, st.cout),), torch.uint8)
-            if tile not in (43, 44) and 'UX' not in rt:
+            if 'UX' not in rt:
                 rt['UX'] = self.alloc((self.lib.ct_conv_wino_x3_packed_bytes(st.cin, st.cout),), torch.uint8)
         else:
             key = 'U' if tile == 2 else 'U4'
@@ -488,10 +478,6 @@ class HipBackend:
         if st.rt['wino'] == 4:
             _lib.check(self.lib.ct_conv_pack_weights_wino4(ptrs, couts, n, st.cin, st.rt['U4'].data_ptr(), self._stream()),
                        'ct_conv_pack_weights_wino4')
-            return
-        if st.rt['wino'] in (43, 44):
-            _lib.check(self.lib.ct_conv_pack_weights_wino4_x3(ptrs, couts, n, st.cin, st.rt['UX4'].data_ptr(), self._stream()),
-                       'ct_conv_pack_weights_wino4_x3')
             return
         if st.rt['wino'] in WINOX_TILES:
             _lib.check(self.lib.ct_conv_pack_weights_wino_x3(ptrs, couts, n, st.cin, st.rt['UX'].data_ptr(), self._stream()),
@@ -559,28 +545,6 @@ class HipBackend:
 
     def run_conv(self, st):
         tile = st.rt.get('wino')
-        if tile == 44:                   # F(4x4,3x3) on the bf16 matrix pipe as transform kernel + GEMM kernel
-            lib, U, ws = self.lib, st.rt['UX4'].data_ptr(), st.rt['VWS']
-            pool = st.rt.get('pool')
-            if pool is not None:
-                t, poh, pow_, full = pool
-                _lib.check(lib.ct_conv2d_wino4_x3_split_pool_fwd(C.byref(st.rt['desc']), U, ws.data_ptr(), ws.numel(),
-                                                                 t.data_ptr(), t.shape[1], 0, poh, pow_, int(full),
-                                                                 self._stream()), st.name)
-                return
-            _lib.check(lib.ct_conv2d_wino4_x3_split_fwd(C.byref(st.rt['desc']), U, ws.data_ptr(), ws.numel(),
-                                                        self._stream()), st.name)
-            return
-        if tile == 43:                   # F(4x4,3x3) on the bf16 matrix pipe (csrc/ct_wino_x3.hip)
-            lib, U = self.lib, st.rt['UX4'].data_ptr()
-            pool = st.rt.get('pool')
-            if pool is not None:
-                t, poh, pow_, full = pool
-                _lib.check(lib.ct_conv2d_wino4_x3_pool_fwd(C.byref(st.rt['desc']), U, t.data_ptr(), t.shape[1], 0, poh, pow_,
-                                                           int(full), self._stream()), st.name)
-                return
-            _lib.check(lib.ct_conv2d_wino4_x3_fwd(C.byref(st.rt['desc']), U, self._stream()), st.name)
-            return
         if tile in WINOX_TILES:          # F(2x2,3x3) on the bf16 matrix pipe (csrc/ct_wino_x3.hip)
             lib, U, dual = self.lib, st.rt['UX'].data_ptr(), WINOX_VARIANT[tile]
             pool = st.rt.get('pool')
@@ -705,11 +669,7 @@ class HipBackend:
         if st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
             best_tile = 0
             for tile in wino_tiles(self, st):
-                try:
-                    self.enable_wino(st, tile=tile)
-                except _lib.CtdetError:        # e.g. the workspace of the two-kernel form would exceed 2 GiB
-                    times.append(float('inf'))
-                    continue
+                self.enable_wino(st, tile=tile)
                 t = self._time_conv(st, iters)
                 times.append(t)
                 if t < best_t:
@@ -731,10 +691,10 @@ def x3_allowed(st):
 
 
 def wino_tiles(backend=None, st=None):
-    """Winograd variants the tuner may pick (st.rt['wino'] codes): CTDET_WINO_TILES, default '2,4,23,24,43' = the two
-    fp32-MFMA kernels and the bf16x3 forms (F(2x2) with two accumulators, F(2x2) in four-wave workgroups, F(4x4)), minus
+    """Winograd variants the tuner may pick (st.rt['wino'] codes): CTDET_WINO_TILES, default '2,4,23,24' = the two
+    fp32-MFMA kernels and the two F(2x2) bf16x3 forms (two accumulators; four-wave workgroups), minus
     what the runtime that owns `backend` excluded (ctx_tile_set) and what the layer's geometry rules out."""
-    tiles = tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4,23,24,43,44').split(',') if t)
+    tiles = tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4,23,24').split(',') if t)
     allowed = getattr(backend, 'wino_tile_set', None)
     if allowed is not None:
         tiles = tuple(t for t in tiles if t in allowed)
@@ -786,10 +746,12 @@ def apply_tuned(backend, st, batch, wino4=True):
         return True
     if isinstance(cfg, str) and cfg.startswith('x3:'):
         xn = backend.x3_names()
-        if cfg in xn and x3_allowed(st):
+        if cfg in xn and x3_allowed(st) and st.cin % backend.x3_bk(xn.index(cfg)) == 0:     # the k-step must divide cin
             backend.enable_x3(st, xn.index(cfg))
             return True
         cfg = tune_table().get(st.tune_key(batch) + '|f32')       # the best fp32-MFMA tile, recorded next to it
+    if cfg == 'valu' and not (st.cin == 3 and (st.kh, st.kw, st.stride, st.dil) == (3, 3, 1, 1) and st.res is None):
+        cfg = None                      # the vector-ALU kernel exists for the 3-channel image layer only
     if cfg in names:
         st.rt['config'] = names.index(cfg) + 1
         st.rt['desc'].config = st.rt['config']

@@ -298,7 +298,17 @@ class TrainRuntime:
         CTDET_PACK_BATCH=0 keeps the per-layer launches."""
         if not self._batched_packs:
             return
+        # cache key of the recorded lists: the parameter storage AND what each layer's launch reads (kernel choice and
+        # packed-weight buffer can change after the first step: enable_x3 / enable_wino / apply_tuned on the shared backend)
         ptrs = [p.data_ptr() for p in self.params]
+        for st in self.plan.steps:
+            if st.kind == 'conv':
+                rt = self.state[st.name].fwd.rt
+                x3 = rt.get('x3')
+                ptrs.append((st.name, rt.get('wino') or 0, -1 if x3 is None else x3,
+                             tuple(sorted((k, v.data_ptr()) for k, v in rt.items()
+                                          if k in ('U', 'U4', 'UX', 'wpk') and v is not None)),
+                             tuple(sorted((bk, t.data_ptr()) for bk, t in rt.get('wx3', {}).items()))))
         if self._pack_table is None or ptrs != self._pack_ptrs:
             lib = self.lib
             _lib.check(lib.ct_pack_record_begin(), 'ct_pack_record_begin')
@@ -308,7 +318,9 @@ class TrainRuntime:
                     if st.kind != 'conv':
                         continue
                     s = self.state[st.name]
-                    self.be.pack_conv(s.fwd)
+                    # bf16x3 forward layers are split by the batched x3 list below (ct_conv_pack_weights_x3 is not
+                    # recordable and would launch right here): only their epilogue is folded
+                    self.be.pack_conv(s.fwd, weights=s.fwd.rt.get('x3') is None)
                     if s.dgrad is not None:
                         self._pack_dgrad(st, s)
             finally:

@@ -313,39 +313,19 @@ int ct_conv2d_wino4_pool_fwd(const ct_conv_desc* desc, const float* upacked, flo
  * the transform-domain products evaluated as six bf16 piece products ("bf16x3", see below) on v_mfma_f32_32x32x16_bf16
  * -- same layers (models/RFB_Net_vgg.py:7-22,219-227,238-248), descriptor, epilogue, pooling fusion and head scatter;
  * cin % 16 == 0.  The weights come pre-transformed AND pre-split from ct_conv_pack_weights_wino_x3
- * (ct_conv_wino_x3_packed_bytes bytes).  dual != 0: the hi.hi products accumulate in their own register block (the
- * large sum sees cin / 16 roundings; error vs fp64 about a quarter of ct_conv2d_wino_fwd's); dual == 0: one
- * accumulator (6 cin / 16 roundings); dual == 2: one accumulator in four-wave workgroups, two per CU. */
+ * (ct_conv_wino_x3_packed_bytes bytes).  variant 1: eight-wave workgroups, the hi.hi products accumulate in their own
+ * register block (the large sum sees cin / 16 roundings; error vs fp64 about a third of ct_conv2d_wino_fwd's, a tenth of
+ * ct_conv2d_wino4_fwd's); variant 2: four-wave workgroups, two per CU, one accumulator (6 cin / 16 roundings) -- the
+ * faster one on most shapes. */
 int ct_conv_wino_x3_supported(const ct_conv_desc* desc);
 size_t ct_conv_wino_x3_packed_bytes(int cin, int cout);
 int ct_conv_pack_weights_wino_x3(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
                                  ct_stream_t stream);
 int ct_conv_pack_weights_wino_x3_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
                                        ct_stream_t stream);
-int ct_conv2d_wino_x3_fwd(const ct_conv_desc* desc, const void* upacked, int dual, ct_stream_t stream);
-int ct_conv2d_wino_x3_pool_fwd(const ct_conv_desc* desc, const void* upacked, int dual, float* pool_out, int pool_ctot,
+int ct_conv2d_wino_x3_fwd(const ct_conv_desc* desc, const void* upacked, int variant, ct_stream_t stream);
+int ct_conv2d_wino_x3_pool_fwd(const ct_conv_desc* desc, const void* upacked, int variant, float* pool_out, int pool_ctot,
                                int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
-/* F(4x4,3x3) on the bf16 matrix pipe: the large-tile counterpart (ct_conv2d_wino4_fwd's contract, interpolation points
- * 0, +-3/4, +-3/2, inf; one accumulator): 36 bf16x3 multiplications per 16 outputs, its own packed layout. */
-size_t ct_conv_wino4_x3_packed_bytes(int cin, int cout);
-int ct_conv_pack_weights_wino4_x3(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
-                                  ct_stream_t stream);
-int ct_conv_pack_weights_wino4_x3_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
-                                        ct_stream_t stream);
-int ct_conv2d_wino4_x3_fwd(const ct_conv_desc* desc, const void* upacked, ct_stream_t stream);
-int ct_conv2d_wino4_x3_pool_fwd(const ct_conv_desc* desc, const void* upacked, float* pool_out, int pool_ctot,
-                                int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
-/* The same convolution as TWO launches: a memory-bound kernel that transforms and splits the input once into
- * `ws` (ct_conv_wino4_x3_workspace_bytes(desc) bytes: the bf16x3 fragments of V in MFMA register order, 13.5 bytes per
- * (output pixel, input channel)) and a GEMM kernel whose main loop has no vector-ALU work (csrc/ct_wino_x3.hip: on a
- * SIMD, VALU and MFMA time add up).  Same packed weights, results and epilogue as ct_conv2d_wino4_x3_fwd; pays where the
- * cout blocks re-use V (cout >= 256) on maps up to ~75 x 75.  The whole batch must fit 2 GiB per tensor. */
-size_t ct_conv_wino4_x3_workspace_bytes(const ct_conv_desc* desc);
-int ct_conv2d_wino4_x3_split_fwd(const ct_conv_desc* desc, const void* upacked, void* ws, size_t ws_bytes,
-                                 ct_stream_t stream);
-int ct_conv2d_wino4_x3_split_pool_fwd(const ct_conv_desc* desc, const void* upacked, void* ws, size_t ws_bytes,
-                                      float* pool_out, int pool_ctot, int pool_coff, int pool_oh, int pool_ow,
-                                      int write_full, ct_stream_t stream);
 
 /* ---- "bf16x3": the fp32 convolution of ct_conv2d_fwd on the bf16 matrix pipe (csrc/ct_conv_x3.hip) ----
  * Same layers (models/RFB_Net_vgg.py:7-22 BasicConv, the plain Conv2d layers, the multibox heads :238-248), the same
