@@ -622,11 +622,15 @@ class HipBackend:
 
     # ---- autotune: time every tile config of a conv step on its real buffers
     def _time_conv(self, st, iters=3, rounds=2):
-        """ms per launch: the better of `rounds` timed bursts of `iters` launches after one warm-up launch."""
+        """ms per launch: the better of `rounds` timed bursts of `iters` launches after one warm-up launch.  Short
+        launches get longer bursts (>= ~1 ms of device time): three 30 us launches are inside the timer's noise, and a
+        flipped choice lands in the committed table."""
         self.run_conv(st)
         torch.cuda.synchronize(self.device)
         best = float('inf')
-        for _ in range(rounds):
+        for r in range(rounds + 1):
+            if r == 1 and best < 1.0 / 3:             # the first burst was the estimate: size the others from it
+                iters = min(64, max(iters, int(1.0 / max(best, 1e-3)) + 1))
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
@@ -691,19 +695,29 @@ def x3_allowed(st):
 
 
 def wino_tiles(backend=None, st=None):
-    """Winograd variants the tuner may pick (st.rt['wino'] codes): CTDET_WINO_TILES, default '2,4,23,24' = the two
-    fp32-MFMA kernels and the two F(2x2) bf16x3 forms (two accumulators; four-wave workgroups), minus
-    what the runtime that owns `backend` excluded (ctx_tile_set) and what the layer's geometry rules out."""
-    tiles = tuple(int(t) for t in os.environ.get('CTDET_WINO_TILES', '2,4,23,24').split(',') if t)
+    """Winograd variants the tuner / the table may use (st.rt['wino'] codes).  Default: the two fp32-MFMA kernels
+    ('2,4').  The F(2x2) bf16x3 forms (23: two accumulators; 24: four-wave workgroups) are faster per layer ALONE
+    (512 -> 512 @38x38: 742 -> 630 us) but not in the two-stream pipeline, where the side stream already fills the idle
+    last round of the 800-workgroup F(4x4) launches (same-box A/B of two tables: 3 360-3 371 vs 3 228-3 398 images/s,
+    DESIGN.md section 4), so the committed table does not hold them; CTDET_WINO_TILES=2,4,23,24 lets the tuner time all
+    four.  A runtime with an accuracy policy (ctx_tile_set: networks with the Context-Transformer block) uses ITS set
+    instead (narrowed by an explicit CTDET_WINO_TILES), plus F(4x4) / fp32 on layers with at most wino4_max_cin input
+    channels."""
+    env = os.environ.get('CTDET_WINO_TILES')
+    tiles = tuple(int(t) for t in (env or '2,4').split(',') if t)
     allowed = getattr(backend, 'wino_tile_set', None)
-    if allowed is not None:
-        tiles = tuple(t for t in tiles if t in allowed)
+    if allowed is not None:             # a runtime's accuracy policy: its set, narrowed by an explicit CTDET_WINO_TILES
+        tiles = tuple(t for t in allowed if env is None or t in tiles)
+        cap = getattr(backend, 'wino4_max_cin', None)
+        if cap and st is not None and st.cin <= cap and 4 not in tiles and (env is None or '4' in env.split(',')):
+            tiles = tiles + (4,)        # short channel sums: F(4x4) / fp32 costs little accuracy there
     if st is not None and not st.rt.get('winox_ok'):
         tiles = tuple(t for t in tiles if t not in WINOX_TILES)
     return tiles
 
 
 CTX_TILES_DEFAULT = '2,23'
+SIDE_AFTER_DEFAULT = ''
 
 
 def ctx_tile_set(net):
@@ -714,17 +728,32 @@ def ctx_tile_set(net):
     output) ~1000x (tools/ctx_parity.py --budget: 970x), so the reference's own fp32 CPU path sits 5..7e-5 from an fp64
     evaluation and every bit of trunk accuracy shows in the 1e-4 parity contract.  Rounds 2-3 chose between the fp32-MFMA
     kernels (F(2x2,3x3) / F(4x4,3x3): raw conf error vs fp64 1.0..1.2e-6, the CPU path 0.93e-6) and accepted that 4 of 9
-    sweep cases exceed 1e-4 against the CPU path.  Round 4: these networks run every Winograd layer on F(2x2,3x3) over
+    sweep cases exceed 1e-4 against the CPU path.  Round 4: these networks run their Winograd layers on F(2x2,3x3) over
     bf16x3 with TWO accumulators (tile code 23: exact +-1 transforms, the large channel sum sees cin / 16 roundings;
-    per-layer error vs fp64 4e-7 against 5e-6 for F(4x4,3x3) / fp32): the device is then CLOSER to fp64 than the CPU
-    path in all 9 sweep cases (3.5..5.9e-5 vs 4.9..7.2e-5, profiles/r04_ctx_parity.txt), which is as far as fp32
-    activation storage goes.  Layers without 16-channel chunks keep F(2x2,3x3) on the fp32 MFMA (tile 2).
+    per-layer error vs fp64 4e-7 against 5e-6 for F(4x4,3x3) / fp32), except the layers with short channel sums
+    (ctx_f4_max_cin).  With every layer on tile 23 the device is CLOSER to fp64 than the CPU path in 8-9 of the 9 sweep
+    cases (3.0..6.1e-5 vs 4.9..7.2e-5), which is as far as fp32 activation storage goes; with the shipped cap all 9 cases
+    are within 1e-4 of the CPU path (profiles/r04_ctx_parity.txt, r04_ctx_policy.txt).  Layers without 16-channel chunks
+    keep F(2x2,3x3) on the fp32 MFMA (tile 2).
     CTDET_CTX_TILES = comma list of allowed tile codes, or 'any' for the unconstrained table."""
     ctx = getattr(net, 'method', None) == 'ours' and getattr(net, 'phase', 1) == 2
     v = os.environ.get('CTDET_CTX_TILES', CTX_TILES_DEFAULT)
     if not ctx or v == 'any':
         return None
     return tuple(int(t) for t in v.split(',') if t)
+
+
+CTX_F4_MAX_CIN_DEFAULT = '128'
+
+
+def ctx_f4_max_cin(net):
+    """Layers of a Context-Transformer network with at most this many input channels keep F(4x4,3x3) / fp32 where the
+    table picks it: its rounding error grows with the length of the channel sum, and on conv1_2 .. conv3_1 (64 / 128
+    input channels at 300 x 300 .. 75 x 75) the bf16x3 form costs the most time.  Measured (profiles/r04_ctx_policy.txt,
+    RFBNet-300 + Context-Transformer bs 32, sweep of 9 randn cases): cap 0: 2 447 images/s, worst GPU-CPU32 1.05e-4, device
+    closer to fp64 than the CPU path in 8 / 9; cap 64: 2 524, 9.6e-5, 6 / 9; **cap 128 (default): 2 565, 9.6e-5 -- all 9 cases
+    within the flat 1e-4 --, 5 / 9**; cap 256: 2 595, 1.30e-4 (3 cases above 1e-4).  CTDET_CTX_F4_MAX_CIN; 0 = none."""
+    return int(os.environ.get('CTDET_CTX_F4_MAX_CIN', CTX_F4_MAX_CIN_DEFAULT)) if ctx_tile_set(net) is not None else 0
 
 
 def apply_tuned(backend, st, batch, wino4=True):
@@ -740,8 +769,13 @@ def apply_tuned(backend, st, batch, wino4=True):
         want = codes[cfg]
         if want == 4 and not wino4:
             want = 2
-        if want not in allowed:         # policy of this runtime: the most accurate allowed variant instead
-            want = 23 if 23 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
+        if getattr(backend, 'wino_tile_set', None) is not None:
+            # accuracy policy of this runtime: F(4x4) / fp32 survives only where the policy allows it (short channel sums),
+            # everything else runs the most accurate allowed variant
+            if not (want == 4 and 4 in allowed):
+                want = 23 if 23 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
+        elif want not in allowed:
+            want = 2 if 2 in allowed or not allowed else allowed[0]
         backend.enable_wino(st, tile=want)
         return True
     if isinstance(cfg, str) and cfg.startswith('x3:'):
@@ -760,8 +794,9 @@ def apply_tuned(backend, st, batch, wino4=True):
 
 
 def run_on_streams(rt, run_step):
-    """Walk rt.plan.steps in order, each step on the stream Runtime._build_schedule gave it (rt.sid), cross-stream
-    producer -> consumer edges as events (rt.xdeps / rt.signal / rt.ev); everything joins the caller's stream."""
+    """Walk the plan's steps in launch order (rt.order: plan order, side-stream steps possibly deferred, see
+    Runtime._build_schedule), each step on the stream the schedule gave it (rt.sid), cross-stream producer -> consumer
+    edges as events (rt.xdeps / rt.signal / rt.ev); everything joins the caller's stream."""
     steps = rt.plan.steps
     if rt.side is None:
         for st in steps:
@@ -771,17 +806,19 @@ def run_on_streams(rt, run_step):
     for sd in rt.sides:
         sd.wait_stream(main)
     streams = [main] + rt.sides
-    i, n = 0, len(steps)
-    while i < n:
-        k = rt.sid[i]
+    order = getattr(rt, 'order', None) or list(range(len(steps)))
+    pos, n = 0, len(order)
+    while pos < n:
+        k = rt.sid[order[pos]]
         with torch.cuda.stream(streams[k]):
-            while i < n and rt.sid[i] == k:
+            while pos < n and rt.sid[order[pos]] == k:
+                i = order[pos]
                 for j in rt.xdeps[i]:
                     streams[k].wait_event(rt.ev[j])
                 run_step(steps[i])
                 if i in rt.signal:
                     rt.ev[i].record(streams[k])
-                i += 1
+                pos += 1
     for sd in rt.sides:
         main.wait_stream(sd)
 
@@ -805,6 +842,7 @@ class Runtime:
         # live autotune only for shapes the table does not know (CTDET_TUNE=0 disables, =2 forces)
         mode = os.environ.get('CTDET_TUNE', '1') if tune is None else ('1' if tune else '0')
         backend.wino_tile_set = ctx_tile_set(net)
+        backend.wino4_max_cin = ctx_f4_max_cin(net)
         self.tuned = False
         self.event_log = None        # set to a list to collect (step, start_event, end_event) per conv
         if getattr(backend, 'tune_conv', None) is not None:
@@ -912,6 +950,18 @@ class Runtime:
             for b in writes(st):
                 writers.setdefault(b, []).append(i)
         self.sid = sid
+        # Launch order.  The side work (Norm branch, heads: 38x38 / 19x19 layers that fill the chip) only depends on
+        # conv4_3 / conv7, while the END of the trunk (extras.1 .. extras.6 and their heads: 10x10 .. 1x1 maps, ~30 launches
+        # of 25 .. 80 workgroups) cannot fill 256 CUs.  CTDET_SIDE_AFTER = name of a trunk step: the side-stream steps that
+        # precede it in plan order are launched right after it instead, so they run beside the small layers rather than
+        # beside conv5 .. conv7, which fill the chip on their own.
+        self.order = list(range(len(steps)))
+        after = os.environ.get('CTDET_SIDE_AFTER', SIDE_AFTER_DEFAULT)
+        names = [st.name for st in steps]
+        if after and after in names:
+            k = names.index(after)
+            early = [i for i in range(k) if sid[i] != 0]
+            self.order = [i for i in range(k + 1) if sid[i] == 0] + early + list(range(k + 1, len(steps)))
         self.sides = [torch.cuda.Stream(self.backend.device) for _ in range(max(sid))]
         self.side = self.sides[0]
         self.ev = {j: torch.cuda.Event() for j in self.signal}

@@ -235,3 +235,31 @@ def test_rfbnet_bf16_vs_oracle_on_bf16_rounded_activations(size, monkeypatch):
         # further from the EXACT oracle than bf16 storage itself puts the oracle, and far inside the 3e-2 budget.
         assert dev < 2.0 * own and dev < 3e-2, (name, dev, own)      # measured ratios 0.9 .. 1.6 (max-norm of 1e5..1e6 values)
         assert dev > 1e-4, name                     # really the bf16 path
+
+
+def test_rfbnet512_bf16_at_the_benched_batch_vs_oracle(monkeypatch):
+    """the bf16 engine at the shape bench.py times for BASELINE configs[4] (RFBNet-512, bs 16 per GPU -- the
+    batch selects the 256 x 256 tile, csrc/ct_conv_bf16.hip) against the oracle on the first and the last image: exact
+    fp32 and with every convolution operand rounded to bfloat16 (the criterion of the bs-1 test above)."""
+    from models.RFB_Net_vgg import build_net
+    from oracle import rfbnet_ref
+    net = build_net(types.SimpleNamespace(method='ours', phase=1, setting='transfer'), 512, 20)
+    net.load_state_dict(synth.fill_state_dict(net.state_dict()))
+    net = net.cuda().eval()
+    net.device = 'cuda'
+    net.conv_dtype = 'bf16'
+    B = 16
+    x = synth.images(B, 512, 'randn', 4321)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    pick = [0, B - 1]
+    with torch.no_grad():
+        got = [t.cpu()[pick] for t in net.forward_raw(x.to(DEV))]
+        exact = rfbnet_ref.forward(sd, x[pick], 512, 20, raw=True)
+        monkeypatch.setattr(rfbnet_ref, 'F', _RoundedF())
+        want = rfbnet_ref.forward(sd, x[pick], 512, 20, raw=True)
+    for name, a, b, c in zip(('loc', 'conf', 'obj'), got, want, exact):
+        for i in range(2):
+            dev = float((a[i].reshape(c[i].shape) - c[i]).abs().max() / c[i].abs().max())
+            own = float((b[i] - c[i]).abs().max() / c[i].abs().max())
+            assert dev < 2.0 * own and dev < 3e-2, (name, pick[i], dev, own)
+            assert dev > 1e-4, (name, pick[i])

@@ -276,3 +276,30 @@ def test_wino4_streamk_matches_plain_grid(pool, monkeypatch):
     assert rel_err(outs[1].cpu(), outs[0].cpu()) < 1e-5         # other summation order in the cut items only
     assert not torch.equal(outs[1], outs[0])                     # ... so the stream-K path really ran
     assert torch.equal(outs[1], outs[2])                         # and is deterministic
+
+
+def test_autotune_times_every_variant_and_keeps_a_correct_one(monkeypatch):
+    """HipBackend.tune_conv (the path behind tools/tune_convs.py and CTDET_TUNE=1, which the test suite itself pins off):
+    every direct tile, the bf16x3 tiles and the four Winograd variants are timed on the layer's real buffers; whatever
+    wins must still produce the reference result."""
+    monkeypatch.setenv('CTDET_TUNE', '1')
+    monkeypatch.setenv('CTDET_WINO_TILES', '2,4,23,24')        # default: the two fp32-MFMA kernels only
+    g = torch.Generator().manual_seed(77)
+    B, Cin, H, Wd, Cout = 2, 64, 19, 19, 96
+    x = torch.randn(B, Cin, H, Wd, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    b = torch.rand(Cout, generator=g) - 0.5
+    be = engine.HipBackend('cuda:0')
+    st = engine.ConvStep('t', [engine.ConvPart(torch.nn.Parameter(w.cuda(), requires_grad=False),
+                                               torch.nn.Parameter(b.cuda(), requires_grad=False), None, True)],
+                         Cin, 3, 3, 1, 1, 1, 1, 'x', 0, H, Wd, 'y', 0)
+    bufs = {'x': x.cuda(), 'y': torch.full((B, Cout, H, Wd), float('nan'), device='cuda')}
+    be.prepare_conv(st, bufs, B)
+    best, times = be.tune_conv(st)
+    finite = [t for t in times if t != float('inf')]
+    assert len(finite) >= 4 + len(engine.wino_tiles(be, st)) and min(finite) > 0
+    assert set(engine.wino_tiles(be, st)) == {2, 4, 23, 24}
+    bufs['y'].fill_(float('nan'))
+    be.run_conv(st)
+    torch.cuda.synchronize()
+    assert rel_err(bufs['y'].cpu(), _ref_conv(x, [(w, b, None, True)], 1, 1, 1)) < TOL

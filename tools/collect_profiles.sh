@@ -43,12 +43,17 @@ timeout 300 python tools/nms_probe.py > "$O/nms_probe.txt" 2>&1
 timeout 300 python tools/attn_probe.py > "$O/attn_probe.txt" 2>&1
 timeout 400 python tools/x3_probe.py > "$O/x3_probe.txt" 2>&1
 timeout 300 python tools/wino_accuracy.py > "$O/wino_accuracy.txt" 2>&1
-timeout 900 python tools/ctx_parity.py --budget --sweep --policies 0,256,1 > "$O/ctx_parity.txt" 2>&1
+timeout 1500 python tools/ctx_parity.py --budget --sweep --policies 2+23,2+4 > "$O/ctx_parity.txt" 2>&1
+timeout 1500 bash tools/ctx_policy.sh > "$O/ctx_policy.txt" 2>&1
 timeout 300 python bench.py --train --steps 5 --warmup 2 > "$O/bench_train.json.log" 2> "$O/bench_train.err"
 timeout 300 python bench.py --gpus 2 --share-devices --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > "$O/bench_2rank_rehearsal.json.log" 2> "$O/bench_2rank_rehearsal.err"
 timeout 300 python bench.py --train --gpus 2 --share-devices --steps 3 --warmup 1 > "$O/bench_train_2rank_rehearsal.json.log" 2> "$O/bench_train_2rank_rehearsal.err"
 timeout 300 python tools/ctx_attn_time.py > "$O/ctx_attn_time.txt" 2>&1
 bash tools/wino_pmc.sh base.19 ${TAG}_w4 > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_w4/summary.txt" "$O/wino4_pmc.txt"
+# the three Winograd kernels on the same layer: SQ counters behind "SIMD time = MFMA cycles + 4 cycles per VALU instruction"
+bash tools/wino_pmc.sh base.19 ${TAG}_x3q 24 x3q > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_x3q/summary.txt" "$O/wino_x3q_pmc.txt"
+bash tools/wino_pmc.sh base.19 ${TAG}_x3d 23 "wino_f2x2_3x3_x3<" > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_x3d/summary.txt" "$O/wino_x3_pmc.txt"
+CTDET_WINO_TILES=2,4,23,24 TILES=2,4,23,24 timeout 600 python tools/wino_one.py base.2 base.5 base.7 base.10 base.12 base.17 base.19 base.24 head.0 > "$O/wino_variants.txt" 2>&1
 bash tools/bf16_pmc.sh ${TAG}_bf16 > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_bf16/summary.txt" "$O/bf16_pmc.txt"
 cd "$R"
 # keep what prof_summary.py needs, drop the bulky traces

@@ -17,18 +17,23 @@ ap.add_argument('--budget', action='store_true'); ap.add_argument('--sweep', act
 ap.add_argument('--policies', default='2+23'); ap.add_argument('--batches', default='2,8,32')
 ap.add_argument('--seeds', default='1234,7,99'); ap.add_argument('--kinds', default='randn,u8')
 ap.add_argument('--size', type=int, default=300); ap.add_argument('--budget-batch', type=int, default=8)
+ap.add_argument('--f4-max-cin', default='', help='CTDET_CTX_F4_MAX_CIN: F(4x4)/fp32 allowed on layers with at most this many input channels')
 ap.add_argument('--force-tile', default='', help='CTDET_WINO_FORCE: 23 = F(2x2,3x3) on bf16x3 with two accumulators on every Winograd layer')
 a = ap.parse_args()
 names = {'2+23': 'F(2x2,3x3) on bf16x3 (two accumulators) on every Winograd layer', '2': 'F(2x2,3x3) / fp32 MFMA only',
          '2+4': 'fp32-MFMA Winograd kernels as the table picks them', 'any': 'the unconstrained table'}
 if a.force_tile:
     os.environ['CTDET_WINO_FORCE'] = a.force_tile
+if a.f4_max_cin:
+    os.environ['CTDET_CTX_F4_MAX_CIN'] = a.f4_max_cin
 for pol in a.policies.split(','):
     os.environ['CTDET_CTX_TILES'] = pol.replace('+', ',')
     net = cc.build(a.size, 60)
     label = names.get(pol, 'tile codes ' + pol)
     if a.force_tile:
         label += '; then every Winograd layer forced to tile code %s' % a.force_tile
+    if a.f4_max_cin:
+        label += '; F(4x4)/fp32 kept on layers with <= %s input channels' % a.f4_max_cin
     if a.budget:
         for batch in (a.budget_batch,):
             rt = net.runtime(batch)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Error map of one Winograd variant on a small case (development aid): python tools/dev/wx_debug.py TILE B Cin H W Cout"""
+"""Error map of one Winograd variant on a small case (development aid): python tools/wino_debug.py TILE B Cin H W Cout"""
 import os, sys
 import torch
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, 'context-transformer_amd')); sys.path.insert(0, REPO)
 from ctdet import engine
 tile, B, Cin, H, W, Cout = [int(v) for v in sys.argv[1:7]]
