@@ -28,6 +28,7 @@ SOURCES = {
     'ct_wino.hip': [],
     'ct_wino4.hip': [],
     'ct_wino_x3.hip': [],
+    'ct_wino4s.hip': [],
     'ct_wino_wgrad.hip': [],
     'ct_wino4_wgrad.hip': [],
     'ct_conv_bf16.hip': [],

@@ -1,0 +1,553 @@
+// libctdet: Winograd F(4x4,3x3) as THREE kernels with the transform-domain GEMMs on the bf16 matrix pipe ("bf16x3") --
+// the wide 3x3 / stride 1 / dilation 1 / pad 1 layers of the RFBNet-VGG stack (models/RFB_Net_vgg.py:219-227 conv3_x ..
+// conv5_x of the VGG trunk, :238-248 the multibox heads on the 38x38 / 19x19 sources).  Same ct_conv_desc contract and
+// fused epilogue as ct_conv2d_wino4_fwd, same transforms (ct_wino4_points.h), same fp32 results up to summation order.
+//
+//   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        per 4x4 output tile, 6x6 input patch d
+//
+// Why three kernels.  On a SIMD the vector ALU and the matrix pipe do not overlap ("law 1": SIMD time
+// = 32 or 64 cycles per MFMA + 4 cycles per wave64 VALU instruction), and a fused Winograd workgroup repeats the input
+// transform for every block of 64 output channels: ct_wino4.hip spends 6.7 VALU instructions per fp32 MFMA and stays at
+// 0.52 of the pipe, the fused bf16x3 forms of ct_wino_x3.hip 8-11 per bf16 MFMA.  A fused workgroup also owns ALL 36
+// transform points of a 32-tile x 64-cout block, which is a bad GEMM shape: 331 KB of operands per 16 channels, more than
+// the 64 B/clk a CU pulls through its L1 ("law 2").  Here
+//   1. wino4s_in    transforms and splits every (tile, channel) ONCE: V = B^T d B, V = hi + mid + lo (three bfloat16
+//                   pieces, exact), written as ready-made MFMA operand fragments -- memory-bound, 13.5 bytes per (output
+//                   pixel, input channel);
+//   2. wino4s_gemm  36 independent GEMMs  M[xi][cout][tile] = sum_c U[xi][cout][c] V[xi][c][tile]  in 128 x 128 blocks:
+//                   both operands arrive in LDS by DMA (buffer_load ... lds, 1 KB per wave instruction, no VGPR staging),
+//                   a wave reads twelve 16-byte fragments and issues 24 v_mfma_f32_32x32x16_bf16 (the six piece products
+//                   hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) per 16-channel step -- NO vector-ALU work in the loop;
+//   3. wino4s_out   y = A^T M A per (cout, tile) and the usual epilogue (scale / shift, residual, ReLU / floor, fused 2x2
+//                   max-pool, NCHW or head scatter) -- memory-bound, 9 bytes per (output pixel, output channel).
+// The price is HBM traffic (V and M live in a workspace: 354 + 236 MB for 512 -> 512 @38x38, bs 32), which is why this
+// form is for layers with >= 256 channels on maps up to 75 x 75; the fused kernels keep the rest.
+#include "ct_common.h"
+#include "ct_wino_pack.h"
+#include "ct_wino4_points.h"
+#include "ct_wino4_emit.h"
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef int i32x3 __attribute__((ext_vector_type(3)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kInvalidOff = 0x7FFFFFF0;
+constexpr long long kMaxBufBytes = 0x7FFFFF00LL;
+constexpr int CC = 16;                      // input channels per k-step (one bf16 MFMA k-group)
+constexpr int TB = 32;                      // tiles per transform workgroup = one operand fragment
+constexpr int NXI = 36;                     // transform points
+constexpr int BM = ctdet::kWino4sBM;        // output channels per GEMM workgroup
+constexpr int BT = 128;                     // tiles per GEMM workgroup
+constexpr int FRAG = ctdet::kWino4sFragBytes;          // [k half 2][row 32][8 bf16]
+constexpr int OPB = ctdet::kWino4sChunkBytes;          // one operand block of a k-step: [sub 4][piece 3][1 KB] = 12 KB
+constexpr int NBUF = 3;                     // LDS ring: two k-steps in flight
+constexpr int GEMM_LDS_BYTES = NBUF * 2 * OPB;         // 72 KB: two workgroups per CU
+constexpr int PT_STRIDE = CC * TB;          // wino4s_in: floats per point in LDS, V[point][channel 16][tile 32]
+constexpr int IN_LDS_BYTES = NXI * PT_STRIDE * 4;      // 72 KB
+
+struct Wino4sArgs {
+    const float* in;
+    const unsigned short* U;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    const float* lo;
+    float* out;
+    unsigned in_bytes, out_bytes, res_bytes;
+    int Cin, H, W, in_ctot, in_coff;
+    int M, chunks, kblocks;
+    int TY, TX, NT, tblk32, tblk128, Tpad;
+    int out_ctot, out_coff, res_ctot, res_coff;
+    float res_scale;
+    int relu;
+    float* pool_out;         // optional fused 2x2 / stride 2 max-pool of the activation (NCHW), else null
+    int pool_ctot, pool_coff, pool_oh, pool_ow, write_full;
+    int nseg;
+    ct_out_segment seg[3];
+    unsigned short* V;       // workspace: [point 36][tile block 128][chunk][sub 4][piece 3][1 KB]
+    float* Mw;               // workspace: [point 36][cout (kblocks * 128)][tile (Tpad)]
+    size_t v_plane, u_plane; // bytes per point
+    size_t m_plane;          // floats per point
+    int chunks_per_wg;       // wino4s_in: blockIdx.y owns chunks [y * chunks_per_wg, ...)
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+using ctdet::w4::bt6;
+using ctdet::w4::at4;
+
+// x = hi + mid + lo exactly (3 x 8 significant bits by truncation); the upper halves of the three words are the pieces
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l)
+{
+    h = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+    const float r1 = x - __builtin_bit_cast(float, h);
+    m = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+    l = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, m));
+}
+
+__device__ __forceinline__ int pack_hi(unsigned e0, unsigned e1)      // [bf16 e0 | bf16 e1 << 16]
+{
+    return (int)__builtin_amdgcn_perm(e1, e0, 0x07060302u);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 1. input transform + split.  Workgroup = (32 tiles, a run of 16-channel chunks), 256 threads.  Per chunk every thread
+// loads two 6x6 patches (tile = lane & 31, channels 4 wave + h and 4 wave + 2 + h; twelve 12-byte buffer loads each,
+// out-of-map rows / columns read as zero), applies B^T d B in registers and writes the 36 values lane-linearly to LDS
+// V[point][channel][tile]; then wave w splits the points 9w .. 9w+8 -- a lane reads its 8 channels of a point, splits
+// them into three pieces and stores 16 bytes of each: one 1 KB fragment per (point, piece) and wave instruction.
+__global__ __launch_bounds__(256, 2) void wino4s_in(const Wino4sArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tblk = blockIdx.x;
+    const int tb0 = tblk * TB;
+    const int HW = a.H * a.W;
+    const int c_begin = blockIdx.y * a.chunks_per_wg, c_end = min(a.chunks, c_begin + a.chunks_per_wg);
+    if (c_begin >= c_end) return;
+
+    int voffr[6];
+    bool mc[6], lp;
+    int hy_delta;
+    {
+        const int T = tb0 + l31;
+        const bool live = T < a.NT;
+        const int n = T / (a.TY * a.TX);
+        const int rem = T - n * (a.TY * a.TX);
+        const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) mc[c] = (unsigned)(x0 + c) < (unsigned)a.W;
+        // a buffer load whose first byte lies before the row is dropped whole, so the left-edge tiles load from x = 0 and
+        // shift (their column 0 is padding anyway)
+        lp = tx == 0;
+        hy_delta = lp ? 8 : 12;
+        const long base = (((long)n * a.in_ctot + a.in_coff + h) * a.H + y0) * (long)a.W + x0 + (lp ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
+            voffr[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const int chunk_bytes = CC * HW * 4;
+    const int chan_base = 4 * wave * HW * 4;
+
+    struct Half { i32x3 r[6]; };
+    auto load_patch = [&](int c, int q, Half& hx, Half& hy) {
+        const int soff = c * chunk_bytes + chan_base + q * (2 * HW * 4);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            hx.r[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, voffr[i], soff, 0);
+            hy.r[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, voffr[i] == kInvalidOff ? kInvalidOff : voffr[i] + hy_delta, soff, 0);
+        }
+    };
+    float* const vw_base = lds + wave * 128 + lane;          // channel 4 wave + 2 q + h, tile l31
+    auto transform_store = [&](const Half& hx, const Half& hy, int q) {
+        float t[6][6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            float d[6], o[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const f32x3 qv = __builtin_bit_cast(f32x3, (c < 3 ? hx : hy).r[i]);
+                const float v = c == 1 ? (lp ? qv.x : qv.y) : c == 2 ? (lp ? qv.y : qv.z) : c % 3 == 0 ? qv.x : c % 3 == 1 ? qv.y : qv.z;
+                d[i] = mc[c] ? v : 0.f;
+            }
+            bt6(d, o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][c] = o[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float v[6];
+            bt6(t[i], v);
+            float* vp = vw_base + q * 64 + (i * 6) * PT_STRIDE;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) vp[j * PT_STRIDE] = v[j];
+        }
+    };
+    const float* const vr_base = lds + (8 * h) * TB + l31;
+    // destination of this workgroup's fragments inside a point's plane: (128-tile block, chunk, sub-block, piece)
+    unsigned char* const vdst = reinterpret_cast<unsigned char*>(a.V) + (size_t)(tblk >> 2) * a.chunks * OPB +
+                                (tblk & 3) * (3 * FRAG) + lane * 16;
+
+    Half x0h, y0h, x1h, y1h;
+    load_patch(c_begin, 0, x0h, y0h);
+    load_patch(c_begin, 1, x1h, y1h);
+    for (int c = c_begin; c < c_end; ++c) {
+        transform_store(x0h, y0h, 0);
+        transform_store(x1h, y1h, 1);
+        if (c + 1 < c_end) {                       // the next chunk's rows are under way while this one is split and stored
+            load_patch(c + 1, 0, x0h, y0h);
+            load_patch(c + 1, 1, x1h, y1h);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const int xi = 9 * wave + p;
+            const float* ptr = vr_base + xi * PT_STRIDE;
+            float raw[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[e] = ptr[e * TB];
+            i32x4 fb[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                split3(raw[2 * q], h0, m0, l0);
+                split3(raw[2 * q + 1], h1, m1, l1);
+                fb[0][q] = pack_hi(h0, h1);
+                fb[1][q] = pack_hi(m0, m1);
+                fb[2][q] = pack_hi(l0, l1);
+            }
+            unsigned char* dst = vdst + (size_t)xi * a.v_plane + (size_t)c * OPB;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<i32x4*>(dst + pc * FRAG) = fb[pc];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 2. the GEMMs.  Workgroup = one point xi, 128 couts x 128 tiles, 256 threads = 2 x 2 waves of 64 x 64 (four 32x32
+// accumulator blocks; DUAL: the hi.hi products in their own accumulator, as ct_conv_x3.hip).  A = U (rows = couts),
+// B = V (columns = tiles), so a lane's accumulator registers are 32 consecutive tiles of one cout: M[xi][cout][tile]
+// rows, which is the order wino4s_out reads.  Per 16-channel step the workgroup needs 12 KB of each operand, stored in
+// HBM exactly as the LDS image: wave w copies sub-block w of both (six 1 KB DMA instructions), three buffers deep.
+// Grid: (point, tile block, cout block) with the cout block fastest -- the workgroups that share a V block (the large
+// operand) are neighbours -- and every XCD gets a contiguous run of that sequence, so they also share an L2.
+template <bool DUAL>
+__global__ __launch_bounds__(256, 2) void wino4s_gemm(const Wino4sArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 1, wc = wave >> 1;
+    int wg;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, local = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int cb = wg % a.kblocks;
+    const int rest = wg / a.kblocks;
+    const int tb = rest % a.tblk128;
+    const int xi = rest / a.tblk128;
+    const unsigned strip = (unsigned)a.chunks * OPB;
+    const __amdgpu_buffer_rsrc_t rU = make_rsrc(reinterpret_cast<const unsigned char*>(a.U) + (size_t)xi * a.u_plane + (size_t)cb * strip, strip);
+    const __amdgpu_buffer_rsrc_t rV = make_rsrc(reinterpret_cast<const unsigned char*>(a.V) + (size_t)xi * a.v_plane + (size_t)tb * strip, strip);
+
+    f32x16 acc[2][2], acs[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acs[i][j][r] = 0.f; }
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int voff = lane * 16;
+    auto load_step = [&](int c, int buf) {
+        unsigned char* Ad = lds_raw + buf * (2 * OPB) + wave * (3 * FRAG);
+        unsigned char* Bd = Ad + OPB;
+        const int soff = c * OPB + wave * (3 * FRAG);
+        (void)Ad; (void)Bd; (void)soff;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rU, (lds_ptr)(Ad + pc * FRAG), 16, voff, soff + pc * FRAG, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_ptr)(Bd + pc * FRAG), 16, voff, soff + pc * FRAG, 0, 0);
+        }
+#endif
+    };
+    constexpr int PIECES = 6;                          // DMA instructions per step and wave
+    const int chunks = a.chunks;
+    // the six piece products, small ones first: (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+    const unsigned char* const Abase = lds_raw + (2 * wr) * (3 * FRAG) + voff;
+    const unsigned char* const Bbase = lds_raw + OPB + (2 * wc) * (3 * FRAG) + voff;
+    auto read_frags = [&](int buf, i32x4 (&fa)[2][3], i32x4 (&fb)[2][3]) {
+        const unsigned char* A = Abase + buf * (2 * OPB);
+        const unsigned char* B = Bbase + buf * (2 * OPB);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                fa[i][pc] = *reinterpret_cast<const i32x4*>(A + (i * 3 + pc) * FRAG);
+                fb[i][pc] = *reinterpret_cast<const i32x4*>(B + (i * 3 + pc) * FRAG);
+            }
+    };
+    auto mfmas = [&](const i32x4 (&fa)[2][3], const i32x4 (&fb)[2][3]) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x16& dst = (DUAL && p < 5) ? acs[i][j] : acc[i][j];
+                    dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][PA[p]]),
+                                                                  __builtin_bit_cast(bf16x8, fb[j][PB[p]]), dst, 0, 0, 0);
+                }
+    };
+    // Software pipeline over the barrier: the fragments of step c are in registers before its MFMAs start -- they were
+    // read from LDS behind the MFMAs of step c - 1.  Top of iteration c: wait for this wave's DMA pieces of step c + 1,
+    // barrier (now step c + 1 is complete in LDS, and every wave has finished READING step c: its buffer is free for
+    // step c + 3), issue that DMA, issue the twelve fragment reads of step c + 1, then the 24 MFMAs of step c.
+    // Ring of three buffers: step c + 1 (being read), c + 2 (in flight), c + 3 (just issued).
+    // Barriers are bare s_barrier instructions with hand-written waits: __syncthreads() carries a workgroup fence that the
+    // compiler implements as s_waitcnt vmcnt(0), which would drain the DMA queue (the steps in flight) at every step.
+    load_step(0, 0);
+    if (chunks > 1) load_step(1, 1);
+    if (chunks > 2) load_step(2, 2);
+    if (chunks > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+    else if (chunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    i32x4 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];
+    read_frags(0, fa0, fb0);
+    auto top = [&](int c) {                             // before the MFMAs of step c; returns after issuing the DMA of step c + 3
+        // outstanding DMA groups of this wave, oldest first: steps c + 1, c + 2 (those that exist); lgkmcnt(0): this wave's
+        // fragment reads of step c (issued one MFMA phase ago) are done before its buffer is handed back
+        if (c + 2 < chunks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (c + 3 < chunks) load_step(c + 3, c % 3);
+    };
+    int c = 0;
+    for (; c + 1 < chunks; c += 2) {
+        top(c);
+        read_frags((c + 1) % 3, fa1, fb1);
+        mfmas(fa0, fb0);
+        top(c + 1);
+        if (c + 2 < chunks) read_frags((c + 2) % 3, fa0, fb0);
+        mfmas(fa1, fb1);
+    }
+    if (c < chunks) mfmas(fa0, fb0);
+
+    // M[xi][cout][tile]: register r of block (i, j) = cout 32 (2 wr + i) + (r & 3) + 8 (r >> 2) + 4 kg, tile 32 (2 wc + j) + l31
+    float* const Mp = a.Mw + (size_t)xi * a.m_plane + (size_t)(cb * BM + 64 * wr + 4 * kg) * a.Tpad + tb * BT + 64 * wc + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = DUAL ? acc[i][j][r] + acs[i][j][r] : acc[i][j][r];
+                Mp[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * a.Tpad + 32 * j] = v;
+            }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 3. output transform + epilogue.  Thread = one (cout, tile): 36 coalesced loads (lanes = 64 consecutive tiles of a
+// cout row), y = A^T M A, the epilogue of ct_wino4.hip.
+__global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
+{
+    const int T = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int co = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (T >= a.NT || co >= a.M) return;
+    const float* src = a.Mw + (size_t)co * a.Tpad + T;
+    float m[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) m[i][j] = __builtin_nontemporal_load(src + (size_t)(i * 6 + j) * a.m_plane);
+    float t[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) at4(m[i], t[i]);
+    float y[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const float col[6] = {t[0][b], t[1][b], t[2][b], t[3][b], t[4][b], t[5][b]};
+        float o[4];
+        at4(col, o);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[r][b] = o[r];
+    }
+    const int n = T / (a.TY * a.TX);
+    const int rem = T - n * (a.TY * a.TX);
+    const int ty = rem / a.TX, tx = rem - ty * a.TX;
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res_bytes);
+    ctdet::w4::emit_tile4(a, rout, rres, n, ty, tx, co, y);
+}
+
+bool wino4s_ok(const ct_conv_desc* d)
+{
+    return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+           d->cin % CC == 0 && d->nseg >= 0 && d->nseg <= 3 && (d->nseg == 0 || !d->res) && !d->transposed &&
+           d->oh == d->h && d->ow == d->w;
+}
+
+struct Sizes { int TY, TX, NT, Tpad, kblocks, chunks; size_t v_plane, m_plane, v_bytes, m_bytes; };
+
+Sizes sizes_of(int batch, int oh, int ow, int cin, int cout)
+{
+    Sizes s{};
+    s.TY = (oh + 3) / 4; s.TX = (ow + 3) / 4;
+    s.NT = batch * s.TY * s.TX;
+    s.Tpad = (s.NT + BT - 1) / BT * BT;
+    s.kblocks = (cout + BM - 1) / BM;
+    s.chunks = cin / CC;
+    s.v_plane = (size_t)(s.Tpad / BT) * s.chunks * OPB;
+    s.m_plane = (size_t)s.kblocks * BM * s.Tpad;
+    s.v_bytes = ctdet::align_up(s.v_plane * NXI, 256);
+    s.m_bytes = s.m_plane * NXI * 4;
+    return s;
+}
+
+}  // namespace
+
+extern "C" int ct_conv_wino4s_supported(const ct_conv_desc* d) { return d && wino4s_ok(d) ? 1 : 0; }
+
+extern "C" size_t ct_conv_wino4s_packed_bytes(int cin, int cout)
+{
+    if (cin <= 0 || cout <= 0 || cin % CC) return 0;
+    return (size_t)NXI * ((cout + BM - 1) / BM) * (cin / CC) * OPB;
+}
+
+extern "C" size_t ct_conv_wino4s_workspace_bytes(const ct_conv_desc* d)
+{
+    if (!d || !wino4s_ok(d) || d->batch <= 0 || d->cout <= 0) return 0;
+    const Sizes s = sizes_of(d->batch, d->oh, d->ow, d->cin, d->cout);
+    return s.v_bytes + s.m_bytes;
+}
+
+extern "C" int ct_conv_pack_weights_wino4s(const float* const* w, const int* cout, int nparts, int cin,
+                                           void* upacked, ct_stream_t stream)
+{
+    return ctdet::pack_wino_any(w, cout, nparts, cin, 0, 44, (float*)upacked, stream, "ct_conv_pack_weights_wino4s");
+}
+
+extern "C" int ct_conv_pack_weights_wino4s_dgrad(const float* const* w, const int* cout, int nparts, int cin,
+                                                 void* upacked, ct_stream_t stream)
+{
+    return ctdet::pack_wino_any(w, cout, nparts, cin, 1, 44, (float*)upacked, stream, "ct_conv_pack_weights_wino4s_dgrad");
+}
+
+extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upacked, void* workspace,
+                                         size_t workspace_bytes, int variant, float* pool_out, int pool_ctot,
+                                         int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream)
+{
+    CT_REQUIRE(d && upacked && workspace, "ct_conv2d_wino4s_fwd: null pointer");
+    CT_REQUIRE(d->in && (d->out || d->nseg > 0) && d->scale && d->shift, "ct_conv2d_wino4s_fwd: null tensor");
+    if (!wino4s_ok(d))
+        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wino4s_fwd: needs 3x3 stride 1 dilation 1 pad 1, cin %% 16 == 0 "
+                           "(got %dx%d s%d d%d p%d cin=%d nseg=%d)", d->kh, d->kw, d->stride, d->dil,
+                           d->pad_h, d->cin, d->nseg);
+    CT_REQUIRE(variant == 1 || variant == 2, "ct_conv2d_wino4s_fwd: variant %d (1 = two accumulators, 2 = one)", variant);
+    CT_REQUIRE(d->batch > 0 && d->cout > 0, "ct_conv2d_wino4s_fwd: bad shape");
+    CT_REQUIRE(write_full || pool_out, "ct_conv2d_wino4s_pool_fwd: nothing to write");
+    if (pool_out) {
+        CT_REQUIRE(pool_coff >= 0 && pool_coff + d->cout <= pool_ctot, "ct_conv2d_wino4s_pool_fwd: pooled output slice");
+        CT_REQUIRE((pool_oh == d->oh / 2 || pool_oh == (d->oh + 1) / 2) && (pool_ow == d->ow / 2 || pool_ow == (d->ow + 1) / 2),
+                   "ct_conv2d_wino4s_pool_fwd: pooled size %dx%d for a %dx%d map", pool_oh, pool_ow, d->oh, d->ow);
+    }
+    CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "ct_conv2d_wino4s_fwd: input slice");
+    if (d->nseg == 0)
+        CT_REQUIRE(d->out_coff >= 0 && d->out_coff + d->cout <= d->out_ctot, "ct_conv2d_wino4s_fwd: output slice");
+    else {
+        CT_REQUIRE(!pool_out && write_full, "ct_conv2d_wino4s_fwd: pooling with segmented output");
+        for (int g = 0; g < d->nseg; ++g) CT_REQUIRE(d->seg[g].ptr, "ct_conv2d_wino4s_fwd: null segment");
+    }
+    CT_REQUIRE(!d->res || (d->res_coff >= 0 && d->res_coff + d->cout <= d->res_ctot), "ct_conv2d_wino4s_fwd: residual slice");
+    const long long img_in_bytes = (long long)d->in_ctot * d->h * d->w * 4;
+    CT_REQUIRE(img_in_bytes < kMaxBufBytes, "ct_conv2d_wino4s_fwd: one image exceeds 2 GiB");
+    const long long img_out_bytes = d->nseg ? 4 : (long long)d->out_ctot * d->oh * d->ow * 4;
+    const long long img_res_bytes = d->res ? (long long)d->res_ctot * d->oh * d->ow * 4 : 0;
+    CT_REQUIRE(img_out_bytes < kMaxBufBytes && img_res_bytes < kMaxBufBytes, "ct_conv2d_wino4s_fwd: one image exceeds 2 GiB");
+    const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / std::max(img_in_bytes, std::max(img_out_bytes, img_res_bytes)));
+    {
+        const Sizes s = sizes_of(std::min(d->batch, max_chunk), d->oh, d->ow, d->cin, d->cout);
+        CT_REQUIRE(workspace_bytes >= s.v_bytes + s.m_bytes, "ct_conv2d_wino4s_fwd: workspace of %zu bytes, needs %zu "
+                   "(ct_conv_wino4s_workspace_bytes)", workspace_bytes, s.v_bytes + s.m_bytes);
+        CT_REQUIRE((size_t)s.chunks * OPB < (size_t)kMaxBufBytes, "ct_conv2d_wino4s_fwd: too many input channels");
+    }
+    hipStream_t st = ctdet::as_stream(stream);
+    {
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute((const void*)wino4s_in, hipFuncAttributeMaxDynamicSharedMemorySize, IN_LDS_BYTES);
+            if (attr_err == hipSuccess)
+                attr_err = hipFuncSetAttribute((const void*)wino4s_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+            if (attr_err == hipSuccess)
+                attr_err = hipFuncSetAttribute((const void*)wino4s_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        });
+        CT_HIP(attr_err);
+    }
+    const int OHW = d->oh * d->ow;
+    for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
+        const int nb = std::min(max_chunk, d->batch - b0);
+        const Sizes s = sizes_of(nb, d->oh, d->ow, d->cin, d->cout);
+        Wino4sArgs a{};
+        a.in = d->in + (size_t)b0 * d->in_ctot * d->h * d->w;
+        a.U = static_cast<const unsigned short*>(upacked);
+        a.scale = d->scale; a.shift = d->shift; a.lo = d->lo;
+        a.res = d->res ? d->res + (size_t)b0 * d->res_ctot * OHW : nullptr;
+        a.out = d->nseg ? nullptr : d->out + (size_t)b0 * d->out_ctot * OHW;
+        a.nseg = d->nseg;
+        for (int g = 0; g < d->nseg; ++g) {
+            a.seg[g] = d->seg[g];
+            a.seg[g].ptr += (size_t)b0 * d->seg[g].img_stride;
+        }
+        a.in_bytes = (unsigned)(img_in_bytes * nb);
+        a.out_bytes = (unsigned)(img_out_bytes * nb);
+        a.res_bytes = (unsigned)(img_res_bytes * nb);
+        a.Cin = d->cin; a.H = d->h; a.W = d->w; a.in_ctot = d->in_ctot; a.in_coff = d->in_coff;
+        a.M = d->cout; a.chunks = s.chunks; a.kblocks = s.kblocks;
+        a.TY = s.TY; a.TX = s.TX; a.NT = s.NT; a.Tpad = s.Tpad;
+        a.tblk32 = s.Tpad / TB; a.tblk128 = s.Tpad / BT;
+        a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
+        a.res_ctot = d->res_ctot; a.res_coff = d->res_coff; a.res_scale = d->res_scale;
+        a.relu = d->relu;
+        a.pool_out = pool_out ? pool_out + (size_t)b0 * pool_ctot * pool_oh * pool_ow : nullptr;
+        a.pool_ctot = pool_ctot; a.pool_coff = pool_coff; a.pool_oh = pool_oh; a.pool_ow = pool_ow;
+        a.write_full = write_full;
+        a.V = static_cast<unsigned short*>(workspace);
+        a.Mw = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + s.v_bytes);
+        a.v_plane = s.v_plane;
+        a.u_plane = (size_t)s.kblocks * s.chunks * OPB;
+        a.m_plane = s.m_plane;
+        // transform: ~2048 workgroups (four rounds of two per CU) unless the layer has fewer (tile block, chunk) pairs
+        const long pairs = (long)a.tblk32 * a.chunks;
+        a.chunks_per_wg = (int)std::max<long>(1, std::min<long>(a.chunks, pairs / 2048));
+        const int ygroups = (a.chunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
+        {
+            CT_PROF("wino4s_in", st);
+            hipLaunchKernelGGL(wino4s_in, dim3(a.tblk32, ygroups), dim3(256), IN_LDS_BYTES, st, a);
+            CT_LAUNCH_CHECK("wino4s_in");
+        }
+        {
+            CT_PROF("wino4s_gemm", st);
+            const int nwg = NXI * a.tblk128 * a.kblocks;
+            if (variant == 1) hipLaunchKernelGGL(wino4s_gemm<true>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, a);
+            else hipLaunchKernelGGL(wino4s_gemm<false>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, a);
+            CT_LAUNCH_CHECK("wino4s_gemm");
+        }
+        {
+            CT_PROF("wino4s_out", st);
+            hipLaunchKernelGGL(wino4s_out, dim3((a.NT + 63) / 64, (a.M + 3) / 4), dim3(256), 0, st, a);
+            CT_LAUNCH_CHECK("wino4s_out");
+        }
+    }
+    return CT_OK;
+}
+
+extern "C" int ct_conv2d_wino4s_fwd(const ct_conv_desc* d, const void* upacked, void* workspace, size_t workspace_bytes,
+                                    int variant, ct_stream_t stream)
+{
+    return ct_conv2d_wino4s_pool_fwd(d, upacked, workspace, workspace_bytes, variant, nullptr, 0, 0, 0, 0, 1, stream);
+}

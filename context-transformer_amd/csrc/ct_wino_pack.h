@@ -13,7 +13,8 @@ struct WinoPackArgs {
     int nparts, cin, cout, chunks, kblocks;
     int dgrad;               // 1: weights of the data-gradient convolution (channels swapped, taps flipped)
     int cin_fwd;
-    int tile;                // 2: F(2x2,3x3) layout, 4: F(4x4,3x3) layout, 23: F(2x2,3x3) split into bf16x3 pieces
+    int tile;                // 2: F(2x2,3x3) layout, 4: F(4x4,3x3) layout, 23: F(2x2,3x3) split into bf16x3 pieces,
+                             // 44: F(4x4,3x3) bf16x3 pieces as the GEMM operand of ct_wino4s.hip
     float* U;
 };
 
@@ -23,6 +24,10 @@ constexpr int kWino2ChunkFloats = 16 * 4 * 64 * 2;  // F(2x2): [wave 8][piece 4]
 constexpr int kWino4ChunkFloats = 8 * 9 * 64 * 4;   // F(4x4): [wave 8][point 9][lane 64][4]
 constexpr int kWinoX3CC = 16;                       // ct_wino_x3.hip: input channels per chunk (one bf16 MFMA k-group)
 constexpr int kWinoX3ChunkBytes = 8 * 2 * 2 * 3 * 64 * 16;   // [wave 8][point 2][cout half 2][piece 3][lane 64][8 bf16]
+
+constexpr int kWino4sBM = 128;                      // ct_wino4s.hip: output channels per GEMM workgroup (four 32-row fragments)
+constexpr int kWino4sFragBytes = 1024;              // one MFMA operand fragment: [k half 2][row 32][8 bf16]
+constexpr int kWino4sChunkBytes = 4 * 3 * kWino4sFragBytes;   // [sub 4][piece 3] of one (128-row block, 16-channel chunk)
 
 // forward: g = w[co][ci];  data gradient: this conv's (co, ci) = forward (ci, co), taps rotated 180 degrees
 __device__ __forceinline__ const float* wino_taps(const WinoPackArgs& p, int co, int ci)
@@ -165,9 +170,65 @@ __device__ __forceinline__ void winox3_pack_body(const WinoPackArgs& p, long fir
     }
 }
 
+// ct_wino4s.hip: U[point 36][cout block of 128][chunk 16 ch][sub 4][piece 3][k half 2][row 32][8 bf16] -- per transform
+// point a [cout] x [cin] GEMM operand whose (128 couts x 16 channels) blocks are 12 KB of ready-made
+// v_mfma_f32_32x32x16_bf16 fragments, copied to LDS by DMA without touching a register.  One thread = one (cout, cin)
+// filter: G g G^T in double (as wino4_pack_body), rounded to fp32 once, then the exact three-piece split.
+__device__ __forceinline__ void wino4s_pack_body(const WinoPackArgs& p, long first, long stride)
+{
+    const long total = (long)p.kblocks * kWino4sBM * p.cin;
+    const size_t plane = (size_t)p.kblocks * p.chunks * kWino4sChunkBytes / 2;       // bf16 elements per point
+    unsigned short* const out = reinterpret_cast<unsigned short*>(p.U);
+    for (long idx = first; idx < total; idx += stride) {
+        const int ci = (int)(idx % p.cin);
+        const int co = (int)(idx / p.cin);
+        float g[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g[i][j] = 0.f;
+        if (co < p.cout) {
+            const float* w = wino_taps(p, co, ci);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) g[i][j] = p.dgrad ? w[(2 - i) * 3 + (2 - j)] : w[i * 3 + j];
+        }
+        double t[6][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double o[6];
+            w4::gmul6(g[0][j], g[1][j], g[2][j], o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+        }
+        const int cb = co / kWino4sBM, sub = (co % kWino4sBM) / 32, chunk = ci / 16, kh = (ci % 16) / 8;
+        unsigned short* base = out + ((((size_t)cb * p.chunks + chunk) * 4 + sub) * 3) * (kWino4sFragBytes / 2) +
+                               (kh * 32 + co % 32) * 8 + ci % 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double o[6];
+            w4::gmul6(t[i][0], t[i][1], t[i][2], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const float val = (float)o[j];
+                const unsigned hb = __builtin_bit_cast(unsigned, val) & 0xFFFF0000u;
+                const float r1 = val - __builtin_bit_cast(float, hb);
+                const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+                const unsigned lb = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, mb));
+                unsigned short* q = base + (size_t)(i * 6 + j) * plane;
+                q[0] = (unsigned short)(hb >> 16);
+                q[kWino4sFragBytes / 2] = (unsigned short)(mb >> 16);
+                q[2 * (kWino4sFragBytes / 2)] = (unsigned short)(lb >> 16);
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void wino_pack_any(const WinoPackArgs& p, long first, long stride)
 {
-    if (p.tile == 23) winox3_pack_body(p, first, stride);
+    if (p.tile == 44) wino4s_pack_body(p, first, stride);
+    else if (p.tile == 23) winox3_pack_body(p, first, stride);
     else if (p.tile == 4) wino4_pack_body(p, first, stride);
     else wino2_pack_body(p, first, stride);
 }

@@ -134,6 +134,13 @@ SIGNATURES = {
     'ct_conv_pack_weights_wino_x3_dgrad': (_I, [_P, _P, _I, _I, _P, _P]),
     'ct_conv2d_wino_x3_fwd': (_I, [C.POINTER(ConvDesc), _P, _I, _P]),
     'ct_conv2d_wino_x3_pool_fwd': (_I, [C.POINTER(ConvDesc), _P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'ct_conv_wino4s_supported': (_I, [C.POINTER(ConvDesc)]),
+    'ct_conv_wino4s_packed_bytes': (_Z, [_I, _I]),
+    'ct_conv_wino4s_workspace_bytes': (_Z, [C.POINTER(ConvDesc)]),
+    'ct_conv_pack_weights_wino4s': (_I, [_P, _P, _I, _I, _P, _P]),
+    'ct_conv_pack_weights_wino4s_dgrad': (_I, [_P, _P, _I, _I, _P, _P]),
+    'ct_conv2d_wino4s_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _Z, _I, _P]),
+    'ct_conv2d_wino4s_pool_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _Z, _I, _P, _I, _I, _I, _I, _I, _P]),
     'ct_conv_wino4_supported': (_I, [C.POINTER(ConvDesc)]),
     'ct_conv_wino4_packed_floats': (_Z, [_I, _I]),
     'ct_conv_pack_weights_wino4': (_I, [_P, _P, _I, _I, _P, _P]),

@@ -348,12 +348,18 @@ WINO = -1          # ConvStep.rt['config'] value selecting the Winograd F(2x2,3x
 WINO4 = -2         # ... the Winograd F(4x4,3x3) kernel
 WINOX = -3         # ... F(2x2,3x3) on the bf16 matrix pipe (bf16x3), two accumulators (csrc/ct_wino_x3.hip)
 WINOXQ = -5        # ... one accumulator, four-wave workgroups (two per CU)
+WINO4S = -6        # ... F(4x4,3x3) as transform / bf16x3 GEMM / transform kernels, two accumulators (csrc/ct_wino4s.hip)
+WINO4SQ = -7       # ... one accumulator
 # st.rt['wino'] values: 2, 4 = the fp32-MFMA kernels' tile sizes; F(2x2,3x3) on bf16x3: 23 = two accumulators (eight
 # waves), 24 = one accumulator in the four-wave / two-workgroups-per-CU form
-WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXQ: 24}
-WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 24: 'winoxq'}
+# 44 / 45 = F(4x4,3x3) in the three-kernel form with the GEMMs on bf16x3 (two / one accumulator)
+WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXQ: 24, WINO4S: 44, WINO4SQ: 45}
+WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 24: 'winoxq', 44: 'wino4s', 45: 'wino4sq'}
 WINOX_TILES = (23, 24)
 WINOX_VARIANT = {23: 1, 24: 2}               # the `variant` argument of ct_conv2d_wino_x3_fwd
+WINO4S_TILES = (44, 45)
+WINO4S_VARIANT = {44: 1, 45: 2}              # the `variant` argument of ct_conv2d_wino4s_fwd
+F4_TILES = (4, 44, 45)                       # every variant with F(4x4,3x3)'s rounding (accuracy policies treat them alike)
 
 
 class HipBackend:
@@ -439,6 +445,7 @@ class HipBackend:
         rt['desc'] = d
         rt['wino_ok'] = bool(lib.ct_conv_wino_supported(C.byref(d)))
         rt['winox_ok'] = bool(lib.ct_conv_wino_x3_supported(C.byref(d)))
+        rt['wino4s_ok'] = bool(lib.ct_conv_wino4s_supported(C.byref(d)))
         if rt.get('config', 0) in WINO_TILE:
             self.enable_wino(st, tile=WINO_TILE[rt['config']])
 
@@ -456,9 +463,18 @@ class HipBackend:
             raise _lib.CtdetError('%s: geometry has no Winograd path' % st.name)
         rt['x3'] = None
         tile = int(tile or 2)
-        if tile not in (2, 4) + WINOX_TILES:
-            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23 or 24)' % (st.name, tile))
-        if tile in WINOX_TILES:
+        if tile not in (2, 4) + WINOX_TILES + WINO4S_TILES:
+            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23, 24, 44 or 45)' % (st.name, tile))
+        if tile not in WINO4S_TILES:
+            rt.pop('ws4s', None)            # the three-kernel form's V / M workspace (hundreds of MB)
+        if tile in WINO4S_TILES:
+            if not rt.get('wino4s_ok'):
+                raise _lib.CtdetError('%s: geometry has no three-kernel Winograd path (cin %% 16)' % st.name)
+            if 'U4S' not in rt:
+                rt['U4S'] = self.alloc((self.lib.ct_conv_wino4s_packed_bytes(st.cin, st.cout),), torch.uint8)
+            if 'ws4s' not in rt:
+                rt['ws4s'] = self.alloc((self.lib.ct_conv_wino4s_workspace_bytes(C.byref(rt['desc'])),), torch.uint8)
+        elif tile in WINOX_TILES:
             if not rt.get('winox_ok'):
                 raise _lib.CtdetError('%s: geometry has no Winograd bf16x3 path (cin %% 16)' % st.name)
             if 'UX' not in rt:
@@ -482,6 +498,10 @@ class HipBackend:
         if st.rt['wino'] in WINOX_TILES:
             _lib.check(self.lib.ct_conv_pack_weights_wino_x3(ptrs, couts, n, st.cin, st.rt['UX'].data_ptr(), self._stream()),
                        'ct_conv_pack_weights_wino_x3')
+            return
+        if st.rt['wino'] in WINO4S_TILES:
+            _lib.check(self.lib.ct_conv_pack_weights_wino4s(ptrs, couts, n, st.cin, st.rt['U4S'].data_ptr(), self._stream()),
+                       'ct_conv_pack_weights_wino4s')
             return
         _lib.check(self.lib.ct_conv_pack_weights_wino(ptrs, couts, n, st.cin, st.rt['U'].data_ptr(), self._stream()),
                    'ct_conv_pack_weights_wino')
@@ -545,6 +565,18 @@ class HipBackend:
 
     def run_conv(self, st):
         tile = st.rt.get('wino')
+        if tile in WINO4S_TILES:         # F(4x4,3x3): transform / bf16x3 GEMM / transform (csrc/ct_wino4s.hip)
+            lib, U, ws, var = self.lib, st.rt['U4S'].data_ptr(), st.rt['ws4s'], WINO4S_VARIANT[tile]
+            pool = st.rt.get('pool')
+            if pool is not None:
+                t, poh, pow_, full = pool
+                _lib.check(lib.ct_conv2d_wino4s_pool_fwd(C.byref(st.rt['desc']), U, ws.data_ptr(), ws.numel(), var,
+                                                         t.data_ptr(), t.shape[1], 0, poh, pow_, int(full), self._stream()),
+                           st.name)
+                return
+            _lib.check(lib.ct_conv2d_wino4s_fwd(C.byref(st.rt['desc']), U, ws.data_ptr(), ws.numel(), var, self._stream()),
+                       st.name)
+            return
         if tile in WINOX_TILES:          # F(2x2,3x3) on the bf16 matrix pipe (csrc/ct_wino_x3.hip)
             lib, U, dual = self.lib, st.rt['UX'].data_ptr(), WINOX_VARIANT[tile]
             pool = st.rt.get('pool')
@@ -713,6 +745,8 @@ def wino_tiles(backend=None, st=None):
             tiles = tiles + (4,)        # short channel sums: F(4x4) / fp32 costs little accuracy there
     if st is not None and not st.rt.get('winox_ok'):
         tiles = tuple(t for t in tiles if t not in WINOX_TILES)
+    if st is not None and not st.rt.get('wino4s_ok'):
+        tiles = tuple(t for t in tiles if t not in WINO4S_TILES)
     return tiles
 
 
@@ -767,7 +801,7 @@ def apply_tuned(backend, st, batch, wino4=True):
     if cfg in codes and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
         allowed = wino_tiles(backend, st)
         want = codes[cfg]
-        if want == 4 and not wino4:
+        if want in F4_TILES and not wino4:
             want = 2
         if getattr(backend, 'wino_tile_set', None) is not None:
             # accuracy policy of this runtime: F(4x4) / fp32 survives only where the policy allows it (short channel sums),
@@ -776,6 +810,11 @@ def apply_tuned(backend, st, batch, wino4=True):
                 want = 23 if 23 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
         elif want not in allowed:
             want = 2 if 2 in allowed or not allowed else allowed[0]
+        # experiment hook: CTDET_W4S_MIN_CIN=n moves the table's F(4x4,3x3) layers with >= n input channels to the
+        # three-kernel form (44) without re-tuning
+        w4s = int(os.environ.get('CTDET_W4S_MIN_CIN', '0') or 0)
+        if want == 4 and w4s and st.cin >= w4s and st.rt.get('wino4s_ok') and getattr(backend, 'wino_tile_set', None) is None:
+            want = int(os.environ.get('CTDET_W4S_TILE', '44'))
         backend.enable_wino(st, tile=want)
         return True
     if isinstance(cfg, str) and cfg.startswith('x3:'):

@@ -327,6 +327,29 @@ int ct_conv2d_wino_x3_fwd(const ct_conv_desc* desc, const void* upacked, int var
 int ct_conv2d_wino_x3_pool_fwd(const ct_conv_desc* desc, const void* upacked, int variant, float* pool_out, int pool_ctot,
                                int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
 
+/* Winograd F(4x4,3x3) in three kernels with the transform-domain GEMMs on the bf16 matrix pipe (csrc/ct_wino4s.hip): the
+ * wide 3x3 layers of the VGG trunk and the multibox heads (models/RFB_Net_vgg.py:219-227 conv3_x .. conv5_x, :238-248)
+ * -- same descriptor, transforms (interpolation points 0, +-3/4, +-3/2, inf), epilogue, pooling fusion and head scatter as
+ * ct_conv2d_wino4_fwd, fp32 results equal to it up to summation order; cin % 16 == 0.  An input-transform kernel writes
+ * V = B^T d B once per (tile, channel), split exactly into three bfloat16 pieces, as MFMA operand fragments; 36 GEMMs
+ * M[xi] = U[xi] V[xi] (128 x 128 blocks, operands by LDS-DMA, six piece products per multiply-add, no vector-ALU work in
+ * the loop); an output-transform kernel applies A^T M A and the epilogue.  V and M live in the caller's `workspace`
+ * (ct_conv_wino4s_workspace_bytes(desc) bytes: 13.5 bytes per (output pixel, input channel) + 9 per (output pixel,
+ * output channel); launches on different streams need different workspaces).  Weights: ct_conv_pack_weights_wino4s
+ * (ct_conv_wino4s_packed_bytes bytes).  variant 1: the hi.hi products in their own accumulator; 2: one accumulator. */
+int ct_conv_wino4s_supported(const ct_conv_desc* desc);
+size_t ct_conv_wino4s_packed_bytes(int cin, int cout);
+size_t ct_conv_wino4s_workspace_bytes(const ct_conv_desc* desc);
+int ct_conv_pack_weights_wino4s(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                ct_stream_t stream);
+int ct_conv_pack_weights_wino4s_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                      ct_stream_t stream);
+int ct_conv2d_wino4s_fwd(const ct_conv_desc* desc, const void* upacked, void* workspace, size_t workspace_bytes,
+                         int variant, ct_stream_t stream);
+int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* desc, const void* upacked, void* workspace, size_t workspace_bytes,
+                              int variant, float* pool_out, int pool_ctot, int pool_coff, int pool_oh, int pool_ow,
+                              int write_full, ct_stream_t stream);
+
 /* ---- "bf16x3": the fp32 convolution of ct_conv2d_fwd on the bf16 matrix pipe (csrc/ct_conv_x3.hip) ----
  * Same layers (models/RFB_Net_vgg.py:7-22 BasicConv, the plain Conv2d layers, the multibox heads :238-248), the same
  * descriptor (NCHW fp32 in / out, channel slices, residual, per-channel floor, head scatter, ksplit slabs) and the

@@ -217,6 +217,85 @@ def test_phase2_training_step_vs_oracle_autograd(size, setting):
     assert not bad, sorted(bad.items())[:12]
 
 
+def _ctx_step_on_device_pattern(size, setting, C, B, batch_stats, seed):
+    """Every parameter gradient of one RFBNet + Context-Transformer training step against float64 autograd on the linear
+    piece the DEVICE evaluated: the plan replayed by tests/emu_backend.py with the device's ReLU pattern and pool arg-max,
+    and the Context-Transformer block (the oracle's context_block) differentiated AT the device's raw conf logits --
+    the float64 logits are shifted onto the device's values by a constant, so the block's Jacobian is the one the
+    device's backward has to reproduce while the gradient still flows into the float64 trunk.  (The block amplifies a
+    1e-6 difference of its input ~1000x, tests/ctx_cases.py; differentiating it at the float64 trunk's own logits would
+    measure that amplification again, not the backward kernels.)
+    -> (net, {name: normalised error}, {name: reference gradient}, forward errors)"""
+    from emu_backend import replay_plan_autograd
+    net = _net(size, C, setting).train()
+    if not batch_stats:
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.eval()
+    x = synth.images(B, size, 'randn', seed)
+    sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    out = net(x.cuda())
+    g = torch.Generator().manual_seed(seed + 1)
+    R = [torch.randn(t.shape, generator=g) / t.numel() ** 0.5 for t in out]
+    sum((t * r.cuda()).sum() for t, r in zip(out, R)).backward()
+    trt = net.train_runtime(B)
+    named = dict(net.named_parameters())
+    leaf = {id(p): sd[n].double().requires_grad_(n != 'scale') for n, p in named.items()}
+
+    def masks(st, off, cout):
+        return (trt.bufs[st.dst][:, st.dst_coff + off:st.dst_coff + off + cout] > 0).cpu()
+    loc64, raw64, obj64 = replay_plan_autograd(trt.plan, leaf, x, masks, pool_inputs=lambda st: trt.bufs[st.src].cpu(),
+                                               batch_stats=batch_stats)
+    raw_dev = trt.bufs['conf'].view(B, -1).cpu()
+    fwd = {'loc': rel_err(out[0].detach().cpu().reshape(B, -1), loc64.detach().float()),
+           'raw conf': rel_err(raw_dev, raw64.detach().float()),
+           'obj': rel_err(out[2].detach().cpu().reshape(B, -1), obj64.detach().float())}
+    at = raw64 + (raw_dev.double() - raw64).detach()            # the device's point, the float64 graph
+    pooled = []
+    for st in sorted((s for s in trt.plan.steps if s.kind == 'ctxpool'), key=lambda s: s.dst_base):
+        n = st.h * st.w * st.ch
+        cut = lambda t: t[:, st.src_base:st.src_base + n].reshape(B, st.h, st.w, st.ch).permute(0, 3, 1, 2)
+        _, idx = F.max_pool2d(cut(raw_dev), st.k, st.k, ceil_mode=True, return_indices=True)
+        y = cut(at).flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+        pooled.append(y.permute(0, 2, 3, 1).reshape(B, -1))
+    pooled = torch.cat(pooled, 1)
+    assert torch.equal(pooled.detach().float(), trt.bufs['pool'].view(B, -1).cpu())
+    blk_sd = {n: leaf[id(p)] for n, p in named.items() if n.split('.')[0] in
+              ('theta', 'phi', 'g', 'Wz', 'OBJ_Target', 'fc_base', 'scale')}
+    conf64 = rfbnet_ref.context_block(blk_sd, at.view(B, -1, C), pooled.view(B, -1, C), setting)
+    fwd['conf'] = rel_err(out[1].detach().cpu(), conf64.detach().float())
+    sum((t.reshape(B, -1) * r.double().reshape(B, -1)).sum() for t, r in zip((loc64, conf64, obj64), R)).backward()
+    errs, refs = {}, {}
+    for n, p in named.items():
+        if n == 'scale':
+            assert p.grad is None
+            continue
+        assert p.grad is not None, n
+        refs[n] = leaf[id(p)].grad
+        errs[n] = rel_err(p.grad.cpu().double(), refs[n])
+    return net, errs, refs, fwd
+
+
+@pytest.mark.parametrize('size,B', [(300, 8), (512, 8)])
+def test_phase2_frozen_bn_gradients_match_fp64_on_the_device_activation_pattern(size, B):
+    """VERDICT r03 'weak' item: the RFBNet-512 + Context-Transformer bs-8 step (the training configuration bench.py /
+    tools/train_bench.py time, BASELINE configs[3]) with every parameter gradient -- trunk, heads and the block's own
+    -- held to 1e-4 of float64 autograd, BatchNorm in eval mode (a fine-tune that keeps the statistics).  See
+    _ctx_step_on_device_pattern for what is compared."""
+    net, errs, refs, fwd = _ctx_step_on_device_pattern(size, 'transfer', 60, B, False, 777)
+    for n in ('loc', 'raw conf', 'obj', 'conf'):
+        assert fwd[n] < 1e-4, (n, fwd)
+    gmax = max(float(v.abs().max()) for v in refs.values())
+    worst = {}
+    for n, e in errs.items():
+        if float(refs[n].abs().max()) < 1e-9 * gmax:        # phi.bias: softmax is shift-invariant, true gradient 0
+            assert float(dict(net.named_parameters())[n].grad.abs().max()) < 1e-4 * gmax, n
+            continue
+        if e >= 1e-4:
+            worst[n] = e
+    assert not worst, ' '.join('%s:%.1e' % kv for kv in sorted(worst.items(), key=lambda kv: -kv[1])[:12])
+
+
 def test_init_reweight_on_device_vs_oracle():
     """train.py:252-286 through the product: model(x, init=True) + ct_match_batched + class means."""
     from layers.functions import PriorBox

@@ -1,5 +1,6 @@
-"""Winograd F(2x2,3x3) and F(4x4,3x3) convolutions (ct_conv2d_wino_fwd, ct_conv2d_wino4_fwd, and F(2x2,3x3) on the
-bf16 matrix pipe: ct_conv2d_wino_x3_fwd, eight-wave / two accumulators and four-wave / one accumulator) against torch-CPU conv2d
+"""Winograd F(2x2,3x3) and F(4x4,3x3) convolutions (ct_conv2d_wino_fwd, ct_conv2d_wino4_fwd, F(2x2,3x3) on the
+bf16 matrix pipe: ct_conv2d_wino_x3_fwd, eight-wave / two accumulators and four-wave / one accumulator, and F(4x4,3x3) as
+transform / bf16x3 GEMM / transform kernels: ct_conv2d_wino4s_fwd, two / one accumulator) against torch-CPU conv2d
 and against the direct implicit-GEMM kernel: same descriptor, same fused epilogues, 1e-4 relative (north_star's fp32
 bar; F(4x4,3x3)'s own rounding is about 2e-5 of the output range at 512 input channels, checked below against fp64)."""
 import zlib
@@ -14,9 +15,9 @@ from test_gpu_kernels import _bn, _ref_conv, _run_conv
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 W = engine.WINO
-VARIANTS = [engine.WINO, engine.WINO4, engine.WINOX, engine.WINOXQ]
-VIDS = ['f2x2', 'f4x4', 'f2x2_x3', 'f2x2_x3q']
-X3V = (engine.WINOX, engine.WINOXQ)         # cin must be a multiple of 16 (one bf16 MFMA k-group)
+VARIANTS = [engine.WINO, engine.WINO4, engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ]
+VIDS = ['f2x2', 'f4x4', 'f2x2_x3', 'f2x2_x3q', 'f4x4_s', 'f4x4_sq']
+X3V = (engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ)         # cin must be a multiple of 16 (one bf16 MFMA k-group)
 
 
 def _cin(W, cin):
@@ -170,8 +171,8 @@ def test_conv_input_above_2gib_is_chunked(use_wino):
         assert rel_err(got[n:n + 1], want) < TOL, n
 
 
-@pytest.mark.parametrize('W,bound', [(engine.WINO, 3e-6), (engine.WINO4, 5e-5), (engine.WINOX, 1e-6), (engine.WINOXQ, 2e-6)],
-                         ids=VIDS)
+@pytest.mark.parametrize('W,bound', [(engine.WINO, 3e-6), (engine.WINO4, 5e-5), (engine.WINOX, 1e-6), (engine.WINOXQ, 2e-6),
+                                     (engine.WINO4S, 5e-5), (engine.WINO4SQ, 5e-5)], ids=VIDS)
 def test_wino_rounding_error_vs_fp64(W, bound):
     """The transform-domain rounding of each variant on the deepest VGG shape (512 input channels, post-ReLU input):
     max error over the output range against an fp64 convolution.  Measured 1e-6 for F(2x2,3x3) and 2e-5 for
@@ -283,7 +284,7 @@ def test_autotune_times_every_variant_and_keeps_a_correct_one(monkeypatch):
     every direct tile, the bf16x3 tiles and the four Winograd variants are timed on the layer's real buffers; whatever
     wins must still produce the reference result."""
     monkeypatch.setenv('CTDET_TUNE', '1')
-    monkeypatch.setenv('CTDET_WINO_TILES', '2,4,23,24')        # default: the two fp32-MFMA kernels only
+    monkeypatch.setenv('CTDET_WINO_TILES', '2,4,23,24,44,45')        # default: the two fp32-MFMA kernels only
     g = torch.Generator().manual_seed(77)
     B, Cin, H, Wd, Cout = 2, 64, 19, 19, 96
     x = torch.randn(B, Cin, H, Wd, generator=g)
@@ -298,7 +299,7 @@ def test_autotune_times_every_variant_and_keeps_a_correct_one(monkeypatch):
     best, times = be.tune_conv(st)
     finite = [t for t in times if t != float('inf')]
     assert len(finite) >= 4 + len(engine.wino_tiles(be, st)) and min(finite) > 0
-    assert set(engine.wino_tiles(be, st)) == {2, 4, 23, 24}
+    assert set(engine.wino_tiles(be, st)) == {2, 4, 23, 24, 44, 45}
     bufs['y'].fill_(float('nan'))
     be.run_conv(st)
     torch.cuda.synchronize()

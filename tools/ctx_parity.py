@@ -48,18 +48,23 @@ for pol in a.policies.split(','):
         print('   %5s %5s %6s | %-10s %-10s %-10s | %-10s %-10s %-5s | %s' % ('batch', 'seed', 'input', 'GPU-CPU32', 'GPU-fp64', 'CPU32-fp64',
                                                                           'q GPU-64', 'q CPU-64', 'ratio', 'verdict'))
         sd32, sd64 = cc.state(net), cc.state(net, torch.float64)
-        bad = far = 0
+        bad, far, worst_cpu = {}, {}, {}
         for batch in [int(b) for b in a.batches.split(',')]:
             for seed in [int(s) for s in a.seeds.split(',')]:
                 for kind in a.kinds.split(','):
                     r = cc.sweep_case(net, a.size, 60, 'transfer', batch, seed, kind, sd32, sd64)
                     v = cc.verdict(r)
-                    bad += v != 'ok'
-                    far += r['gpu_fp64'] > r['cpu32_fp64']
+                    bad[kind] = bad.get(kind, 0) + (v != 'ok')
+                    far[kind] = far.get(kind, 0) + (r['gpu_fp64'] > r['cpu32_fp64'])
+                    worst_cpu[kind] = max(worst_cpu.get(kind, 0.0), r['cpu32_fp64'])
                     print('   %5d %5d %6s | %.2e   %.2e   %.2e   | %.2e   %.2e   %.2f  | %s'
                           % (batch, seed, kind, r['gpu_cpu32'], r['gpu_fp64'], r['cpu32_fp64'], r['q_gpu_fp64'],
                              r['q_cpu32_fp64'], r['q_gpu_fp64'] / r['q_cpu32_fp64'], v), flush=True)
-        print('   cases not within 1e-4 of the fp32 CPU path: %d' % bad)
-        print('   cases where the device is further from fp64 than the CPU fp32 path (max norm): %d' % far)
+        for kind in bad:
+            # un-normalised 0..255 inputs saturate the random-weight network: the fp32 CPU path itself is 1e-3 .. 1e-1 from
+            # fp64 there (the block's arg-max flips), so those rows show the conditioning, they cannot be judged at 1e-4
+            note = '' if worst_cpu[kind] < 1e-3 else '   [CPU fp32 itself up to %.1e from fp64: ill-conditioned input, not judged]' % worst_cpu[kind]
+            print('   %-5s cases not within 1e-4 of the fp32 CPU path: %d; device further from fp64 than the CPU fp32 path (max norm): %d%s'
+                  % (kind, bad[kind], far[kind], note))
     del net
     torch.cuda.empty_cache()

@@ -13,7 +13,8 @@ SHAPES = {  # B, Cin, H, W, Cout
     'base.19': (32, 512, 38, 38, 512), 'base.24': (32, 512, 19, 19, 512), 'head.0': (32, 512, 38, 38, 156),
     'base.19.b4': (4, 512, 38, 38, 512), 'base.2.b4': (4, 64, 300, 300, 64),
     'base.24.b4': (4, 512, 19, 19, 512), 'head.0.b4': (4, 512, 38, 38, 156), 'head.1.b4': (4, 1024, 19, 19, 156),
-    'base.24.b8': (8, 512, 19, 19, 512),
+    'base.24.b8': (8, 512, 19, 19, 512), 'base.14': (32, 256, 75, 75, 256), 'head.1': (32, 1024, 19, 19, 156),
+    'base.17b': (32, 256, 38, 38, 512), 'c512.4': (32, 512, 64, 64, 512),
     'small': (2, 16, 21, 37, 40), 'tiny': (1, 8, 8, 8, 64), 'b2.b2': (2, 64, 300, 300, 64),
 }
 names = sys.argv[1:] or ['base.2', 'base.7', 'base.12', 'base.19', 'base.24']
@@ -33,8 +34,8 @@ for name in names:
     ref = None
     if os.environ.get('CHECK', '1') != '0' and B * Cin * H * W <= 64 << 20:
         ref = torch.relu(torch.nn.functional.conv2d(bufs['x'].double(), w.double(), b.double(), padding=1))
-    for tile in [int(t) for t in os.environ.get('TILES', '2,4,23,24').split(',')]:
-        if tile in (23, 24) and Cin % 16:
+    for tile in [int(t) for t in os.environ.get('TILES', '2,4,23,24,44,45').split(',')]:
+        if tile in (23, 24, 44, 45) and Cin % 16:
             continue
         be.enable_wino(st, tile=tile)
         bufs['y'].fill_(float('nan'))
@@ -52,8 +53,8 @@ for name in names:
         ms = e0.elapsed_time(e1) / iters
         fl = st.flops(B)
         # executed matrix work: F(2x2) 16/36, F(4x4) 36/144 of the direct count; bf16x3 = six bf16 products each
-        ex = 0.25 if tile == 4 else (16 / 36) * (6 if tile in (23, 24) else 1)
-        peak = 2500.0 if tile in (23, 24) else 157.3
+        ex = 0.25 if tile == 4 else 0.25 * 6 if tile in (44, 45) else (16 / 36) * (6 if tile in (23, 24) else 1)
+        peak = 2500.0 if tile in (23, 24, 44, 45) else 157.3
         print('%-10s F%-2d %4d->%-4d @%3dx%-3d bs%-2d  %8.1f us  %6.1f TF algorithmic  %6.1f TF executed = %.3f of %.1f%s'
               % (name, tile, Cin, Cout, H, W, B, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 * ex, fl / ms / 1e9 * ex / peak, peak, err),
               flush=True)
