@@ -67,9 +67,12 @@ PEAK_HBM_GBS = 8000.0               # HBM3E spec (6.3 TB/s achievable, MI355X_MI
 # multiplications executed / direct-convolution multiplications: F(2x2,3x3) 16 per 4 outputs x 9, F(4x4,3x3) 36 per 16 x 9
 # st.rt['wino'] codes 23 / 24 are F(2x2,3x3) on the bf16 pipe (csrc/ct_wino_x3.hip): every
 # transform-domain multiplication is six bf16 MFMA products (bf16x3), priced against the bf16 MFMA peak
-WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0, 23: 16.0 / 36.0, 24: 16.0 / 36.0}
-WINOGRAD_KERNEL = {2: 'wino_f2x2_3x3_f32', 4: 'wino_f4x4_3x3_f32', 23: 'wino_f2x2_3x3_x3', 24: 'wino_f2x2_3x3_x3q'}
-WINOGRAD_X3 = (23, 24)
+WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0, 23: 16.0 / 36.0, 24: 16.0 / 36.0, 44: 36.0 / 144.0, 45: 36.0 / 144.0}
+# 44 / 45: one conv launch = three kernels (csrc/ct_wino4s.hip: wino4s_in, wino4s_gemm<dual>, wino4s_out)
+WINOGRAD_KERNEL = {2: 'wino_f2x2_3x3_f32', 4: 'wino_f4x4_3x3_f32', 23: 'wino_f2x2_3x3_x3', 24: 'wino_f2x2_3x3_x3q',
+                   44: 'wino4s(in+gemm+out)', 45: 'wino4sq(in+gemm+out)'}
+WINOGRAD_X3 = (23, 24, 44, 45)
+WINOGRAD_F4 = (4, 44, 45)
 
 
 def _lib_config_name(cfg):
@@ -249,7 +252,7 @@ def conv_roofline(rt, batch, pmc):
         'flops_per_launch': round(fx / n),
         'flops_definition': 'multiply-adds x2 executed on the matrix pipe per launch' +
                             (' = direct-convolution flops x %s (Winograd F(%dx%d,3x3), output-tile padding not counted)%s'
-                             % ('36/144' if wino == 4 else '16/36', 4 if wino == 4 else 2, 4 if wino == 4 else 2,
+                             % ('36/144' if wino in WINOGRAD_F4 else '16/36', 4 if wino in WINOGRAD_F4 else 2, 4 if wino in WINOGRAD_F4 else 2,
                                 ' x 6 (bf16x3 split, bf16 MFMA pipe)' if wino in WINOGRAD_X3 else '') if wino else
                              ' = direct-convolution flops x 6 (bf16x3 split, bf16 MFMA pipe)' if name.startswith('conv_x3') else ''),
         'algorithmic_flops_per_launch': round(f / n),
@@ -311,6 +314,20 @@ def stage_rooflines(pipe, x, steps, pmc):
         # 20 B row in + 4 B kept index out per candidate (SURVEY 8d "20N in + 4N out"), both NMS passes share it
         'nms_segments_kernel': ('hbm', cand * 24),
     }
+    w4s = [st for st in pipe.rt.conv_steps() if int(st.rt.get('wino') or 0) in (44, 45)]
+    if w4s:
+        # the three kernels of the F(4x4,3x3) / bf16x3 layers, summed over the layers of a step (csrc/ct_wino4s.hip):
+        # tiles padded to 128, couts to 128; V = 36 points x 3 bf16 pieces, M = 36 points x fp32
+        gf = ib = ob = 0.0
+        for st in w4s:
+            tiles = B * ((st.oh + 3) // 4) * ((st.ow + 3) // 4)
+            tpad, mpad = -(-tiles // 128) * 128, -(-st.cout // 128) * 128
+            gf += 36.0 * tpad * st.cin * mpad * 2 * 6
+            ib += 4.0 * B * st.cin * st.h * st.w + 6.0 * 36 * tpad * st.cin
+            ob += 4.0 * 36 * tiles * st.cout + 4.0 * B * st.cout * st.oh * st.ow
+        work['wino4s_gemm'] = ('mfma_bf16', gf)
+        work['wino4s_in'] = ('hbm', ib)
+        work['wino4s_out'] = ('hbm', ob)
     if net.method == 'ours' and net.phase == 2:
         d, M = net.num_classes, pipe.rt.plan.M
         work['ctx_attn_kernel'] = ('mfma', B * 4.0 * P * M * d)      # QK^T and PV contractions, 2 flop per multiply-add
@@ -324,7 +341,9 @@ def stage_rooflines(pipe, x, steps, pmc):
         t, cnt = agg[kname]
         per_launch = amount / (cnt / steps)
         avg = t / cnt
-        if bound == 'mfma':
+        if bound == 'mfma_bf16':
+            ach, peak, unit, bound = per_launch / avg / 1e12, PEAK_BF16_MFMA_TFLOPS, 'TFLOP/s', 'mfma'
+        elif bound == 'mfma':
             ach, peak, unit = per_launch / avg / 1e12, PEAK_F32_MFMA_TFLOPS, 'TFLOP/s'
         else:
             ach, peak, unit = per_launch / avg / 1e9, PEAK_HBM_GBS, 'GB/s'
@@ -679,12 +698,28 @@ def main():
         pipe.rt.event_log = None
         log('stage rooflines (library profile scopes, 5 extra steps)')
         roof['stages'] = stage_rooflines(pipe, x, 5, pmc)
+        g = roof['stages'].get('wino4s_gemm')
+        if roof['kernel'].startswith('wino4s') and g:
+            # the dominant conv launch is a three-kernel one: the line's kernel-level fields describe its matrix kernel
+            # (HIP events of the library's profile scopes on the launch stream, 5 eager steps), the launch-level numbers
+            # (transform kernels included) stay in `dominant_launch`
+            roof['dominant_launch'] = {k: roof[k] for k in ('kernel', 'launches', 'avg_launch_us', 'achieved', 'frac',
+                                                            'flops_per_launch', 'flops_definition')}
+            roof.update({'kernel': 'wino4s_gemm', 'bound': 'mfma', 'achieved': g['achieved'], 'peak': g['peak'],
+                         'frac': g['frac'], 'traffic': g['traffic'], 'avg_launch_us': g['avg_launch_us'],
+                         'launches': int(round(g['launches_per_step'] * 5)), 'flops_per_launch': g['algorithmic_per_launch'],
+                         'flops_definition': 'multiply-adds x2 executed on the bf16 matrix pipe per launch: 36 transform points x '
+                                             '(tiles padded to 128) x cin x (cout padded to 128) x 6 piece products (bf16x3), '
+                                             'averaged over the layers that run this kernel',
+                         'measured_sustained_peak': {'bf16_mfma_tflops_gaussian_operands': 1722, 'bf16_mfma_tflops_zero_operands': 2474,
+                                                     'source': 'tools/ubench/mfma_power.hip, profiles/r04_mfma_power.txt: a loop of '
+                                                               'MFMAs without any memory traffic; this box lowers its clock under real data'}})
         roof['traffic_source'] = sorted({v[1] for v in pmc.values()}) or None
     counts = int(pipe.post.out_count.sum().item())
     def kind(st):
         w = int(st.rt.get('wino') or 0)
         if w:
-            return 'winograd_x3' if w in WINOGRAD_X3 else 'winograd'
+            return 'winograd_x3' if w in WINOGRAD_X3 else 'winograd'      # 23 / 24 fused F(2x2), 44 / 45 three-kernel F(4x4)
         if st.rt.get('x3') is not None:
             return 'bf16x3'
         cfg = st.rt['desc'].config

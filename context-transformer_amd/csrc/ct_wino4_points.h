@@ -52,6 +52,31 @@ __device__ __forceinline__ void at4(const float (&m)[6], float (&y)[4])
     y[3] = fmaf(Q3, s, P3 * n) + m[5];
 }
 
+// The same two transforms in double (ct_wino4s.hip: its transform kernels are memory-bound, so B^T d B and A^T M A are
+// evaluated in double and rounded ONCE -- the fp32 chains above round after every operation).
+__device__ __forceinline__ void bt6d(const double (&d)[6], double (&o)[6])
+{
+    const double a = d[4] - (double)Q2 * d[2];
+    const double b = (double)P * (d[3] - (double)Q2 * d[1]);
+    const double c = d[4] - (double)P2 * d[2];
+    const double e = (double)Q * (d[3] - (double)P2 * d[1]);
+    o[0] = (double)P2Q2 * d[0] - (double)SPQ * d[2] + d[4];
+    o[1] = a + b;
+    o[2] = a - b;
+    o[3] = c + e;
+    o[4] = c - e;
+    o[5] = (double)P2Q2 * d[1] - (double)SPQ * d[3] + d[5];
+}
+
+__device__ __forceinline__ void at4d(const double (&m)[6], double (&y)[4])
+{
+    const double p = m[1] + m[2], n = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
+    y[0] = m[0] + p + r;
+    y[1] = (double)Q * s + (double)P * n;
+    y[2] = (double)Q2 * r + (double)P2 * p;
+    y[3] = (double)Q3 * s + (double)P3 * n + m[5];
+}
+
 // e -> A e   (A = (A^T)^T: rows [1 0 0 0], [1 +-p p2 +-p3], [1 +-q q2 +-q3], [0 0 0 1])
 __device__ __forceinline__ void a6(const float (&e)[4], float (&o)[6])
 {

@@ -94,6 +94,19 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
     l = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, m));
 }
 
+// the same from a double: hi and mid by truncation, lo ROUNDED to nearest (x - hi - mid is exact in double), so the three
+// pieces carry x to 2^-25 relative
+__device__ __forceinline__ void split3d(double x, unsigned& h, unsigned& m, unsigned& l)
+{
+    h = __builtin_bit_cast(unsigned, (float)x) & 0xFFFF0000u;
+    // (float)x may round UP past x: the remainder is then negative, which the signed pieces carry just as well
+    const double r1 = x - (double)__builtin_bit_cast(float, h);
+    m = __builtin_bit_cast(unsigned, (float)r1) & 0xFFFF0000u;
+    const float r2 = (float)(r1 - (double)__builtin_bit_cast(float, m));
+    const unsigned rb = __builtin_bit_cast(unsigned, r2);
+    l = rb + 0x7FFFu + ((rb >> 16) & 1u);              // round to nearest even into the upper half
+}
+
 __device__ __forceinline__ int pack_hi(unsigned e0, unsigned e1)      // [bf16 e0 | bf16 e1 << 16]
 {
     return (int)__builtin_amdgcn_perm(e1, e0, 0x07060302u);
@@ -364,17 +377,21 @@ __global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) m[i][j] = __builtin_nontemporal_load(src + (size_t)(i * 6 + j) * a.m_plane);
-    float t[6][4];
+    // A^T M A in double, rounded once: this kernel waits for HBM, the fp32 chain of ct_wino4.hip rounds ~10 times per output
+    double t[6][4];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) at4(m[i], t[i]);
+    for (int i = 0; i < 6; ++i) {
+        const double row[6] = {m[i][0], m[i][1], m[i][2], m[i][3], m[i][4], m[i][5]};
+        ctdet::w4::at4d(row, t[i]);
+    }
     float y[4][4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-        const float col[6] = {t[0][b], t[1][b], t[2][b], t[3][b], t[4][b], t[5][b]};
-        float o[4];
-        at4(col, o);
+        const double col[6] = {t[0][b], t[1][b], t[2][b], t[3][b], t[4][b], t[5][b]};
+        double o[4];
+        ctdet::w4::at4d(col, o);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) y[r][b] = o[r];
+        for (int r = 0; r < 4; ++r) y[r][b] = (float)o[r];
     }
     const int n = T / (a.TY * a.TX);
     const int rem = T - n * (a.TY * a.TX);

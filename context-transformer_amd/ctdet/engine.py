@@ -727,16 +727,17 @@ def x3_allowed(st):
 
 
 def wino_tiles(backend=None, st=None):
-    """Winograd variants the tuner / the table may use (st.rt['wino'] codes).  Default: the two fp32-MFMA kernels
-    ('2,4').  The F(2x2) bf16x3 forms (23: two accumulators; 24: four-wave workgroups) are faster per layer ALONE
-    (512 -> 512 @38x38: 742 -> 630 us) but not in the two-stream pipeline, where the side stream already fills the idle
-    last round of the 800-workgroup F(4x4) launches (same-box A/B of two tables: 3 360-3 371 vs 3 228-3 398 images/s,
-    DESIGN.md section 4), so the committed table does not hold them; CTDET_WINO_TILES=2,4,23,24 lets the tuner time all
-    four.  A runtime with an accuracy policy (ctx_tile_set: networks with the Context-Transformer block) uses ITS set
-    instead (narrowed by an explicit CTDET_WINO_TILES), plus F(4x4) / fp32 on layers with at most wino4_max_cin input
-    channels."""
+    """Winograd variants the tuner / the table may use (st.rt['wino'] codes).  Default '2,4,44': the two fp32-MFMA kernels
+    and the three-kernel F(4x4,3x3) / bf16x3 form with two accumulators (csrc/ct_wino4s.hip).  The fused F(2x2) bf16x3
+    forms (23: two accumulators; 24: four-wave workgroups) are faster than the fused fp32 kernels per layer ALONE
+    (512 -> 512 @38x38: 742 -> 630 us) but not in the two-stream pipeline (same-box A/B of two tables: 3 360-3 371 vs
+    3 228-3 398 images/s) and slower than tile 44 wherever that applies, so the committed table does
+    not hold them; CTDET_WINO_TILES=2,4,23,24,44,45 lets the tuner time all six.  A runtime with an accuracy policy
+    (ctx_tile_set: networks with the Context-Transformer block) uses ITS set instead (narrowed by an explicit
+    CTDET_WINO_TILES), plus F(4x4) / fp32 on layers with at most wino4_max_cin input channels (and tile 44 from
+    ctx_w4s_min_cin input channels up, see apply_tuned)."""
     env = os.environ.get('CTDET_WINO_TILES')
-    tiles = tuple(int(t) for t in (env or '2,4').split(',') if t)
+    tiles = tuple(int(t) for t in (env or '2,4,44').split(',') if t)
     allowed = getattr(backend, 'wino_tile_set', None)
     if allowed is not None:             # a runtime's accuracy policy: its set, narrowed by an explicit CTDET_WINO_TILES
         tiles = tuple(t for t in allowed if env is None or t in tiles)
@@ -790,6 +791,19 @@ def ctx_f4_max_cin(net):
     return int(os.environ.get('CTDET_CTX_F4_MAX_CIN', CTX_F4_MAX_CIN_DEFAULT)) if ctx_tile_set(net) is not None else 0
 
 
+CTX_W4S_MIN_CIN_DEFAULT = '128'
+
+
+def ctx_w4s_min_cin(net):
+    """Layers of a Context-Transformer network with at least this many input channels that the table runs on F(4x4,3x3)
+    (fused or three-kernel) use the three-kernel bf16x3 form with two accumulators (tile 44: error vs fp64 2e-6 per layer
+    against 5e-6 for the fused fp32 kernel, and 1.7x its speed on the wide layers).  Measured (profiles/r04_ctx_policy.txt,
+    RFBNet-300 + Context-Transformer bs 32, 9 randn sweep cases, same session): 0 (none): 2 594 images/s, worst GPU-CPU32
+    9.25e-5; 256: 3 015, 1.02e-4 (one case above 1e-4); **128 (default): 2 915, 8.9e-5 -- all nine inside the flat 1e-4**.
+    CTDET_CTX_W4S_MIN_CIN; 0 = none."""
+    return int(os.environ.get('CTDET_CTX_W4S_MIN_CIN', CTX_W4S_MIN_CIN_DEFAULT)) if ctx_tile_set(net) is not None else 0
+
+
 def apply_tuned(backend, st, batch, wino4=True):
     """Give a prepared conv step the committed tile choice for its shape; False if the table has none.
     wino4=False maps a 'wino4' entry to 'wino'.  A Winograd entry the runtime's policy excludes (ctx_tile_set) becomes the
@@ -806,7 +820,10 @@ def apply_tuned(backend, st, batch, wino4=True):
         if getattr(backend, 'wino_tile_set', None) is not None:
             # accuracy policy of this runtime: F(4x4) / fp32 survives only where the policy allows it (short channel sums),
             # everything else runs the most accurate allowed variant
-            if not (want == 4 and 4 in allowed):
+            w4s_min = getattr(backend, 'ctx_w4s_min_cin', 0)
+            if want in F4_TILES and w4s_min and st.cin >= w4s_min and st.rt.get('wino4s_ok'):
+                want = 44                   # three-kernel F(4x4) with two accumulators: 0.4x the rounding of the fused fp32 form
+            elif not (want == 4 and 4 in allowed):
                 want = 23 if 23 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
         elif want not in allowed:
             want = 2 if 2 in allowed or not allowed else allowed[0]
@@ -882,6 +899,7 @@ class Runtime:
         mode = os.environ.get('CTDET_TUNE', '1') if tune is None else ('1' if tune else '0')
         backend.wino_tile_set = ctx_tile_set(net)
         backend.wino4_max_cin = ctx_f4_max_cin(net)
+        backend.ctx_w4s_min_cin = ctx_w4s_min_cin(net)
         self.tuned = False
         self.event_log = None        # set to a list to collect (step, start_event, end_event) per conv
         if getattr(backend, 'tune_conv', None) is not None:

@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib, ops
-from .engine import ConvPart, ConvStep, HipBackend, Plan, Runtime, apply_tuned, run_on_streams
+from .engine import WINO4S_TILES, ConvPart, ConvStep, HipBackend, Plan, Runtime, apply_tuned, run_on_streams
 
 
 class _StepState:
@@ -58,6 +58,7 @@ class TrainRuntime:
             for prm in self.ctx_params.values():
                 self._reg(prm)
         wino_ws = 0
+        w4s_ws = 0              # bytes: workspace of the three-kernel Winograd data gradients
         # CTDET_TRAIN_WINO4=0 keeps forward and data-gradient convolutions on F(2x2,3x3) where the table says F(4x4,3x3)
         wino4 = os.environ.get('CTDET_TRAIN_WINO4', '1') != '0'
         for st in self.plan.steps:
@@ -138,8 +139,16 @@ class TrainRuntime:
                         # cout = 156; the data gradient has cout = the source's channel count)
                         s.dgrad_tile = 4 if s.fwd.rt.get('wino') not in (None, False, 0, 2) or (wino4 and st.segs and st.oh * st.ow >= 361 and
                                                                          self.lib.ct_conv_wino4_supported(C.byref(w2))) else 2
-                        sizeof = self.lib.ct_conv_wino4_packed_floats if s.dgrad_tile == 4 else self.lib.ct_conv_wino_packed_floats
-                        s.U_d = al((sizeof(zc, st.cin),))
+                        # ... and its three-kernel bf16x3 form (tile 44) where the forward launch runs that one
+                        # (CTDET_TRAIN_W4S=0 keeps the fused kernel); V / M workspace shared by all data gradients
+                        if s.fwd.rt.get('wino') in WINO4S_TILES and os.environ.get('CTDET_TRAIN_W4S', '1') != '0' and \
+                                self.lib.ct_conv_wino4s_supported(C.byref(w2)):
+                            s.dgrad_tile = 44
+                            s.U_d = al((self.lib.ct_conv_wino4s_packed_bytes(zc, st.cin) // 4,))
+                            w4s_ws = max(w4s_ws, self.lib.ct_conv_wino4s_workspace_bytes(C.byref(w2)))
+                        else:
+                            sizeof = self.lib.ct_conv_wino4_packed_floats if s.dgrad_tile == 4 else self.lib.ct_conv_wino_packed_floats
+                            s.U_d = al((sizeof(zc, st.cin),))
             # direct data gradients on the bf16 matrix pipe (bf16x3, ct_conv2d_x3_fwd transposed): every layer without
             # a Winograd data gradient whose channel counts fit the k-step; CTDET_X3=0 keeps ct_conv2d_fwd
             s.dgrad_x3 = None
@@ -187,6 +196,7 @@ class TrainRuntime:
         # the per-launch memsets.
         self.prezero = os.environ.get('CTDET_PREZERO', '1') != '0'
         self.wgrad_ws = al((max(wino_ws // 4, 1),))
+        self.dgrad_ws4s = torch.empty(max(w4s_ws, 1), device=backend.device, dtype=torch.uint8)
         if self.prezero:
             bn_floats = sum(t.numel() for s_ in self.state.values() for t in getattr(s_, 'scratch', []))
             self.bn_scratch = al((max(bn_floats, 1),), torch.float64)
@@ -279,7 +289,8 @@ class TrainRuntime:
         ptrs = (C.c_void_p * n)(*[w for w, _ in wts])
         couts = (C.c_int * n)(*[c for _, c in wts])
         if s.dgrad_wino is not None:
-            pack = self.lib.ct_conv_pack_weights_wino4_dgrad if s.dgrad_tile == 4 else self.lib.ct_conv_pack_weights_wino_dgrad
+            pack = {4: self.lib.ct_conv_pack_weights_wino4_dgrad, 44: self.lib.ct_conv_pack_weights_wino4s_dgrad}.get(
+                s.dgrad_tile, self.lib.ct_conv_pack_weights_wino_dgrad)
             _lib.check(pack(ptrs, couts, n, st.cin, s.U_d.data_ptr(), self._s()), st.name + ' pack dgrad (winograd)')
         elif s.dgrad_x3 is not None:
             if getattr(self, '_recording', False):
@@ -589,8 +600,12 @@ class TrainRuntime:
                     if not self._batched_packs:
                         self._pack_dgrad(st, s)
                     s.dgrad_wino.res = self.grads[st.src].data_ptr() if acc else None
-                    run = lib.ct_conv2d_wino4_fwd if s.dgrad_tile == 4 else lib.ct_conv2d_wino_fwd
-                    _lib.check(run(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self._s()), st.name + ' dgrad (winograd)')
+                    if s.dgrad_tile == 44:
+                        _lib.check(lib.ct_conv2d_wino4s_fwd(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self.dgrad_ws4s.data_ptr(),
+                                                            self.dgrad_ws4s.numel(), 1, self._s()), st.name + ' dgrad (winograd 4s)')
+                    else:
+                        run = lib.ct_conv2d_wino4_fwd if s.dgrad_tile == 4 else lib.ct_conv2d_wino_fwd
+                        _lib.check(run(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self._s()), st.name + ' dgrad (winograd)')
                 else:
                     if not self._batched_packs:
                         self._pack_dgrad(st, s)

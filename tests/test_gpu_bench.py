@@ -30,14 +30,20 @@ def test_bench_line_contract():
     r = d['roofline']
     # the dominant kernel's own pipe: fp32 MFMA, or the bf16 MFMA for a bf16x3 kernel (six bf16 products per fp32 multiply-add)
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s'
-    on_bf16 = r['kernel'].startswith('conv_x3_f32') or '_x3' in r['kernel']      # bf16x3 kernels, direct or Winograd
+    # bf16x3 kernels: direct, fused Winograd F(2x2), or the GEMM kernel of the three-kernel F(4x4) form
+    on_bf16 = r['kernel'].startswith('conv_x3_f32') or '_x3' in r['kernel'] or r['kernel'].startswith('wino4s')
     assert r['peak'] == (2500.0 if on_bf16 else 157.3)
     assert 0.0 < r['frac'] <= 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     if r['kernel'].startswith('conv_x3_f32'):
         assert abs(r['flops_per_launch'] / r['algorithmic_flops_per_launch'] - 6.0) < 1e-6
     assert 'arith' in d and 'bf16x3' in d['arith']
     assert len(d['per_rank_ms_per_step']) == 1 and d['dist']['rccl_ranks'] == 1
-    if r['kernel'].startswith('wino'):
+    if r['kernel'] == 'wino4s_gemm':
+        # a three-kernel launch dominates: kernel-level fields = its matrix kernel, launch-level ones kept beside them
+        assert r['dominant_launch']['kernel'].startswith('wino4s') and r['dominant_launch']['avg_launch_us'] > r['avg_launch_us']
+        assert r['stages']['wino4s_in']['bound'] == 'hbm' and r['stages']['wino4s_out']['bound'] == 'hbm'
+        assert 0 < r['stages']['wino4s_in']['frac'] < 1 and 0 < r['stages']['wino4s_out']['frac'] < 1
+    elif r['kernel'].startswith('wino'):
         assert r['winograd_mult_ratio'] in (round(16 / 36, 4), 0.25)
         assert abs(r['flops_per_launch'] / r['algorithmic_flops_per_launch'] - r['winograd_mult_ratio'] * (6 if on_bf16 else 1)) < 1e-3
         assert r['algorithmic_frac'] > r['frac']

@@ -96,21 +96,21 @@ def test_rfb300_phase2_context_transformer(golden, setting, C):
 
 def test_winograd_tile_policy_and_phase2_full_tensor_parity(monkeypatch):
     """Networks with the Context-Transformer block (whose softmax amplifies the trunk's fp32 rounding ~1000x) run every
-    Winograd layer with more than 128 input channels on the most accurate variant -- F(2x2,3x3) on bf16x3 with two
-    accumulators (tile code 23; F(2x2,3x3) on the fp32 MFMA where the layer has no 16-channel chunks) -- and keep the table's
-    F(4x4,3x3) only on the short channel sums (engine.ctx_tile_set, ctx_f4_max_cin); every other network takes the committed
-    table as it is.  CTDET_CTX_TILES overrides the set ('any' = the table).  Every output ELEMENT (not a
-    sample) of the block stays within 1e-4 of the reference's CPU arithmetic here (bs 2, seed 1234;
-    tests/test_gpu_ctx_parity.py sweeps batch sizes and seeds)."""
+    Winograd layer with at least 128 input channels on one of the two accurate bf16x3 variants: where the table picks
+    F(4x4,3x3), its three-kernel form with two accumulators (tile code 44: error vs fp64 2e-6 against 5e-6 for the fused
+    fp32 kernel), else F(2x2,3x3) on bf16x3 with two accumulators (23; F(2x2,3x3) on the fp32 MFMA where the layer has no
+    16-channel chunks); the fused F(4x4,3x3) / fp32 kernel survives only on the short channel sums (engine.ctx_tile_set,
+    ctx_f4_max_cin, ctx_w4s_min_cin); every other network takes the committed table as it is.  CTDET_CTX_TILES overrides the
+    set ('any' = the table).  Every output ELEMENT (not a sample) of the block stays within 1e-4 of the reference's CPU
+    arithmetic here (bs 2, seed 1234; tests/test_gpu_ctx_parity.py sweeps batch sizes and seeds)."""
     net = _net(300, 60, 2, 'transfer')
     rt = net.runtime(2)
     for r in (rt, net.runtime(32)):
         tiles = [st.rt.get('wino') for st in r.conv_steps() if st.rt.get('wino')]
-        assert tiles and set(tiles) <= {2, 4, 23}, tiles
-        # long channel sums on the most accurate variant; F(4x4) / fp32 only where the sum is short (engine.ctx_f4_max_cin)
-        assert all(st.rt.get('wino') == 23 for st in r.conv_steps() if st.rt.get('wino') and st.cin % 16 == 0 and st.cin > 128)
-        assert all(st.cin <= 128 for st in r.conv_steps() if st.rt.get('wino') == 4)
-    assert any(st.rt.get('wino') == 23 and st.cin == 512 for st in net.runtime(32).conv_steps())
+        assert tiles and set(tiles) <= {2, 4, 23, 44}, tiles
+        assert all(st.rt.get('wino') in (23, 44) for st in r.conv_steps() if st.rt.get('wino') and st.cin % 16 == 0 and st.cin >= 128)
+        assert all(st.cin < 128 for st in r.conv_steps() if st.rt.get('wino') == 4)
+    assert any(st.rt.get('wino') == 44 and st.cin == 512 for st in net.runtime(32).conv_steps())
     x = synth.images(2, 300, 'randn', 1234)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     with torch.no_grad():
@@ -119,6 +119,7 @@ def test_winograd_tile_policy_and_phase2_full_tensor_parity(monkeypatch):
     for a, b, name in zip(got, want, ('loc', 'conf', 'obj')):
         assert rel_err(a.reshape(b.shape), b) < TOL, (name, rel_err(a.reshape(b.shape), b))
     monkeypatch.setenv('CTDET_CTX_F4_MAX_CIN', '0')
+    monkeypatch.setenv('CTDET_CTX_W4S_MIN_CIN', '0')
     monkeypatch.setenv('CTDET_CTX_TILES', '2')
     assert {st.rt.get('wino') for st in _net(300, 60, 2, 'transfer').runtime(32).conv_steps() if st.rt.get('wino')} == {2}
     monkeypatch.setenv('CTDET_CTX_TILES', 'any')

@@ -284,7 +284,7 @@ def test_autotune_times_every_variant_and_keeps_a_correct_one(monkeypatch):
     every direct tile, the bf16x3 tiles and the four Winograd variants are timed on the layer's real buffers; whatever
     wins must still produce the reference result."""
     monkeypatch.setenv('CTDET_TUNE', '1')
-    monkeypatch.setenv('CTDET_WINO_TILES', '2,4,23,24,44,45')        # default: the two fp32-MFMA kernels only
+    monkeypatch.setenv('CTDET_WINO_TILES', '2,4,23,24,44,45')        # default: 2,4,44
     g = torch.Generator().manual_seed(77)
     B, Cin, H, Wd, Cout = 2, 64, 19, 19, 96
     x = torch.randn(B, Cin, H, Wd, generator=g)

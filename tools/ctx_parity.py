@@ -11,6 +11,9 @@ for p in (os.path.join(REPO, 'context-transformer_amd'), REPO, os.path.join(REPO
 os.environ.setdefault('CTDET_TUNE', '0')
 import torch  # noqa: E402
 import ctx_cases as cc  # noqa: E402
+# the CPU fp32 reference depends on the thread count (torch's convolutions split their sums by thread: the same case is
+# 4.9e-5 from fp64 at 8 threads and 6.6e-5 at 128); the test suite pins 8 (tests/conftest.py, like tools/gen_goldens.py)
+torch.set_num_threads(int(os.environ.get('CTDET_REF_THREADS', '8')))
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--budget', action='store_true'); ap.add_argument('--sweep', action='store_true')

@@ -26,6 +26,8 @@ for name in names:
     b = torch.nn.Parameter(torch.zeros(Cout, device=DEV), requires_grad=False)
     st = engine.ConvStep(name, [engine.ConvPart(w, b, None, True)], Cin, 3, 3, 1, 1, 1, 1, 'x', 0, H, W, 'y', 0)
     bufs = {'x': torch.randn(B, Cin, H, W, device=DEV), 'y': torch.empty(B, Cout, H, W, device=DEV)}
+    if os.environ.get('ZERO'):                # all-zero activations: same instruction stream, idle multipliers (power experiment)
+        bufs['x'].zero_()
     be.prepare_conv(st, bufs, B)
     if os.environ.get('SK'):                  # stream-K: the launch has the device to itself
         skws = torch.empty(256 * 2 * 64 * 32 * 16, device=DEV)
