@@ -34,6 +34,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x3 __attribute__((ext_vector_type(3)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -75,6 +76,19 @@ struct Wino4sArgs {
     size_t v_plane, u_plane; // bytes per point
     size_t m_plane;          // floats per point
     int chunks_per_wg;       // wino4s_in: blockIdx.y owns chunks [y * chunks_per_wg, ...)
+};
+
+// 36 GEMMs  M[xi][row][col] = sum_k A[xi][row][k] B[xi][col][k], both operands as 12 KB fragment blocks
+// [point][block of 128 rows][k chunk of 16][sub 4][piece 3][1 KB] (forward: A = U rows = cout, B = V rows = tiles, k = cin;
+// weight gradient: A = E rows = cout, B = V rows = cin, k = tiles).  blockIdx.y = k split: chunks [y * chunks_per_split, ...)
+// into slab y of M (forward: one split).
+struct GemmArgs {
+    const unsigned char* A;
+    const unsigned char* B;
+    float* M;
+    size_t a_plane, b_plane;     // bytes per point
+    size_t m_plane, m_slab;      // floats per point / per k split
+    int chunks, chunks_per_split, rowblocks, colblocks, ldm;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -240,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void wino4s_in(const Wino4sArgs a)
 // Grid: (point, tile block, cout block) with the cout block fastest -- the workgroups that share a V block (the large
 // operand) are neighbours -- and every XCD gets a contiguous run of that sequence, so they also share an L2.
 template <bool DUAL>
-__global__ __launch_bounds__(256, 2) void wino4s_gemm(const Wino4sArgs a)
+__global__ __launch_bounds__(256, 2) void wino4s_gemm(const GemmArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
@@ -253,13 +267,15 @@ __global__ __launch_bounds__(256, 2) void wino4s_gemm(const Wino4sArgs a)
         const int q = nwg >> 3, r = nwg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
     }
-    const int cb = wg % a.kblocks;
-    const int rest = wg / a.kblocks;
-    const int tb = rest % a.tblk128;
-    const int xi = rest / a.tblk128;
+    const int cb = wg % a.rowblocks;
+    const int rest = wg / a.rowblocks;
+    const int tb = rest % a.colblocks;
+    const int xi = rest / a.colblocks;
     const unsigned strip = (unsigned)a.chunks * OPB;
-    const __amdgpu_buffer_rsrc_t rU = make_rsrc(reinterpret_cast<const unsigned char*>(a.U) + (size_t)xi * a.u_plane + (size_t)cb * strip, strip);
-    const __amdgpu_buffer_rsrc_t rV = make_rsrc(reinterpret_cast<const unsigned char*>(a.V) + (size_t)xi * a.v_plane + (size_t)tb * strip, strip);
+    const int k_begin = blockIdx.y * a.chunks_per_split;
+    const int chunks = min(a.chunks, k_begin + a.chunks_per_split) - k_begin;      // steps of this workgroup
+    const __amdgpu_buffer_rsrc_t rU = make_rsrc(a.A + (size_t)xi * a.a_plane + (size_t)cb * strip, strip);
+    const __amdgpu_buffer_rsrc_t rV = make_rsrc(a.B + (size_t)xi * a.b_plane + (size_t)tb * strip, strip);
 
     f32x16 acc[2][2], acs[2][2];
 #pragma unroll
@@ -274,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void wino4s_gemm(const Wino4sArgs a)
     auto load_step = [&](int c, int buf) {
         unsigned char* Ad = lds_raw + buf * (2 * OPB) + wave * (3 * FRAG);
         unsigned char* Bd = Ad + OPB;
-        const int soff = c * OPB + wave * (3 * FRAG);
+        const int soff = (k_begin + c) * OPB + wave * (3 * FRAG);
         (void)Ad; (void)Bd; (void)soff;
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -285,7 +301,6 @@ __global__ __launch_bounds__(256, 2) void wino4s_gemm(const Wino4sArgs a)
 #endif
     };
     constexpr int PIECES = 6;                          // DMA instructions per step and wave
-    const int chunks = a.chunks;
     // the six piece products, small ones first: (mid,mid) (lo,hi) (hi,lo) (mid,hi) (hi,mid) (hi,hi)
     constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
     const unsigned char* const Abase = lds_raw + (2 * wr) * (3 * FRAG) + voff;
@@ -351,7 +366,8 @@ __global__ __launch_bounds__(256, 2) void wino4s_gemm(const Wino4sArgs a)
     if (c < chunks) mfmas(fa0, fb0);
 
     // M[xi][cout][tile]: register r of block (i, j) = cout 32 (2 wr + i) + (r & 3) + 8 (r >> 2) + 4 kg, tile 32 (2 wc + j) + l31
-    float* const Mp = a.Mw + (size_t)xi * a.m_plane + (size_t)(cb * BM + 64 * wr + 4 * kg) * a.Tpad + tb * BT + 64 * wc + l31;
+    float* const Mp = a.M + (size_t)blockIdx.y * a.m_slab + (size_t)xi * a.m_plane + (size_t)(cb * BM + 64 * wr + 4 * kg) * a.ldm +
+                      tb * BT + 64 * wc + l31;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void wino4s_gemm(const Wino4sArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = DUAL ? acc[i][j][r] + acs[i][j][r] : acc[i][j][r];
-                Mp[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * a.Tpad + 32 * j] = v;
+                Mp[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * a.ldm + 32 * j] = v;
             }
 }
 
@@ -399,6 +415,226 @@ __global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res_bytes);
     ctdet::w4::emit_tile4(a, rout, rres, n, ty, tx, co, y);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient in the same form:  dw = G^T [ sum_tiles (A e A^T) .* (B^T d B) ] G  with 4x4 tiles e of dZ and 6x6 input
+// patches d (F(3x3,4x4), the arithmetic of ct_wino4_wgrad.hip) is, per transform point, the GEMM
+//   dU[xi][cout][cin] = sum_t E[xi][cout][t] V[xi][cin][t]
+// with the TILE index as k.  wino4s_tk writes either operand -- IS_E: E = A e A^T from dZ, else V = B^T d B from the layer's
+// input -- split into three bfloat16 pieces, as fragments [point][block of 128 channels][chunk of 16 tiles][sub 4][piece 3]
+// [k half 2][channel 32][8 tiles]; wino4s_gemm (k split over blockIdx.y, one slab of dU per split) is the forward kernel;
+// wino4s_wgrad_finish adds the slabs in order and applies G^T . G.
+constexpr int TK_CH_STRIDE = TB + 1;                          // LDS: V[point][channel 16][33]: conflict-free writes, 2-way reads
+constexpr int TK_PT_STRIDE = CC * TK_CH_STRIDE;
+constexpr int TK_LDS_BYTES = NXI * TK_PT_STRIDE * 4;          // 76 KB
+
+struct TkArgs {
+    const float* src;        // NCHW, channel slice [coff, coff + C) of a buffer with ctot channels
+    unsigned src_bytes;
+    int C, H, W, ctot, coff;
+    int TY, TX, NT, tblk32, kchunks;       // kchunks = 2 * tblk32 (16 tiles each)
+    int chunks;              // channel chunks of 16 (C rounded up)
+    int chunks_per_wg;
+    unsigned char* dst;
+    size_t plane;            // bytes per point
+};
+
+template <bool IS_E>
+__global__ __launch_bounds__(256, 2) void wino4s_tk(const TkArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tblk = blockIdx.x;
+    const int HW = a.H * a.W;
+    const int c_begin = blockIdx.y * a.chunks_per_wg, c_end = min(a.chunks, c_begin + a.chunks_per_wg);
+    if (c_begin >= c_end) return;
+    constexpr int NR = IS_E ? 4 : 6;                 // rows / columns of the spatial block a thread loads
+    int voffr[NR];
+    bool mc[NR], lp = false;
+    {
+        const int T = tblk * TB + l31;
+        const bool live = T < a.NT;
+        const int n = T / (a.TY * a.TX);
+        const int rem = T - n * (a.TY * a.TX);
+        const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        const int y0 = 4 * ty - (IS_E ? 0 : 1), x0 = 4 * tx - (IS_E ? 0 : 1);
+#pragma unroll
+        for (int c = 0; c < NR; ++c) mc[c] = (unsigned)(x0 + c) < (unsigned)a.W;
+        if (!IS_E) lp = tx == 0;                     // see wino4s_in: left-edge patches load from x = 0 and shift
+        const long base = (((long)n * a.ctot + a.coff + h) * a.H + y0) * (long)a.W + x0 + (lp ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
+            voffr[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
+        }
+    }
+    const int hy_delta = lp ? 8 : 12;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.src, a.src_bytes);
+    const int chunk_bytes = CC * HW * 4;
+    const int chan_base = 4 * wave * HW * 4;
+    float* const vw_base = lds + (4 * wave + h) * TK_CH_STRIDE + l31;      // channel 4 wave + 2 q + h, tile l31
+    // pack stage: lane = (k chunk kc of the two 16-tile chunks, k half kh, channel rr): 8 consecutive tiles of one channel
+    const int kc = lane >> 5, kh = (lane >> 4) & 1, rr = lane & 15;
+    const float* const vr_base = lds + rr * TK_CH_STRIDE + kc * 16 + kh * 8;
+
+    for (int c = c_begin; c < c_end; ++c) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ch = c * CC + 4 * wave + 2 * q + h;
+            const bool chok = ch < a.C;
+            const int soff = c * chunk_bytes + chan_base + q * (2 * HW * 4);
+            float t[6][NR];
+            if constexpr (IS_E) {
+                float e[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rin, chok ? voffr[i] : kInvalidOff, soff, 0);
+                    const f32x4 q4 = __builtin_bit_cast(f32x4, r);
+                    e[i][0] = q4.x;
+                    e[i][1] = mc[1] ? q4.y : 0.f;
+                    e[i][2] = mc[2] ? q4.z : 0.f;
+                    e[i][3] = mc[3] ? q4.w : 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float col[4] = {e[0][j], e[1][j], e[2][j], e[3][j]};
+                    float o[6];
+                    ctdet::w4::a6(col, o);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+                }
+            } else {
+                i32x3 hx[6], hy[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int vo = chok ? voffr[i] : kInvalidOff;
+                    hx[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, vo, soff, 0);
+                    hy[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, vo == kInvalidOff ? kInvalidOff : vo + hy_delta, soff, 0);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) {
+                    float d[6], o[6];
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        const f32x3 qv = __builtin_bit_cast(f32x3, cc < 3 ? hx[i] : hy[i]);
+                        const float v = cc == 1 ? (lp ? qv.x : qv.y) : cc == 2 ? (lp ? qv.y : qv.z) : cc % 3 == 0 ? qv.x : cc % 3 == 1 ? qv.y : qv.z;
+                        d[i] = mc[cc] ? v : 0.f;
+                    }
+                    bt6(d, o);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) t[i][cc] = o[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float v[6];
+                if constexpr (IS_E) {
+                    const float row[4] = {t[i][0], t[i][1], t[i][2], t[i][3]};
+                    ctdet::w4::a6(row, v);
+                } else {
+                    const float row[6] = {t[i][0], t[i][1], t[i][2], t[i][3], t[i][4], t[i][5]};
+                    bt6(row, v);
+                }
+                float* vp = vw_base + q * (2 * TK_CH_STRIDE) + (i * 6) * TK_PT_STRIDE;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) vp[j * TK_PT_STRIDE] = v[j];
+            }
+        }
+        __syncthreads();
+        // rows c * 16 .. + 15 of the operand: 128-row block c >> 3, 32-row sub-block (c >> 1) & 3, upper / lower half c & 1
+        unsigned char* const dst0 = a.dst + ((size_t)(c >> 3) * a.kchunks + 2 * tblk + kc) * OPB + ((c >> 1) & 3) * (3 * FRAG) +
+                                    (kh * 32 + (c & 1) * 16 + rr) * 16;
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const int xi = 9 * wave + p;
+            const float* ptr = vr_base + xi * TK_PT_STRIDE;
+            float raw[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[e] = ptr[e];
+            i32x4 fb[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                split3(raw[2 * q], h0, m0, l0);
+                split3(raw[2 * q + 1], h1, m1, l1);
+                fb[0][q] = pack_hi(h0, h1);
+                fb[1][q] = pack_hi(m0, m1);
+                fb[2][q] = pack_hi(l0, l1);
+            }
+            unsigned char* dst = dst0 + (size_t)xi * a.plane;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<i32x4*>(dst + pc * FRAG) = fb[pc];
+        }
+        __syncthreads();
+    }
+}
+
+// dw[k][c][3][3] = G^T (sum over slabs of dU[.][k][c]) G; slabs added in order (no atomics: results do not depend on timing)
+__global__ __launch_bounds__(256) void wino4s_wgrad_finish(const float* __restrict__ dU, float* __restrict__ dw, int Cout, int Cin,
+                                                           int ld, size_t plane, size_t slab, int slabs)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cout * Cin) return;
+    const int k = i / Cin, c = i - k * Cin;
+    const float* src = dU + (size_t)k * ld + c;
+    float w[3][6];
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+        float u[6], o[3];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            float sum = src[(size_t)(m * 6 + n) * plane];
+            for (int sl = 1; sl < slabs; ++sl) sum += src[(size_t)sl * slab + (size_t)(m * 6 + n) * plane];
+            u[m] = sum;
+        }
+        ctdet::w4::gt3(u, o);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) w[m][n] = o[m];
+    }
+    float* out = dw + (size_t)i * 9;
+#pragma unroll
+    for (int m = 0; m < 3; ++m) {
+        float o[3];
+        ctdet::w4::gt3(w[m], o);
+        out[m * 3 + 0] = o[0];
+        out[m * 3 + 1] = o[1];
+        out[m * 3 + 2] = o[2];
+    }
+}
+
+struct WgSizes { int TY, TX, NT, tblk32, kchunks, rb, cb, splits, cps; size_t e_plane, v_plane, m_plane, m_slab, e_bytes, v_bytes, m_bytes; };
+
+WgSizes wg_sizes_of(int batch, int oh, int ow, int cin, int cout)
+{
+    WgSizes s{};
+    s.TY = (oh + 3) / 4; s.TX = (ow + 3) / 4;
+    s.NT = batch * s.TY * s.TX;
+    s.tblk32 = (s.NT + TB - 1) / TB;
+    s.kchunks = 2 * s.tblk32;
+    s.rb = (cout + BM - 1) / BM;
+    s.cb = (cin + BT - 1) / BT;
+    // k splits: about three rounds of two workgroups per CU, at least 8 k-steps each
+    const int wgs = NXI * s.rb * s.cb;
+    s.splits = std::max(1, std::min((1536 + wgs - 1) / wgs, s.kchunks / 8));
+    s.cps = (s.kchunks + s.splits - 1) / s.splits;
+    s.splits = (s.kchunks + s.cps - 1) / s.cps;
+    s.e_plane = (size_t)s.rb * s.kchunks * OPB;
+    s.v_plane = (size_t)s.cb * s.kchunks * OPB;
+    s.m_plane = (size_t)s.rb * BM * s.cb * BT;
+    s.m_slab = s.m_plane * NXI;
+    s.e_bytes = ctdet::align_up(s.e_plane * NXI, 256);
+    s.v_bytes = ctdet::align_up(s.v_plane * NXI, 256);
+    s.m_bytes = s.m_slab * s.splits * 4;
+    return s;
+}
+
+bool wino4s_wg_ok(const ct_conv_desc* d)
+{
+    return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+           d->oh == d->h && d->ow == d->w && !d->transposed && d->cin >= 16 && d->cin % CC == 0 && d->cout >= 1 &&
+           (long long)d->in_ctot * d->h * d->w * 4 < kMaxBufBytes;
 }
 
 bool wino4s_ok(const ct_conv_desc* d)
@@ -549,9 +785,13 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
         }
         {
             CT_PROF("wino4s_gemm", st);
+            GemmArgs g{};
+            g.A = reinterpret_cast<const unsigned char*>(a.U); g.B = reinterpret_cast<const unsigned char*>(a.V); g.M = a.Mw;
+            g.a_plane = a.u_plane; g.b_plane = a.v_plane; g.m_plane = a.m_plane; g.m_slab = 0;
+            g.chunks = g.chunks_per_split = a.chunks; g.rowblocks = a.kblocks; g.colblocks = a.tblk128; g.ldm = a.Tpad;
             const int nwg = NXI * a.tblk128 * a.kblocks;
-            if (variant == 1) hipLaunchKernelGGL(wino4s_gemm<true>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, a);
-            else hipLaunchKernelGGL(wino4s_gemm<false>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, a);
+            if (variant == 1) hipLaunchKernelGGL(wino4s_gemm<true>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
+            else hipLaunchKernelGGL(wino4s_gemm<false>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
             CT_LAUNCH_CHECK("wino4s_gemm");
         }
         {
@@ -567,4 +807,90 @@ extern "C" int ct_conv2d_wino4s_fwd(const ct_conv_desc* d, const void* upacked, 
                                     int variant, ct_stream_t stream)
 {
     return ct_conv2d_wino4s_pool_fwd(d, upacked, workspace, workspace_bytes, variant, nullptr, 0, 0, 0, 0, 1, stream);
+}
+
+extern "C" int ct_conv_wgrad_wino4s_supported(const ct_conv_desc* d) { return d && wino4s_wg_ok(d) ? 1 : 0; }
+
+extern "C" size_t ct_conv_wgrad_wino4s_workspace_bytes(const ct_conv_desc* d)
+{
+    if (!d || !wino4s_wg_ok(d) || d->batch <= 0) return 0;
+    const WgSizes s = wg_sizes_of(d->batch, d->oh, d->ow, d->cin, d->cout);
+    return s.e_bytes + s.v_bytes + s.m_bytes;
+}
+
+extern "C" int ct_conv2d_wgrad_wino4s(const ct_conv_desc* d, const float* dz, int dz_ctot, int dz_coff, float* dw,
+                                      void* workspace, size_t workspace_bytes, ct_stream_t stream)
+{
+    CT_REQUIRE(d && dz && dw && workspace && d->in, "ct_conv2d_wgrad_wino4s: null pointer");
+    if (!wino4s_wg_ok(d))
+        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wgrad_wino4s: needs 3x3 stride 1 dilation 1 pad 1, cin %% 16 == 0 "
+                           "(got %dx%d s%d d%d p%d cin=%d)", d->kh, d->kw, d->stride, d->dil, d->pad_h, d->cin);
+    CT_REQUIRE(d->batch > 0, "ct_conv2d_wgrad_wino4s: bad shape");
+    CT_REQUIRE(dz_coff >= 0 && dz_coff + d->cout <= dz_ctot, "ct_conv2d_wgrad_wino4s: dz slice");
+    CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "ct_conv2d_wgrad_wino4s: input slice");
+    const long long x_bytes = (long long)d->batch * d->in_ctot * d->h * d->w * 4;
+    const long long z_bytes = (long long)d->batch * dz_ctot * d->oh * d->ow * 4;
+    CT_REQUIRE(x_bytes < kMaxBufBytes && z_bytes < kMaxBufBytes, "ct_conv2d_wgrad_wino4s: a tensor exceeds 2 GiB (use ct_conv2d_wgrad_wino4)");
+    const WgSizes s = wg_sizes_of(d->batch, d->oh, d->ow, d->cin, d->cout);
+    CT_REQUIRE(workspace_bytes >= s.e_bytes + s.v_bytes + s.m_bytes, "ct_conv2d_wgrad_wino4s: workspace of %zu bytes, needs %zu",
+               workspace_bytes, s.e_bytes + s.v_bytes + s.m_bytes);
+    CT_REQUIRE((size_t)s.kchunks * OPB < (size_t)kMaxBufBytes, "ct_conv2d_wgrad_wino4s: too many tiles for one launch");
+    hipStream_t st = ctdet::as_stream(stream);
+    {
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute((const void*)wino4s_tk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS_BYTES);
+            if (attr_err == hipSuccess)
+                attr_err = hipFuncSetAttribute((const void*)wino4s_tk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, TK_LDS_BYTES);
+            if (attr_err == hipSuccess)
+                attr_err = hipFuncSetAttribute((const void*)wino4s_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        });
+        CT_HIP(attr_err);
+    }
+    unsigned char* E = static_cast<unsigned char*>(workspace);
+    unsigned char* V = E + s.e_bytes;
+    float* M = reinterpret_cast<float*>(V + s.v_bytes);
+    auto launch_tk = [&](bool is_e) -> int {
+        TkArgs t{};
+        t.src = is_e ? dz : d->in;
+        t.src_bytes = (unsigned)(is_e ? z_bytes : x_bytes);
+        t.C = is_e ? d->cout : d->cin; t.H = d->h; t.W = d->w;
+        t.ctot = is_e ? dz_ctot : d->in_ctot; t.coff = is_e ? dz_coff : d->in_coff;
+        t.TY = s.TY; t.TX = s.TX; t.NT = s.NT; t.tblk32 = s.tblk32; t.kchunks = s.kchunks;
+        t.chunks = (is_e ? s.rb : s.cb) * (BM / CC);       // every 16-channel chunk of the padded 128-row blocks: rows past C are zeros
+        const long pairs = (long)t.tblk32 * t.chunks;
+        t.chunks_per_wg = (int)std::max<long>(1, std::min<long>(t.chunks, pairs / 2048));
+        t.dst = is_e ? E : V;
+        t.plane = is_e ? s.e_plane : s.v_plane;
+        const dim3 grid(t.tblk32, (t.chunks + t.chunks_per_wg - 1) / t.chunks_per_wg);
+        if (is_e) hipLaunchKernelGGL(wino4s_tk<true>, grid, dim3(256), TK_LDS_BYTES, st, t);
+        else hipLaunchKernelGGL(wino4s_tk<false>, grid, dim3(256), TK_LDS_BYTES, st, t);
+        CT_LAUNCH_CHECK("wino4s_tk");
+        return CT_OK;
+    };
+    {
+        CT_PROF("wino4s_tk_e", st);
+        const int rc = launch_tk(true);
+        if (rc != CT_OK) return rc;
+    }
+    {
+        CT_PROF("wino4s_tk_v", st);
+        const int rc = launch_tk(false);
+        if (rc != CT_OK) return rc;
+    }
+    {
+        CT_PROF("wino4s_gemm_wgrad", st);
+        GemmArgs g{};
+        g.A = E; g.B = V; g.M = M;
+        g.a_plane = s.e_plane; g.b_plane = s.v_plane; g.m_plane = s.m_plane; g.m_slab = s.m_slab;
+        g.chunks = s.kchunks; g.chunks_per_split = s.cps; g.rowblocks = s.rb; g.colblocks = s.cb; g.ldm = s.cb * BT;
+        hipLaunchKernelGGL(wino4s_gemm<true>, dim3(NXI * s.rb * s.cb, s.splits), dim3(256), GEMM_LDS_BYTES, st, g);
+        CT_LAUNCH_CHECK("wino4s_gemm (weight gradient)");
+    }
+    const int KC = d->cout * d->cin;
+    hipLaunchKernelGGL(wino4s_wgrad_finish, dim3((KC + 255) / 256), dim3(256), 0, st, M, dw, d->cout, d->cin, s.cb * BT, s.m_plane,
+                       s.m_slab, s.splits);
+    CT_LAUNCH_CHECK("wino4s_wgrad_finish");
+    return CT_OK;
 }

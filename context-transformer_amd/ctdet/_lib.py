@@ -111,6 +111,9 @@ SIGNATURES = {
     'ct_conv_wgrad_wino4_supported': (_I, [C.POINTER(ConvDesc)]),
     'ct_conv_wgrad_wino4_workspace_bytes': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'ct_conv2d_wgrad_wino4': (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P, _P]),
+    'ct_conv_wgrad_wino4s_supported': (_I, [C.POINTER(ConvDesc)]),
+    'ct_conv_wgrad_wino4s_workspace_bytes': (_Z, [C.POINTER(ConvDesc)]),
+    'ct_conv2d_wgrad_wino4s': (_I, [C.POINTER(ConvDesc), _P, _I, _I, _P, _P, _Z, _P]),
     'ct_bn_train_stats': (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _F, _P, _P, _P, _P]),
     'ct_bn_train_apply': (_I, [_P, _P, _P, _P, _P, _F, _I, _P, _P, _I, _I, _F, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'ct_bn_train_backward': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _F, _I, _P, _F, _P, _I, _I, _I,

@@ -826,7 +826,8 @@ def apply_tuned(backend, st, batch, wino4=True):
             elif not (want == 4 and 4 in allowed):
                 want = 23 if 23 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
         elif want not in allowed:
-            want = 2 if 2 in allowed or not allowed else allowed[0]
+            # a three-kernel F(4x4) entry without tile 44 in the set (CTDET_WINO_TILES=2,4) is the fused F(4x4) kernel's layer
+            want = 4 if want in WINO4S_TILES and 4 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
         # experiment hook: CTDET_W4S_MIN_CIN=n moves the table's F(4x4,3x3) layers with >= n input channels to the
         # three-kernel form (44) without re-tuning
         w4s = int(os.environ.get('CTDET_W4S_MIN_CIN', '0') or 0)

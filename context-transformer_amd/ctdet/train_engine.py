@@ -59,6 +59,7 @@ class TrainRuntime:
                 self._reg(prm)
         wino_ws = 0
         w4s_ws = 0              # bytes: workspace of the three-kernel Winograd data gradients
+        wg4s_ws = 0             # bytes: workspace of the three-kernel Winograd weight gradients
         # CTDET_TRAIN_WINO4=0 keeps forward and data-gradient convolutions on F(2x2,3x3) where the table says F(4x4,3x3)
         wino4 = os.environ.get('CTDET_TRAIN_WINO4', '1') != '0'
         for st in self.plan.steps:
@@ -178,10 +179,20 @@ class TrainRuntime:
             # 10x10); CTDET_WGRAD_WINO4=0 keeps F(3x3, 2x2)
             s.wgrad_tile = 4 if s.wgrad_wino and st.oh * st.ow >= 361 and \
                 os.environ.get('CTDET_WGRAD_WINO4', '1') != '0' else 2
+            # the three-kernel bf16x3 form (ct_conv2d_wgrad_wino4s) for the wide layers: from CTDET_WGRAD_W4S_MIN_CIN input
+            # channels up (default 256; 0 = never) where cin x cout >= 2^17 -- conv4_x, conv5_x, the 19x19 RFB layers
+            # (profiles/r04_wgrad_probe.txt: 512 -> 512 @38x38 778 -> 503 us, 512 -> 512 @19x19 253 -> 184, 256 -> 512 @38x38
+            # 437 -> 366; the multibox heads (cout 126..156: 238 -> 353) and 256 -> 256 @75x75 (750 -> 804) stay fused).  Its
+            # workspace (E, V, dU slabs) is shared: weight gradients run in stream order.
+            w4s_min = int(os.environ.get('CTDET_WGRAD_W4S_MIN_CIN', '256') or 0)
+            if s.wgrad_wino and s.wgrad_tile == 4 and w4s_min and st.cin >= w4s_min and st.cin * ctot >= (1 << 17) and \
+                    self.lib.ct_conv_wgrad_wino4s_supported(C.byref(w)):
+                s.wgrad_tile = 44
+                wg4s_ws = max(wg4s_ws, int(self.lib.ct_conv_wgrad_wino4s_workspace_bytes(C.byref(w))))
             if s.wgrad_wino:
-                size = self.lib.ct_conv_wgrad_wino4_workspace_bytes if s.wgrad_tile == 4 else \
+                size = self.lib.ct_conv_wgrad_wino4_workspace_bytes if s.wgrad_tile in (4, 44) else \
                     self.lib.ct_conv_wgrad_wino_workspace_bytes
-                s.wgrad_ws_bytes = int(size(C.byref(w)))
+                s.wgrad_ws_bytes = int(size(C.byref(w))) if s.wgrad_tile != 44 else 64
                 wino_ws = max(wino_ws, s.wgrad_ws_bytes)
             for p in st.parts:
                 self._reg(p.weight)
@@ -197,6 +208,7 @@ class TrainRuntime:
         self.prezero = os.environ.get('CTDET_PREZERO', '1') != '0'
         self.wgrad_ws = al((max(wino_ws // 4, 1),))
         self.dgrad_ws4s = torch.empty(max(w4s_ws, 1), device=backend.device, dtype=torch.uint8)
+        self.wgrad_ws4s = torch.empty(max(wg4s_ws, 1), device=backend.device, dtype=torch.uint8)
         if self.prezero:
             bn_floats = sum(t.numel() for s_ in self.state.values() for t in getattr(s_, 'scratch', []))
             self.bn_scratch = al((max(bn_floats, 1),), torch.float64)
@@ -581,7 +593,11 @@ class TrainRuntime:
                 s.ev_dz.record(main)
                 side.wait_event(s.ev_dz)
             with torch.cuda.stream(side if side is not None else main):
-                if s.wgrad_wino:
+                if s.wgrad_wino and s.wgrad_tile == 44:
+                    _lib.check(lib.ct_conv2d_wgrad_wino4s(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
+                                                          self.wgrad_ws4s.data_ptr(), self.wgrad_ws4s.numel(), self._s()),
+                               st.name + ' wgrad (winograd 4s)')
+                elif s.wgrad_wino:
                     fn = lib.ct_conv2d_wgrad_wino4 if s.wgrad_tile == 4 else lib.ct_conv2d_wgrad_wino
                     _lib.check(fn(C.byref(s.wgrad), s.dz.data_ptr(), ctot, 0, s.dw.data_ptr(),
                                   (s.wgrad_ws if self.prezero else self.wgrad_ws).data_ptr(), self._s()),

@@ -431,6 +431,18 @@ size_t ct_conv_wgrad_wino4_workspace_bytes(const ct_conv_desc* d);
 int ct_conv2d_wgrad_wino4(const ct_conv_desc* d, const float* dz, int dz_ctot, int dz_coff, float* dw,
                           void* workspace, ct_stream_t stream);
 
+/* The F(3x3, 4x4) weight gradient in the three-kernel form of ct_conv2d_wino4s_fwd (csrc/ct_wino4s.hip): dZ tiles and input
+ * patches are transformed once (E = A e A^T, V = B^T d B), split exactly into three bfloat16 pieces and stored as MFMA operand
+ * fragments with the TILE index as k; 36 GEMMs dU[xi][cout][cin] = sum_tiles E V^T on the bf16 matrix pipe (the forward form's
+ * kernel, k split over several workgroups per block, one slab of dU per split, no atomics); a finishing kernel adds the slabs
+ * in order and applies G^T . G.  Same arguments and result as ct_conv2d_wgrad_wino4 (train.py:228: autograd's conv
+ * backward-weight for the wide 3x3 layers of models/RFB_Net_vgg.py:219-227,238-248); cin % 16 == 0; the workspace holds
+ * ct_conv_wgrad_wino4s_workspace_bytes(d) bytes (E, V and the dU slabs). */
+int ct_conv_wgrad_wino4s_supported(const ct_conv_desc* d);
+size_t ct_conv_wgrad_wino4s_workspace_bytes(const ct_conv_desc* d);
+int ct_conv2d_wgrad_wino4s(const ct_conv_desc* d, const float* dz, int dz_ctot, int dz_coff, float* dw,
+                           void* workspace, size_t workspace_bytes, ct_stream_t stream);
+
 /* nn.BatchNorm2d(eps 1e-5, momentum 0.01) in training mode (models/RFB_Net_vgg.py:13,19), split in
  * three launches around the conv output z (channel slice [z_coff, z_coff+channels) of an NCHW buffer
  * with z_ctot channels; dz uses the same slicing):

@@ -1,4 +1,5 @@
-"""Winograd F(3x3, 2x2) and F(3x3, 4x4) weight gradients (ct_conv2d_wgrad_wino, ct_conv2d_wgrad_wino4) against
+"""Winograd F(3x3, 2x2) and F(3x3, 4x4) weight gradients (ct_conv2d_wgrad_wino, ct_conv2d_wgrad_wino4, and the three-kernel
+bf16x3 form ct_conv2d_wgrad_wino4s) against
 autograd in float64 and against the direct weight-gradient kernel, through the C ABI.  What train.py:228 `losses.backward()` computes for the 3x3 / stride 1
 weights of models/RFB_Net_vgg.py."""
 import ctypes as C
@@ -74,6 +75,47 @@ def test_wino_wgrad_vs_autograd(g, variant):
                                         _s()), 'wgrad wino again')
     torch.cuda.synchronize()
     assert rel_err(dw2.cpu().double(), w.grad) < tol
+
+
+GEOMS_4S = [  # B, Cin, H, W, Cout, x slice, dz slice -- cin % 16 == 0 (16-channel chunks of the bf16 fragments)
+    (2, 64, 19, 19, 64, None, None), (3, 16, 10, 10, 40, None, None), (2, 80, 19, 17, 130, None, None),
+    (5, 16, 5, 5, 8, None, None), (2, 32, 3, 3, 24, None, None), (4, 16, 1, 1, 8, None, None),
+    (2, 32, 38, 38, 64, (48, 9), (80, 7)), (2, 128, 75, 75, 64, None, None), (2, 256, 38, 38, 156, None, None),
+]
+
+
+@pytest.mark.parametrize('g', GEOMS_4S, ids=[str(i) for i in range(len(GEOMS_4S))])
+def test_wino4s_wgrad_vs_autograd(g):
+    """ct_conv2d_wgrad_wino4s: F(3x3, 4x4) as transform kernels + the bf16x3 GEMM kernel of the forward form (k = tiles,
+    split over workgroups, slabs added in order) against float64 autograd, held to the fused kernel's bound; two calls give
+    bit-identical results (no atomics)."""
+    B, Cin, H, W, Cout, xs, zs = g
+    gen = torch.Generator().manual_seed(11 + Cin + H)
+    xctot, xcoff = xs or (Cin, 0)
+    zctot, zcoff = zs or (Cout, 0)
+    xfull = torch.randn(B, xctot, H, W, generator=gen)
+    dzfull = torch.randn(B, zctot, H, W, generator=gen)
+    x = xfull[:, xcoff:xcoff + Cin].double().requires_grad_(True)
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x, w, None, 1, 1).backward(dzfull[:, zcoff:zcoff + Cout].double())
+    lib = _lib.lib()
+    xd, dzd = xfull.to(DEV), dzfull.to(DEV)
+    d = _desc(xd, B, Cin, H, W, xctot, xcoff, Cout)
+    assert lib.ct_conv_wgrad_wino4s_supported(C.byref(d)) == 1
+    ws = torch.empty(lib.ct_conv_wgrad_wino4s_workspace_bytes(C.byref(d)), device=DEV, dtype=torch.uint8)
+    outs = []
+    for _ in range(2):
+        ws.fill_(0xFF)                      # NaN bit patterns everywhere: nothing unwritten may reach the result
+        dw = torch.full((Cout, Cin, 3, 3), float('nan'), device=DEV)
+        _lib.check(lib.ct_conv2d_wgrad_wino4s(C.byref(d), dzd.data_ptr(), zctot, zcoff, dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              _s()), 'wgrad wino4s')
+        torch.cuda.synchronize()
+        outs.append(dw.cpu())
+    assert rel_err(outs[0].double(), w.grad) < 5e-5, (g, rel_err(outs[0].double(), w.grad))
+    assert torch.equal(outs[0], outs[1])
+    # an undersized workspace is refused
+    rc = lib.ct_conv2d_wgrad_wino4s(C.byref(d), dzd.data_ptr(), zctot, zcoff, dw.data_ptr(), ws.data_ptr(), 1024, _s())
+    assert rc != 0
 
 
 @pytest.mark.parametrize('variant', ['f2', 'f4'])

@@ -53,7 +53,12 @@ bash tools/wino_pmc.sh base.19 ${TAG}_w4 > /dev/null 2>&1; cp "$R/gpurun_out/pmc
 # the three Winograd kernels on the same layer: SQ counters behind "SIMD time = MFMA cycles + 4 cycles per VALU instruction"
 bash tools/wino_pmc.sh base.19 ${TAG}_x3q 24 x3q > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_x3q/summary.txt" "$O/wino_x3q_pmc.txt"
 bash tools/wino_pmc.sh base.19 ${TAG}_x3d 23 "wino_f2x2_3x3_x3<" > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_x3d/summary.txt" "$O/wino_x3_pmc.txt"
-CTDET_WINO_TILES=2,4,23,24 TILES=2,4,23,24 timeout 600 python tools/wino_one.py base.2 base.5 base.7 base.10 base.12 base.17 base.19 base.24 head.0 > "$O/wino_variants.txt" 2>&1
+CTDET_WINO_TILES=2,4,23,24,44 TILES=2,4,23,24,44 timeout 600 python tools/wino_one.py base.2 base.5 base.7 base.10 base.12 base.17 base.19 base.24 head.0 > "$O/wino_variants.txt" 2>&1
+# the three-kernel F(4x4,3x3) form: layer by layer against the fused kernels with its per-kernel split, SQ counters of its GEMM
+# kernel, and the micro-benchmark of what the bf16 matrix pipe sustains on real data
+timeout 900 bash tools/wino4s_probe.sh base.19 base.17b head.0 base.24 head.1 base.12 > /dev/null 2>&1; cp "$R/gpurun_out/wino4s_probe.txt" "$O/wino4s_probe.txt"
+bash tools/wino_pmc.sh base.19 ${TAG}_w4s 44 wino4s_gemm > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_w4s/summary.txt" "$O/wino4s_pmc.txt"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 "$R/tools/ubench/mfma_power.hip" -o /tmp/mfma_power 2>/dev/null && /tmp/mfma_power > "$O/mfma_power.txt" 2>&1
 bash tools/bf16_pmc.sh ${TAG}_bf16 > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_bf16/summary.txt" "$O/bf16_pmc.txt"
 cd "$R"
 # keep what prof_summary.py needs, drop the bulky traces

@@ -1,5 +1,5 @@
-"""Time the direct and the two Winograd weight-gradient kernels (F(3x3,2x2), F(3x3,4x4)) on the RFBNet 3x3 layer shapes
-(batch 32); differences against the direct kernel."""
+"""Time the direct and the Winograd weight-gradient kernels (F(3x3,2x2), F(3x3,4x4) fused, F(3x3,4x4) as transform kernels +
+bf16x3 GEMM) on the RFBNet 3x3 layer shapes (batch 32); differences against the direct kernel."""
 import argparse
 import ctypes as C
 import os
@@ -33,18 +33,24 @@ def main():
         dw = torch.empty(cout, cin, 3, 3, device=dev)
         dw2 = torch.empty_like(dw)
         dw4 = torch.empty_like(dw)
+        dw4s = torch.empty_like(dw)
+        has4s = cin % 16 == 0 and bool(lib.ct_conv_wgrad_wino4s_supported(C.byref(d)))
+        ws4s = torch.empty(lib.ct_conv_wgrad_wino4s_workspace_bytes(C.byref(d)) if has4s else 1, device=dev, dtype=torch.uint8)
         ws = torch.empty(lib.ct_conv_wgrad_wino4_workspace_bytes(C.byref(d)) // 4, device=dev)
         res = []
-        for fn in ('direct', 'wino', 'wino4'):
+        for fn in ('direct', 'wino', 'wino4') + (('wino4s',) if has4s else ()):
             def run():
                 if fn == 'direct':
                     _lib.check(lib.ct_conv2d_wgrad(C.byref(d), dz.data_ptr(), cout, 0, dw.data_ptr(), st), fn)
                 elif fn == 'wino':
                     _lib.check(lib.ct_conv2d_wgrad_wino(C.byref(d), dz.data_ptr(), cout, 0, dw2.data_ptr(),
                                                         ws.data_ptr(), st), fn)
-                else:
+                elif fn == 'wino4':
                     _lib.check(lib.ct_conv2d_wgrad_wino4(C.byref(d), dz.data_ptr(), cout, 0, dw4.data_ptr(),
                                                          ws.data_ptr(), st), fn)
+                else:
+                    _lib.check(lib.ct_conv2d_wgrad_wino4s(C.byref(d), dz.data_ptr(), cout, 0, dw4s.data_ptr(),
+                                                          ws4s.data_ptr(), ws4s.numel(), st), fn)
             run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -57,9 +63,13 @@ def main():
         flops = 2.0 * a.batch * hw * hw * cin * cout * 9
         err = ((dw - dw2).abs().max() / dw.abs().max()).item()
         err4 = ((dw - dw4).abs().max() / dw.abs().max()).item()
-        print('%4d -> %4d @ %3d^2  direct %8.1f us (%5.1f TF)   F2 %8.1f us (%5.1f TF alg) diff %.1e   F4 %8.1f us (%5.1f TF alg) diff %.1e'
+        extra = ''
+        if has4s:
+            extra = '   F4 three-kernel %8.1f us (%5.1f TF alg) diff %.1e' % (res[3] * 1e3, flops / res[3] / 1e9,
+                                                                             ((dw - dw4s).abs().max() / dw.abs().max()).item())
+        print('%4d -> %4d @ %3d^2  direct %8.1f us (%5.1f TF)   F2 %8.1f us (%5.1f TF alg) diff %.1e   F4 %8.1f us (%5.1f TF alg) diff %.1e%s'
               % (cin, cout, hw, res[0] * 1e3, flops / res[0] / 1e9, res[1] * 1e3, flops / res[1] / 1e9, err,
-                 res[2] * 1e3, flops / res[2] / 1e9, err4), flush=True)
+                 res[2] * 1e3, flops / res[2] / 1e9, err4, extra), flush=True)
 
 
 if __name__ == '__main__':

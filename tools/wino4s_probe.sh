@@ -8,8 +8,8 @@ cd /tmp && export TMPDIR=/tmp
   TILES=${TILES:-4,24,44,45} ITERS=${ITERS:-20} python $R/tools/wino_one.py $L
   for l in $L; do
     rm -rf $O/w4s_stats
-    CHECK=0 TILES=${PTILE:-45} ITERS=20 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/w4s_stats -o s -- python $R/tools/wino_one.py $l > /dev/null 2>&1
-    echo "--- $l (tile ${PTILE:-45}): kernel, calls, average us"
+    CHECK=0 TILES=${PTILE:-44} ITERS=20 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/w4s_stats -o s -- python $R/tools/wino_one.py $l > /dev/null 2>&1
+    echo "--- $l (tile ${PTILE:-44}): kernel, calls, average us"
     python - <<PY
 import csv, glob
 for f in glob.glob('$O/w4s_stats/**/*kernel_stats.csv', recursive=True):
@@ -19,4 +19,7 @@ for f in glob.glob('$O/w4s_stats/**/*kernel_stats.csv', recursive=True):
 PY
   done
   rm -rf $O/w4s_stats
+  echo "--- power experiment: the same launches on random and on all-zero activations (identical instruction stream)"
+  CHECK=0 TILES=4,44 ITERS=20 python $R/tools/wino_one.py base.19
+  ZERO=1 CHECK=0 TILES=4,44 ITERS=20 python $R/tools/wino_one.py base.19
 } 2>&1 | tee $O/wino4s_probe.txt
