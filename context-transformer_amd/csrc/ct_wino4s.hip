@@ -108,19 +108,6 @@ __device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsign
     l = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, m));
 }
 
-// the same from a double: hi and mid by truncation, lo ROUNDED to nearest (x - hi - mid is exact in double), so the three
-// pieces carry x to 2^-25 relative
-__device__ __forceinline__ void split3d(double x, unsigned& h, unsigned& m, unsigned& l)
-{
-    h = __builtin_bit_cast(unsigned, (float)x) & 0xFFFF0000u;
-    // (float)x may round UP past x: the remainder is then negative, which the signed pieces carry just as well
-    const double r1 = x - (double)__builtin_bit_cast(float, h);
-    m = __builtin_bit_cast(unsigned, (float)r1) & 0xFFFF0000u;
-    const float r2 = (float)(r1 - (double)__builtin_bit_cast(float, m));
-    const unsigned rb = __builtin_bit_cast(unsigned, r2);
-    l = rb + 0x7FFFu + ((rb >> 16) & 1u);              // round to nearest even into the upper half
-}
-
 __device__ __forceinline__ int pack_hi(unsigned e0, unsigned e1)      // [bf16 e0 | bf16 e1 << 16]
 {
     return (int)__builtin_amdgcn_perm(e1, e0, 0x07060302u);

@@ -828,11 +828,6 @@ def apply_tuned(backend, st, batch, wino4=True):
         elif want not in allowed:
             # a three-kernel F(4x4) entry without tile 44 in the set (CTDET_WINO_TILES=2,4) is the fused F(4x4) kernel's layer
             want = 4 if want in WINO4S_TILES and 4 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
-        # experiment hook: CTDET_W4S_MIN_CIN=n moves the table's F(4x4,3x3) layers with >= n input channels to the
-        # three-kernel form (44) without re-tuning
-        w4s = int(os.environ.get('CTDET_W4S_MIN_CIN', '0') or 0)
-        if want == 4 and w4s and st.cin >= w4s and st.rt.get('wino4s_ok') and getattr(backend, 'wino_tile_set', None) is None:
-            want = int(os.environ.get('CTDET_W4S_TILE', '44'))
         backend.enable_wino(st, tile=want)
         return True
     if isinstance(cfg, str) and cfg.startswith('x3:'):
