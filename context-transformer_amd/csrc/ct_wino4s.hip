@@ -167,6 +167,8 @@ __global__ __launch_bounds__(256, 2) void wino4s_in(const Wino4sArgs a)
         }
     };
     float* const vw_base = lds + wave * 128 + lane;          // channel 4 wave + 2 q + h, tile l31
+    // (B^T d B in double, rounded once, was measured: error vs fp64 2.0e-6 -> 1.7e-6 on 512 -> 512 @38x38, +6 us -- the
+    // remaining error is the accumulation's and the dropped piece products', so the fp32 chain stays)
     auto transform_store = [&](const Half& hx, const Half& hy, int q) {
         float t[6][6];
 #pragma unroll
@@ -319,7 +321,9 @@ __global__ __launch_bounds__(256, 2) void wino4s_gemm(const GemmArgs a)
     // read from LDS behind the MFMAs of step c - 1.  Top of iteration c: wait for this wave's DMA pieces of step c + 1,
     // barrier (now step c + 1 is complete in LDS, and every wave has finished READING step c: its buffer is free for
     // step c + 3), issue that DMA, issue the twelve fragment reads of step c + 1, then the 24 MFMAs of step c.
-    // Ring of three buffers: step c + 1 (being read), c + 2 (in flight), c + 3 (just issued).
+    // Ring of three buffers: step c + 1 (being read), c + 2 (in flight), c + 3 (just issued).  (A ring of two with the
+    // one-accumulator register budget -- 48 KB, three workgroups per CU -- measured the same: 526 vs 469-531 us on
+    // 512 -> 512 @38x38, 3 516-3 526 vs 3 504-3 525 images/s in the pipeline; the kernel is not latency-bound.)
     // Barriers are bare s_barrier instructions with hand-written waits: __syncthreads() carries a workgroup fence that the
     // compiler implements as s_waitcnt vmcnt(0), which would drain the DMA queue (the steps in flight) at every step.
     load_step(0, 0);
@@ -621,7 +625,9 @@ bool wino4s_wg_ok(const ct_conv_desc* d)
 {
     return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
            d->oh == d->h && d->ow == d->w && !d->transposed && d->cin >= 16 && d->cin % CC == 0 && d->cout >= 1 &&
-           (long long)d->in_ctot * d->h * d->w * 4 < kMaxBufBytes;
+           // one launch covers the batch (no chunking): both tensors must stay below 2 GiB as a whole
+           (long long)std::max(d->batch, 1) * d->in_ctot * d->h * d->w * 4 < kMaxBufBytes &&
+           (long long)std::max(d->batch, 1) * d->cout * d->oh * d->ow * 4 < kMaxBufBytes;
 }
 
 bool wino4s_ok(const ct_conv_desc* d)
