@@ -205,12 +205,19 @@ def test_conv_split_k():
 
 def test_maxpool_variants():
     g = torch.Generator().manual_seed(3)
+    # (19, 19) / (32, 32) / odd shapes with k 3, stride 1, pad 1: the plane kernel of pool5 (one plane, odd plane counts,
+    # more than 256 and more than 2 x 256 elements per plane); 65 x 65 > 4096 elements: the generic kernel
     for (H, W, k, s, p, ceil) in [(300, 300, 2, 2, 0, False), (75, 75, 2, 2, 0, True), (19, 19, 3, 1, 1, False),
-                                  (38, 37, 2, 2, 0, True)]:
+                                  (38, 37, 2, 2, 0, True), (32, 32, 3, 1, 1, False), (1, 1, 3, 1, 1, False),
+                                  (7, 23, 3, 1, 1, False), (64, 64, 3, 1, 1, False), (65, 65, 3, 1, 1, False)]:
         x = torch.randn(2, 5, H, W, generator=g)
         got = ops.maxpool2d(_cuda(x), k, s, p, ceil).cpu()
         want = F.max_pool2d(x, k, s, p, ceil_mode=ceil)
         assert got.shape == want.shape and torch.equal(got, want), (H, W, k, s, p, ceil)
+    x = torch.randn(1, 1, 19, 19, generator=g)                 # a single plane
+    assert torch.equal(ops.maxpool2d(_cuda(x), 3, 1, 1, False).cpu(), F.max_pool2d(x, 3, 1, 1))
+    x = torch.randn(3, 683, 19, 19, generator=g)               # 2 049 planes: ragged last workgroup
+    assert torch.equal(ops.maxpool2d(_cuda(x), 3, 1, 1, False).cpu(), F.max_pool2d(x, 3, 1, 1))
 
 
 # ------------------------------------------------------------------ boxes
