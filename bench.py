@@ -317,10 +317,12 @@ def stage_rooflines(pipe, x, steps, pmc):
     w4s = [st for st in pipe.rt.conv_steps() if int(st.rt.get('wino') or 0) in (44, 45)]
     if w4s:
         # the three kernels of the F(4x4,3x3) / bf16x3 layers, summed over the layers of a step (csrc/ct_wino4s.hip):
-        # tiles padded to 128, couts to 128; V = 36 points x 3 bf16 pieces, M = 36 points x fp32
+        # tiles padded to 128, couts to 128; V = 36 points x 3 bf16 pieces, M = 36 points x fp32; dilated layers (pad = dilation)
+        # have their tiles on the dilation sub-lattices
         gf = ib = ob = 0.0
         for st in w4s:
-            tiles = B * ((st.oh + 3) // 4) * ((st.ow + 3) // 4)
+            dl = st.dil              # dilated layers: dl x dl sub-lattices of ceil(oh / dl) x ceil(ow / dl) pixels, tiled like images
+            tiles = B * dl * dl * ((-(-st.oh // dl) + 3) // 4) * ((-(-st.ow // dl) + 3) // 4)
             tpad, mpad = -(-tiles // 128) * 128, -(-st.cout // 128) * 128
             gf += 36.0 * tpad * st.cin * mpad * 2 * 6
             ib += 4.0 * B * st.cin * st.h * st.w + 6.0 * 36 * tpad * st.cin

@@ -76,6 +76,7 @@ struct Wino4sArgs {
     size_t v_plane, u_plane; // bytes per point
     size_t m_plane;          // floats per point
     int chunks_per_wg;       // wino4s_in: blockIdx.y owns chunks [y * chunks_per_wg, ...)
+    int dil;                 // > 1: dilated layer, tiles live on the dil x dil sub-lattices (wino4s_in_dil)
 };
 
 // 36 GEMMs  M[xi][row][col] = sum_k A[xi][row][k] B[xi][col][k], both operands as 12 KB fragment blocks
@@ -207,6 +208,101 @@ __global__ __launch_bounds__(256, 2) void wino4s_in(const Wino4sArgs a)
         if (c + 1 < c_end) {                       // the next chunk's rows are under way while this one is split and stored
             load_patch(c + 1, 0, x0h, y0h);
             load_patch(c + 1, 1, x1h, y1h);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < 9; ++p) {
+            const int xi = 9 * wave + p;
+            const float* ptr = vr_base + xi * PT_STRIDE;
+            float raw[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) raw[e] = ptr[e * TB];
+            i32x4 fb[3];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                split3(raw[2 * q], h0, m0, l0);
+                split3(raw[2 * q + 1], h1, m1, l1);
+                fb[0][q] = pack_hi(h0, h1);
+                fb[1][q] = pack_hi(m0, m1);
+                fb[2][q] = pack_hi(l0, l1);
+            }
+            unsigned char* dst = vdst + (size_t)xi * a.v_plane + (size_t)c * OPB;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<i32x4*>(dst + pc * FRAG) = fb[pc];
+        }
+        __syncthreads();
+    }
+}
+
+// Dilated 3x3 layers (dilation d, pad d: conv6 of models/RFB_Net_vgg.py:226 with d = 6, the RFB branches :38-63,:82-110 with
+// d = 2, 3, 5).  Output pixel (y, x) = (sy + d u, sx + d v) only sees input pixels of its own residue class (sy, sx) mod d, and
+// on that sub-lattice the layer is an ordinary pad-1 3x3 convolution of a ceil(H / d) x ceil(W / d) image -- so the d x d
+// sub-lattices are tiled with F(4x4,3x3) like d x d small images per input image: tile index
+//   T = (((n d + sy) d + sx) TY + ty) TX + tx,   TY = ceil(ceil(H / d) / 4),
+// patch element (i, j) of a tile = input pixel (sy + d (4 ty - 1 + i), sx + d (4 tx - 1 + j)).  A 19x19 map with d = 6 is 36
+// sub-lattices of 4x4 / 3x4 / 3x3 pixels = one tile each: 2.5x fewer multiplications than the direct kernel in spite of the
+// 63 % tile fill.  Only the two transform kernels know about it; V, the GEMMs and M are as for d = 1.  Patches are 36 scalar
+// loads (stride d), no software prefetch: these layers are small.
+__global__ __launch_bounds__(256, 2) void wino4s_in_dil(const Wino4sArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tblk = blockIdx.x;
+    const int HW = a.H * a.W, d = a.dil;
+    const int c_begin = blockIdx.y * a.chunks_per_wg, c_end = min(a.chunks, c_begin + a.chunks_per_wg);
+    if (c_begin >= c_end) return;
+    int rowoff[6], coloff[6];
+    {
+        const int T = tblk * TB + l31;
+        const bool live = T < a.NT;
+        const int per = a.TY * a.TX;
+        int q = T / per;
+        const int rem = T - q * per;
+        const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        const int sx = q % d; q /= d;
+        const int sy = q % d;
+        const int n = q / d;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int y = sy + d * (4 * ty - 1 + i), x = sx + d * (4 * tx - 1 + i);
+            rowoff[i] = (live && (unsigned)y < (unsigned)a.H) ? (int)(((((long)n * a.in_ctot + a.in_coff + h) * a.H + y) * (long)a.W) * 4) : -1;
+            coloff[i] = (unsigned)x < (unsigned)a.W ? x * 4 : -1;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const int chunk_bytes = CC * HW * 4;
+    const int chan_base = 4 * wave * HW * 4;
+    float* const vw_base = lds + wave * 128 + lane;
+    const float* const vr_base = lds + (8 * h) * TB + l31;
+    unsigned char* const vdst = reinterpret_cast<unsigned char*>(a.V) + (size_t)(tblk >> 2) * a.chunks * OPB +
+                                (tblk & 3) * (3 * FRAG) + lane * 16;
+    for (int c = c_begin; c < c_end; ++c) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int soff = c * chunk_bytes + chan_base + q * (2 * HW * 4);
+            float t[6][6];
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) {
+                float dd[6], o[6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const bool ok = rowoff[i] >= 0 && coloff[cc] >= 0;
+                    dd[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, ok ? rowoff[i] + coloff[cc] : kInvalidOff, soff, 0));
+                }
+                bt6(dd, o);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) t[i][cc] = o[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float v[6];
+                bt6(t[i], v);
+                float* vp = vw_base + q * 64 + (i * 6) * PT_STRIDE;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) vp[j * PT_STRIDE] = v[j];
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -399,6 +495,33 @@ __global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
         ctdet::w4::at4d(col, o);
 #pragma unroll
         for (int r = 0; r < 4; ++r) y[r][b] = (float)o[r];
+    }
+    if (a.dil > 1) {
+        // dilated layer (see wino4s_in_dil): the 4x4 outputs of a tile are d pixels apart; scale / shift and the floor only
+        // (the dilated layers of this network have no residual, pooling or head scatter)
+        const int d = a.dil, per = a.TY * a.TX;
+        int q = T / per;
+        const int rem = T - q * per;
+        const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        const int sx = q % d; q /= d;
+        const int sy = q % d;
+        const int n = q / d;
+        const float sc = a.scale[co], sh = a.shift[co];
+        const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
+        float* const plane = a.out + ((size_t)n * a.out_ctot + a.out_coff + co) * a.H * a.W;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int yy = sy + d * (4 * ty + r);
+            if (yy >= a.H) continue;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int xx = sx + d * (4 * tx + c);
+                if (xx >= a.W) continue;
+                const float v = y[r][c] * sc + sh;
+                plane[(size_t)yy * a.W + xx] = v < lo ? lo : v;
+            }
+        }
+        return;
     }
     const int n = T / (a.TY * a.TX);
     const int rem = T - n * (a.TY * a.TX);
@@ -632,18 +755,21 @@ bool wino4s_wg_ok(const ct_conv_desc* d)
 
 bool wino4s_ok(const ct_conv_desc* d)
 {
-    return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
-           d->cin % CC == 0 && d->nseg >= 0 && d->nseg <= 3 && (d->nseg == 0 || !d->res) && !d->transposed &&
-           d->oh == d->h && d->ow == d->w;
+    if (!(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil >= 1 && d->pad_h == d->dil && d->pad_w == d->dil &&
+          d->cin % CC == 0 && d->nseg >= 0 && d->nseg <= 3 && (d->nseg == 0 || !d->res) && !d->transposed &&
+          d->oh == d->h && d->ow == d->w))
+        return false;
+    // dilated: plain NCHW output with scale / shift / floor (what the dilated layers of the network use)
+    return d->dil == 1 || (d->dil <= 8 && d->nseg == 0 && !d->res);
 }
 
 struct Sizes { int TY, TX, NT, Tpad, kblocks, chunks; size_t v_plane, m_plane, v_bytes, m_bytes; };
 
-Sizes sizes_of(int batch, int oh, int ow, int cin, int cout)
+Sizes sizes_of(int batch, int oh, int ow, int cin, int cout, int dil)
 {
     Sizes s{};
-    s.TY = (oh + 3) / 4; s.TX = (ow + 3) / 4;
-    s.NT = batch * s.TY * s.TX;
+    s.TY = ((oh + dil - 1) / dil + 3) / 4; s.TX = ((ow + dil - 1) / dil + 3) / 4;      // per sub-lattice (dil = 1: the map)
+    s.NT = batch * dil * dil * s.TY * s.TX;
     s.Tpad = (s.NT + BT - 1) / BT * BT;
     s.kblocks = (cout + BM - 1) / BM;
     s.chunks = cin / CC;
@@ -667,7 +793,7 @@ extern "C" size_t ct_conv_wino4s_packed_bytes(int cin, int cout)
 extern "C" size_t ct_conv_wino4s_workspace_bytes(const ct_conv_desc* d)
 {
     if (!d || !wino4s_ok(d) || d->batch <= 0 || d->cout <= 0) return 0;
-    const Sizes s = sizes_of(d->batch, d->oh, d->ow, d->cin, d->cout);
+    const Sizes s = sizes_of(d->batch, d->oh, d->ow, d->cin, d->cout, d->dil);
     return s.v_bytes + s.m_bytes;
 }
 
@@ -690,12 +816,13 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
     CT_REQUIRE(d && upacked && workspace, "ct_conv2d_wino4s_fwd: null pointer");
     CT_REQUIRE(d->in && (d->out || d->nseg > 0) && d->scale && d->shift, "ct_conv2d_wino4s_fwd: null tensor");
     if (!wino4s_ok(d))
-        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wino4s_fwd: needs 3x3 stride 1 dilation 1 pad 1, cin %% 16 == 0 "
+        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wino4s_fwd: needs 3x3 stride 1 pad = dilation (dilated: plain NCHW output), cin %% 16 == 0 "
                            "(got %dx%d s%d d%d p%d cin=%d nseg=%d)", d->kh, d->kw, d->stride, d->dil,
                            d->pad_h, d->cin, d->nseg);
     CT_REQUIRE(variant == 1 || variant == 2, "ct_conv2d_wino4s_fwd: variant %d (1 = two accumulators, 2 = one)", variant);
     CT_REQUIRE(d->batch > 0 && d->cout > 0, "ct_conv2d_wino4s_fwd: bad shape");
     CT_REQUIRE(write_full || pool_out, "ct_conv2d_wino4s_pool_fwd: nothing to write");
+    CT_REQUIRE(d->dil == 1 || !pool_out, "ct_conv2d_wino4s_pool_fwd: fused pooling on a dilated layer");
     if (pool_out) {
         CT_REQUIRE(pool_coff >= 0 && pool_coff + d->cout <= pool_ctot, "ct_conv2d_wino4s_pool_fwd: pooled output slice");
         CT_REQUIRE((pool_oh == d->oh / 2 || pool_oh == (d->oh + 1) / 2) && (pool_ow == d->ow / 2 || pool_ow == (d->ow + 1) / 2),
@@ -716,7 +843,7 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
     CT_REQUIRE(img_out_bytes < kMaxBufBytes && img_res_bytes < kMaxBufBytes, "ct_conv2d_wino4s_fwd: one image exceeds 2 GiB");
     const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / std::max(img_in_bytes, std::max(img_out_bytes, img_res_bytes)));
     {
-        const Sizes s = sizes_of(std::min(d->batch, max_chunk), d->oh, d->ow, d->cin, d->cout);
+        const Sizes s = sizes_of(std::min(d->batch, max_chunk), d->oh, d->ow, d->cin, d->cout, d->dil);
         CT_REQUIRE(workspace_bytes >= s.v_bytes + s.m_bytes, "ct_conv2d_wino4s_fwd: workspace of %zu bytes, needs %zu "
                    "(ct_conv_wino4s_workspace_bytes)", workspace_bytes, s.v_bytes + s.m_bytes);
         CT_REQUIRE((size_t)s.chunks * OPB < (size_t)kMaxBufBytes, "ct_conv2d_wino4s_fwd: too many input channels");
@@ -728,6 +855,8 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
         std::call_once(once, [] {
             attr_err = hipFuncSetAttribute((const void*)wino4s_in, hipFuncAttributeMaxDynamicSharedMemorySize, IN_LDS_BYTES);
             if (attr_err == hipSuccess)
+                attr_err = hipFuncSetAttribute((const void*)wino4s_in_dil, hipFuncAttributeMaxDynamicSharedMemorySize, IN_LDS_BYTES);
+            if (attr_err == hipSuccess)
                 attr_err = hipFuncSetAttribute((const void*)wino4s_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
             if (attr_err == hipSuccess)
                 attr_err = hipFuncSetAttribute((const void*)wino4s_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
@@ -737,7 +866,7 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
     const int OHW = d->oh * d->ow;
     for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
         const int nb = std::min(max_chunk, d->batch - b0);
-        const Sizes s = sizes_of(nb, d->oh, d->ow, d->cin, d->cout);
+        const Sizes s = sizes_of(nb, d->oh, d->ow, d->cin, d->cout, d->dil);
         Wino4sArgs a{};
         a.in = d->in + (size_t)b0 * d->in_ctot * d->h * d->w;
         a.U = static_cast<const unsigned short*>(upacked);
@@ -762,6 +891,7 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
         a.pool_out = pool_out ? pool_out + (size_t)b0 * pool_ctot * pool_oh * pool_ow : nullptr;
         a.pool_ctot = pool_ctot; a.pool_coff = pool_coff; a.pool_oh = pool_oh; a.pool_ow = pool_ow;
         a.write_full = write_full;
+        a.dil = d->dil;
         a.V = static_cast<unsigned short*>(workspace);
         a.Mw = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + s.v_bytes);
         a.v_plane = s.v_plane;
@@ -773,7 +903,8 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
         const int ygroups = (a.chunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
         {
             CT_PROF("wino4s_in", st);
-            hipLaunchKernelGGL(wino4s_in, dim3(a.tblk32, ygroups), dim3(256), IN_LDS_BYTES, st, a);
+            if (a.dil > 1) hipLaunchKernelGGL(wino4s_in_dil, dim3(a.tblk32, ygroups), dim3(256), IN_LDS_BYTES, st, a);
+            else hipLaunchKernelGGL(wino4s_in, dim3(a.tblk32, ygroups), dim3(256), IN_LDS_BYTES, st, a);
             CT_LAUNCH_CHECK("wino4s_in");
         }
         {

@@ -459,10 +459,12 @@ class HipBackend:
             if rt.get('wpk_stale'):
                 self.pack_conv(st)
             return
-        if not rt.get('wino_ok'):
+        tile = int(tile or 2)
+        # the three-kernel form also takes dilated 3x3 layers (pad = dilation: tiles on the sub-lattices), which the fused
+        # kernels do not
+        if not (rt.get('wino_ok') or (tile in WINO4S_TILES and rt.get('wino4s_ok'))):
             raise _lib.CtdetError('%s: geometry has no Winograd path' % st.name)
         rt['x3'] = None
-        tile = int(tile or 2)
         if tile not in (2, 4) + WINOX_TILES + WINO4S_TILES:
             raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23, 24, 44 or 45)' % (st.name, tile))
         if tile not in WINO4S_TILES:
@@ -702,7 +704,7 @@ class HipBackend:
                 if t < best_t:
                     best_x3, best_t = cfg, t
             self.enable_x3(st, best_x3)
-        if st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
+        if (st.rt.get('wino_ok') or st.rt.get('wino4s_ok')) and os.environ.get('CTDET_WINO', '1') != '0':
             best_tile = 0
             for tile in wino_tiles(self, st):
                 self.enable_wino(st, tile=tile)
@@ -748,6 +750,8 @@ def wino_tiles(backend=None, st=None):
         tiles = tuple(t for t in tiles if t not in WINOX_TILES)
     if st is not None and not st.rt.get('wino4s_ok'):
         tiles = tuple(t for t in tiles if t not in WINO4S_TILES)
+    if st is not None and not st.rt.get('wino_ok'):          # dilated 3x3: only the three-kernel form
+        tiles = tuple(t for t in tiles if t in WINO4S_TILES)
     return tiles
 
 
@@ -812,7 +816,15 @@ def apply_tuned(backend, st, batch, wino4=True):
     cfg = tune_table().get(st.tune_key(batch))
     names = [backend.lib.ct_conv_config_name(i).decode() for i in range(backend.lib.ct_conv_num_configs())]
     codes = {v: k for k, v in WINO_NAME.items()}
-    if cfg in codes and st.rt.get('wino_ok') and os.environ.get('CTDET_WINO', '1') != '0':
+    usable = cfg in codes and (st.rt.get('wino_ok') or (codes[cfg] in WINO4S_TILES and st.rt.get('wino4s_ok'))) and \
+        os.environ.get('CTDET_WINO', '1') != '0'
+    if usable and st.dil > 1:
+        # dilated layer on the three-kernel form: only where tile 44 is allowed as such -- a runtime with an accuracy policy
+        # (Context-Transformer networks) keeps these layers on the direct bf16x3 kernel (4e-7 against 2e-6 per layer)
+        usable = getattr(backend, 'wino_tile_set', None) is None and codes[cfg] in wino_tiles(backend, st)
+    if cfg in codes and not usable:
+        cfg = tune_table().get(st.tune_key(batch) + '|alt')       # what the layer ran on before the three-kernel form took it
+    if usable:
         allowed = wino_tiles(backend, st)
         want = codes[cfg]
         if want in F4_TILES and not wino4:

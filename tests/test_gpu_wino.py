@@ -48,6 +48,34 @@ def test_wino_matches_reference(case, W):
     assert rel_err(got, direct) < TOL
 
 
+DIL_CASES = [  # name, B, Cin, H, W, Cout, dilation -- conv6 (d 6 @19x19) and the RFB branches (d 2, 3, 5) of the network, odd shapes
+    ('conv6', 2, 32, 19, 19, 48, 6), ('rfb_d2', 2, 16, 19, 19, 40, 2), ('rfb_d3', 1, 32, 38, 38, 33, 3), ('rfb_d5', 2, 16, 38, 37, 24, 5),
+    ('d6_32', 1, 16, 32, 32, 16, 6), ('small_map', 3, 16, 5, 4, 8, 3), ('one_pixel', 2, 16, 1, 1, 5, 2), ('d8', 1, 16, 23, 9, 8, 8),
+]
+
+
+@pytest.mark.parametrize('W', [engine.WINO4S, engine.WINO4SQ], ids=['f4x4_s', 'f4x4_sq'])
+@pytest.mark.parametrize('case', DIL_CASES, ids=[c[0] for c in DIL_CASES])
+def test_wino4s_dilated_layers(case, W):
+    """Dilated 3x3 layers (pad = dilation) on the three-kernel form: the d x d sub-lattices are tiled like small images
+    (csrc/ct_wino4s.hip, wino4s_in_dil).  Against torch-CPU conv2d and the direct kernel, with BatchNorm + ReLU, into a channel
+    slice of a wider buffer (how the RFB branches write their concat buffer)."""
+    name, B, Cin, H, Wd, Cout, dil = case
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    x = torch.randn(B, Cin, H, Wd, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (Cin * 9)) ** 0.5
+    parts = [(w, None, _bn(Cout, g), True)]
+    want = _ref_conv(x, parts, 1, dil, dil)
+    got = _run_conv(x, parts, 1, dil, dil, config=W, out_ctot=Cout + 11, out_coff=4)
+    assert rel_err(got[:, 4:4 + Cout], want) < TOL
+    assert torch.isnan(got[:, :4]).all() and torch.isnan(got[:, 4 + Cout:]).all()
+    direct = _run_conv(x, parts, 1, dil, dil, config=0)
+    assert rel_err(got[:, 4:4 + Cout], direct) < TOL
+    # the fused kernels refuse the geometry
+    with pytest.raises(_lib.CtdetError):
+        _run_conv(x, parts, 1, dil, dil, config=engine.WINO4)
+
+
 @pytest.mark.parametrize('W', VARIANTS, ids=VIDS)
 def test_wino_fused_epilogues(W):
     g = torch.Generator().manual_seed(11)
@@ -75,7 +103,9 @@ def test_wino_fused_epilogues(W):
 def test_wino_rejects_other_geometries(W):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, 16, 9, 9, generator=g)
-    for (k, stride, pad, dil, cin) in ((3, 2, 1, 1, 16), (3, 1, 2, 2, 16), (1, 1, 0, 1, 16), (3, 1, 0, 1, 16)):
+    # the three-kernel form takes dilated layers with pad = dilation (test_wino4s_dilated_layers); pad != dilation stays out
+    dilated = (3, 1, 1, 2, 16) if W in (engine.WINO4S, engine.WINO4SQ) else (3, 1, 2, 2, 16)
+    for (k, stride, pad, dil, cin) in ((3, 2, 1, 1, 16), dilated, (1, 1, 0, 1, 16), (3, 1, 0, 1, 16)):
         w = torch.randn(8, cin, k, k, generator=g)
         with pytest.raises(_lib.CtdetError):
             _run_conv(x, [(w, None, None, False)], stride, pad, dil, config=W)
