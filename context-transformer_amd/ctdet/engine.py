@@ -796,6 +796,10 @@ def ctx_f4_max_cin(net):
 
 
 CTX_W4S_MIN_CIN_DEFAULT = '128'
+# Context-Transformer networks: their dilated layers (conv6, the RFB branches) on the three-kernel form too, from
+# ctx_w4s_min_cin input channels up.  Measured (same session, 9 randn sweep cases, 8-thread reference): off: 2 885 images/s, two
+# cases at 1.00e-4 ('truth' verdict), GPU-fp64 <= 7.6e-5; on: 2 973 images/s, one case at 1.03e-4, GPU-fp64 <= 6.8e-5 -- on.
+CTX_DIL_W4S_DEFAULT = '1'
 
 
 def ctx_w4s_min_cin(net):
@@ -819,9 +823,14 @@ def apply_tuned(backend, st, batch, wino4=True):
     usable = cfg in codes and (st.rt.get('wino_ok') or (codes[cfg] in WINO4S_TILES and st.rt.get('wino4s_ok'))) and \
         os.environ.get('CTDET_WINO', '1') != '0'
     if usable and st.dil > 1:
-        # dilated layer on the three-kernel form: only where tile 44 is allowed as such -- a runtime with an accuracy policy
-        # (Context-Transformer networks) keeps these layers on the direct bf16x3 kernel (4e-7 against 2e-6 per layer)
-        usable = getattr(backend, 'wino_tile_set', None) is None and codes[cfg] in wino_tiles(backend, st)
+        # dilated layer on the three-kernel form: where tile 44 is allowed as such; a runtime with an accuracy policy
+        # (Context-Transformer networks) takes it from ctx_w4s_min_cin input channels up (CTDET_CTX_DIL_W4S=0: never --
+        # the layer then runs the table's previous choice, '|alt')
+        policy = getattr(backend, 'wino_tile_set', None) is not None
+        if policy:
+            usable = os.environ.get('CTDET_CTX_DIL_W4S', CTX_DIL_W4S_DEFAULT) != '0' and st.cin >= getattr(backend, 'ctx_w4s_min_cin', 0) > 0
+        else:
+            usable = codes[cfg] in wino_tiles(backend, st)
     if cfg in codes and not usable:
         cfg = tune_table().get(st.tune_key(batch) + '|alt')       # what the layer ran on before the three-kernel form took it
     if usable:

@@ -191,3 +191,27 @@ def test_init_weight_rules_match_reference(golden, tag, size, C, phase, setting)
         net.normalize()
         assert np.array_equal(net.OBJ_Target.weight.data.numpy(), g[tag + '_normalized'])     # :316-318, same expression
         assert torch.allclose(net.OBJ_Target.weight.data.norm(dim=1), torch.ones(net.OBJ_Target.weight.shape[0]), atol=1e-6)
+
+
+def test_committed_tune_table_is_consistent():
+    """ctdet/conv_tune_gfx950.json: every value names a kernel choice the engine knows; a dilated layer that the table gives
+    to the three-kernel Winograd form keeps its previous choice under '|alt' (what a runtime with an accuracy policy, or one
+    without tile 44, falls back to -- engine.apply_tuned), and no fallback is itself a Winograd name."""
+    import json
+    import re
+    from ctdet import engine
+    table = json.load(open(engine.TUNE_TABLE))
+    wino = set(engine.WINO_NAME.values())
+    for key, val in table.items():
+        assert isinstance(val, str) and val, key
+        if key.endswith('|alt') or key.endswith('|f32'):
+            assert val not in wino, (key, val)
+            assert key.rsplit('|', 1)[0] in table, key
+            continue
+        m = re.match(r'(\d+)x(\d+)_s(\d+)_d(\d+)_c(\d+)_m(\d+)_(\d+)x(\d+)_b(\d+)', key)
+        assert m, key
+        kh, kw, stride, dil, cin = (int(m.group(i)) for i in (1, 2, 3, 4, 5))
+        if val in wino:
+            assert (kh, kw, stride) == (3, 3, 1), (key, val)
+            if dil > 1:
+                assert val in ('wino4s', 'wino4sq') and cin % 16 == 0 and key + '|alt' in table, (key, val)

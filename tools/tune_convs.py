@@ -51,8 +51,10 @@ for case in a.cases:
             be.enable_wino(st, tile=44)
             t_new = min(be._time_conv(st), be._time_conv(st))
             if t_new < (1.0 - a.w4s) * t_cur:
-                if not cur_tile and isinstance(table.get(key), str):
-                    table[key + '|alt'] = table[key]        # non-Winograd layer (dilated): what to run where tile 44 is not allowed
+                if not cur_tile and isinstance(table.get(key), str) and table[key] not in engine.WINO_NAME.values():
+                    # non-Winograd layer (dilated): what to run where tile 44 is not allowed (the first case that moves a shape
+                    # records it; a later case sees 'wino4s' in the table and leaves the record alone)
+                    table[key + '|alt'] = table[key]
                 table[key] = 'wino4s'
                 moved.append('%s %.0f->%.0f us' % (st.name, t_cur * 1e3, t_new * 1e3))
             else:                               # back to what the table says
