@@ -552,6 +552,7 @@ struct TkArgs {
     int chunks_per_wg;
     unsigned char* dst;
     size_t plane;            // bytes per point
+    int dil;                 // > 1: tiles on the dil x dil sub-lattices (see wino4s_in_dil)
 };
 
 template <bool IS_E>
@@ -567,21 +568,34 @@ __global__ __launch_bounds__(256, 2) void wino4s_tk(const TkArgs a)
     constexpr int NR = IS_E ? 4 : 6;                 // rows / columns of the spatial block a thread loads
     int voffr[NR];
     bool mc[NR], lp = false;
+    int coloff[NR];                                  // dilated layers: byte offset of column j inside a row, -1 = outside
+    const bool dilated = a.dil > 1;
     {
         const int T = tblk * TB + l31;
         const bool live = T < a.NT;
-        const int n = T / (a.TY * a.TX);
-        const int rem = T - n * (a.TY * a.TX);
+        const int per = a.TY * a.TX, d = a.dil;
+        int q = T / per;
+        const int rem = T - q * per;
         const int ty = rem / a.TX, tx = rem - ty * a.TX;
-        const int y0 = 4 * ty - (IS_E ? 0 : 1), x0 = 4 * tx - (IS_E ? 0 : 1);
+        const int sx = q % d; q /= d;                // d = 1: sx = sy = 0, q = image
+        const int sy = q % d;
+        const int n = q / d;
+        const int u0 = 4 * ty - (IS_E ? 0 : 1), v0 = 4 * tx - (IS_E ? 0 : 1);
 #pragma unroll
-        for (int c = 0; c < NR; ++c) mc[c] = (unsigned)(x0 + c) < (unsigned)a.W;
-        if (!IS_E) lp = tx == 0;                     // see wino4s_in: left-edge patches load from x = 0 and shift
-        const long base = (((long)n * a.ctot + a.coff + h) * a.H + y0) * (long)a.W + x0 + (lp ? 1 : 0);
+        for (int c = 0; c < NR; ++c) {
+            const int x = sx + d * (v0 + c);
+            mc[c] = (unsigned)x < (unsigned)a.W;
+            coloff[c] = mc[c] ? x * 4 : -1;
+        }
+        if (!IS_E && !dilated) lp = tx == 0;         // see wino4s_in: left-edge patches load from x = 0 and shift
+        const long plane0 = ((long)n * a.ctot + a.coff + h) * a.H;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
-            const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
-            voffr[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
+            const int y = sy + d * (u0 + i);
+            const bool ok = live && (unsigned)y < (unsigned)a.H;
+            // d = 1: offset of the first loaded column (vector loads); dilated: offset of the row start (scalar loads)
+            const long first = dilated ? 0 : (long)(v0 + (lp ? 1 : 0));
+            voffr[i] = ok ? (int)(((plane0 + y) * (long)a.W + first) * 4) : kInvalidOff;
         }
     }
     const int hy_delta = lp ? 8 : 12;
@@ -602,14 +616,24 @@ __global__ __launch_bounds__(256, 2) void wino4s_tk(const TkArgs a)
             float t[6][NR];
             if constexpr (IS_E) {
                 float e[4][4];
+                if (dilated) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rin, chok ? voffr[i] : kInvalidOff, soff, 0);
-                    const f32x4 q4 = __builtin_bit_cast(f32x4, r);
-                    e[i][0] = q4.x;
-                    e[i][1] = mc[1] ? q4.y : 0.f;
-                    e[i][2] = mc[2] ? q4.z : 0.f;
-                    e[i][3] = mc[3] ? q4.w : 0.f;
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const bool ok = chok && voffr[i] != kInvalidOff && coloff[j] >= 0;
+                            e[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, ok ? voffr[i] + coloff[j] : kInvalidOff, soff, 0));
+                        }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const i32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rin, chok ? voffr[i] : kInvalidOff, soff, 0);
+                        const f32x4 q4 = __builtin_bit_cast(f32x4, r);
+                        e[i][0] = q4.x;
+                        e[i][1] = mc[1] ? q4.y : 0.f;
+                        e[i][2] = mc[2] ? q4.z : 0.f;
+                        e[i][3] = mc[3] ? q4.w : 0.f;
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -620,25 +644,40 @@ __global__ __launch_bounds__(256, 2) void wino4s_tk(const TkArgs a)
                     for (int i = 0; i < 6; ++i) t[i][j] = o[i];
                 }
             } else {
-                i32x3 hx[6], hy[6];
+                if (dilated) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const int vo = chok ? voffr[i] : kInvalidOff;
-                    hx[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, vo, soff, 0);
-                    hy[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, vo == kInvalidOff ? kInvalidOff : vo + hy_delta, soff, 0);
-                }
+                    for (int cc = 0; cc < 6; ++cc) {
+                        float d[6], o[6];
 #pragma unroll
-                for (int cc = 0; cc < 6; ++cc) {
-                    float d[6], o[6];
+                        for (int i = 0; i < 6; ++i) {
+                            const bool ok = chok && voffr[i] != kInvalidOff && coloff[cc] >= 0;
+                            d[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, ok ? voffr[i] + coloff[cc] : kInvalidOff, soff, 0));
+                        }
+                        bt6(d, o);
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) t[i][cc] = o[i];
+                    }
+                } else {
+                    i32x3 hx[6], hy[6];
 #pragma unroll
                     for (int i = 0; i < 6; ++i) {
-                        const f32x3 qv = __builtin_bit_cast(f32x3, cc < 3 ? hx[i] : hy[i]);
-                        const float v = cc == 1 ? (lp ? qv.x : qv.y) : cc == 2 ? (lp ? qv.y : qv.z) : cc % 3 == 0 ? qv.x : cc % 3 == 1 ? qv.y : qv.z;
-                        d[i] = mc[cc] ? v : 0.f;
+                        const int vo = chok ? voffr[i] : kInvalidOff;
+                        hx[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, vo, soff, 0);
+                        hy[i] = __builtin_amdgcn_raw_buffer_load_b96(rin, vo == kInvalidOff ? kInvalidOff : vo + hy_delta, soff, 0);
                     }
-                    bt6(d, o);
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) t[i][cc] = o[i];
+                    for (int cc = 0; cc < 6; ++cc) {
+                        float d[6], o[6];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) {
+                            const f32x3 qv = __builtin_bit_cast(f32x3, cc < 3 ? hx[i] : hy[i]);
+                            const float v = cc == 1 ? (lp ? qv.x : qv.y) : cc == 2 ? (lp ? qv.y : qv.z) : cc % 3 == 0 ? qv.x : cc % 3 == 1 ? qv.y : qv.z;
+                            d[i] = mc[cc] ? v : 0.f;
+                        }
+                        bt6(d, o);
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) t[i][cc] = o[i];
+                    }
                 }
             }
 #pragma unroll
@@ -720,11 +759,11 @@ __global__ __launch_bounds__(256) void wino4s_wgrad_finish(const float* __restri
 
 struct WgSizes { int TY, TX, NT, tblk32, kchunks, rb, cb, splits, cps; size_t e_plane, v_plane, m_plane, m_slab, e_bytes, v_bytes, m_bytes; };
 
-WgSizes wg_sizes_of(int batch, int oh, int ow, int cin, int cout)
+WgSizes wg_sizes_of(int batch, int oh, int ow, int cin, int cout, int dil)
 {
     WgSizes s{};
-    s.TY = (oh + 3) / 4; s.TX = (ow + 3) / 4;
-    s.NT = batch * s.TY * s.TX;
+    s.TY = ((oh + dil - 1) / dil + 3) / 4; s.TX = ((ow + dil - 1) / dil + 3) / 4;      // per sub-lattice (dil = 1: the map)
+    s.NT = batch * dil * dil * s.TY * s.TX;
     s.tblk32 = (s.NT + TB - 1) / TB;
     s.kchunks = 2 * s.tblk32;
     s.rb = (cout + BM - 1) / BM;
@@ -746,7 +785,7 @@ WgSizes wg_sizes_of(int batch, int oh, int ow, int cin, int cout)
 
 bool wino4s_wg_ok(const ct_conv_desc* d)
 {
-    return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+    return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil >= 1 && d->dil <= 8 && d->pad_h == d->dil && d->pad_w == d->dil &&
            d->oh == d->h && d->ow == d->w && !d->transposed && d->cin >= 16 && d->cin % CC == 0 && d->cout >= 1 &&
            // one launch covers the batch (no chunking): both tensors must stay below 2 GiB as a whole
            (long long)std::max(d->batch, 1) * d->in_ctot * d->h * d->w * 4 < kMaxBufBytes &&
@@ -938,7 +977,7 @@ extern "C" int ct_conv_wgrad_wino4s_supported(const ct_conv_desc* d) { return d 
 extern "C" size_t ct_conv_wgrad_wino4s_workspace_bytes(const ct_conv_desc* d)
 {
     if (!d || !wino4s_wg_ok(d) || d->batch <= 0) return 0;
-    const WgSizes s = wg_sizes_of(d->batch, d->oh, d->ow, d->cin, d->cout);
+    const WgSizes s = wg_sizes_of(d->batch, d->oh, d->ow, d->cin, d->cout, d->dil);
     return s.e_bytes + s.v_bytes + s.m_bytes;
 }
 
@@ -947,7 +986,7 @@ extern "C" int ct_conv2d_wgrad_wino4s(const ct_conv_desc* d, const float* dz, in
 {
     CT_REQUIRE(d && dz && dw && workspace && d->in, "ct_conv2d_wgrad_wino4s: null pointer");
     if (!wino4s_wg_ok(d))
-        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wgrad_wino4s: needs 3x3 stride 1 dilation 1 pad 1, cin %% 16 == 0 "
+        return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wgrad_wino4s: needs 3x3 stride 1 pad = dilation, cin %% 16 == 0 "
                            "(got %dx%d s%d d%d p%d cin=%d)", d->kh, d->kw, d->stride, d->dil, d->pad_h, d->cin);
     CT_REQUIRE(d->batch > 0, "ct_conv2d_wgrad_wino4s: bad shape");
     CT_REQUIRE(dz_coff >= 0 && dz_coff + d->cout <= dz_ctot, "ct_conv2d_wgrad_wino4s: dz slice");
@@ -955,7 +994,7 @@ extern "C" int ct_conv2d_wgrad_wino4s(const ct_conv_desc* d, const float* dz, in
     const long long x_bytes = (long long)d->batch * d->in_ctot * d->h * d->w * 4;
     const long long z_bytes = (long long)d->batch * dz_ctot * d->oh * d->ow * 4;
     CT_REQUIRE(x_bytes < kMaxBufBytes && z_bytes < kMaxBufBytes, "ct_conv2d_wgrad_wino4s: a tensor exceeds 2 GiB (use ct_conv2d_wgrad_wino4)");
-    const WgSizes s = wg_sizes_of(d->batch, d->oh, d->ow, d->cin, d->cout);
+    const WgSizes s = wg_sizes_of(d->batch, d->oh, d->ow, d->cin, d->cout, d->dil);
     CT_REQUIRE(workspace_bytes >= s.e_bytes + s.v_bytes + s.m_bytes, "ct_conv2d_wgrad_wino4s: workspace of %zu bytes, needs %zu",
                workspace_bytes, s.e_bytes + s.v_bytes + s.m_bytes);
     CT_REQUIRE((size_t)s.kchunks * OPB < (size_t)kMaxBufBytes, "ct_conv2d_wgrad_wino4s: too many tiles for one launch");
@@ -987,6 +1026,7 @@ extern "C" int ct_conv2d_wgrad_wino4s(const ct_conv_desc* d, const float* dz, in
         t.chunks_per_wg = (int)std::max<long>(1, std::min<long>(t.chunks, pairs / 2048));
         t.dst = is_e ? E : V;
         t.plane = is_e ? s.e_plane : s.v_plane;
+        t.dil = d->dil;
         const dim3 grid(t.tblk32, (t.chunks + t.chunks_per_wg - 1) / t.chunks_per_wg);
         if (is_e) hipLaunchKernelGGL(wino4s_tk<true>, grid, dim3(256), TK_LDS_BYTES, st, t);
         else hipLaunchKernelGGL(wino4s_tk<false>, grid, dim3(256), TK_LDS_BYTES, st, t);

@@ -150,6 +150,22 @@ class TrainRuntime:
                         else:
                             sizeof = self.lib.ct_conv_wino4_packed_floats if s.dgrad_tile == 4 else self.lib.ct_conv_wino_packed_floats
                             s.U_d = al((sizeof(zc, st.cin),))
+                # dilated 3x3 layers (pad = dilation) whose forward launch runs the three-kernel form: their data gradient is
+                # the same dilated convolution with channels swapped and taps rotated -> the same kernels (tiles on the
+                # dilation sub-lattices); the dilated output transform has no accumulate, so a source gradient that was already
+                # written goes through a scratch tensor (does not happen in these networks)
+                elif (st.kh, st.kw, st.stride) == (3, 3, 1) and st.dil > 1 and st.ph == st.pw == st.dil and zc % 16 == 0 and \
+                        s.fwd.rt.get('wino') in WINO4S_TILES and os.environ.get('CTDET_TRAIN_W4S', '1') != '0' and \
+                        os.environ.get('CTDET_TRAIN_W4S_DIL', '1') != '0':
+                    w2 = _lib.ConvDesc()
+                    C.memmove(C.byref(w2), C.byref(d), C.sizeof(d))
+                    w2.transposed = 0
+                    w2.ksplit, w2.ksplit_ws, w2.ksplit_ws_floats = 0, None, 0
+                    if self.lib.ct_conv_wino4s_supported(C.byref(w2)):
+                        s.dgrad_wino = w2
+                        s.dgrad_tile = 44
+                        s.U_d = al((self.lib.ct_conv_wino4s_packed_bytes(zc, st.cin) // 4,))
+                        w4s_ws = max(w4s_ws, self.lib.ct_conv_wino4s_workspace_bytes(C.byref(w2)))
             # direct data gradients on the bf16 matrix pipe (bf16x3, ct_conv2d_x3_fwd transposed): every layer without
             # a Winograd data gradient whose channel counts fit the k-step; CTDET_X3=0 keeps ct_conv2d_fwd
             s.dgrad_x3 = None
@@ -185,8 +201,13 @@ class TrainRuntime:
             # 437 -> 366; the multibox heads (cout 126..156: 238 -> 353) and 256 -> 256 @75x75 (750 -> 804) stay fused).  Its
             # workspace (E, V, dU slabs) is shared: weight gradients run in stream order.
             w4s_min = int(os.environ.get('CTDET_WGRAD_W4S_MIN_CIN', '256') or 0)
-            if s.wgrad_wino and s.wgrad_tile == 4 and w4s_min and st.cin >= w4s_min and st.cin * ctot >= (1 << 17) and \
+            # dilated 3x3 layers (conv6: 512 -> 1024, dilation 6) have no fused Winograd weight gradient; the three-kernel form
+            # takes them with the tiles on the dilation sub-lattices, under the same size rule
+            dilated = (st.kh, st.kw, st.stride) == (3, 3, 1) and st.dil > 1 and st.ph == st.pw == st.dil and \
+                os.environ.get('CTDET_TRAIN_W4S_DIL', '1') != '0'
+            if (s.wgrad_wino and s.wgrad_tile == 4 or dilated) and w4s_min and st.cin >= w4s_min and st.cin * ctot >= (1 << 17) and \
                     self.lib.ct_conv_wgrad_wino4s_supported(C.byref(w)):
+                s.wgrad_wino = True
                 s.wgrad_tile = 44
                 wg4s_ws = max(wg4s_ws, int(self.lib.ct_conv_wgrad_wino4s_workspace_bytes(C.byref(w))))
             if s.wgrad_wino:
@@ -616,7 +637,16 @@ class TrainRuntime:
                     if not self._batched_packs:
                         self._pack_dgrad(st, s)
                     s.dgrad_wino.res = self.grads[st.src].data_ptr() if acc else None
-                    if s.dgrad_tile == 44:
+                    if s.dgrad_tile == 44 and st.dil > 1 and acc:
+                        g = self.grads[st.src]
+                        tmp = torch.empty((g.shape[0], st.cin, st.h, st.w), device=g.device)
+                        w3 = _lib.ConvDesc()
+                        C.memmove(C.byref(w3), C.byref(s.dgrad_wino), C.sizeof(w3))
+                        w3.res, w3.out, w3.out_ctot, w3.out_coff = None, tmp.data_ptr(), st.cin, 0
+                        _lib.check(lib.ct_conv2d_wino4s_fwd(C.byref(w3), s.U_d.data_ptr(), self.dgrad_ws4s.data_ptr(),
+                                                            self.dgrad_ws4s.numel(), 1, self._s()), st.name + ' dgrad (winograd 4s, dilated)')
+                        g[:, st.src_coff:st.src_coff + st.cin] += tmp
+                    elif s.dgrad_tile == 44:
                         _lib.check(lib.ct_conv2d_wino4s_fwd(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self.dgrad_ws4s.data_ptr(),
                                                             self.dgrad_ws4s.numel(), 1, self._s()), st.name + ' dgrad (winograd 4s)')
                     else:

@@ -81,6 +81,9 @@ GEOMS_4S = [  # B, Cin, H, W, Cout, x slice, dz slice -- cin % 16 == 0 (16-chann
     (2, 64, 19, 19, 64, None, None), (3, 16, 10, 10, 40, None, None), (2, 80, 19, 17, 130, None, None),
     (5, 16, 5, 5, 8, None, None), (2, 32, 3, 3, 24, None, None), (4, 16, 1, 1, 8, None, None),
     (2, 32, 38, 38, 64, (48, 9), (80, 7)), (2, 128, 75, 75, 64, None, None), (2, 256, 38, 38, 156, None, None),
+    # dilated (pad = dilation): conv6's d 6 at 19x19, the RFB branches' d 2 / 3 / 5, odd shapes -- 8th field
+    (2, 32, 19, 19, 48, None, None, 6), (2, 16, 19, 19, 40, None, None, 2), (1, 32, 38, 37, 33, None, None, 3),
+    (2, 16, 38, 38, 24, (20, 3), (30, 5), 5), (3, 16, 5, 4, 8, None, None, 3), (2, 16, 1, 1, 5, None, None, 2),
 ]
 
 
@@ -89,7 +92,8 @@ def test_wino4s_wgrad_vs_autograd(g):
     """ct_conv2d_wgrad_wino4s: F(3x3, 4x4) as transform kernels + the bf16x3 GEMM kernel of the forward form (k = tiles,
     split over workgroups, slabs added in order) against float64 autograd, held to the fused kernel's bound; two calls give
     bit-identical results (no atomics)."""
-    B, Cin, H, W, Cout, xs, zs = g
+    B, Cin, H, W, Cout, xs, zs = g[:7]
+    dil = g[7] if len(g) > 7 else 1
     gen = torch.Generator().manual_seed(11 + Cin + H)
     xctot, xcoff = xs or (Cin, 0)
     zctot, zcoff = zs or (Cout, 0)
@@ -97,10 +101,10 @@ def test_wino4s_wgrad_vs_autograd(g):
     dzfull = torch.randn(B, zctot, H, W, generator=gen)
     x = xfull[:, xcoff:xcoff + Cin].double().requires_grad_(True)
     w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
-    F.conv2d(x, w, None, 1, 1).backward(dzfull[:, zcoff:zcoff + Cout].double())
+    F.conv2d(x, w, None, 1, dil, dil).backward(dzfull[:, zcoff:zcoff + Cout].double())
     lib = _lib.lib()
     xd, dzd = xfull.to(DEV), dzfull.to(DEV)
-    d = _desc(xd, B, Cin, H, W, xctot, xcoff, Cout)
+    d = _desc(xd, B, Cin, H, W, xctot, xcoff, Cout, pad=dil, dil=dil)
     assert lib.ct_conv_wgrad_wino4s_supported(C.byref(d)) == 1
     ws = torch.empty(lib.ct_conv_wgrad_wino4s_workspace_bytes(C.byref(d)), device=DEV, dtype=torch.uint8)
     outs = []
