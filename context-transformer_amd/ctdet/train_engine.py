@@ -205,7 +205,12 @@ class TrainRuntime:
             # takes them with the tiles on the dilation sub-lattices, under the same size rule
             dilated = (st.kh, st.kw, st.stride) == (3, 3, 1) and st.dil > 1 and st.ph == st.pw == st.dil and \
                 os.environ.get('CTDET_TRAIN_W4S_DIL', '1') != '0'
-            if (s.wgrad_wino and s.wgrad_tile == 4 or dilated) and w4s_min and st.cin >= w4s_min and st.cin * ctot >= (1 << 17) and \
+            # dilated layers: the alternative is the direct fp32 kernel, so the rule is looser -- conv6 and the 256-channel RFB
+            # branches (same-box A/B of the step: 2^17 / 2^16 / 2^14 with 128 channels: 38.2-40.1 / 37.7-38.2 / 38.4-38.5 ms)
+            dil_prod = int(os.environ.get('CTDET_WGRAD_W4S_DIL_PROD', str(1 << 16)))
+            dil_cin = int(os.environ.get('CTDET_WGRAD_W4S_DIL_CIN', '256'))
+            if ((s.wgrad_wino and s.wgrad_tile == 4 and st.cin >= w4s_min and st.cin * ctot >= (1 << 17)) or
+                    (dilated and st.cin >= dil_cin and st.cin * ctot >= dil_prod)) and w4s_min and \
                     self.lib.ct_conv_wgrad_wino4s_supported(C.byref(w)):
                 s.wgrad_wino = True
                 s.wgrad_tile = 44
