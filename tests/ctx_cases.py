@@ -77,10 +77,11 @@ def verdict(r, tol=1e-4, cap=1.25e-4):
     8 threads and 6.63e-5 at 128, and the device's distance to "the CPU path" moves with it (1.00e-4 vs 7.9e-5, the
     device's own output bit-identical).  A device that is TWICE as close to fp64 as the CPU path (every Winograd layer on
     F(2x2,3x3) / bf16x3, two accumulators: 3.5..5.3e-5 from fp64, closer than the CPU path in 9 of 9 cases) still lands
-    1.10e-4 from the 8-thread CPU path in one case (profiles/r04_ctx_policy.txt).  So 1e-4 against the CPU path is met
-    where the CPU path's own error allows it (8 of 9 cases at 8 threads, 9 of 9 at 128 with the shipped policy), and the
-    contract that can be held flat is the one against the exact value: device within 1e-4 of fp64 in the max norm
-    (measured 3.8..7.6e-5 over the sweep), within 1.25e-4 of the CPU path.  Rounds 2-3 accepted 'no further from fp64
+    1.10e-4 from the 8-thread CPU path in one case under one tile table and 9.7e-5 under the next (DESIGN.md section 2,
+    profiles/r04_ctx_policy.txt).  So 1e-4 against the CPU path is met where the CPU path's own error allows it (8 of 9
+    cases at 8 threads, 7 of 9 at 128 with the shipped policy; the others 1.03..1.05e-4), and the contract that can be
+    held flat is the one against the exact value: device within 1e-4 of fp64 in the max norm (measured 4.6..6.8e-5 over
+    the sweep), within 1.25e-4 of the CPU path.  Rounds 2-3 accepted 'no further from fp64
     than 1.75 x the CPU path at the 99.99 % quantile and within 2.5e-4': that waiver is gone; tests/conftest.py pins the
     reference to 8 threads (the count tools/gen_goldens.py captured the goldens with)."""
     if r['gpu_cpu32'] <= tol:
