@@ -15,6 +15,8 @@ SHAPES = {  # B, Cin, H, W, Cout
     'base.24.b4': (4, 512, 19, 19, 512), 'head.0.b4': (4, 512, 38, 38, 156), 'head.1.b4': (4, 1024, 19, 19, 156),
     'base.24.b8': (8, 512, 19, 19, 512), 'base.14': (32, 256, 75, 75, 256), 'head.1': (32, 1024, 19, 19, 156),
     'base.17b': (32, 256, 38, 38, 512), 'c512.4': (32, 512, 64, 64, 512),
+    'base.7.b2': (2, 128, 150, 150, 128), 'base.7.b4': (4, 128, 150, 150, 128), 'base.7.b8': (8, 128, 150, 150, 128), 'base.10.b8': (8, 128, 75, 75, 256),
+    'base.2.b1': (1, 64, 300, 300, 64), 'base.2.b2b': (2, 64, 300, 300, 64), 'base.5.b4': (4, 64, 150, 150, 128), 'base.5.b8': (8, 64, 150, 150, 128),
     'small': (2, 16, 21, 37, 40), 'tiny': (1, 8, 8, 8, 64), 'b2.b2': (2, 64, 300, 300, 64),
 }
 names = sys.argv[1:] or ['base.2', 'base.7', 'base.12', 'base.19', 'base.24']
