@@ -712,6 +712,8 @@ class HipBackend:
                 times.append(t)
                 if t < best_t:
                     best_tile, best_t = tile, t
+            # what the layer would run without a Winograd kernel: recorded next to a dilated layer's 'wino4s' entry ('|alt')
+            st.rt['alt'] = self.x3_names()[best_x3] if best_x3 is not None else self.lib.ct_conv_config_name(best).decode()
             if best_tile:
                 self.enable_wino(st, tile=best_tile)
             else:
@@ -1058,6 +1060,10 @@ class Runtime:
             f32 = lib.ct_conv_config_name(st.rt['desc'].config - 1).decode() if st.rt['desc'].config > 0 else None
             if st.rt.get('wino'):
                 out[key] = WINO_NAME[st.rt['wino']]
+                if st.dil > 1 and st.rt.get('alt'):       # apply_tuned's fallback where tile 44 may not be used on a dilated layer
+                    out[key + '|alt'] = st.rt['alt']
+                    if f32 and st.rt['alt'].startswith('x3:'):
+                        out[key + '|f32'] = f32
             elif st.rt.get('x3') is not None:
                 out[key] = xn[st.rt['x3']]
                 if f32:
