@@ -123,3 +123,46 @@ def test_f4_transform_header_matches_these_matrices():
     sp, dp, sq, dq = d[1] + d[2], d[1] - d[2], d[3] + d[4], d[3] - d[4]
     gt = np.array([d[0] / _N0 + sp / _NP + sq / _NQ, _P / _NP * dp + _Q / _NQ * dq, _P2 / _NP * sp + _Q2 / _NQ * sq + d[5]])
     assert np.allclose(gt, MATS[4]['G'].T @ d)
+
+
+@pytest.mark.parametrize('geom', [(19, 19, 6), (19, 19, 2), (38, 37, 3), (38, 38, 5), (32, 32, 6), (5, 4, 3), (1, 1, 2), (23, 9, 8)])
+def test_dilated_layer_is_d2_pad1_layers_on_its_sublattices_and_the_tile_numbering(geom):
+    """csrc/ct_wino4s.hip (wino4s_in_dil, the dilated branch of wino4s_out, wino4s_tk): a 3x3 convolution with dilation d and
+    pad d is, on each of the d x d residue classes (sy, sx) of the pixel grid, an ordinary pad-1 3x3 convolution of the
+    ceil(H / d) x ceil(W / d) sub-image -- checked against conv2d in float64 -- and the kernels' tile numbering
+    T = (((n d + sy) d + sx) TY + ty) TX + tx with patch element (i, j) = pixel (sy + d (4 ty - 1 + i), sx + d (4 tx - 1 + j))
+    visits every output pixel exactly once and every patch element at the pixel the sub-lattice convolution reads."""
+    H, W, d = geom
+    g = torch.Generator().manual_seed(H * 100 + W + d)
+    N, C, K = 2, 3, 4
+    x = torch.randn(N, C, H, W, generator=g, dtype=torch.float64)
+    w = torch.randn(K, C, 3, 3, generator=g, dtype=torch.float64)
+    want = F.conv2d(x, w, None, 1, d, d)
+    got = torch.zeros_like(want)
+    for sy in range(d):
+        for sx in range(d):
+            sub = x[:, :, sy::d, sx::d]
+            if sub.numel():
+                got[:, :, sy::d, sx::d] = F.conv2d(sub, w, None, 1, 1, 1)
+    assert torch.allclose(got, want, atol=1e-12)
+    # tile geometry as the kernels decode it
+    TY, TX = (-(-H // d) + 3) // 4, (-(-W // d) + 3) // 4
+    NT = N * d * d * TY * TX
+    seen = torch.zeros(N, H, W, dtype=torch.int64)
+    xp = F.pad(x, (d, d, d, d))
+    for T in range(NT):
+        q, rem = divmod(T, TY * TX)
+        ty, tx = divmod(rem, TX)
+        q, sx = divmod(q, d)
+        n, sy = divmod(q, d)
+        for r in range(4):
+            for c in range(4):
+                yy, xx = sy + d * (4 * ty + r), sx + d * (4 * tx + c)
+                if yy < H and xx < W:
+                    seen[n, yy, xx] += 1
+                    # the output's 3x3 window = patch elements (r .. r + 2, c .. c + 2) of this tile
+                    win = torch.stack([torch.stack([xp[n, :, d + sy + d * (4 * ty - 1 + r + a), d + sx + d * (4 * tx - 1 + c + b)]
+                                                    for b in range(3)], -1) for a in range(3)], -2)      # [C, 3, 3]
+                    if T % 7 == 0 and r == c:                  # a sample is enough: the loop is pure Python
+                        assert torch.allclose((win.unsqueeze(0) * w).sum((1, 2, 3)), want[n, :, yy, xx], atol=1e-12)
+    assert int(seen.min()) == 1 and int(seen.max()) == 1
