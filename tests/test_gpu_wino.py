@@ -202,12 +202,13 @@ def test_conv_input_above_2gib_is_chunked(use_wino):
 
 
 @pytest.mark.parametrize('W,bound', [(engine.WINO, 3e-6), (engine.WINO4, 5e-5), (engine.WINOX, 1e-6), (engine.WINOXQ, 2e-6),
-                                     (engine.WINO4S, 5e-5), (engine.WINO4SQ, 5e-5)], ids=VIDS)
+                                     (engine.WINO4S, 6e-6), (engine.WINO4SQ, 1.2e-5)], ids=VIDS)
 def test_wino_rounding_error_vs_fp64(W, bound):
     """The transform-domain rounding of each variant on the deepest VGG shape (512 input channels, post-ReLU input):
     max error over the output range against an fp64 convolution.  Measured 1e-6 for F(2x2,3x3) and 2e-5 for
     F(4x4,3x3) (interpolation points 0, +-1, +-2, inf; transform entries up to 8).  The bf16x3 forms sum 16 channels
-    inside an MFMA before one rounding; with two accumulators the large sum sees cin / 16 roundings."""
+    inside an MFMA before one rounding; with two accumulators the large sum sees cin / 16 roundings.  The three-kernel
+    F(4x4,3x3) form (bf16x3 GEMMs, output transform in double): measured 2.0e-6 with two accumulators, 4.5e-6 with one."""
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 512, 38, 38, generator=g).relu()
