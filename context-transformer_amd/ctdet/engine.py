@@ -456,6 +456,7 @@ class HipBackend:
         rt = st.rt
         if not on:
             rt['wino'] = False
+            rt.pop('ws4s', None)            # the three-kernel form's V / M workspace (hundreds of MB)
             if rt.get('wpk_stale'):
                 self.pack_conv(st)
             return
