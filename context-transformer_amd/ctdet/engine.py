@@ -370,6 +370,31 @@ class HipBackend:
         if self.device.type != 'cuda':
             raise _lib.CtdetError('HipBackend needs a HIP device, got %s' % device)
         self.lib = _lib.lib()
+        # V / M workspace of the three-kernel Winograd form (csrc/ct_wino4s.hip): ONE buffer per stream of the schedule,
+        # sized for the largest layer on it -- launches of a stream run one after another (st.rt['ws_key'] = the stream
+        # index the Runtime gave the step, 0 before there is a schedule).  Per-layer buffers were ~6 GB per RFBNet-300
+        # runtime at bs 32 and > 10 GB for RFBNet-512.
+        self.ws_pool = {}
+
+    def ws_reserve(self, key, nbytes):
+        t = self.ws_pool.get(key)
+        if t is None or t.numel() < nbytes:
+            self.ws_pool[key] = None            # drop the old buffer before allocating the larger one
+            self.ws_pool[key] = self.alloc((nbytes,), torch.uint8)
+
+    def ws_rebuild(self, steps):
+        """(Re)size the pool to what the given conv steps need, per key; called once the schedule is known."""
+        need = {}
+        for st in steps:
+            if st.rt.get('wino') in WINO4S_TILES:
+                k = st.rt.get('ws_key', 0)
+                need[k] = max(need.get(k, 0), st.rt.get('ws4s_bytes', 0))
+        for k in list(self.ws_pool):
+            if k not in need or self.ws_pool[k] is None or self.ws_pool[k].numel() != need[k]:
+                self.ws_pool[k] = None
+        for k, n in need.items():
+            if self.ws_pool.get(k) is None:
+                self.ws_pool[k] = self.alloc((n,), torch.uint8)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -456,7 +481,7 @@ class HipBackend:
         rt = st.rt
         if not on:
             rt['wino'] = False
-            rt.pop('ws4s', None)            # the three-kernel form's V / M workspace (hundreds of MB)
+            rt.pop('ws4s_bytes', None)      # the three-kernel form's V / M workspace need (ws_rebuild shrinks the pool)
             if rt.get('wpk_stale'):
                 self.pack_conv(st)
             return
@@ -469,14 +494,14 @@ class HipBackend:
         if tile not in (2, 4) + WINOX_TILES + WINO4S_TILES:
             raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23, 24, 44 or 45)' % (st.name, tile))
         if tile not in WINO4S_TILES:
-            rt.pop('ws4s', None)            # the three-kernel form's V / M workspace (hundreds of MB)
+            rt.pop('ws4s_bytes', None)
         if tile in WINO4S_TILES:
             if not rt.get('wino4s_ok'):
                 raise _lib.CtdetError('%s: geometry has no three-kernel Winograd path (cin %% 16)' % st.name)
             if 'U4S' not in rt:
                 rt['U4S'] = self.alloc((self.lib.ct_conv_wino4s_packed_bytes(st.cin, st.cout),), torch.uint8)
-            if 'ws4s' not in rt:
-                rt['ws4s'] = self.alloc((self.lib.ct_conv_wino4s_workspace_bytes(C.byref(rt['desc'])),), torch.uint8)
+            rt['ws4s_bytes'] = self.lib.ct_conv_wino4s_workspace_bytes(C.byref(rt['desc']))
+            self.ws_reserve(rt.get('ws_key', 0), rt['ws4s_bytes'])
         elif tile in WINOX_TILES:
             if not rt.get('winox_ok'):
                 raise _lib.CtdetError('%s: geometry has no Winograd bf16x3 path (cin %% 16)' % st.name)
@@ -569,7 +594,7 @@ class HipBackend:
     def run_conv(self, st):
         tile = st.rt.get('wino')
         if tile in WINO4S_TILES:         # F(4x4,3x3): transform / bf16x3 GEMM / transform (csrc/ct_wino4s.hip)
-            lib, U, ws, var = self.lib, st.rt['U4S'].data_ptr(), st.rt['ws4s'], WINO4S_VARIANT[tile]
+            lib, U, ws, var = self.lib, st.rt['U4S'].data_ptr(), self.ws_pool[st.rt.get('ws_key', 0)], WINO4S_VARIANT[tile]
             pool = st.rt.get('pool')
             if pool is not None:
                 t, poh, pow_, full = pool
@@ -828,12 +853,14 @@ def apply_tuned(backend, st, batch, wino4=True):
     if usable and st.dil > 1:
         # dilated layer on the three-kernel form: where tile 44 is allowed as such; a runtime with an accuracy policy
         # (Context-Transformer networks) takes it from ctx_w4s_min_cin input channels up (CTDET_CTX_DIL_W4S=0: never --
-        # the layer then runs the table's previous choice, '|alt')
+        # the layer then runs the table's previous choice, '|alt').  Only tiles 44 / 45 exist for these layers: a caller
+        # that rules out F(4x4) (wino4=False) gets the '|alt' entry as well.
         policy = getattr(backend, 'wino_tile_set', None) is not None
         if policy:
             usable = os.environ.get('CTDET_CTX_DIL_W4S', CTX_DIL_W4S_DEFAULT) != '0' and st.cin >= getattr(backend, 'ctx_w4s_min_cin', 0) > 0
         else:
             usable = codes[cfg] in wino_tiles(backend, st)
+        usable = usable and wino4
     if cfg in codes and not usable:
         cfg = tune_table().get(st.tune_key(batch) + '|alt')       # what the layer ran on before the three-kernel form took it
     if usable:
@@ -931,11 +958,14 @@ class Runtime:
             # and has the geometry for it is moved to that variant
             force = int(os.environ.get('CTDET_WINO_FORCE', '0') or 0)
             for st in (self.conv_steps() if force else ()):
-                if st.rt.get('wino') and (st.rt.get('winox_ok') or force in (2, 4)):
+                # dilated layers only exist on the three-kernel form: they keep it unless that is what is being forced
+                geo = st.rt.get('wino4s_ok') if force in WINO4S_TILES else st.rt.get('wino_ok')
+                if st.rt.get('wino') and geo and (st.rt.get('winox_ok') or force in (2, 4) + WINO4S_TILES):
                     backend.enable_wino(st, tile=force)
         self._fuse_pools()
         self._mark_exclusive()
         self._build_schedule()
+        self._share_workspaces()
 
     def _fuse_pools(self):
         """MaxPool2d(2, 2) directly behind a Winograd conv: the 2x2 output tile is the pooling window, so
@@ -1037,11 +1067,22 @@ class Runtime:
         names = [st.name for st in steps]
         if after and after in names:
             k = names.index(after)
-            early = [i for i in range(k) if sid[i] != 0]
-            self.order = [i for i in range(k + 1) if sid[i] == 0] + early + list(range(k + 1, len(steps)))
+            # only the side stream proper (Norm / heads / context pooling) is deferred: with CTDET_STREAMS > 2 the RFB branch
+            # streams feed main-stream steps at or before the anchor, whose waits must see this pass's events
+            early = [i for i in range(k) if sid[i] == 1]
+            self.order = [i for i in range(k + 1) if sid[i] != 1] + early + list(range(k + 1, len(steps)))
         self.sides = [torch.cuda.Stream(self.backend.device) for _ in range(max(sid))]
         self.side = self.sides[0]
         self.ev = {j: torch.cuda.Event() for j in self.signal}
+
+    def _share_workspaces(self):
+        """One three-kernel-Winograd workspace per stream of the schedule (HipBackend.ws_pool) instead of one per layer."""
+        if not hasattr(self.backend, 'ws_rebuild'):
+            return
+        for i, st in enumerate(self.plan.steps):
+            if st.kind == 'conv':
+                st.rt['ws_key'] = self.sid[i] if self.side is not None else 0
+        self.backend.ws_rebuild(self.conv_steps())
 
     def autotune(self, steps=None):
         self.bufs['x'].normal_()

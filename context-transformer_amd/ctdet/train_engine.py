@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib, ops
-from .engine import WINO4S_TILES, ConvPart, ConvStep, HipBackend, Plan, Runtime, apply_tuned, run_on_streams
+from .engine import F4_TILES, WINO4S_TILES, ConvPart, ConvStep, HipBackend, Plan, Runtime, apply_tuned, run_on_streams
 
 
 class _StepState:
@@ -138,8 +138,9 @@ class TrainRuntime:
                         # F(4x4,3x3) where the forward launch of this layer uses it (same map, channels swapped) and on
                         # the multibox heads from 19x19 maps up (their forward launch is a bf16x3 / F(2x2) one chosen for
                         # cout = 156; the data gradient has cout = the source's channel count)
-                        s.dgrad_tile = 4 if s.fwd.rt.get('wino') not in (None, False, 0, 2) or (wino4 and st.segs and st.oh * st.ow >= 361 and
-                                                                         self.lib.ct_conv_wino4_supported(C.byref(w2))) else 2
+                        w4_ok = bool(self.lib.ct_conv_wino4_supported(C.byref(w2)))
+                        s.dgrad_tile = 4 if w4_ok and (s.fwd.rt.get('wino') in F4_TILES or
+                                                       (wino4 and st.segs and st.oh * st.ow >= 361)) else 2
                         # ... and its three-kernel bf16x3 form (tile 44) where the forward launch runs that one
                         # (CTDET_TRAIN_W4S=0 keeps the fused kernel); V / M workspace shared by all data gradients
                         if s.fwd.rt.get('wino') in WINO4S_TILES and os.environ.get('CTDET_TRAIN_W4S', '1') != '0' and \

@@ -46,9 +46,11 @@ def subset(batch):
     return sorted({0, batch // 2, batch - 1})
 
 
-def sweep_case(net, size, C, setting, batch, seed, kind, sd32=None, sd64=None):
+def sweep_case(net, size, C, setting, batch, seed, kind, sd32=None, sd64=None, extra_threads=()):
     """-> dict with e(GPU,CPU32), e(GPU,fp64), e(CPU32,fp64) of the block's output `conf` (every element of the
-    oracle's image subset) and the raw loc / obj errors vs CPU32."""
+    oracle's image subset) and the raw loc / obj errors vs CPU32.  extra_threads: further torch thread counts at which
+    the fp32 CPU reference is evaluated again (torch's CPU convolutions split their sums by thread, so the reference moves
+    with the host): 'gpu_cpu32@N' / 'cpu32_fp64@N' per count."""
     sd32 = sd32 or state(net)
     sd64 = sd64 or state(net, torch.float64)
     x = synth.images(batch, size, kind, seed)
@@ -59,7 +61,17 @@ def sweep_case(net, size, C, setting, batch, seed, kind, sd32=None, sd64=None):
         raw32 = rfbnet_ref.forward(sd32, x[idx], size, C, 2, 'ours', setting, init=True)
         w32 = rfbnet_ref.forward(sd32, x[idx], size, C, 2, 'ours', setting, raw=True)
         w64 = rfbnet_ref.forward(sd64, x[idx].double(), size, C, 2, 'ours', setting, raw=True)
-    return {'batch': batch, 'seed': seed, 'kind': kind, 'images': idx,
+        extra = {}
+        base_threads = torch.get_num_threads()
+        for nt in extra_threads:
+            torch.set_num_threads(int(nt))
+            try:
+                wn = rfbnet_ref.forward(sd32, x[idx], size, C, 2, 'ours', setting, raw=True)
+            finally:
+                torch.set_num_threads(base_threads)
+            extra['gpu_cpu32@%d' % nt] = rel(got[1], wn[1])
+            extra['cpu32_fp64@%d' % nt] = rel(wn[1], w64[1])
+    return {**extra, 'batch': batch, 'seed': seed, 'kind': kind, 'images': idx,
             'gpu_cpu32': rel(got[1], w32[1]), 'gpu_fp64': rel(got[1], w64[1]), 'cpu32_fp64': rel(w32[1], w64[1]),
             'q_gpu_fp64': qrel(got[1], w64[1]), 'q_cpu32_fp64': qrel(w32[1], w64[1]),
             'loc_gpu_cpu32': rel(got[0], w32[0]), 'obj_gpu_cpu32': rel(got[2], w32[2]),

@@ -21,6 +21,7 @@ ap.add_argument('--policies', default='2+23'); ap.add_argument('--batches', defa
 ap.add_argument('--seeds', default='1234,7,99'); ap.add_argument('--kinds', default='randn,u8')
 ap.add_argument('--size', type=int, default=300); ap.add_argument('--budget-batch', type=int, default=8)
 ap.add_argument('--f4-max-cin', default='', help='CTDET_CTX_F4_MAX_CIN: F(4x4)/fp32 allowed on layers with at most this many input channels')
+ap.add_argument('--also-threads', default='', help='comma list: evaluate the fp32 CPU reference again at these thread counts (same device output)')
 ap.add_argument('--force-tile', default='', help='CTDET_WINO_FORCE: 23 = F(2x2,3x3) on bf16x3 with two accumulators on every Winograd layer')
 a = ap.parse_args()
 names = {'2+23': 'the shipped policy: bf16x3 with two accumulators -- three-kernel F(4x4,3x3) where the table picks F(4x4) from '
@@ -57,15 +58,23 @@ for pol in a.policies.split(','):
         for batch in [int(b) for b in a.batches.split(',')]:
             for seed in [int(s) for s in a.seeds.split(',')]:
                 for kind in a.kinds.split(','):
-                    r = cc.sweep_case(net, a.size, 60, 'transfer', batch, seed, kind, sd32, sd64)
+                    r = cc.sweep_case(net, a.size, 60, 'transfer', batch, seed, kind, sd32, sd64,
+                                      extra_threads=[int(t) for t in a.also_threads.split(',') if t])
                     v = cc.verdict(r)
                     bad[kind] = bad.get(kind, 0) + (v != 'ok')
                     far[kind] = far.get(kind, 0) + (r['gpu_fp64'] > r['cpu32_fp64'])
                     worst_cpu[kind] = max(worst_cpu.get(kind, 0.0), r['cpu32_fp64'])
                     print('   %5d %5d %6s | %.2e   %.2e   %.2e   | %.2e   %.2e   %.2f  | %s'
                           % (batch, seed, kind, r['gpu_cpu32'], r['gpu_fp64'], r['cpu32_fp64'], r['q_gpu_fp64'],
-                             r['q_cpu32_fp64'], r['q_gpu_fp64'] / r['q_cpu32_fp64'], v), flush=True)
-        for kind in bad:
+                             r['q_cpu32_fp64'], r['q_gpu_fp64'] / r['q_cpu32_fp64'], v) +
+                          ''.join('  | @%s threads: GPU-CPU32 %.2e CPU32-fp64 %.2e' % (t, r['gpu_cpu32@' + t], r['cpu32_fp64@' + t])
+                                  for t in a.also_threads.split(',') if t), flush=True)
+                    for t in a.also_threads.split(','):
+                        if t:
+                            bad[kind + '@' + t] = bad.get(kind + '@' + t, 0) + (r['gpu_cpu32@' + t] > 1e-4)
+        for kind in [k for k in bad if '@' in k]:
+            print('   %-9s cases above 1e-4 against the fp32 CPU path at that thread count: %d' % (kind, bad[kind]))
+        for kind in [k for k in bad if '@' not in k]:
             # un-normalised 0..255 inputs saturate the random-weight network: the fp32 CPU path itself is 1e-3 .. 1e-1 from
             # fp64 there (the block's arg-max flips), so those rows show the conditioning, they cannot be judged at 1e-4
             note = '' if worst_cpu[kind] < 1e-3 else '   [CPU fp32 itself up to %.1e from fp64: ill-conditioned input, not judged]' % worst_cpu[kind]
