@@ -67,12 +67,13 @@ PEAK_HBM_GBS = 8000.0               # HBM3E spec (6.3 TB/s achievable, MI355X_MI
 # multiplications executed / direct-convolution multiplications: F(2x2,3x3) 16 per 4 outputs x 9, F(4x4,3x3) 36 per 16 x 9
 # st.rt['wino'] codes 23 / 24 are F(2x2,3x3) on the bf16 pipe (csrc/ct_wino_x3.hip): every
 # transform-domain multiplication is six bf16 MFMA products (bf16x3), priced against the bf16 MFMA peak
-WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0, 23: 16.0 / 36.0, 24: 16.0 / 36.0, 44: 36.0 / 144.0, 45: 36.0 / 144.0}
+WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0, 23: 16.0 / 36.0, 24: 16.0 / 36.0, 44: 36.0 / 144.0, 45: 36.0 / 144.0,
+                       46: 36.0 / 144.0}
 # 44 / 45: one conv launch = three kernels (csrc/ct_wino4s.hip: wino4s_in, wino4s_gemm<dual>, wino4s_out)
 WINOGRAD_KERNEL = {2: 'wino_f2x2_3x3_f32', 4: 'wino_f4x4_3x3_f32', 23: 'wino_f2x2_3x3_x3', 24: 'wino_f2x2_3x3_x3q',
-                   44: 'wino4s(in+gemm+out)', 45: 'wino4sq(in+gemm+out)'}
-WINOGRAD_X3 = (23, 24, 44, 45)
-WINOGRAD_F4 = (4, 44, 45)
+                   44: 'wino4s(in+gemm+out)', 45: 'wino4sq(in+gemm+out)', 46: 'wino_f4x4_3x3_x3'}
+WINOGRAD_X3 = (23, 24, 44, 45, 46)       # 46: F(4x4,3x3) fused on bf16x3 (csrc/ct_wino4f.hip)
+WINOGRAD_F4 = (4, 44, 45, 46)
 
 
 def _lib_config_name(cfg):
@@ -319,15 +320,17 @@ def stage_rooflines(pipe, x, steps, pmc):
         # the three kernels of the F(4x4,3x3) / bf16x3 layers, summed over the layers of a step (csrc/ct_wino4s.hip):
         # tiles padded to 128, couts to 128; V = 36 points x 3 bf16 pieces, M = 36 points x fp32; dilated layers (pad = dilation)
         # have their tiles on the dilation sub-lattices
-        gf = ib = ob = 0.0
+        gf = gfp = ib = ob = 0.0
         for st in w4s:
             dl = st.dil              # dilated layers: dl x dl sub-lattices of ceil(oh / dl) x ceil(ow / dl) pixels, tiled like images
             tiles = B * dl * dl * ((-(-st.oh // dl) + 3) // 4) * ((-(-st.ow // dl) + 3) // 4)
             tpad, mpad = -(-tiles // 128) * 128, -(-st.cout // 128) * 128
-            gf += 36.0 * tpad * st.cin * mpad * 2 * 6
+            gf += 36.0 * tiles * st.cin * st.cout * 2 * 6          # useful work: the layer's own tiles and couts
+            gfp += 36.0 * tpad * st.cin * mpad * 2 * 6             # what the 128 x 128 blocks execute
             ib += 4.0 * B * st.cin * st.h * st.w + 6.0 * 36 * tpad * st.cin
             ob += 4.0 * 36 * tiles * st.cout + 4.0 * B * st.cout * st.oh * st.ow
         work['wino4s_gemm'] = ('mfma_bf16', gf)
+        gemm_padded = gfp
         work['wino4s_in'] = ('hbm', ib)
         work['wino4s_out'] = ('hbm', ob)
     if net.method == 'ours' and net.phase == 2:
@@ -352,6 +355,10 @@ def stage_rooflines(pipe, x, steps, pmc):
         out[key] = {'bound': bound, 'achieved': round(ach, 2), 'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4),
                     'launches_per_step': round(cnt / steps, 2), 'avg_launch_us': round(avg * 1e6, 2),
                     'algorithmic_per_launch': int(per_launch), 'traffic': pmc_lookup(pmc, kname)}
+        if key == 'wino4s_gemm':
+            # the MFMAs the 128 x 128 blocks issue, padding included (tiles and couts rounded up to 128)
+            out[key]['executed_incl_padding_per_launch'] = int(gemm_padded / (cnt / steps))
+            out[key]['executed_incl_padding_frac'] = round(gemm_padded / (cnt / steps) / avg / 1e12 / peak, 4)
     out['other_kernels_us_per_step'] = {k: round(v[0] / steps * 1e6, 2) for k, v in sorted(agg.items())
                                         if k not in [w.split('.')[0] for w in work]}
     out['candidates_per_step'] = cand
@@ -710,9 +717,10 @@ def main():
             roof.update({'kernel': 'wino4s_gemm', 'bound': 'mfma', 'achieved': g['achieved'], 'peak': g['peak'],
                          'frac': g['frac'], 'traffic': g['traffic'], 'avg_launch_us': g['avg_launch_us'],
                          'launches': int(round(g['launches_per_step'] * 5)), 'flops_per_launch': g['algorithmic_per_launch'],
-                         'flops_definition': 'multiply-adds x2 executed on the bf16 matrix pipe per launch: 36 transform points x '
-                                             '(tiles padded to 128) x cin x (cout padded to 128) x 6 piece products (bf16x3), '
-                                             'averaged over the layers that run this kernel',
+                         'flops_definition': 'USEFUL multiply-adds x2 on the bf16 matrix pipe per launch: 36 transform points x the '
+                                             'layer\'s tiles x cin x cout x 6 piece products (bf16x3), averaged over the layers that run '
+                                             'this kernel; the padding of tiles and couts to 128 is not counted '
+                                             '(stages.wino4s_gemm.executed_incl_padding_frac has it)',
                          'measured_sustained_peak': {'bf16_mfma_tflops_gaussian_operands': 1722, 'bf16_mfma_tflops_zero_operands': 2474,
                                                      'source': 'tools/ubench/mfma_power.hip, profiles/r04_mfma_power.txt: a loop of '
                                                                'MFMAs without any memory traffic; this box lowers its clock under real data'}})

@@ -422,7 +422,7 @@ int ctdet::pack_wino_any(const float* const* w, const int* cout, int nparts, int
     p.cin_fwd = cin;
     p.cin = dgrad ? tot : cin;          // input channels of THIS convolution
     p.cout = dgrad ? cin : tot;
-    const int cc = tile == 23 || tile == 44 ? ctdet::kWinoX3CC : CC;          // 23 / 44: the bf16x3 layouts (16-channel k-groups)
+    const int cc = tile == 23 || tile == 44 || tile == 46 ? ctdet::kWinoX3CC : CC;          // the bf16x3 layouts (16-channel k-groups)
     CT_REQUIRE(p.cin > 0 && p.cin % cc == 0, "%s: %d input channels, must be a multiple of %d", who, p.cin, cc);
     p.chunks = p.cin / cc;
     p.kblocks = tile == 44 ? (p.cout + ctdet::kWino4sBM - 1) / ctdet::kWino4sBM : (p.cout + KB - 1) / KB;
@@ -431,7 +431,7 @@ int ctdet::pack_wino_any(const float* const* w, const int* cout, int nparts, int
         ctdet::pack_record(1, &p, sizeof(p));
         return CT_OK;
     }
-    const long total = tile == 44 ? (long)p.kblocks * ctdet::kWino4sBM * p.cin :
+    const long total = tile == 44 ? (long)p.kblocks * ctdet::kWino4sBM * p.cin : tile == 46 ? (long)p.kblocks * KB * p.cin :
                        (long)p.kblocks * p.chunks * (tile == 4 ? 512 : tile == 23 ? 2048 : ctdet::kWino2ChunkFloats);      // threads
     hipLaunchKernelGGL(wino_pack_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
                        ctdet::as_stream(stream), p);

@@ -1,0 +1,498 @@
+// libctdet: Winograd F(4x4,3x3), FUSED, with the transform-domain products on the bf16 matrix pipe ("bf16x3") -- the narrow
+// 3x3 / stride 1 / dilation 1 / pad 1 layers on the large maps of the RFBNet-VGG stack (models/RFB_Net_vgg.py:323-336:
+// conv1_2, conv2_1, conv2_2, conv3_1; at 512 x 512 also conv3_2 / conv3_3; :219-227 the trunk they belong to).  Same
+// ct_conv_desc contract, transforms (ct_wino4_points.h) and fused epilogue as ct_conv2d_wino4_fwd.
+//
+//   Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A        per 4x4 output tile, 6x6 input patch d
+//
+// Where this kernel sits.  ct_wino4.hip (fused, fp32 MFMA) multiplies on the slowest matrix rate of the chip; ct_wino4s.hip
+// (three kernels, bf16x3) needs V and M in HBM -- 13.5 + 9 bytes per output pixel and channel -- which does not pay below
+// 256 channels on 150 x 150 / 300 x 300 maps (64 -> 64 @300x300 bs 32: V alone 2.5 GB).  Here everything stays on chip and the
+// products run as the six bf16 piece products (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid; 0.375 of the fp32-MFMA time):
+//   workgroup (512 threads, 8 waves) = 32 output tiles x ONE block of 64 output channels, 16-channel chunks
+//     * phase T (all waves): every thread owns one (tile, channel) patch of the chunk.  The 6x6 patch arrives in LDS by DMA
+//       (per row a 16-byte and two 4-byte buffer_load ... lds, issued a whole phase M earlier: no VGPR holds it while the MFMAs run);
+//       B^T d B in registers, the 36 transform-domain values go lane-linearly to V[point 36][channel 16][tile 32] (fp32, 72 KB);
+//     * phase M: wave w multiplies the points 4w .. 4w+3 for both cout halves and point 32 + w/2 for cout half w & 1
+//       (nine 32x32 accumulator blocks = 144 registers, 54 v_mfma_f32_32x32x16_bf16 per chunk).  It is the only reader of
+//       its full points, so the bf16x3 split happens after the LDS read (8 ds_read_b32 + 44 VALU per point); its A fragments
+//       (U, pre-transformed and pre-split by ct_conv_pack_weights_wino4f) come straight from L2 in MFMA register order,
+//       3 KB "units" = (point, cout half), two units ahead;
+//     * V is single-buffered: barrier after T, barrier after M.  On a SIMD the vector ALU and the matrix pipe do not overlap
+//       anyway ("law 1"), so separating the phases costs the barriers only and leaves the registers to
+//       one phase at a time (144 accumulators + 36 patch / transform values OR 36 U + 24 V fragment registers);
+//   after the channel loop the accumulators pass through LDS in two passes of 32 couts (144 KB), each thread applies
+//   A^T M A for two (cout, tile) pairs per pass and the shared epilogue (ct_wino4_emit.h: scale / shift, residual, ReLU /
+//   floor, the four 2x2 pooling windows of a tile, NCHW or head scatter).
+// One accumulator per output, piece products smallest first: with cin <= 256 the large sum sees cin / 16 * 6 roundings
+// (the fp32 MFMA: cin), measured in tests/test_gpu_wino.py::test_wino_rounding_error_vs_fp64.
+#include "ct_common.h"
+#include "ct_wino_pack.h"
+#include "ct_wino4_points.h"
+#include "ct_wino4_emit.h"
+#include <algorithm>
+#include <cstdlib>
+#include <mutex>
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kInvalidOff = 0x7FFFFFF0;
+constexpr long long kMaxBufBytes = 0x7FFFFF00LL;
+constexpr int CC = ctdet::kWinoX3CC;        // 16 channels per chunk = one MFMA k-group
+constexpr int TB = 32;                      // tiles per workgroup
+constexpr int KB = ctdet::kWinoKB;          // 64 output channels per workgroup
+constexpr int NXI = 36;                     // transform points
+constexpr int PT_STRIDE = CC * TB;          // 512 floats per point: V[channel 16][tile 32]
+constexpr int V_BYTES = NXI * PT_STRIDE * 4;               // 72 KB
+// One patch row (6 floats) per lane = one 16-byte DMA (columns 0..3) + two 4-byte ones (columns 4, 5).  A 12-byte DMA
+// would need two per row, but the hardware places a lane's 12 bytes at lane x 16 (tools/ubench/lds_dma12.hip,
+// profiles/r05_lds_dma12.txt): 2 KB per row instead of 1.5 KB, and V + stage would not fit the 160 KB.
+constexpr int ROW_Q_BYTES = 64 * 16;        // [lane 64][16 B]
+constexpr int ROW_E_BYTES = 64 * 4;         // [lane 64][4 B]
+constexpr int ROW_BYTES = ROW_Q_BYTES + 2 * ROW_E_BYTES;   // 1536
+constexpr int STAGE_WAVE_BYTES = 6 * ROW_BYTES;            // every lane's 6x6 patch: 9 KB per wave
+constexpr int STAGE_BYTES = 8 * STAGE_WAVE_BYTES;          // 72 KB
+constexpr int MXI = 32 * 32;                // output staging M[point][cout 32][tile 32]
+constexpr int W4F_LDS_BYTES = NXI * MXI * 4;               // 144 KB = V + patch stage
+static_assert(V_BYTES + STAGE_BYTES == W4F_LDS_BYTES, "LDS plan");
+constexpr int UNIT_BYTES = ctdet::kWino4fUnitBytes;
+constexpr int U_WAVE_BYTES = ctdet::kWino4fWaveBytes;
+constexpr int U_CHUNK_BYTES = ctdet::kWino4fChunkBytes;
+
+struct Wino4fArgs {
+    const float* in;
+    const unsigned char* U;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    const float* lo;
+    float* out;
+    unsigned in_bytes, out_bytes, res_bytes, u_bytes;
+    int Cin, H, W, in_ctot, in_coff;
+    int M, chunks, kblocks;
+    int TY, TX, NT, tile_blocks;
+    int out_ctot, out_coff, res_ctot, res_coff;
+    float res_scale;
+    int relu;
+    float* pool_out;         // optional fused 2x2 / stride 2 max-pool of the activation (NCHW), else null
+    int pool_ctot, pool_coff, pool_oh, pool_ow, write_full;
+    int nseg;                // > 0: channels-last scatter into the flattened head buffers (ct_out_segment)
+    ct_out_segment seg[3];
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+using ctdet::w4::bt6;
+using ctdet::w4::at4;
+
+// x = hi + mid + lo exactly (3 x 8 significant bits by truncation); the upper halves of the three words are the pieces
+__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l)
+{
+    h = __builtin_bit_cast(unsigned, x) & 0xFFFF0000u;
+    const float r1 = x - __builtin_bit_cast(float, h);
+    m = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+    l = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, m));
+}
+
+__device__ __forceinline__ int pack_hi(unsigned e0, unsigned e1)      // [bf16 e0 | bf16 e1 << 16]
+{
+    return (int)__builtin_amdgcn_perm(e1, e0, 0x07060302u);
+}
+
+// Measurement build only (CTDET_EXTRA_FLAGS=-DCTDET_W4F_TRACE, tools/w4f_trace.py): wave 0 of every workgroup stamps the
+// shader clock at its phase boundaries into ct_wino4f_trace_buffer()[workgroup][8].
+#ifdef CTDET_W4F_TRACE
+__device__ unsigned long long* g_w4f_trace = nullptr;
+#define W4F_STAMP(k)                                                                                   \
+    do {                                                                                               \
+        if (g_w4f_trace && tid == 0) g_w4f_trace[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define W4F_STAMP(k) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float* const lds = reinterpret_cast<float*>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // blockIdx -> (XCD-local sequence, cout block fastest), as in ct_wino4.hip: the cout blocks of a tile block run together
+    // on one XCD and share its input patches through that XCD's L2
+    const int jx = blockIdx.x >> 3;
+    const int kb = jx % a.kblocks;
+    const int tblk = (jx / a.kblocks) * 8 + (blockIdx.x & 7);
+    if (tblk >= a.tile_blocks) return;
+    W4F_STAMP(0);
+    const int tb0 = tblk * TB;
+    const int HW = a.H * a.W;
+
+    // ---- patch role: tile = l31, channel in chunk = 2 wave + h.  Rows outside the map use the out-of-range offset (the DMA
+    // writes zeros for such lanes); a buffer load whose first byte lies before the row is dropped whole, so the left-edge
+    // tiles load their 16-byte piece from x = 0 and shift (their column 0 is padding anyway: ct_wino4s.hip)
+    int voffq[6];
+    bool mc[6], lp;
+    int d4;                                   // byte distance from the 16-byte piece to column 4
+    {
+        const int T = tb0 + l31;
+        const bool live = T < a.NT;
+        const int n = T / (a.TY * a.TX);
+        const int rem = T - n * (a.TY * a.TX);
+        const int ty = rem / a.TX, tx = rem - ty * a.TX;
+        const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) mc[c] = (unsigned)(x0 + c) < (unsigned)a.W;
+        lp = tx == 0;
+        d4 = lp ? 12 : 16;
+        const long base = (((long)n * a.in_ctot + a.in_coff + h) * a.H + y0) * (long)a.W + x0 + (lp ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
+            voffq[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
+        }
+    }
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
+    const __amdgpu_buffer_rsrc_t rU = make_rsrc(a.U, a.u_bytes);
+    const int chunk_bytes = CC * HW * 4;
+    const int chan_base = 2 * wave * HW * 4;
+    const int last = a.chunks - 1;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    unsigned char* const stage = lds_raw + V_BYTES + wave * STAGE_WAVE_BYTES;     // this wave's patch rows: [row 6][half 2][lane 64][12 B]
+
+    auto dma_patch = [&](int c) {
+        const int soff = c * chunk_bytes + chan_base;
+        (void)soff;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int v4 = voffq[i] + d4;          // an invalid row stays out of range: 0x7FFFFFF0 + 16 as an unsigned offset
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(stage + i * ROW_BYTES), 16, voffq[i], soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(stage + i * ROW_BYTES + ROW_Q_BYTES), 4, v4, soff, 0, 0);
+            // column 5 through the scalar offset: the instruction's immediate offset would move the LDS destination as well
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_ptr)(stage + i * ROW_BYTES + ROW_Q_BYTES + ROW_E_BYTES), 4, v4, soff + 4, 0, 0);
+        }
+#endif
+    };
+
+    const unsigned char* const sq = stage + lane * 16;         // this lane's 16-byte piece of row 0
+    const unsigned char* const se = stage + ROW_Q_BYTES + lane * 4;
+    float* const vw = lds + wave * 64 + lane;                  // V[point][channel 2 wave + h][tile l31] = lane-linear
+    const float* const vr = lds + (8 * h) * TB + l31;          // B fragment: channels 8h .. 8h+7 of tile l31
+
+    // ---- A fragments: unit u of this wave = 3 KB [piece 3][lane 64][16 B]
+    const int u_voff = wave * U_WAVE_BYTES + lane * 16;
+    const int u_kb = kb * a.chunks;
+    auto load_u = [&](int c, int unit, i32x4 (&dst)[3]) {
+        const int soff = (u_kb + c) * U_CHUNK_BYTES + unit * UNIT_BYTES;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) dst[pc] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, soff + pc * 1024, 0);
+    };
+    auto read_raw = [&](int xi, float (&raw)[8]) {
+        const float* p = vr + xi * PT_STRIDE;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) raw[e] = p[e * TB];
+    };
+    auto split_all = [&](const float (&raw)[8], i32x4 (&fb)[3]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3(raw[2 * q], h0, m0, l0);
+            split3(raw[2 * q + 1], h1, m1, l1);
+            fb[0][q] = pack_hi(h0, h1);
+            fb[1][q] = pack_hi(m0, m1);
+            fb[2][q] = pack_hi(l0, l1);
+        }
+    };
+    const int xi0 = 4 * wave, xi_half = 32 + (wave >> 1);
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    // the six piece products, smallest first: (mid, mid), (lo, hi), (hi, lo), (mid, hi), (hi, mid), (hi, hi)   [A piece, B piece]
+    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+#define W4F_UNIT(X, UA, FB)                                                                                          \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int t_ = 0; t_ < 6; ++t_)                                                             \
+            acc[X] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, UA[PA[t_]]),                 \
+                                                             __builtin_bit_cast(bf16x8, FB[PB[t_]]), acc[X], 0, 0, 0); \
+    } while (0)
+
+    dma_patch(0);
+    i32x4 ua0[3], ua1[3], ua2[3];
+    for (int c = 0; c < a.chunks; ++c) {
+        // ================= phase T: patch(c), staged by DMA during the previous phase M, -> V
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        load_u(c, 0, ua0);                       // the first two units of phase M: a whole phase T of latency
+        load_u(c, 1, ua1);
+        {
+            float t[6][6];
+            float dd[6][6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const f32x4 q = *reinterpret_cast<const f32x4*>(sq + i * ROW_BYTES);
+                float e4 = *reinterpret_cast<const float*>(se + i * ROW_BYTES);
+                float e5 = *reinterpret_cast<const float*>(se + i * ROW_BYTES + ROW_E_BYTES);
+                float qx = q.x, qy = q.y, qz = q.z, qw = q.w;
+                // unconditional reads, then selects: not exec-masked read / wait blocks
+                asm("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qw), "+v"(e4), "+v"(e5));
+                dd[i][0] = (mc[0] && !lp) ? qx : 0.f;
+                dd[i][1] = mc[1] ? (lp ? qx : qy) : 0.f;
+                dd[i][2] = mc[2] ? (lp ? qy : qz) : 0.f;
+                dd[i][3] = mc[3] ? (lp ? qz : qw) : 0.f;
+                dd[i][4] = mc[4] ? e4 : 0.f;
+                dd[i][5] = mc[5] ? e5 : 0.f;
+            }
+            // the stage is free again once its reads have returned: the next chunk's rows are under way during the transform
+            // and the whole phase M
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            dma_patch(min(c + 1, last));
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) {
+                const float d[6] = {dd[0][cc], dd[1][cc], dd[2][cc], dd[3][cc], dd[4][cc], dd[5][cc]};
+                float o[6];
+                bt6(d, o);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) t[i][cc] = o[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                float v[6];
+                bt6(t[i], v);
+                float* vp = vw + (i * 6) * PT_STRIDE;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) vp[j * PT_STRIDE] = v[j];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (c == 0) W4F_STAMP(1);
+        // ================= phase M: nine units (point, cout half); U two units ahead, the next point's fragments split behind
+        // the current point's MFMAs
+        {
+            float raw[8];
+            i32x4 fbA[3], fbB[3];
+            read_raw(xi0, raw);
+            split_all(raw, fbA);
+            // point 0
+            load_u(c, 2, ua2);
+            read_raw(xi0 + 1, raw);
+            W4F_UNIT(0, ua0, fbA);
+            load_u(c, 3, ua0);
+            split_all(raw, fbB);
+            W4F_UNIT(1, ua1, fbA);
+            // point 1
+            load_u(c, 4, ua1);
+            read_raw(xi0 + 2, raw);
+            W4F_UNIT(2, ua2, fbB);
+            load_u(c, 5, ua2);
+            split_all(raw, fbA);
+            W4F_UNIT(3, ua0, fbB);
+            // point 2
+            load_u(c, 6, ua0);
+            read_raw(xi0 + 3, raw);
+            W4F_UNIT(4, ua1, fbA);
+            load_u(c, 7, ua1);
+            split_all(raw, fbB);
+            W4F_UNIT(5, ua2, fbA);
+            // point 3
+            load_u(c, 8, ua2);
+            read_raw(xi_half, raw);
+            W4F_UNIT(6, ua0, fbB);
+            split_all(raw, fbA);
+            W4F_UNIT(7, ua1, fbB);
+            // the shared point 32 + wave / 2, cout half wave & 1
+            W4F_UNIT(8, ua2, fbA);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+#undef W4F_UNIT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the clamped re-load of the last chunk's rows
+    __syncthreads();
+    W4F_STAMP(2);
+
+    // ---- output transform: two passes of 32 couts through LDS  M[point][cout 32][tile 32]
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        // accumulator register r of a block = cout (r & 3) + 8 (r >> 2) + 4 h of its half, tile l31
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                lds[(xi0 + p) * MXI + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[2 * p + pass][r];
+        if ((wave & 1) == pass) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                lds[xi_half * MXI + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[8][r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 512 * it;
+            const int kk = idx >> 5, tl = idx & 31;
+            const int co = kb * KB + 32 * pass + kk;
+            const int T = tb0 + tl;
+            if (T >= a.NT || co >= a.M) continue;
+            const int n = T / (a.TY * a.TX);
+            const int rem = T - n * (a.TY * a.TX);
+            const int ty = rem / a.TX, tx = rem - ty * a.TX;
+            float z[4][6];
+            const float* mp = lds + kk * 32 + tl;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                float m[6], y[4];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) m[i] = mp[(i * 6 + j) * MXI];
+                at4(m, y);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z[i][j] = y[i];
+            }
+            float y[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) at4(z[i], y[i]);
+            ctdet::w4::emit_tile4(a, rout, rres, n, ty, tx, co, y);
+        }
+        if (pass == 0) {
+            __syncthreads();
+            W4F_STAMP(3);
+        }
+    }
+    W4F_STAMP(4);
+}
+
+bool wino4f_ok(const ct_conv_desc* d)
+{
+    return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
+           d->cin % CC == 0 && d->nseg >= 0 && d->nseg <= 3 && (d->nseg == 0 || !d->res) && !d->transposed &&
+           d->oh == d->h && d->ow == d->w;
+}
+
+}  // namespace
+
+extern "C" int ct_conv_wino4f_supported(const ct_conv_desc* d) { return d && wino4f_ok(d) ? 1 : 0; }
+
+#ifdef CTDET_W4F_TRACE
+extern "C" int ct_wino4f_set_trace(unsigned long long* buf)      // device buffer of 8 words per workgroup, or null
+{
+    CT_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_w4f_trace), &buf, sizeof(buf)));
+    return CT_OK;
+}
+#endif
+
+extern "C" size_t ct_conv_wino4f_packed_bytes(int cin, int cout)
+{
+    if (cin <= 0 || cout <= 0 || cin % CC) return 0;
+    return (size_t)((cout + KB - 1) / KB) * (cin / CC) * U_CHUNK_BYTES;
+}
+
+extern "C" int ct_conv_pack_weights_wino4f(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                           ct_stream_t stream)
+{
+    return ctdet::pack_wino_any(w, cout, nparts, cin, 0, 46, (float*)upacked, stream, "ct_conv_pack_weights_wino4f");
+}
+
+extern "C" int ct_conv_pack_weights_wino4f_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                                 ct_stream_t stream)
+{
+    return ctdet::pack_wino_any(w, cout, nparts, cin, 1, 46, (float*)upacked, stream, "ct_conv_pack_weights_wino4f_dgrad");
+}
+
+extern "C" int ct_conv2d_wino4f_pool_fwd(const ct_conv_desc* d, const void* upacked, float* pool_out, int pool_ctot,
+                                         int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream)
+{
+    const char* who = "ct_conv2d_wino4f_fwd";
+    CT_REQUIRE(d && upacked, "%s: null pointer", who);
+    CT_REQUIRE(d->in && (d->out || d->nseg > 0) && d->scale && d->shift, "%s: null tensor", who);
+    if (!wino4f_ok(d))
+        return ctdet::fail(CT_ERR_UNSUPPORTED, "%s: needs 3x3 stride 1 dilation 1 pad 1, cin %% 16 == 0 "
+                           "(got %dx%d s%d d%d p%d cin=%d nseg=%d)", who, d->kh, d->kw, d->stride, d->dil,
+                           d->pad_h, d->cin, d->nseg);
+    CT_REQUIRE(d->batch > 0 && d->cout > 0, "%s: bad shape", who);
+    CT_REQUIRE(write_full || pool_out, "%s: nothing to write", who);
+    if (pool_out) {
+        CT_REQUIRE(pool_coff >= 0 && pool_coff + d->cout <= pool_ctot, "%s: pooled output slice", who);
+        CT_REQUIRE((pool_oh == d->oh / 2 || pool_oh == (d->oh + 1) / 2) && (pool_ow == d->ow / 2 || pool_ow == (d->ow + 1) / 2),
+                   "%s: pooled size %dx%d for a %dx%d map", who, pool_oh, pool_ow, d->oh, d->ow);
+    }
+    CT_REQUIRE(d->in_coff >= 0 && d->in_coff + d->cin <= d->in_ctot, "%s: input slice", who);
+    if (d->nseg == 0)
+        CT_REQUIRE(d->out_coff >= 0 && d->out_coff + d->cout <= d->out_ctot, "%s: output slice", who);
+    else {
+        CT_REQUIRE(!pool_out && write_full, "%s: pooling with segmented output", who);
+        for (int g = 0; g < d->nseg; ++g) CT_REQUIRE(d->seg[g].ptr, "%s: null segment", who);
+    }
+    CT_REQUIRE(!d->res || (d->res_coff >= 0 && d->res_coff + d->cout <= d->res_ctot), "%s: residual slice", who);
+    const long long img_in_bytes = (long long)d->in_ctot * d->h * d->w * 4;
+    CT_REQUIRE(img_in_bytes < kMaxBufBytes, "%s: one image exceeds 2 GiB", who);
+    const long long img_out_bytes = d->nseg ? 4 : (long long)d->out_ctot * d->oh * d->ow * 4;
+    const long long img_res_bytes = d->res ? (long long)d->res_ctot * d->oh * d->ow * 4 : 0;
+    CT_REQUIRE(img_out_bytes < kMaxBufBytes && img_res_bytes < kMaxBufBytes, "%s: one image exceeds 2 GiB", who);
+    const size_t u_bytes = ct_conv_wino4f_packed_bytes(d->cin, d->cout);
+    CT_REQUIRE(u_bytes < (size_t)kMaxBufBytes, "%s: packed weights exceed 2 GiB", who);
+    const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / std::max(img_in_bytes, std::max(img_out_bytes, img_res_bytes)));
+    hipStream_t st = ctdet::as_stream(stream);
+    {
+        static std::once_flag once;
+        static hipError_t attr_err = hipSuccess;
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute((const void*)wino_f4x4_3x3_x3, hipFuncAttributeMaxDynamicSharedMemorySize, W4F_LDS_BYTES);
+        });
+        CT_HIP(attr_err);
+    }
+    const int OHW = d->oh * d->ow;
+    for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
+        const int nb = std::min(max_chunk, d->batch - b0);
+        Wino4fArgs a{};
+        a.in = d->in + (size_t)b0 * d->in_ctot * d->h * d->w;
+        a.U = static_cast<const unsigned char*>(upacked);
+        a.u_bytes = (unsigned)u_bytes;
+        a.scale = d->scale; a.shift = d->shift; a.lo = d->lo;
+        a.res = d->res ? d->res + (size_t)b0 * d->res_ctot * OHW : nullptr;
+        a.out = d->nseg ? nullptr : d->out + (size_t)b0 * d->out_ctot * OHW;
+        a.nseg = d->nseg;
+        for (int g = 0; g < d->nseg; ++g) {
+            a.seg[g] = d->seg[g];
+            a.seg[g].ptr += (size_t)b0 * d->seg[g].img_stride;
+        }
+        a.in_bytes = (unsigned)(img_in_bytes * nb);
+        a.out_bytes = (unsigned)(img_out_bytes * nb);
+        a.res_bytes = (unsigned)(img_res_bytes * nb);
+        a.Cin = d->cin; a.H = d->h; a.W = d->w; a.in_ctot = d->in_ctot; a.in_coff = d->in_coff;
+        a.M = d->cout; a.chunks = d->cin / CC;
+        a.TY = (d->oh + 3) / 4; a.TX = (d->ow + 3) / 4;
+        a.NT = nb * a.TY * a.TX;
+        a.tile_blocks = (a.NT + TB - 1) / TB;
+        a.out_ctot = d->out_ctot; a.out_coff = d->out_coff;
+        a.res_ctot = d->res_ctot; a.res_coff = d->res_coff; a.res_scale = d->res_scale;
+        a.relu = d->relu;
+        a.pool_out = pool_out ? pool_out + (size_t)b0 * pool_ctot * pool_oh * pool_ow : nullptr;
+        a.pool_ctot = pool_ctot; a.pool_coff = pool_coff; a.pool_oh = pool_oh; a.pool_ow = pool_ow;
+        a.write_full = write_full;
+        a.kblocks = (d->cout + KB - 1) / KB;
+        // 8 XCD-local sequences of (tile block group, cout block); sequences past the last tile block exit at once
+        const int groups = (a.tile_blocks + 7) / 8;
+        CT_PROF("wino_f4x4_3x3_x3", st);
+        hipLaunchKernelGGL(wino_f4x4_3x3_x3, dim3(8 * groups * a.kblocks), dim3(512), W4F_LDS_BYTES, st, a);
+        CT_LAUNCH_CHECK("wino_f4x4_3x3_x3");
+    }
+    return CT_OK;
+}
+
+extern "C" int ct_conv2d_wino4f_fwd(const ct_conv_desc* d, const void* upacked, ct_stream_t stream)
+{
+    return ct_conv2d_wino4f_pool_fwd(d, upacked, nullptr, 0, 0, 0, 0, 1, stream);
+}

@@ -14,7 +14,8 @@ struct WinoPackArgs {
     int dgrad;               // 1: weights of the data-gradient convolution (channels swapped, taps flipped)
     int cin_fwd;
     int tile;                // 2: F(2x2,3x3) layout, 4: F(4x4,3x3) layout, 23: F(2x2,3x3) split into bf16x3 pieces,
-                             // 44: F(4x4,3x3) bf16x3 pieces as the GEMM operand of ct_wino4s.hip
+                             // 44: F(4x4,3x3) bf16x3 pieces as the GEMM operand of ct_wino4s.hip,
+                             // 46: F(4x4,3x3) bf16x3 pieces in the per-wave unit order of ct_wino4f.hip
     float* U;
 };
 
@@ -28,6 +29,12 @@ constexpr int kWinoX3ChunkBytes = 8 * 2 * 2 * 3 * 64 * 16;   // [wave 8][point 2
 constexpr int kWino4sBM = 128;                      // ct_wino4s.hip: output channels per GEMM workgroup (four 32-row fragments)
 constexpr int kWino4sFragBytes = 1024;              // one MFMA operand fragment: [k half 2][row 32][8 bf16]
 constexpr int kWino4sChunkBytes = 4 * 3 * kWino4sFragBytes;   // [sub 4][piece 3] of one (128-row block, 16-channel chunk)
+
+// ct_wino4f.hip (fused F(4x4,3x3) on bf16x3): per (cout block of 64, 16-channel chunk) eight wave regions of nine 3 KB
+// "units" = (transform point, cout half), each [piece 3][lane 64][8 bf16]
+constexpr int kWino4fUnitBytes = 3 * 1024;
+constexpr int kWino4fWaveBytes = 9 * kWino4fUnitBytes;
+constexpr int kWino4fChunkBytes = 8 * kWino4fWaveBytes;       // = 36 points x 64 couts x 16 channels x 3 pieces x 2 bytes
 
 // forward: g = w[co][ci];  data gradient: this conv's (co, ci) = forward (ci, co), taps rotated 180 degrees
 __device__ __forceinline__ const float* wino_taps(const WinoPackArgs& p, int co, int ci)
@@ -225,9 +232,68 @@ __device__ __forceinline__ void wino4s_pack_body(const WinoPackArgs& p, long fir
     }
 }
 
+// ct_wino4f.hip: U[cout block of 64][chunk 16 ch][wave 8][unit 9][piece 3][lane 64][8 bf16].  Wave w multiplies the
+// transform points 4w .. 4w+3 for both cout halves (units 2 (xi & 3) + half) and point 32 + (w >> 1) for the cout half w & 1
+// (unit 8); lane (l31, hh) of a unit holds cout = 64 kb + 32 half + l31, channels 16 chunk + 8 hh .. + 7 of one bf16 piece:
+// the A operand of v_mfma_f32_32x32x16_bf16.  One thread = one (cout, cin) filter: G g G^T in double, rounded once, then
+// the exact three-piece split (as wino4s_pack_body).
+__device__ __forceinline__ void wino4f_pack_body(const WinoPackArgs& p, long first, long stride)
+{
+    const long total = (long)p.kblocks * kWinoKB * p.cin;
+    unsigned short* const out = reinterpret_cast<unsigned short*>(p.U);
+    for (long idx = first; idx < total; idx += stride) {
+        const int ci = (int)(idx % p.cin);
+        const int co = (int)(idx / p.cin);
+        float g[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g[i][j] = 0.f;
+        if (co < p.cout) {
+            const float* w = wino_taps(p, co, ci);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) g[i][j] = p.dgrad ? w[(2 - i) * 3 + (2 - j)] : w[i * 3 + j];
+        }
+        double t[6][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double o[6];
+            w4::gmul6(g[0][j], g[1][j], g[2][j], o);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i][j] = o[i];
+        }
+        const int kb = co / kWinoKB, half = (co % kWinoKB) / 32, chunk = ci / 16;
+        const int ln = (co % 32) + 32 * ((ci % 16) / 8);
+        unsigned short* base = out + ((size_t)kb * p.chunks + chunk) * (kWino4fChunkBytes / 2) + ln * 8 + ci % 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double o[6];
+            w4::gmul6(t[i][0], t[i][1], t[i][2], o);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int xi = i * 6 + j;
+                const int wv = xi < 32 ? xi >> 2 : 2 * (xi - 32) + half;
+                const int unit = xi < 32 ? 2 * (xi & 3) + half : 8;
+                const float val = (float)o[j];
+                const unsigned hb = __builtin_bit_cast(unsigned, val) & 0xFFFF0000u;
+                const float r1 = val - __builtin_bit_cast(float, hb);
+                const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+                const unsigned lb = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, mb));
+                unsigned short* q = base + (size_t)wv * (kWino4fWaveBytes / 2) + unit * (kWino4fUnitBytes / 2);
+                q[0] = (unsigned short)(hb >> 16);
+                q[512] = (unsigned short)(mb >> 16);
+                q[1024] = (unsigned short)(lb >> 16);
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void wino_pack_any(const WinoPackArgs& p, long first, long stride)
 {
-    if (p.tile == 44) wino4s_pack_body(p, first, stride);
+    if (p.tile == 46) wino4f_pack_body(p, first, stride);
+    else if (p.tile == 44) wino4s_pack_body(p, first, stride);
     else if (p.tile == 23) winox3_pack_body(p, first, stride);
     else if (p.tile == 4) wino4_pack_body(p, first, stride);
     else wino2_pack_body(p, first, stride);

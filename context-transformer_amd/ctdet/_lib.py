@@ -144,6 +144,12 @@ SIGNATURES = {
     'ct_conv_pack_weights_wino4s_dgrad': (_I, [_P, _P, _I, _I, _P, _P]),
     'ct_conv2d_wino4s_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _Z, _I, _P]),
     'ct_conv2d_wino4s_pool_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _Z, _I, _P, _I, _I, _I, _I, _I, _P]),
+    'ct_conv_wino4f_supported': (_I, [C.POINTER(ConvDesc)]),
+    'ct_conv_wino4f_packed_bytes': (_Z, [_I, _I]),
+    'ct_conv_pack_weights_wino4f': (_I, [_P, _P, _I, _I, _P, _P]),
+    'ct_conv_pack_weights_wino4f_dgrad': (_I, [_P, _P, _I, _I, _P, _P]),
+    'ct_conv2d_wino4f_fwd': (_I, [C.POINTER(ConvDesc), _P, _P]),
+    'ct_conv2d_wino4f_pool_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P]),
     'ct_conv_wino4_supported': (_I, [C.POINTER(ConvDesc)]),
     'ct_conv_wino4_packed_floats': (_Z, [_I, _I]),
     'ct_conv_pack_weights_wino4': (_I, [_P, _P, _I, _I, _P, _P]),

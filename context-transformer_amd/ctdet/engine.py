@@ -350,16 +350,18 @@ WINOX = -3         # ... F(2x2,3x3) on the bf16 matrix pipe (bf16x3), two accumu
 WINOXQ = -5        # ... one accumulator, four-wave workgroups (two per CU)
 WINO4S = -6        # ... F(4x4,3x3) as transform / bf16x3 GEMM / transform kernels, two accumulators (csrc/ct_wino4s.hip)
 WINO4SQ = -7       # ... one accumulator
+WINO4F = -8        # ... F(4x4,3x3) fused on bf16x3, one 64-cout block per workgroup (csrc/ct_wino4f.hip): the narrow layers on big maps
 # st.rt['wino'] values: 2, 4 = the fp32-MFMA kernels' tile sizes; F(2x2,3x3) on bf16x3: 23 = two accumulators (eight
 # waves), 24 = one accumulator in the four-wave / two-workgroups-per-CU form
-# 44 / 45 = F(4x4,3x3) in the three-kernel form with the GEMMs on bf16x3 (two / one accumulator)
-WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXQ: 24, WINO4S: 44, WINO4SQ: 45}
-WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 24: 'winoxq', 44: 'wino4s', 45: 'wino4sq'}
+# 44 / 45 = F(4x4,3x3) in the three-kernel form with the GEMMs on bf16x3 (two / one accumulator); 46 = F(4x4,3x3) fused on bf16x3
+WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXQ: 24, WINO4S: 44, WINO4SQ: 45, WINO4F: 46}
+WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 24: 'winoxq', 44: 'wino4s', 45: 'wino4sq', 46: 'wino4f'}
 WINOX_TILES = (23, 24)
 WINOX_VARIANT = {23: 1, 24: 2}               # the `variant` argument of ct_conv2d_wino_x3_fwd
 WINO4S_TILES = (44, 45)
 WINO4S_VARIANT = {44: 1, 45: 2}              # the `variant` argument of ct_conv2d_wino4s_fwd
-F4_TILES = (4, 44, 45)                       # every variant with F(4x4,3x3)'s rounding (accuracy policies treat them alike)
+WINO4F_TILES = (46,)
+F4_TILES = (4, 44, 45, 46)                   # every variant with F(4x4,3x3)'s rounding (accuracy policies treat them alike)
 
 
 class HipBackend:
@@ -471,6 +473,7 @@ class HipBackend:
         rt['wino_ok'] = bool(lib.ct_conv_wino_supported(C.byref(d)))
         rt['winox_ok'] = bool(lib.ct_conv_wino_x3_supported(C.byref(d)))
         rt['wino4s_ok'] = bool(lib.ct_conv_wino4s_supported(C.byref(d)))
+        rt['wino4f_ok'] = bool(lib.ct_conv_wino4f_supported(C.byref(d)))
         if rt.get('config', 0) in WINO_TILE:
             self.enable_wino(st, tile=WINO_TILE[rt['config']])
 
@@ -491,8 +494,8 @@ class HipBackend:
         if not (rt.get('wino_ok') or (tile in WINO4S_TILES and rt.get('wino4s_ok'))):
             raise _lib.CtdetError('%s: geometry has no Winograd path' % st.name)
         rt['x3'] = None
-        if tile not in (2, 4) + WINOX_TILES + WINO4S_TILES:
-            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23, 24, 44 or 45)' % (st.name, tile))
+        if tile not in (2, 4) + WINOX_TILES + WINO4S_TILES + WINO4F_TILES:
+            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23, 24, 44, 45 or 46)' % (st.name, tile))
         if tile not in WINO4S_TILES:
             rt.pop('ws4s_bytes', None)
         if tile in WINO4S_TILES:
@@ -502,6 +505,11 @@ class HipBackend:
                 rt['U4S'] = self.alloc((self.lib.ct_conv_wino4s_packed_bytes(st.cin, st.cout),), torch.uint8)
             rt['ws4s_bytes'] = self.lib.ct_conv_wino4s_workspace_bytes(C.byref(rt['desc']))
             self.ws_reserve(rt.get('ws_key', 0), rt['ws4s_bytes'])
+        elif tile in WINO4F_TILES:
+            if not rt.get('wino4f_ok'):
+                raise _lib.CtdetError('%s: geometry has no fused F(4x4,3x3) bf16x3 path (cin %% 16)' % st.name)
+            if 'U4F' not in rt:
+                rt['U4F'] = self.alloc((self.lib.ct_conv_wino4f_packed_bytes(st.cin, st.cout),), torch.uint8)
         elif tile in WINOX_TILES:
             if not rt.get('winox_ok'):
                 raise _lib.CtdetError('%s: geometry has no Winograd bf16x3 path (cin %% 16)' % st.name)
@@ -530,6 +538,10 @@ class HipBackend:
         if st.rt['wino'] in WINO4S_TILES:
             _lib.check(self.lib.ct_conv_pack_weights_wino4s(ptrs, couts, n, st.cin, st.rt['U4S'].data_ptr(), self._stream()),
                        'ct_conv_pack_weights_wino4s')
+            return
+        if st.rt['wino'] in WINO4F_TILES:
+            _lib.check(self.lib.ct_conv_pack_weights_wino4f(ptrs, couts, n, st.cin, st.rt['U4F'].data_ptr(), self._stream()),
+                       'ct_conv_pack_weights_wino4f')
             return
         _lib.check(self.lib.ct_conv_pack_weights_wino(ptrs, couts, n, st.cin, st.rt['U'].data_ptr(), self._stream()),
                    'ct_conv_pack_weights_wino')
@@ -604,6 +616,16 @@ class HipBackend:
                 return
             _lib.check(lib.ct_conv2d_wino4s_fwd(C.byref(st.rt['desc']), U, ws.data_ptr(), ws.numel(), var, self._stream()),
                        st.name)
+            return
+        if tile in WINO4F_TILES:         # F(4x4,3x3) fused on the bf16 matrix pipe (csrc/ct_wino4f.hip)
+            lib, U = self.lib, st.rt['U4F'].data_ptr()
+            pool = st.rt.get('pool')
+            if pool is not None:
+                t, poh, pow_, full = pool
+                _lib.check(lib.ct_conv2d_wino4f_pool_fwd(C.byref(st.rt['desc']), U, t.data_ptr(), t.shape[1], 0, poh, pow_,
+                                                         int(full), self._stream()), st.name)
+                return
+            _lib.check(lib.ct_conv2d_wino4f_fwd(C.byref(st.rt['desc']), U, self._stream()), st.name)
             return
         if tile in WINOX_TILES:          # F(2x2,3x3) on the bf16 matrix pipe (csrc/ct_wino_x3.hip)
             lib, U, dual = self.lib, st.rt['UX'].data_ptr(), WINOX_VARIANT[tile]
@@ -778,6 +800,8 @@ def wino_tiles(backend=None, st=None):
         tiles = tuple(t for t in tiles if t not in WINOX_TILES)
     if st is not None and not st.rt.get('wino4s_ok'):
         tiles = tuple(t for t in tiles if t not in WINO4S_TILES)
+    if st is not None and not st.rt.get('wino4f_ok'):
+        tiles = tuple(t for t in tiles if t not in WINO4F_TILES)
     if st is not None and not st.rt.get('wino_ok'):          # dilated 3x3: only the three-kernel form
         tiles = tuple(t for t in tiles if t in WINO4S_TILES)
     return tiles

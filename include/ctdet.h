@@ -350,6 +350,23 @@ int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* desc, const void* upacked, voi
                               int variant, float* pool_out, int pool_ctot, int pool_coff, int pool_oh, int pool_ow,
                               int write_full, ct_stream_t stream);
 
+/* Winograd F(4x4,3x3) FUSED with the transform-domain products on the bf16 matrix pipe (csrc/ct_wino4f.hip): the narrow
+ * 3x3 layers on the large maps (models/RFB_Net_vgg.py:323-336 conv1_2 .. conv3_1; conv3_2 / conv3_3 at 512 x 512), where the
+ * three-kernel form's workspace traffic does not pay and the fp32-MFMA kernel is bound by the slowest matrix rate -- same
+ * descriptor, transforms, epilogue, pooling fusion and head scatter as ct_conv2d_wino4_fwd, fp32 results equal to it up to
+ * summation order; cin % 16 == 0.  One workgroup = 32 tiles x one block of 64 couts: patches arrive in LDS by DMA, the
+ * transform runs once per (tile, channel, 64 couts), V stays in LDS as fp32 and is split into the three bfloat16 pieces by
+ * the wave that multiplies it; no workspace.  Weights: ct_conv_pack_weights_wino4f (ct_conv_wino4f_packed_bytes bytes). */
+int ct_conv_wino4f_supported(const ct_conv_desc* desc);
+size_t ct_conv_wino4f_packed_bytes(int cin, int cout);
+int ct_conv_pack_weights_wino4f(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                ct_stream_t stream);
+int ct_conv_pack_weights_wino4f_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                      ct_stream_t stream);
+int ct_conv2d_wino4f_fwd(const ct_conv_desc* desc, const void* upacked, ct_stream_t stream);
+int ct_conv2d_wino4f_pool_fwd(const ct_conv_desc* desc, const void* upacked, float* pool_out, int pool_ctot, int pool_coff,
+                              int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
+
 /* ---- "bf16x3": the fp32 convolution of ct_conv2d_fwd on the bf16 matrix pipe (csrc/ct_conv_x3.hip) ----
  * Same layers (models/RFB_Net_vgg.py:7-22 BasicConv, the plain Conv2d layers, the multibox heads :238-248), the same
  * descriptor (NCHW fp32 in / out, channel slices, residual, per-channel floor, head scatter, ksplit slabs) and the

@@ -15,9 +15,9 @@ from test_gpu_kernels import _bn, _ref_conv, _run_conv
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 W = engine.WINO
-VARIANTS = [engine.WINO, engine.WINO4, engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ]
-VIDS = ['f2x2', 'f4x4', 'f2x2_x3', 'f2x2_x3q', 'f4x4_s', 'f4x4_sq']
-X3V = (engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ)         # cin must be a multiple of 16 (one bf16 MFMA k-group)
+VARIANTS = [engine.WINO, engine.WINO4, engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ, engine.WINO4F]
+VIDS = ['f2x2', 'f4x4', 'f2x2_x3', 'f2x2_x3q', 'f4x4_s', 'f4x4_sq', 'f4x4_f']
+X3V = (engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ, engine.WINO4F)         # cin must be a multiple of 16 (one bf16 MFMA k-group)
 
 
 def _cin(W, cin):
@@ -202,7 +202,7 @@ def test_conv_input_above_2gib_is_chunked(use_wino):
 
 
 @pytest.mark.parametrize('W,bound', [(engine.WINO, 3e-6), (engine.WINO4, 5e-5), (engine.WINOX, 1e-6), (engine.WINOXQ, 2e-6),
-                                     (engine.WINO4S, 6e-6), (engine.WINO4SQ, 1.2e-5)], ids=VIDS)
+                                     (engine.WINO4S, 6e-6), (engine.WINO4SQ, 1.2e-5), (engine.WINO4F, 1.2e-5)], ids=VIDS)
 def test_wino_rounding_error_vs_fp64(W, bound):
     """The transform-domain rounding of each variant on the deepest VGG shape (512 input channels, post-ReLU input):
     max error over the output range against an fp64 convolution.  Measured 1e-6 for F(2x2,3x3) and 2e-5 for

@@ -38,8 +38,8 @@ for name in names:
     ref = None
     if os.environ.get('CHECK', '1') != '0' and B * Cin * H * W <= 64 << 20:
         ref = torch.relu(torch.nn.functional.conv2d(bufs['x'].double(), w.double(), b.double(), padding=1))
-    for tile in [int(t) for t in os.environ.get('TILES', '2,4,23,24,44,45').split(',')]:
-        if tile in (23, 24, 44, 45) and Cin % 16:
+    for tile in [int(t) for t in os.environ.get('TILES', '2,4,23,24,44,45,46').split(',')]:
+        if tile in (23, 24, 44, 45, 46) and Cin % 16:
             continue
         be.enable_wino(st, tile=tile)
         bufs['y'].fill_(float('nan'))
@@ -57,8 +57,8 @@ for name in names:
         ms = e0.elapsed_time(e1) / iters
         fl = st.flops(B)
         # executed matrix work: F(2x2) 16/36, F(4x4) 36/144 of the direct count; bf16x3 = six bf16 products each
-        ex = 0.25 if tile == 4 else 0.25 * 6 if tile in (44, 45) else (16 / 36) * (6 if tile in (23, 24) else 1)
-        peak = 2500.0 if tile in (23, 24, 44, 45) else 157.3
+        ex = 0.25 if tile == 4 else 0.25 * 6 if tile in (44, 45, 46) else (16 / 36) * (6 if tile in (23, 24) else 1)
+        peak = 2500.0 if tile in (23, 24, 44, 45, 46) else 157.3
         print('%-10s F%-2d %4d->%-4d @%3dx%-3d bs%-2d  %8.1f us  %6.1f TF algorithmic  %6.1f TF executed = %.3f of %.1f%s'
               % (name, tile, Cin, Cout, H, W, B, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 * ex, fl / ms / 1e9 * ex / peak, peak, err),
               flush=True)
