@@ -382,8 +382,8 @@ __global__ void wino_pack_kernel(const ctdet::WinoPackArgs p)
 // all Winograd layers of a training step in one launch: blockIdx.y = recorded item (ct_pack_run)
 __global__ void wino_pack_batched_kernel(const ctdet::WinoPackArgs* __restrict__ items)
 {
-    const ctdet::WinoPackArgs p = items[blockIdx.y];
-    ctdet::wino_pack_any(p, blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
+    // by reference: a local copy of the record would put its w[] / mbeg[] arrays (indexed by a run-time part number) into scratch
+    ctdet::wino_pack_any(items[blockIdx.y], blockIdx.x * (long)blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x);
 }
 
 bool wino_ok(const ct_conv_desc* d)

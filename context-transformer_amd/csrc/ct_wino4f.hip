@@ -107,32 +107,43 @@ __device__ __forceinline__ int pack_hi(unsigned e0, unsigned e1)      // [bf16 e
 }
 
 // Measurement build only (CTDET_EXTRA_FLAGS=-DCTDET_W4F_TRACE, tools/w4f_trace.py): wave 0 of every workgroup stamps the
-// shader clock at its phase boundaries into ct_wino4f_trace_buffer()[workgroup][8].
+// 100 MHz real-time counter (s_memrealtime: the shader clock counters of different XCDs are unrelated) at its phase boundaries into ct_wino4f_trace_buffer()[workgroup][8].
 #ifdef CTDET_W4F_TRACE
 __device__ unsigned long long* g_w4f_trace = nullptr;
 #define W4F_STAMP(k)                                                                                   \
     do {                                                                                               \
-        if (g_w4f_trace && tid == 0) g_w4f_trace[(size_t)blockIdx.x * 8 + (k)] = __builtin_readcyclecounter(); \
+        if (g_w4f_trace && tid == 0) g_w4f_trace[(size_t)blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
 #else
 #define W4F_STAMP(k) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a)
+// SEG: the launch scatters into the flattened head buffers (a.nseg > 0).  The plain instantiation drops that path and the
+// 24 scalar registers of its three segment records, which a persistent loop would otherwise carry through its main loop.
+// PLAIN: no residual, no per-channel floor, no head scatter (a.res == a.lo == nullptr, a.nseg == 0): what the narrow trunk layers
+// this kernel exists for use (bias + ReLU, optionally the fused 2x2 max-pool) -- the epilogue then needs a third of the scalar
+// registers and none of those branches.
+template <bool SEG, bool PLAIN>
+__global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
 {
+    const Wino4fArgs& a = a_in;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* const lds = reinterpret_cast<float*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // blockIdx -> (XCD-local sequence, cout block fastest), as in ct_wino4.hip: the cout blocks of a tile block run together
-    // on one XCD and share its input patches through that XCD's L2
-    const int jx = blockIdx.x >> 3;
-    const int kb = jx % a.kblocks;
-    const int tblk = (jx / a.kblocks) * 8 + (blockIdx.x & 7);
-    if (tblk >= a.tile_blocks) return;
-    W4F_STAMP(0);
-    const int tb0 = tblk * TB;
     const int HW = a.H * a.W;
+    // Persistent grid: workgroup b walks the work items b, b + gridDim.x, ... (gridDim.x is a multiple of 8: an item keeps its XCD)
+    // Item order = the plain grid's of ct_wino4.hip: item -> (XCD-local sequence, cout block fastest), so the cout blocks of a
+    // tile block run at the same time on one XCD and share its input patches through that XCD's L2.  (Measured against the
+    // opposite order -- cout block slowest, every workgroup of a round on the same 1.7 MB slice of U: 128 -> 128 @150x150 659 vs
+    // 610-640 us; the input then comes from HBM once per cout block, 368 MB each at that shape.)
+    const int nitems = 8 * ((a.tile_blocks + 7) / 8) * a.kblocks;
+    auto item_tblk = [&](int vb) { return ((vb >> 3) / a.kblocks) * 8 + (vb & 7); };
+    auto item_kb = [&](int vb) { return (vb >> 3) % a.kblocks; };
+    auto next_valid = [&](int vb) {           // first item >= vb of this workgroup's sequence that has a tile block
+        while (vb < nitems && item_tblk(vb) >= a.tile_blocks) vb += gridDim.x;
+        return vb;
+    };
 
     // ---- patch role: tile = l31, channel in chunk = 2 wave + h.  Rows outside the map use the out-of-range offset (the DMA
     // writes zeros for such lanes); a buffer load whose first byte lies before the row is dropped whole, so the left-edge
@@ -140,8 +151,8 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a)
     int voffq[6];
     bool mc[6], lp;
     int d4;                                   // byte distance from the 16-byte piece to column 4
-    {
-        const int T = tb0 + l31;
+    auto setup_patch = [&](int vb) {
+        const int T = item_tblk(vb) * TB + l31;
         const bool live = T < a.NT;
         const int n = T / (a.TY * a.TX);
         const int rem = T - n * (a.TY * a.TX);
@@ -157,14 +168,14 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a)
             const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
             voffq[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
         }
-    }
+    };
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
     const __amdgpu_buffer_rsrc_t rU = make_rsrc(a.U, a.u_bytes);
     const int chunk_bytes = CC * HW * 4;
     const int chan_base = 2 * wave * HW * 4;
     const int last = a.chunks - 1;
     typedef __attribute__((address_space(3))) void* lds_ptr;
-    unsigned char* const stage = lds_raw + V_BYTES + wave * STAGE_WAVE_BYTES;     // this wave's patch rows: [row 6][half 2][lane 64][12 B]
+    unsigned char* const stage = lds_raw + V_BYTES + wave * STAGE_WAVE_BYTES;     // this wave's patch rows: [row 6][1536 B]
 
     auto dma_patch = [&](int c) {
         const int soff = c * chunk_bytes + chan_base;
@@ -188,12 +199,6 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a)
 
     // ---- A fragments: unit u of this wave = 3 KB [piece 3][lane 64][16 B]
     const int u_voff = wave * U_WAVE_BYTES + lane * 16;
-    const int u_kb = kb * a.chunks;
-    auto load_u = [&](int c, int unit, i32x4 (&dst)[3]) {
-        const int soff = (u_kb + c) * U_CHUNK_BYTES + unit * UNIT_BYTES;
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc) dst[pc] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, soff + pc * 1024, 0);
-    };
     auto read_raw = [&](int xi, float (&raw)[8]) {
         const float* p = vr + xi * PT_STRIDE;
 #pragma unroll
@@ -212,12 +217,6 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a)
     };
     const int xi0 = 4 * wave, xi_half = 32 + (wave >> 1);
 
-    f32x16 acc[9];
-#pragma unroll
-    for (int j = 0; j < 9; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
     // the six piece products, smallest first: (mid, mid), (lo, hi), (hi, lo), (mid, hi), (hi, mid), (hi, hi)   [A piece, B piece]
     constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
 #define W4F_UNIT(X, UA, FB)                                                                                          \
@@ -227,151 +226,200 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a)
                                                              __builtin_bit_cast(bf16x8, FB[PB[t_]]), acc[X], 0, 0, 0); \
     } while (0)
 
+    int vb = next_valid(blockIdx.x);
+    if (vb >= nitems) return;
+    setup_patch(vb);
     dma_patch(0);
-    i32x4 ua0[3], ua1[3], ua2[3];
-    for (int c = 0; c < a.chunks; ++c) {
-        // ================= phase T: patch(c), staged by DMA during the previous phase M, -> V
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        load_u(c, 0, ua0);                       // the first two units of phase M: a whole phase T of latency
-        load_u(c, 1, ua1);
-        {
-            float t[6][6];
-            float dd[6][6];
+    while (vb < nitems) {
+        W4F_STAMP(0);
+        const int kb = item_kb(vb);
+        const int tb0 = item_tblk(vb) * TB;
+        const int vb_next = next_valid(vb + gridDim.x);
+        const int u_kb = kb * a.chunks;
+        auto load_u = [&](int c, int unit, i32x4 (&dst)[3]) {
+            const int soff = (u_kb + c) * U_CHUNK_BYTES + unit * UNIT_BYTES;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const f32x4 q = *reinterpret_cast<const f32x4*>(sq + i * ROW_BYTES);
-                float e4 = *reinterpret_cast<const float*>(se + i * ROW_BYTES);
-                float e5 = *reinterpret_cast<const float*>(se + i * ROW_BYTES + ROW_E_BYTES);
-                float qx = q.x, qy = q.y, qz = q.z, qw = q.w;
-                // unconditional reads, then selects: not exec-masked read / wait blocks
-                asm("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qw), "+v"(e4), "+v"(e5));
-                dd[i][0] = (mc[0] && !lp) ? qx : 0.f;
-                dd[i][1] = mc[1] ? (lp ? qx : qy) : 0.f;
-                dd[i][2] = mc[2] ? (lp ? qy : qz) : 0.f;
-                dd[i][3] = mc[3] ? (lp ? qz : qw) : 0.f;
-                dd[i][4] = mc[4] ? e4 : 0.f;
-                dd[i][5] = mc[5] ? e5 : 0.f;
+            for (int pc = 0; pc < 3; ++pc) dst[pc] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, soff + pc * 1024, 0);
+        };
+        f32x16 acc[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        i32x4 ua0[3], ua1[3], ua2[3];
+        for (int c = 0; c < a.chunks; ++c) {
+            // ================= phase T: patch(c), staged by DMA during the previous phase M (chunk 0: during the previous
+            // item's output passes), -> V
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            load_u(c, 0, ua0);                       // the first two units of phase M: a whole phase T of latency
+            load_u(c, 1, ua1);
+            {
+                float t[6][6];
+                float dd[6][6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const f32x4 q = *reinterpret_cast<const f32x4*>(sq + i * ROW_BYTES);
+                    float e4 = *reinterpret_cast<const float*>(se + i * ROW_BYTES);
+                    float e5 = *reinterpret_cast<const float*>(se + i * ROW_BYTES + ROW_E_BYTES);
+                    float qx = q.x, qy = q.y, qz = q.z, qw = q.w;
+                    // unconditional reads, then selects: not exec-masked read / wait blocks
+                    asm("" : "+v"(qx), "+v"(qy), "+v"(qz), "+v"(qw), "+v"(e4), "+v"(e5));
+                    dd[i][0] = (mc[0] && !lp) ? qx : 0.f;
+                    dd[i][1] = mc[1] ? (lp ? qx : qy) : 0.f;
+                    dd[i][2] = mc[2] ? (lp ? qy : qz) : 0.f;
+                    dd[i][3] = mc[3] ? (lp ? qz : qw) : 0.f;
+                    dd[i][4] = mc[4] ? e4 : 0.f;
+                    dd[i][5] = mc[5] ? e5 : 0.f;
+                }
+                // the stage is free again once its reads have returned: the next rows -- chunk c + 1, or chunk 0 of this
+                // workgroup's NEXT item -- are under way during the transform, the whole phase M and the output passes
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (c < last) {
+                    dma_patch(c + 1);
+                } else if (vb_next < nitems) {
+                    setup_patch(vb_next);
+                    dma_patch(0);
+                }
+#pragma unroll
+                for (int cc = 0; cc < 6; ++cc) {
+                    const float d[6] = {dd[0][cc], dd[1][cc], dd[2][cc], dd[3][cc], dd[4][cc], dd[5][cc]};
+                    float o[6];
+                    bt6(d, o);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) t[i][cc] = o[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    float v[6];
+                    bt6(t[i], v);
+                    float* vp = vw + (i * 6) * PT_STRIDE;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) vp[j * PT_STRIDE] = v[j];
+                }
             }
-            // the stage is free again once its reads have returned: the next chunk's rows are under way during the transform
-            // and the whole phase M
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            dma_patch(min(c + 1, last));
-#pragma unroll
-            for (int cc = 0; cc < 6; ++cc) {
-                const float d[6] = {dd[0][cc], dd[1][cc], dd[2][cc], dd[3][cc], dd[4][cc], dd[5][cc]};
-                float o[6];
-                bt6(d, o);
-#pragma unroll
-                for (int i = 0; i < 6; ++i) t[i][cc] = o[i];
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (c == 0) W4F_STAMP(1);
+            // ================= phase M: nine units (point, cout half); U two units ahead, the next point's fragments split
+            // behind the current point's MFMAs
+            {
+                float raw[8];
+                i32x4 fbA[3], fbB[3];
+                read_raw(xi0, raw);
+                split_all(raw, fbA);
+                // point 0
+                load_u(c, 2, ua2);
+                read_raw(xi0 + 1, raw);
+                W4F_UNIT(0, ua0, fbA);
+                load_u(c, 3, ua0);
+                split_all(raw, fbB);
+                W4F_UNIT(1, ua1, fbA);
+                // point 1
+                load_u(c, 4, ua1);
+                read_raw(xi0 + 2, raw);
+                W4F_UNIT(2, ua2, fbB);
+                load_u(c, 5, ua2);
+                split_all(raw, fbA);
+                W4F_UNIT(3, ua0, fbB);
+                // point 2
+                load_u(c, 6, ua0);
+                read_raw(xi0 + 3, raw);
+                W4F_UNIT(4, ua1, fbA);
+                load_u(c, 7, ua1);
+                split_all(raw, fbB);
+                W4F_UNIT(5, ua2, fbA);
+                // point 3
+                load_u(c, 8, ua2);
+                read_raw(xi_half, raw);
+                W4F_UNIT(6, ua0, fbB);
+                split_all(raw, fbA);
+                W4F_UNIT(7, ua1, fbB);
+                // the shared point 32 + wave / 2, cout half wave & 1
+                W4F_UNIT(8, ua2, fbA);
             }
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                float v[6];
-                bt6(t[i], v);
-                float* vp = vw + (i * 6) * PT_STRIDE;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) vp[j * PT_STRIDE] = v[j];
-            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (c == 0) W4F_STAMP(1);
-        // ================= phase M: nine units (point, cout half); U two units ahead, the next point's fragments split behind
-        // the current point's MFMAs
+        W4F_STAMP(2);
+
+        // ---- output transform: four passes of 16 couts through the V region  M[point][cout 16][tile 32] (72 KB; the stage
+        // region is receiving the next item's first rows).  Quarter q = cout half q >> 1, accumulator registers 8 (q & 1) ..
+        // + 7 of its blocks: register r of a block = cout (r & 3) + 8 (r >> 2) + 4 h of the half, tile l31.  Barriers are bare
+        // s_barrier instructions: __syncthreads() would wait for the DMA in flight.
+        // The epilogue's ~30 argument words are re-read from the kernel-argument segment per item, through a pointer the
+        // compiler cannot see through: read once at kernel entry they would stay live across the main loop of every item of
+        // this persistent workgroup and push its masks and descriptors out of the scalar registers.
+        Wino4fArgs e;
+#if defined(__HIP_DEVICE_COMPILE__)
         {
-            float raw[8];
-            i32x4 fbA[3], fbB[3];
-            read_raw(xi0, raw);
-            split_all(raw, fbA);
-            // point 0
-            load_u(c, 2, ua2);
-            read_raw(xi0 + 1, raw);
-            W4F_UNIT(0, ua0, fbA);
-            load_u(c, 3, ua0);
-            split_all(raw, fbB);
-            W4F_UNIT(1, ua1, fbA);
-            // point 1
-            load_u(c, 4, ua1);
-            read_raw(xi0 + 2, raw);
-            W4F_UNIT(2, ua2, fbB);
-            load_u(c, 5, ua2);
-            split_all(raw, fbA);
-            W4F_UNIT(3, ua0, fbB);
-            // point 2
-            load_u(c, 6, ua0);
-            read_raw(xi0 + 3, raw);
-            W4F_UNIT(4, ua1, fbA);
-            load_u(c, 7, ua1);
-            split_all(raw, fbB);
-            W4F_UNIT(5, ua2, fbA);
-            // point 3
-            load_u(c, 8, ua2);
-            read_raw(xi_half, raw);
-            W4F_UNIT(6, ua0, fbB);
-            split_all(raw, fbA);
-            W4F_UNIT(7, ua1, fbB);
-            // the shared point 32 + wave / 2, cout half wave & 1
-            W4F_UNIT(8, ua2, fbA);
+            typedef const __attribute__((address_space(4))) int* kernarg_words;
+            kernarg_words kp = (kernarg_words)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));
+            static_assert(sizeof(Wino4fArgs) % 4 == 0, "argument record in words");
+            int words[sizeof(Wino4fArgs) / 4];
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(Wino4fArgs) / 4); ++i) words[i] = kp[i];
+            __builtin_memcpy(&e, words, sizeof(e));
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+#else
+        e = a_in;
+#endif
+        if (!SEG) e.nseg = 0;
+        if (PLAIN) { e.res = nullptr; e.lo = nullptr; }
+        const __amdgpu_buffer_rsrc_t rout = make_rsrc(e.out, e.out_bytes);
+        const __amdgpu_buffer_rsrc_t rres = make_rsrc(e.res, e.res ? e.res_bytes : 0u);
+        const int o_kk = tid >> 5, o_tl = tid & 31;
+        const int o_T = tb0 + o_tl;
+        const int o_n = o_T / (a.TY * a.TX);
+        const int o_rem = o_T - o_n * (a.TY * a.TX);
+        const int o_ty = o_rem / a.TX, o_tx = o_rem - o_ty * a.TX;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    lds[(xi0 + p) * (16 * 32) + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[2 * p + (q >> 1)][8 * (q & 1) + r];
+            if ((wave & 1) == (q >> 1)) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r)
+                    lds[xi_half * (16 * 32) + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[8][8 * (q & 1) + r];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {
+                const int co = kb * KB + 16 * q + o_kk;
+                if (o_T < a.NT && co < a.M) {
+                    const int n = o_n, ty = o_ty, tx = o_tx;
+                    float z[4][6];
+                    const float* mp = lds + o_kk * 32 + o_tl;
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        float m[6], y[4];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) m[i] = mp[(i * 6 + j) * (16 * 32)];
+                        at4(m, y);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) z[i][j] = y[i];
+                    }
+                    float y[4][4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) at4(z[i], y[i]);
+                    ctdet::w4::emit_tile4(e, rout, rres, n, ty, tx, co, y);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (q == 1) W4F_STAMP(3);
+        }
+        W4F_STAMP(4);
+        vb = vb_next;
     }
 #undef W4F_UNIT
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the clamped re-load of the last chunk's rows
-    __syncthreads();
-    W4F_STAMP(2);
-
-    // ---- output transform: two passes of 32 couts through LDS  M[point][cout 32][tile 32]
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
-    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        // accumulator register r of a block = cout (r & 3) + 8 (r >> 2) + 4 h of its half, tile l31
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                lds[(xi0 + p) * MXI + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[2 * p + pass][r];
-        if ((wave & 1) == pass) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                lds[xi_half * MXI + ((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = acc[8][r];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + 512 * it;
-            const int kk = idx >> 5, tl = idx & 31;
-            const int co = kb * KB + 32 * pass + kk;
-            const int T = tb0 + tl;
-            if (T >= a.NT || co >= a.M) continue;
-            const int n = T / (a.TY * a.TX);
-            const int rem = T - n * (a.TY * a.TX);
-            const int ty = rem / a.TX, tx = rem - ty * a.TX;
-            float z[4][6];
-            const float* mp = lds + kk * 32 + tl;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                float m[6], y[4];
-#pragma unroll
-                for (int i = 0; i < 6; ++i) m[i] = mp[(i * 6 + j) * MXI];
-                at4(m, y);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) z[i][j] = y[i];
-            }
-            float y[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) at4(z[i], y[i]);
-            ctdet::w4::emit_tile4(a, rout, rres, n, ty, tx, co, y);
-        }
-        if (pass == 0) {
-            __syncthreads();
-            W4F_STAMP(3);
-        }
-    }
-    W4F_STAMP(4);
 }
 
 bool wino4f_ok(const ct_conv_desc* d)
@@ -449,7 +497,10 @@ extern "C" int ct_conv2d_wino4f_pool_fwd(const ct_conv_desc* d, const void* upac
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
         std::call_once(once, [] {
-            attr_err = hipFuncSetAttribute((const void*)wino_f4x4_3x3_x3, hipFuncAttributeMaxDynamicSharedMemorySize, W4F_LDS_BYTES);
+            const void* fs[] = {(const void*)wino_f4x4_3x3_x3<false, false>, (const void*)wino_f4x4_3x3_x3<false, true>,
+                                (const void*)wino_f4x4_3x3_x3<true, false>};
+            for (const void* f : fs)
+                if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, W4F_LDS_BYTES);
         });
         CT_HIP(attr_err);
     }
@@ -485,8 +536,19 @@ extern "C" int ct_conv2d_wino4f_pool_fwd(const ct_conv_desc* d, const void* upac
         a.kblocks = (d->cout + KB - 1) / KB;
         // 8 XCD-local sequences of (tile block group, cout block); sequences past the last tile block exit at once
         const int groups = (a.tile_blocks + 7) / 8;
+        const int items = 8 * groups * a.kblocks;
+        // persistent: one workgroup per CU (144 KB of LDS each) walks the items with a stride of the grid size
+        static const int cus = [] {
+            int dev = 0, n = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                n = 256;
+            return std::max(8, n / 8 * 8);
+        }();
         CT_PROF("wino_f4x4_3x3_x3", st);
-        hipLaunchKernelGGL(wino_f4x4_3x3_x3, dim3(8 * groups * a.kblocks), dim3(512), W4F_LDS_BYTES, st, a);
+        const dim3 grid(std::min(items, cus));
+        if (a.nseg > 0) hipLaunchKernelGGL((wino_f4x4_3x3_x3<true, false>), grid, dim3(512), W4F_LDS_BYTES, st, a);
+        else if (!a.res && !a.lo) hipLaunchKernelGGL((wino_f4x4_3x3_x3<false, true>), grid, dim3(512), W4F_LDS_BYTES, st, a);
+        else hipLaunchKernelGGL((wino_f4x4_3x3_x3<false, false>), grid, dim3(512), W4F_LDS_BYTES, st, a);
         CT_LAUNCH_CHECK("wino_f4x4_3x3_x3");
     }
     return CT_OK;

@@ -779,8 +779,9 @@ def x3_allowed(st):
 
 
 def wino_tiles(backend=None, st=None):
-    """Winograd variants the tuner / the table may use (st.rt['wino'] codes).  Default '2,4,44': the two fp32-MFMA kernels
-    and the three-kernel F(4x4,3x3) / bf16x3 form with two accumulators (csrc/ct_wino4s.hip).  The fused F(2x2) bf16x3
+    """Winograd variants the tuner / the table may use (st.rt['wino'] codes).  Default '2,4,44,46': the two fp32-MFMA kernels,
+    the three-kernel F(4x4,3x3) / bf16x3 form with two accumulators (csrc/ct_wino4s.hip) and the fused F(4x4,3x3) / bf16x3
+    kernel for the narrow layers on big maps (csrc/ct_wino4f.hip).  The fused F(2x2) bf16x3
     forms (23: two accumulators; 24: four-wave workgroups) are faster than the fused fp32 kernels per layer ALONE
     (512 -> 512 @38x38: 742 -> 630 us) but not in the two-stream pipeline (same-box A/B of two tables: 3 360-3 371 vs
     3 228-3 398 images/s) and slower than tile 44 wherever that applies, so the committed table does
@@ -789,13 +790,14 @@ def wino_tiles(backend=None, st=None):
     CTDET_WINO_TILES), plus F(4x4) / fp32 on layers with at most wino4_max_cin input channels (and tile 44 from
     ctx_w4s_min_cin input channels up, see apply_tuned)."""
     env = os.environ.get('CTDET_WINO_TILES')
-    tiles = tuple(int(t) for t in (env or '2,4,44').split(',') if t)
+    tiles = tuple(int(t) for t in (env or '2,4,44,46').split(',') if t)
     allowed = getattr(backend, 'wino_tile_set', None)
     if allowed is not None:             # a runtime's accuracy policy: its set, narrowed by an explicit CTDET_WINO_TILES
         tiles = tuple(t for t in allowed if env is None or t in tiles)
         cap = getattr(backend, 'wino4_max_cin', None)
-        if cap and st is not None and st.cin <= cap and 4 not in tiles and (env is None or '4' in env.split(',')):
-            tiles = tiles + (4,)        # short channel sums: F(4x4) / fp32 costs little accuracy there
+        f4 = ctx_f4_tile()
+        if cap and st is not None and st.cin <= cap and f4 not in tiles and (env is None or str(f4) in env.split(',')):
+            tiles = tiles + (f4,)       # short channel sums: F(4x4) costs little accuracy there
     if st is not None and not st.rt.get('winox_ok'):
         tiles = tuple(t for t in tiles if t not in WINOX_TILES)
     if st is not None and not st.rt.get('wino4s_ok'):
@@ -823,9 +825,9 @@ def ctx_tile_set(net):
     bf16x3 with TWO accumulators (tile code 23: exact +-1 transforms, the large channel sum sees cin / 16 roundings;
     per-layer error vs fp64 4e-7 against 5e-6 for F(4x4,3x3) / fp32), except the layers with short channel sums
     (ctx_f4_max_cin).  With every layer on tile 23 the device is CLOSER to fp64 than the CPU path in 8-9 of the 9 sweep
-    cases (3.0..6.1e-5 vs 4.9..7.2e-5), which is as far as fp32 activation storage goes; with the shipped cap all 9 cases
-    are within 1e-4 of the CPU path (profiles/r04_ctx_parity.txt, r04_ctx_policy.txt).  Layers without 16-channel chunks
-    keep F(2x2,3x3) on the fp32 MFMA (tile 2).
+    cases (3.0..6.1e-5 vs 4.9..7.2e-5), which is as far as fp32 activation storage goes; with the shipped cap (fused F(4x4)
+    up to 256 input channels, ctx_f4_max_cin) all 9 cases are within 1e-4 of the CPU path at 8 and at 128 reference threads
+    (profiles/r05_ctx_policy.txt).  Layers without 16-channel chunks keep F(2x2,3x3) on the fp32 MFMA (tile 2).
     CTDET_CTX_TILES = comma list of allowed tile codes, or 'any' for the unconstrained table."""
     ctx = getattr(net, 'method', None) == 'ours' and getattr(net, 'phase', 1) == 2
     v = os.environ.get('CTDET_CTX_TILES', CTX_TILES_DEFAULT)
@@ -834,33 +836,45 @@ def ctx_tile_set(net):
     return tuple(int(t) for t in v.split(',') if t)
 
 
-CTX_F4_MAX_CIN_DEFAULT = '128'
+CTX_F4_MAX_CIN_DEFAULT = '256'
 
 
 def ctx_f4_max_cin(net):
-    """Layers of a Context-Transformer network with at most this many input channels keep F(4x4,3x3) / fp32 where the
-    table picks it: its rounding error grows with the length of the channel sum, and on conv1_2 .. conv3_1 (64 / 128
-    input channels at 300 x 300 .. 75 x 75) the bf16x3 form costs the most time.  Measured (profiles/r04_ctx_policy.txt,
-    RFBNet-300 + Context-Transformer bs 32, sweep of 9 randn cases): cap 0: 2 447 images/s, worst GPU-CPU32 1.05e-4, device
-    closer to fp64 than the CPU path in 8 / 9; cap 64: 2 524, 9.6e-5, 6 / 9; **cap 128 (default): 2 565, 9.6e-5 -- all 9 cases
-    within the flat 1e-4 --, 5 / 9**; cap 256: 2 595, 1.30e-4 (3 cases above 1e-4).  CTDET_CTX_F4_MAX_CIN; 0 = none."""
+    """Layers of a Context-Transformer network with at most this many input channels keep a fused F(4x4,3x3) kernel where the
+    table picks one (ctx_f4_tile): its rounding error grows with the length of the channel sum, and on conv1_2 .. conv3_1
+    (64 / 128 input channels at 300 x 300 .. 75 x 75) F(2x2,3x3) costs the most time.  Chosen by the round-5 sweep
+    (profiles/r05_ctx_policy.txt: RFBNet-300 + Context-Transformer bs 32, 9 randn cases, every case judged against the fp32 CPU
+    path at 8 AND at 128 reference threads; pairs = ctx_w4s_min_cin / this cap):
+      0 / 0    2 353 images/s   worst GPU-CPU32 9.7e-5 at 8 threads, 1.02e-4 at 128 (one case above 1e-4)
+      0 / 64   2 440            8.5e-5 / 9.6e-5      all 18 inside 1e-4
+      0 / 256  2 471            9.0e-5 / 9.2e-5      all 18 inside 1e-4   <- default
+      128 / 128 (round 4)  2 898   1.03e-4 / 1.05e-4   3 of 18 above 1e-4: the opt-in fast policy
+    CTDET_CTX_F4_MAX_CIN; 0 = none."""
     return int(os.environ.get('CTDET_CTX_F4_MAX_CIN', CTX_F4_MAX_CIN_DEFAULT)) if ctx_tile_set(net) is not None else 0
 
 
-CTX_W4S_MIN_CIN_DEFAULT = '128'
-# Context-Transformer networks: their dilated layers (conv6, the RFB branches) on the three-kernel form too, from
-# ctx_w4s_min_cin input channels up.  Measured (same session, 9 randn sweep cases, 8-thread reference): off: 2 885 images/s, two
-# cases at 1.00e-4 ('truth' verdict), GPU-fp64 <= 7.6e-5; on: 2 973 images/s, one case at 1.03e-4, GPU-fp64 <= 6.8e-5 -- on.
+CTX_F4_TILE_DEFAULT = '4'
+
+
+def ctx_f4_tile():
+    """Which F(4x4,3x3) kernel the layers below ctx_f4_max_cin run: 4 = fused on the fp32 MFMA (csrc/ct_wino4.hip), 46 = fused on
+    bf16x3 (csrc/ct_wino4f.hip; layers without 16-channel chunks keep 4).  CTDET_CTX_F4_TILE."""
+    return int(os.environ.get('CTDET_CTX_F4_TILE', CTX_F4_TILE_DEFAULT))
+
+
+CTX_W4S_MIN_CIN_DEFAULT = '0'
+# Context-Transformer networks with ctx_w4s_min_cin > 0: their dilated layers (conv6, the RFB branches) on the three-kernel form
+# too, from that many input channels up (CTDET_CTX_DIL_W4S=0: never)
 CTX_DIL_W4S_DEFAULT = '1'
 
 
 def ctx_w4s_min_cin(net):
     """Layers of a Context-Transformer network with at least this many input channels that the table runs on F(4x4,3x3)
     (fused or three-kernel) use the three-kernel bf16x3 form with two accumulators (tile 44: error vs fp64 2e-6 per layer
-    against 5e-6 for the fused fp32 kernel, and 1.7x its speed on the wide layers).  Measured (profiles/r04_ctx_policy.txt,
-    RFBNet-300 + Context-Transformer bs 32, 9 randn sweep cases, same session): 0 (none): 2 594 images/s, worst GPU-CPU32
-    9.25e-5; 256: 3 015, 1.02e-4 (one case above 1e-4); **128 (default): 2 915, 8.9e-5 -- all nine inside the flat 1e-4**.
-    CTDET_CTX_W4S_MIN_CIN; 0 = none."""
+    against 3-4e-7 for F(2x2,3x3) / bf16x3 with two accumulators, at 1.7x the speed on the wide layers).  Default 0 = never:
+    with tile 44 on the 512-channel layers one to three of the 18 (case, reference thread count) pairs of the sweep land at
+    1.03-1.05e-4 from the fp32 CPU path (ctx_f4_max_cin has the table), and north_star's contract is a flat 1e-4.
+    CTDET_CTX_W4S_MIN_CIN=128 CTDET_CTX_F4_MAX_CIN=128 is the round-4 policy: +17 % images/s for callers who accept that."""
     return int(os.environ.get('CTDET_CTX_W4S_MIN_CIN', CTX_W4S_MIN_CIN_DEFAULT)) if ctx_tile_set(net) is not None else 0
 
 
@@ -896,13 +910,17 @@ def apply_tuned(backend, st, batch, wino4=True):
             # accuracy policy of this runtime: F(4x4) / fp32 survives only where the policy allows it (short channel sums),
             # everything else runs the most accurate allowed variant
             w4s_min = getattr(backend, 'ctx_w4s_min_cin', 0)
+            f4 = ctx_f4_tile()
+            f4 = f4 if f4 in allowed else 4     # tile 46 needs 16-channel chunks
             if want in F4_TILES and w4s_min and st.cin >= w4s_min and st.rt.get('wino4s_ok'):
                 want = 44                   # three-kernel F(4x4) with two accumulators: 0.4x the rounding of the fused fp32 form
-            elif not (want == 4 and 4 in allowed):
+            elif want in (4,) + WINO4F_TILES and f4 in allowed:
+                want = f4                   # a fused F(4x4) entry below ctx_f4_max_cin input channels (wino_tiles put f4 into the set)
+            else:
                 want = 23 if 23 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
         elif want not in allowed:
-            # a three-kernel F(4x4) entry without tile 44 in the set (CTDET_WINO_TILES=2,4) is the fused F(4x4) kernel's layer
-            want = 4 if want in WINO4S_TILES and 4 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
+            # a three-kernel / fused-bf16x3 F(4x4) entry without its tile in the set (CTDET_WINO_TILES=2,4) is the fused fp32 F(4x4) kernel's layer
+            want = 4 if want in WINO4S_TILES + WINO4F_TILES and 4 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
         backend.enable_wino(st, tile=want)
         return True
     if isinstance(cfg, str) and cfg.startswith('x3:'):

@@ -78,27 +78,15 @@ def sweep_case(net, size, C, setting, batch, seed, kind, sd32=None, sd64=None, e
             'rawconf_gpu_cpu32': rel(raw_gpu, raw32)}
 
 
-def verdict(r, tol=1e-4, cap=1.25e-4):
-    """'ok': every element of the block's output within tol of the reference's fp32 CPU arithmetic.
-    'truth': some element above tol, but every element is within tol of the fp64 evaluation of the reference network
-    (max norm, no quantile, no slack) AND within `cap` of the fp32 CPU path.  Else 'FAIL'.
-
-    Why the second clause exists: the fp64 block multiplies a perturbation of its input by ~1000 (budget below), so the
-    reference's own fp32 CPU path sits 4.8..7.2e-5 from fp64 -- and WHERE in that band depends on the host's thread count,
-    because torch's CPU convolutions split their sums by thread: the same (bs 32, seed 1234) case is 4.88e-5 from fp64 at
-    8 threads and 6.63e-5 at 128, and the device's distance to "the CPU path" moves with it (1.00e-4 vs 7.9e-5, the
-    device's own output bit-identical).  A device that is TWICE as close to fp64 as the CPU path (every Winograd layer on
-    F(2x2,3x3) / bf16x3, two accumulators: 3.5..5.3e-5 from fp64, closer than the CPU path in 9 of 9 cases) still lands
-    1.10e-4 from the 8-thread CPU path in one case under one tile table and 9.7e-5 under the next (DESIGN.md section 2,
-    profiles/r04_ctx_policy.txt).  So 1e-4 against the CPU path is met where the CPU path's own error allows it (8 of 9
-    cases at 8 threads, 7 of 9 at 128 with the shipped policy; the others 1.03..1.05e-4), and the contract that can be
-    held flat is the one against the exact value: device within 1e-4 of fp64 in the max norm (measured 4.6..6.8e-5 over
-    the sweep), within 1.25e-4 of the CPU path.  Rounds 2-3 accepted 'no further from fp64
-    than 1.75 x the CPU path at the 99.99 % quantile and within 2.5e-4': that waiver is gone; tests/conftest.py pins the
-    reference to 8 threads (the count tools/gen_goldens.py captured the goldens with)."""
-    if r['gpu_cpu32'] <= tol:
-        return 'ok'
-    return 'truth' if (r['gpu_fp64'] <= tol and r['gpu_cpu32'] <= cap) else 'FAIL'
+def verdict(r, tol=1e-4):
+    """'ok': every element of the block's output within tol of the reference's fp32 CPU arithmetic; else 'FAIL'.  north_star's
+    contract, flat: no second clause (rounds 2-4 accepted cases above 1e-4 that were within 1e-4 of fp64; the shipped tile
+    policy -- engine.ctx_f4_max_cin / ctx_w4s_min_cin -- now holds 1e-4 against the CPU path in all nine sweep cases, with the
+    CPU reference at 8 and at 128 threads: profiles/r05_ctx_policy.txt).  What makes this a narrow pass, for the record: the
+    block multiplies a perturbation of its input by ~1000 (budget below), the reference's own fp32 CPU path sits 4.8..7.2e-5
+    from an fp64 evaluation and moves inside that band with the host's thread count (torch's CPU convolutions split their
+    sums by thread: tests/conftest.py pins 8 threads, the count tools/gen_goldens.py captured the goldens with)."""
+    return 'ok' if r['gpu_cpu32'] <= tol else 'FAIL'
 
 
 def pool_from_conf(conf, size, C):

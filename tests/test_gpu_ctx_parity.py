@@ -5,14 +5,13 @@ reference's fp32 CPU arithmetic AND an fp64 evaluation (models/RFB_Net_vgg.py:25
 What is asserted (tools/ctx_parity.py --budget, profiles/r04_ctx_parity.txt):
   * the block's INPUT (raw conf-head output) and loc / obj: 1e-4 vs the CPU fp32 path (measured: 2e-6);
   * the block's own arithmetic on an identical input: 1e-4 (measured 1.0e-5; torch-CPU fp32's is 1.6e-5);
-  * the composite: 1e-4 vs the CPU fp32 path; where the worst of the 7e5 elements exceeds it, every element must be
-    within 1e-4 of an fp64 evaluation of the reference network (max norm) and within 1.25e-4 of the CPU path
-    (ctx_cases.verdict: the fp64 block amplifies a perturbation of its input ~1000x, the CPU path itself is 4.8..7.2e-5
-    from fp64 and moves inside that band with the host's thread count; conftest.py pins 8 threads).
+  * the composite: 1e-4 vs the CPU fp32 path, every element, no second clause (ctx_cases.verdict; the fp64 block amplifies a
+    perturbation of its input ~1000x, the CPU path itself is 4.8..7.2e-5 from fp64 and moves inside that band with the host's
+    thread count; conftest.py pins 8 threads; the shipped tile policy also holds at 128: profiles/r05_ctx_policy.txt).
 Inputs are 'randn' (SURVEY 8d (i)).  On image-like 'u8' inputs (8d (ii), |x| ~ 128) the logits are ~1e4 and the
 block is chaotic in fp32: torch-CPU fp32 itself is 1e-3 .. 1e-1 away from fp64 there, so no fp32 implementation has a
-parity to meet; that case only checks the block's input.  The shipped Winograd tile policy (engine.ctx_tile_set: the
-bf16x3 forms with two accumulators -- three-kernel F(4x4,3x3) from 128 input channels up, F(2x2,3x3) elsewhere) runs here."""
+parity to meet; that case only checks the block's input.  The shipped Winograd tile policy (engine.ctx_tile_set: F(2x2,3x3) on
+bf16x3 with two accumulators; a fused F(4x4,3x3) kernel up to 256 input channels) runs here."""
 import pytest
 import torch
 
@@ -33,7 +32,7 @@ def test_phase2_parity_sweep(net300, batch, seed):
     net, sd32, sd64 = net300
     r = cc.sweep_case(net, 300, 60, 'transfer', batch, seed, 'randn', sd32, sd64)
     assert r['loc_gpu_cpu32'] < 1e-4 and r['obj_gpu_cpu32'] < 1e-4 and r['rawconf_gpu_cpu32'] < 1e-4, r
-    assert cc.verdict(r) != 'FAIL', r
+    assert cc.verdict(r) == 'ok', r
 
 
 def test_phase2_parity_512_at_the_per_gpu_batch_of_configs3():

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Context-Transformer parity sweep + error budget on the MI355X (measurement tool; the oracle is the checker):
     python tools/ctx_parity.py [--budget] [--sweep] [--policies 2+23,any] [--batches 2,8,32]
-Policies = values of CTDET_CTX_TILES with '+' for ',' (engine.ctx_tile_set): '2+23' = the shipped policy (the accurate bf16x3
-variants: three-kernel F(4x4,3x3) / F(2x2,3x3) with two accumulators, see engine.ctx_w4s_min_cin), '2' = F(2x2,3x3) on the
+Policies = values of CTDET_CTX_TILES with '+' for ',' (engine.ctx_tile_set): '2+23' = the shipped policy (F(2x2,3x3) / bf16x3
+with two accumulators, a fused F(4x4,3x3) kernel on the short channel sums, see engine.ctx_f4_max_cin), '2' = F(2x2,3x3) on the
 fp32 MFMA only, '2+4' = the two fp32-MFMA kernels as the table picks them (round 3), 'any' = the unconstrained table."""
 import argparse, os, sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,8 +24,8 @@ ap.add_argument('--f4-max-cin', default='', help='CTDET_CTX_F4_MAX_CIN: F(4x4)/f
 ap.add_argument('--also-threads', default='', help='comma list: evaluate the fp32 CPU reference again at these thread counts (same device output)')
 ap.add_argument('--force-tile', default='', help='CTDET_WINO_FORCE: 23 = F(2x2,3x3) on bf16x3 with two accumulators on every Winograd layer')
 a = ap.parse_args()
-names = {'2+23': 'the shipped policy: bf16x3 with two accumulators -- three-kernel F(4x4,3x3) where the table picks F(4x4) from '
-                 'CTDET_CTX_W4S_MIN_CIN (128) input channels up, F(2x2,3x3) elsewhere; fused F(4x4) / fp32 up to CTDET_CTX_F4_MAX_CIN (128)',
+names = {'2+23': 'the shipped tile set: F(2x2,3x3) / bf16x3 with two accumulators; fused F(4x4,3x3) (CTDET_CTX_F4_TILE, default 4) up to '
+                 'CTDET_CTX_F4_MAX_CIN (256) input channels; three-kernel F(4x4,3x3) from CTDET_CTX_W4S_MIN_CIN (0 = never) input channels up',
          '2': 'F(2x2,3x3) / fp32 MFMA only',
          '2+4': 'fp32-MFMA Winograd kernels as the table picks them', 'any': 'the unconstrained table'}
 if a.force_tile:

@@ -12,4 +12,11 @@ for f in bench_full.json.log rfb300_bench.json.log rfb512_bench.json.log rfb300c
 done
 [ -s $S/ctx_parity.txt ] && grep -v "amdgpu.ids" $S/ctx_parity.txt > $D/${R}_ctx_parity.txt
 python tools/prof_summary.py $S/train_stats > $D/${R}_train_kernel_stats.md 2>/dev/null || true
+# a published summary that is empty or a Python traceback is not evidence: refuse it
+bad=0
+for f in $D/${R}_*; do
+  if [ ! -s "$f" ]; then echo "EMPTY: $f" >&2; rm -f "$f"; bad=1; fi
+  if grep -q "^Traceback (most recent call last)" "$f" 2>/dev/null; then echo "TRACEBACK: $f" >&2; bad=1; fi
+done
 ls $D | grep "^${R}_" | wc -l
+exit $bad

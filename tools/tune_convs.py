@@ -21,6 +21,9 @@ ap.add_argument('--out', default=engine.TUNE_TABLE)
 ap.add_argument('--w4s', type=float, default=0.0, metavar='MARGIN',
                 help='targeted pass instead of a full re-tune: keep the table, time every layer that has the three-kernel '
                      'F(4x4,3x3) form (tile 44) against its current choice and move it when 44 is faster by MARGIN (e.g. 0.03)')
+ap.add_argument('--w4f', type=float, default=0.0, metavar='MARGIN',
+                help='the same targeted pass for the fused F(4x4,3x3) / bf16x3 kernel (tile 46, csrc/ct_wino4f.hip): every 3x3 / '
+                     'stride 1 / dilation 1 layer with 16-channel chunks, with its pooling fusion as the runtime runs it')
 ap.add_argument('--cases', nargs='*', default=['300:32:20:1', '300:32:60:2:transfer', '300:4:20:1', '300:1:20:1',
                                                  '300:2:20:1', '512:32:20:1', '512:1:20:1', '300:2:60:2:transfer',
                                                  '300:2:15:2:incre', '512:1:60:2:transfer', '300:8:20:1', '300:16:20:1',
@@ -36,35 +39,39 @@ for case in a.cases:
     net = build_net(types.SimpleNamespace(method='ours', phase=phase, setting=setting), size, C)
     net.load_state_dict(synth.fill_state_dict(net.state_dict()))
     net = net.eval().cuda(); net.device = 'cuda'
-    if a.w4s:
+    if a.w4s or a.w4f:
         os.environ['CTDET_TUNE'] = '0'
         rt = net.runtime(batch)
-        be, moved = rt.backend, []
-        for st in rt.conv_steps():
-            if not st.rt.get('wino4s_ok'):
+        be = rt.backend
+        for tile, margin, ok_key, group in ((44, a.w4s, 'wino4s_ok', engine.WINO4S_TILES), (46, a.w4f, 'wino4f_ok', engine.WINO4F_TILES)):
+            if not margin:
                 continue
-            key = st.tune_key(batch)
-            cur_tile, cur_x3 = st.rt.get('wino'), st.rt.get('x3')
-            if cur_tile in engine.WINO4S_TILES:
-                continue
-            t_cur = min(be._time_conv(st), be._time_conv(st))
-            be.enable_wino(st, tile=44)
-            t_new = min(be._time_conv(st), be._time_conv(st))
-            if t_new < (1.0 - a.w4s) * t_cur:
-                if not cur_tile and isinstance(table.get(key), str) and table[key] not in engine.WINO_NAME.values():
-                    # non-Winograd layer (dilated): what to run where tile 44 is not allowed (the first case that moves a shape
-                    # records it; a later case sees 'wino4s' in the table and leaves the record alone)
-                    table[key + '|alt'] = table[key]
-                table[key] = 'wino4s'
-                moved.append('%s %.0f->%.0f us' % (st.name, t_cur * 1e3, t_new * 1e3))
-            else:                               # back to what the table says
-                if cur_tile:
-                    be.enable_wino(st, tile=cur_tile)
-                else:
-                    be.enable_wino(st, False)
-                    if cur_x3 is not None:
-                        be.enable_x3(st, cur_x3)
-        print('%s: moved to wino4s: %s' % (case, '; '.join(moved) or 'none'), flush=True)
+            moved = []
+            for st in rt.conv_steps():
+                if not st.rt.get(ok_key):
+                    continue
+                key = st.tune_key(batch)
+                cur_tile, cur_x3 = st.rt.get('wino'), st.rt.get('x3')
+                if cur_tile in group:
+                    continue
+                t_cur = min(be._time_conv(st), be._time_conv(st))
+                be.enable_wino(st, tile=tile)
+                t_new = min(be._time_conv(st), be._time_conv(st))
+                if t_new < (1.0 - margin) * t_cur:
+                    if not cur_tile and isinstance(table.get(key), str) and table[key] not in engine.WINO_NAME.values():
+                        # non-Winograd layer (dilated): what to run where tile 44 is not allowed (the first case that moves a shape
+                        # records it; a later case sees 'wino4s' in the table and leaves the record alone)
+                        table[key + '|alt'] = table[key]
+                    table[key] = engine.WINO_NAME[tile]
+                    moved.append('%s %.0f->%.0f us' % (st.name, t_cur * 1e3, t_new * 1e3))
+                else:                               # back to what the table says
+                    if cur_tile:
+                        be.enable_wino(st, tile=cur_tile)
+                    else:
+                        be.enable_wino(st, False)
+                        if cur_x3 is not None:
+                            be.enable_x3(st, cur_x3)
+            print('%s: moved to %s: %s' % (case, engine.WINO_NAME[tile], '; '.join(moved) or 'none'), flush=True)
         del rt, net
         torch.cuda.empty_cache()
         continue

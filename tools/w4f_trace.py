@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where a workgroup of the fused F(4x4,3x3) / bf16x3 kernel (csrc/ct_wino4f.hip) spends its life: shader-clock stamps of
-wave 0 at the phase boundaries, from a measurement build of the library:
+wave 0 (s_memrealtime, 100 MHz) at the phase boundaries, from a measurement build of the library:
     CTDET_EXTRA_FLAGS=-DCTDET_W4F_TRACE python context-transformer_amd/build.py --force && python tools/w4f_trace.py [shape ...]
 Columns: prologue (entry -> V(0) complete), main loop, first / second output pass, and the gap between consecutive
 workgroups on a CU slot (end of one -> entry of the next one that started after it, estimated from the sorted stamps)."""
@@ -26,22 +26,24 @@ for name in sys.argv[1:] or ['base.2', 'base.7']:
     for _ in range(3):
         be.run_conv(st)
     tiles = B * ((H + 3) // 4) * ((W + 3) // 4)
-    nwg = 8 * (((tiles + 31) // 32 + 7) // 8) * ((Cout + 63) // 64)
+    nwg = min(256, 8 * (((tiles + 31) // 32 + 7) // 8) * ((Cout + 63) // 64))      # persistent grid: the stamps of a workgroup's LAST item remain
     trace = torch.zeros(nwg * 8, dtype=torch.int64, device=DEV)
     _lib.check(lib.ct_wino4f_set_trace(trace.data_ptr()), 'set_trace')
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); be.run_conv(st); e1.record(); torch.cuda.synchronize()
     _lib.check(lib.ct_wino4f_set_trace(None), 'set_trace')
     t = trace.view(nwg, 8).cpu().double()
-    t = t[t[:, 4] > 0]
+    n_all = int((t[:, 4] > 0).sum())
+    t = t[(t[:, :5] > 0).all(1)]
+    if len(t) < n_all:
+        print('   (%d of %d workgroups have an incomplete set of stamps: dropped)' % (n_all - len(t), n_all))
     us = e0.elapsed_time(e1) * 1e3
     span = float(t[:, 4].max() - t[:, 0].min())
-    tick = us / span           # microseconds per counter tick, from the launch's own wall time
+    tick = 0.01                # s_memrealtime: 100 MHz
     d = [(t[:, k + 1] - t[:, k]) * tick for k in range(4)]
-    print('%-8s %d->%d @%dx%d bs%d: launch %.1f us, %d workgroups (%.2f rounds of 256), counter span %.3g ticks'
-          % (name, Cin, Cout, H, W, B, us, len(t), len(t) / 256.0, span))
-    for lab, v in zip(('prologue', 'main loop', 'output pass 0', 'output pass 1'), d):
+    print('%-8s %d->%d @%dx%d bs%d: launch %.1f us, %d workgroups (%.2f rounds of 256), first entry -> last exit %.1f us by the 100 MHz counter'
+          % (name, Cin, Cout, H, W, B, us, len(t), len(t) / 256.0, span * tick))
+    for lab, v in zip(('first phase T', 'main loop', 'output q0+q1', 'output q2+q3'), d):
         print('   %-14s mean %6.2f us   min %6.2f   max %6.2f' % (lab, v.mean(), v.min(), v.max()))
     life = (t[:, 4] - t[:, 0]) * tick
-    print('   %-14s mean %6.2f us;  sum of lives / 256 CUs = %.1f us of the %.1f us launch'
-          % ('whole life', life.mean(), float(life.sum()) / 256, us))
+    print('   %-14s mean %6.2f us per item (last item of each of the %d persistent workgroups)' % ('whole item', life.mean(), len(t)))

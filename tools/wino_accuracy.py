@@ -2,8 +2,8 @@
 """Whole-network rounding error of the conv variants against an fp64 evaluation of the same network
 (oracle/rfbnet_ref.py in double precision -- measurement tool, not product):
     python tools/wino_accuracy.py [--size 300] [--batch 2]
-Every layer the committed tune table routes through a Winograd kernel is forced to one variant (F(2x2,3x3) /
-F(4x4,3x3)); the table gives the largest error of loc / conf / obj over the output range, for phase 1 and for phase 2
+Every 3x3 / stride 1 / dilation 1 layer the committed tune table routes through a Winograd kernel is forced to one variant
+(F(2x2,3x3) / F(4x4,3x3) on the fp32 MFMA, F(2x2,3x3) / three-kernel F(4x4,3x3) / fused F(4x4,3x3) on bf16x3); the table gives the largest error of loc / conf / obj over the output range, for phase 1 and for phase 2
 (after the Context-Transformer block), against fp64 and against the reference's fp32 CPU arithmetic."""
 import argparse, os, sys, types
 import torch
@@ -33,17 +33,21 @@ for phase, C, kind in ((1, 20, 'randn'), (1, 20, 'u8'), (2, 60, 'randn')):
         e64 = ['%s %.2e' % (nm, float((g.reshape(w.shape) - w).abs().max() / w.abs().max()))
                for nm, g, w in zip(('loc', 'conf', 'obj'), got, want)]
         e32 = ['%.2e' % float((g.reshape(w.shape) - w.double()).abs().max() / w.abs().max()) for g, w in zip(got, ref32)]
-        print('RFBNet-%d phase %d %-5s input, %2d layers on %-12s vs fp64: %s   vs the fp32 CPU path: %s'
+        print('RFBNet-%d phase %d %-5s input, %2d layers on %-18s vs fp64: %s   vs the fp32 CPU path: %s'
               % (a.size, phase, kind, n, name, '  '.join(e64), ' '.join(e32)), flush=True)
 
     report('(the fp32 CPU path itself)', 0, [t.double() for t in ref32])
     rt = net.runtime(a.batch)
-    for name, tile in (('F(2x2,3x3)', 2), ('F(4x4,3x3)', 4)):
+    # the layers the committed table routes through a Winograd kernel and that have the fused kernels' geometry (3x3, stride 1,
+    # dilation 1): the dilated layers only exist on the three-kernel form (tile 44) and keep it in every row
+    fused = [st for st in rt.conv_steps() if st.rt.get('wino') and st.rt.get('wino_ok')]
+    variants = [('F(2x2,3x3) fp32', 2), ('F(4x4,3x3) fp32', 4), ('F(2x2) bf16x3 2acc', 23), ('F(4x4) 3-kernel', 44), ('F(4x4) fused x3', 46)]
+    for name, tile in variants:
         n = 0
-        for st in rt.conv_steps():
-            if st.rt.get('wino'):             # the layers the committed table routes through a Winograd kernel
-                rt.backend.enable_wino(st, True, tile=tile)
-                n += 1
+        for st in fused:
+            ok = {23: 'winox_ok', 44: 'wino4s_ok', 46: 'wino4f_ok'}.get(tile)
+            rt.backend.enable_wino(st, True, tile=tile if (ok is None or st.rt.get(ok)) else 2)      # conv1_1-like layers: no 16-channel chunks
+            n += 1
         with torch.no_grad():
             got = [t.double().cpu() for t in net.forward_raw(x.cuda())]
         report(name, n, got)
