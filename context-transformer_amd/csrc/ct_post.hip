@@ -27,7 +27,9 @@ namespace {
 
 typedef unsigned long long u64;
 constexpr int kSortThreads = 512;
-constexpr int kLdsKeys = 4096;       // 32 KiB of keys per workgroup
+// keys a workgroup sorts in LDS (template parameter LK of select_sort_kernel): 4096 = 32 KB; 8192 = 64 KB for RFBNet-512's 32 756
+// priors, whose per-class candidate counts (~8 000 with random weights) otherwise take the bitonic network's long strides
+// through L2 (470 us of the 512 x 512 bs-32 step)
 
 __device__ __forceinline__ void cmpswap(u64& a, u64& b, bool asc)
 {
@@ -40,7 +42,7 @@ __device__ __forceinline__ void cmpswap(u64& a, u64& b, bool asc)
 
 // all sub-stages j = jstart .. 1 of bitonic stage k on one LDS chunk whose first key has
 // global index gbase
-__device__ void lds_substages(u64* sk, int nloc, int k, int jstart, int gbase)
+__device__ __forceinline__ void lds_substages(u64* sk, int nloc, int k, int jstart, int gbase)
 {
     for (int j = jstart; j > 0; j >>= 1) {
         for (int t = threadIdx.x; t < nloc / 2; t += kSortThreads) {
@@ -55,13 +57,15 @@ __device__ void lds_substages(u64* sk, int nloc, int k, int jstart, int gbase)
     }
 }
 
+template <int kLdsKeys>
 __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
     const float* __restrict__ boxes, const float* __restrict__ scores, int batch, int P, int T, float thresh,
     int npow2_cap, u64* __restrict__ keys_ws, float* __restrict__ dets_sorted,
     int* __restrict__ sorted_idx, int* __restrict__ seg_count)
 {
-    __shared__ u64 sk[kLdsKeys];
-    __shared__ int s_cnt;
+    extern __shared__ __attribute__((aligned(16))) u64 sk_dyn[];      // kLdsKeys keys + the candidate counter
+    u64* const sk = sk_dyn;
+    int& s_cnt = *reinterpret_cast<int*>(sk_dyn + kLdsKeys);
     // blockIdx -> (image, class) so that all classes of an image run on ONE XCD (block q is dispatched to XCD q % 8):
     // a class column of scores[b][P][T+1] is a strided read that touches every cache line of the image's score
     // array, so the T workgroups of an image share those lines through one L2 instead of fetching the array once
@@ -413,8 +417,23 @@ extern "C" int ct_postprocess_batched(const float* boxes, const float* scores, i
     const int np2 = std::max(next_pow2(num_priors), 2);
     hipStream_t st = ctdet::as_stream(stream);
     CT_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
-    { CT_PROF("select_sort_kernel", st); hipLaunchKernelGGL(select_sort_kernel, dim3(8 * ((batch + 7) / 8) * num_fg), dim3(kSortThreads), 0, st, boxes, scores, batch, num_priors,
-                       num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count); }
+    {
+        static hipError_t attr_err = [] {
+            hipError_t e = hipFuncSetAttribute((const void*)select_sort_kernel<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 8 + 16);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)select_sort_kernel<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 16);
+            return e;
+        }();
+        CT_HIP(attr_err);
+        CT_PROF("select_sort_kernel", st);
+        const dim3 grid(8 * ((batch + 7) / 8) * num_fg);
+        if (num_priors > 16384)
+            hipLaunchKernelGGL(select_sort_kernel<8192>, grid, dim3(kSortThreads), 8192 * 8 + 16, st, boxes, scores, batch, num_priors,
+                               num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count);
+        else
+            hipLaunchKernelGGL(select_sort_kernel<4096>, grid, dim3(kSortThreads), 4096 * 8 + 16, st, boxes, scores, batch, num_priors,
+                               num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count);
+    }
     CT_LAUNCH_CHECK("select_sort_kernel");
     int rc;
     constexpr int kPrefix = 256;          // candidates per class in the bounding pass

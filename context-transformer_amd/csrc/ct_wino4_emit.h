@@ -19,8 +19,13 @@ __device__ __forceinline__ void emit_tile4(const Args& a, const __amdgpu_buffer_
     const int OH = a.H, OW = a.W;                      // pad 1, stride 1: same spatial size
     const int oy = 4 * ty, ox = 4 * tx;
     const bool c1 = ox + 1 < OW, c2 = ox + 2 < OW, c3 = ox + 3 < OW;
-    const float sc = a.scale[co], sh = a.shift[co];
-    const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
+    float sc = a.scale[co], sh = a.shift[co];
+    float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
+    // The three per-channel values are needed by every row below, and every row sits behind its own `yy >= OH` test: left
+    // alone, the compiler waits for these loads at the first use in EACH row block with s_waitcnt vmcnt(0) -- which from the
+    // second row on also waits for the previous rows' STORES to drain (loads and stores share the counter).  Making the
+    // values opaque here forces the one wait to this point, in front of all stores of the tile.
+    asm volatile("" : "+v"(sc), "+v"(sh), "+v"(lo));
     float pl[2][2] = {{-INFINITY, -INFINITY}, {-INFINITY, -INFINITY}};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -84,6 +84,27 @@ struct Wino4fArgs {
     ct_out_segment seg[3];
 };
 
+// The epilogue's view of the arguments (ct_wino4_emit.h is a template over any record with these members).  The persistent
+// kernel re-reads them from the kernel-argument segment per item as plain words, which makes every pointer a GENERIC one
+// -- flat loads and stores, and a flat store counts on vmcnt AND lgkmcnt, so the compiler drains all stores in front of
+// the next LDS access (four vmcnt(0) per output quarter).  Global-address-space pointer types put them back on the global path.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) float gf32;
+#else
+typedef float gf32;
+#endif
+struct EpiArgs {
+    const gf32* scale;
+    const gf32* shift;
+    const gf32* res;
+    const gf32* lo;
+    gf32* pool_out;
+    int H, W, out_ctot, out_coff, res_ctot, res_coff;
+    float res_scale;
+    int relu, pool_ctot, pool_coff, pool_oh, pool_ow, write_full, nseg;
+    ct_out_segment seg[3];
+};
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -230,29 +251,35 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
     if (vb >= nitems) return;
     setup_patch(vb);
     dma_patch(0);
+    i32x4 ua0[3], ua1[3], ua2[3];
+    bool u_ahead = false;                     // ua0 / ua1 already hold (are receiving) units 0, 1 of this item's first chunk
     while (vb < nitems) {
         W4F_STAMP(0);
         const int kb = item_kb(vb);
         const int tb0 = item_tblk(vb) * TB;
         const int vb_next = next_valid(vb + gridDim.x);
         const int u_kb = kb * a.chunks;
-        auto load_u = [&](int c, int unit, i32x4 (&dst)[3]) {
-            const int soff = (u_kb + c) * U_CHUNK_BYTES + unit * UNIT_BYTES;
+        auto load_u_of = [&](int ukb, int c, int unit, i32x4 (&dst)[3]) {
+            const int soff = (ukb + c) * U_CHUNK_BYTES + unit * UNIT_BYTES;
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) dst[pc] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, soff + pc * 1024, 0);
         };
+        auto load_u = [&](int c, int unit, i32x4 (&dst)[3]) { load_u_of(u_kb, c, unit, dst); };
         f32x16 acc[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-        i32x4 ua0[3], ua1[3], ua2[3];
         for (int c = 0; c < a.chunks; ++c) {
             // ================= phase T: patch(c), staged by DMA during the previous phase M (chunk 0: during the previous
-            // item's output passes), -> V
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            load_u(c, 0, ua0);                       // the first two units of phase M: a whole phase T of latency
-            load_u(c, 1, ua1);
+            // item's output passes), -> V.  Chunk 0 of a follow-up item waits for nothing here: its rows were waited for before the
+            // previous item's output passes and its first U units are under way since then (below) -- a vmcnt(0) at this
+            // point would wait for the previous item's output STORES to drain (loads and stores share the counter).
+            if (c > 0 || !u_ahead) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                load_u(c, 0, ua0);                   // the first two units of phase M: a whole phase T of latency
+                load_u(c, 1, ua1);
+            }
             {
                 float t[6][6];
                 float dd[6][6];
@@ -343,6 +370,7 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
             asm volatile("" ::: "memory");
         }
         W4F_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next item's first rows (issued a phase M ago) are in the stage
 
         // ---- output transform: four passes of 16 couts through the V region  M[point][cout 16][tile 32] (72 KB; the stage
         // region is receiving the next item's first rows).  Quarter q = cout half q >> 1, accumulator registers 8 (q & 1) ..
@@ -366,8 +394,18 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
 #else
         e = a_in;
 #endif
-        if (!SEG) e.nseg = 0;
-        if (PLAIN) { e.res = nullptr; e.lo = nullptr; }
+        EpiArgs ep;
+        ep.scale = (const gf32*)e.scale; ep.shift = (const gf32*)e.shift;
+        ep.res = PLAIN ? nullptr : (const gf32*)e.res;
+        ep.lo = PLAIN ? nullptr : (const gf32*)e.lo;
+        ep.pool_out = (gf32*)e.pool_out;
+        ep.H = e.H; ep.W = e.W; ep.out_ctot = e.out_ctot; ep.out_coff = e.out_coff;
+        ep.res_ctot = e.res_ctot; ep.res_coff = e.res_coff; ep.res_scale = e.res_scale;
+        ep.relu = e.relu; ep.pool_ctot = e.pool_ctot; ep.pool_coff = e.pool_coff; ep.pool_oh = e.pool_oh; ep.pool_ow = e.pool_ow;
+        ep.write_full = e.write_full;
+        ep.nseg = SEG ? e.nseg : 0;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) ep.seg[g] = e.seg[g];
         const __amdgpu_buffer_rsrc_t rout = make_rsrc(e.out, e.out_bytes);
         const __amdgpu_buffer_rsrc_t rres = make_rsrc(e.res, e.res ? e.res_bytes : 0u);
         const int o_kk = tid >> 5, o_tl = tid & 31;
@@ -390,6 +428,16 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (!SEG && q == 3) {          // (the head-scatter instantiation has no registers to spare for it)
+                // every accumulator is in LDS: the first U units of the next item leave BEFORE this quarter's stores, so that
+                // waiting for them later does not wait for those stores
+                u_ahead = vb_next < nitems;
+                if (u_ahead) {
+                    const int ukb_next = item_kb(vb_next) * a.chunks;
+                    load_u_of(ukb_next, 0, 0, ua0);
+                    load_u_of(ukb_next, 0, 1, ua1);
+                }
+            }
             {
                 const int co = kb * KB + 16 * q + o_kk;
                 if (o_T < a.NT && co < a.M) {
@@ -408,7 +456,7 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
                     float y[4][4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) at4(z[i], y[i]);
-                    ctdet::w4::emit_tile4(e, rout, rres, n, ty, tx, co, y);
+                    ctdet::w4::emit_tile4(ep, rout, rres, n, ty, tx, co, y);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
