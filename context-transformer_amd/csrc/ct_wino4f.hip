@@ -172,23 +172,31 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
     int voffq[6];
     bool mc[6], lp;
     int d4;                                   // byte distance from the 16-byte piece to column 4
-    auto setup_patch = [&](int vb) {
+    int x0s;                                  // first patch column of this lane's tile (-1 for the left-edge tiles)
+    // the addresses (integer divisions: computed where few registers are live) ...
+    auto setup_addr = [&](int vb) {
         const int T = item_tblk(vb) * TB + l31;
         const bool live = T < a.NT;
         const int n = T / (a.TY * a.TX);
         const int rem = T - n * (a.TY * a.TX);
         const int ty = rem / a.TX, tx = rem - ty * a.TX;
-        const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) mc[c] = (unsigned)(x0 + c) < (unsigned)a.W;
-        lp = tx == 0;
-        d4 = lp ? 12 : 16;
-        const long base = (((long)n * a.in_ctot + a.in_coff + h) * a.H + y0) * (long)a.W + x0 + (lp ? 1 : 0);
+        const int y0 = 4 * ty - 1;
+        x0s = 4 * tx - 1;
+        const bool left = tx == 0;
+        d4 = left ? 12 : 16;
+        const long base = (((long)n * a.in_ctot + a.in_coff + h) * a.H + y0) * (long)a.W + x0s + (left ? 1 : 0);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
             voffq[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
         }
+    };
+    // ... and the column masks of the tile whose rows are being unpacked (they replace the previous item's only after its last
+    // unpack)
+    auto setup_masks = [&]() {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) mc[c] = (unsigned)(x0s + c) < (unsigned)a.W;
+        lp = x0s < 0;
     };
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
     const __amdgpu_buffer_rsrc_t rU = make_rsrc(a.U, a.u_bytes);
@@ -249,7 +257,8 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
 
     int vb = next_valid(blockIdx.x);
     if (vb >= nitems) return;
-    setup_patch(vb);
+    setup_addr(vb);
+    setup_masks();
     dma_patch(0);
     i32x4 ua0[3], ua1[3], ua2[3];
     bool u_ahead = false;                     // ua0 / ua1 already hold (are receiving) units 0, 1 of this item's first chunk
@@ -280,6 +289,14 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
                 load_u(c, 0, ua0);                   // the first two units of phase M: a whole phase T of latency
                 load_u(c, 1, ua1);
             }
+            const bool prefetch_next = c == last && vb_next < nitems;
+            if (prefetch_next) {              // this item's addresses are dead: its last rows are in the stage
+                // opaque copy: left to itself the compiler computes the next item's addresses at the TOP of this item (they only
+                // depend on vb_next) and carries eight more registers through the whole channel loop
+                int vbn = vb_next;
+                asm volatile("" : "+s"(vbn));
+                setup_addr(vbn);
+            }
             {
                 float t[6][6];
                 float dd[6][6];
@@ -303,8 +320,8 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (c < last) {
                     dma_patch(c + 1);
-                } else if (vb_next < nitems) {
-                    setup_patch(vb_next);
+                } else if (prefetch_next) {
+                    setup_masks();
                     dma_patch(0);
                 }
 #pragma unroll
@@ -329,7 +346,9 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
             asm volatile("" ::: "memory");
             if (c == 0) W4F_STAMP(1);
             // ================= phase M: nine units (point, cout half); U two units ahead, the next point's fragments split
-            // behind the current point's MFMAs
+            // behind the current point's MFMAs.  (The scheduler sinks some of the U loads to 3-5 MFMAs in front of their use to
+            // shorten their live ranges; pinning them where they are written -- sched_barrier after every load -- needs 72 bytes of
+            // scratch per lane at 256 registers and is slower.)
             {
                 float raw[8];
                 i32x4 fbA[3], fbB[3];

@@ -825,8 +825,8 @@ def ctx_tile_set(net):
     bf16x3 with TWO accumulators (tile code 23: exact +-1 transforms, the large channel sum sees cin / 16 roundings;
     per-layer error vs fp64 4e-7 against 5e-6 for F(4x4,3x3) / fp32), except the layers with short channel sums
     (ctx_f4_max_cin).  With every layer on tile 23 the device is CLOSER to fp64 than the CPU path in 8-9 of the 9 sweep
-    cases (3.0..6.1e-5 vs 4.9..7.2e-5), which is as far as fp32 activation storage goes; with the shipped cap (fused F(4x4)
-    up to 256 input channels, ctx_f4_max_cin) all 9 cases are within 1e-4 of the CPU path at 8 and at 128 reference threads
+    cases (3.0..6.1e-5 vs 4.9..7.2e-5), which is as far as fp32 activation storage goes; with the shipped cap (fused F(4x4) / fp32
+    up to 128 input channels, ctx_f4_max_cin) all 9 cases are within 1e-4 of the CPU path at 8 and at 128 reference threads
     (profiles/r05_ctx_policy.txt).  Layers without 16-channel chunks keep F(2x2,3x3) on the fp32 MFMA (tile 2).
     CTDET_CTX_TILES = comma list of allowed tile codes, or 'any' for the unconstrained table."""
     ctx = getattr(net, 'method', None) == 'ours' and getattr(net, 'phase', 1) == 2
@@ -836,20 +836,23 @@ def ctx_tile_set(net):
     return tuple(int(t) for t in v.split(',') if t)
 
 
-CTX_F4_MAX_CIN_DEFAULT = '256'
+CTX_F4_MAX_CIN_DEFAULT = '128'
 
 
 def ctx_f4_max_cin(net):
     """Layers of a Context-Transformer network with at most this many input channels keep a fused F(4x4,3x3) kernel where the
     table picks one (ctx_f4_tile): its rounding error grows with the length of the channel sum, and on conv1_2 .. conv3_1
-    (64 / 128 input channels at 300 x 300 .. 75 x 75) F(2x2,3x3) costs the most time.  Chosen by the round-5 sweep
+    (64 / 128 input channels at 300 x 300 .. 75 x 75) F(2x2,3x3) costs the most time.  Chosen by the round-5 sweeps
     (profiles/r05_ctx_policy.txt: RFBNet-300 + Context-Transformer bs 32, 9 randn cases, every case judged against the fp32 CPU
-    path at 8 AND at 128 reference threads; pairs = ctx_w4s_min_cin / this cap):
-      0 / 0    2 353 images/s   worst GPU-CPU32 9.7e-5 at 8 threads, 1.02e-4 at 128 (one case above 1e-4)
-      0 / 64   2 440            8.5e-5 / 9.6e-5      all 18 inside 1e-4
-      0 / 256  2 471            9.0e-5 / 9.2e-5      all 18 inside 1e-4   <- default
-      128 / 128 (round 4)  2 898   1.03e-4 / 1.05e-4   3 of 18 above 1e-4: the opt-in fast policy
-    CTDET_CTX_F4_MAX_CIN; 0 = none."""
+    path at 8 AND at 128 reference threads; three-kernel form off; (ctx_f4_tile, this cap) on the committed table):
+      (4, 128)   2 570 images/s   worst GPU-CPU32 9.0e-5 at 8 threads, 9.2e-5 at 128   all 18 inside 1e-4   <- default
+      (4, 256)   2 619            1.02e-4 / 1.07e-4    3 of 18 above 1e-4 (conv3_2 / conv3_3: 256-channel sums on the fp32 MFMA)
+      (46, 128)  2 670            1.01e-4 / 9.5e-5     1 of 18 above
+      (46, 256)  2 769            1.01e-4 / 9.7e-5     1 of 18 above
+      cap 0 (every Winograd layer on F(2x2,3x3) / bf16x3): 2 353, 9.7e-5 / 1.02e-4, 1 of 18 above
+      round 4's policy (three-kernel F(4x4) from 128 channels up): 2 898, 1.03e-4 / 1.05e-4, 3 of 18 above
+    All of them are within 7.7e-5 of the fp64 evaluation; which side of 1e-4 the worst of 7e5 elements lands on against a
+    reference that is itself 4.8..7.2e-5 from fp64 is decided by single layers' summation orders.  CTDET_CTX_F4_MAX_CIN; 0 = none."""
     return int(os.environ.get('CTDET_CTX_F4_MAX_CIN', CTX_F4_MAX_CIN_DEFAULT)) if ctx_tile_set(net) is not None else 0
 
 

@@ -11,7 +11,7 @@ What is asserted (tools/ctx_parity.py --budget, profiles/r04_ctx_parity.txt):
 Inputs are 'randn' (SURVEY 8d (i)).  On image-like 'u8' inputs (8d (ii), |x| ~ 128) the logits are ~1e4 and the
 block is chaotic in fp32: torch-CPU fp32 itself is 1e-3 .. 1e-1 away from fp64 there, so no fp32 implementation has a
 parity to meet; that case only checks the block's input.  The shipped Winograd tile policy (engine.ctx_tile_set: F(2x2,3x3) on
-bf16x3 with two accumulators; a fused F(4x4,3x3) kernel up to 256 input channels) runs here."""
+bf16x3 with two accumulators; the fused F(4x4,3x3) / fp32 kernel up to 128 input channels) runs here."""
 import pytest
 import torch
 

@@ -97,7 +97,7 @@ def test_rfb300_phase2_context_transformer(golden, setting, C):
 def test_winograd_tile_policy_and_phase2_full_tensor_parity(monkeypatch):
     """Networks with the Context-Transformer block (whose softmax amplifies the trunk's fp32 rounding ~1000x) run their
     Winograd layers on F(2x2,3x3) / bf16x3 with two accumulators (tile code 23; F(2x2,3x3) on the fp32 MFMA where the layer has no
-    16-channel chunks); a fused F(4x4,3x3) kernel survives only up to 256 input channels, where the table picks one
+    16-channel chunks); a fused F(4x4,3x3) kernel survives only up to 128 input channels, where the table picks one
     (engine.ctx_tile_set, ctx_f4_max_cin, ctx_f4_tile); the three-kernel form (tile 44) is opt-in (ctx_w4s_min_cin).  Every other
     network takes the committed table as it is.  CTDET_CTX_TILES overrides the set ('any' = the table).  Every output ELEMENT
     (not a sample) of the block stays within 1e-4 of the reference's CPU arithmetic here (bs 2, seed 1234;
@@ -107,8 +107,8 @@ def test_winograd_tile_policy_and_phase2_full_tensor_parity(monkeypatch):
     for r in (rt, net.runtime(32)):
         tiles = [st.rt.get('wino') for st in r.conv_steps() if st.rt.get('wino')]
         assert tiles and set(tiles) <= {2, 4, 23, 46}, tiles
-        assert all(st.rt.get('wino') == 23 for st in r.conv_steps() if st.rt.get('wino') and st.cin % 16 == 0 and st.cin > 256)
-        assert all(st.cin <= 256 for st in r.conv_steps() if st.rt.get('wino') in (4, 46))
+        assert all(st.rt.get('wino') == 23 for st in r.conv_steps() if st.rt.get('wino') and st.cin % 16 == 0 and st.cin > 128)
+        assert all(st.cin <= 128 for st in r.conv_steps() if st.rt.get('wino') in (4, 46))
     assert any(st.rt.get('wino') == 23 and st.cin == 512 for st in net.runtime(32).conv_steps())
     # the opt-in fast policy of round 4: three-kernel F(4x4) from 128 input channels up
     monkeypatch.setenv('CTDET_CTX_W4S_MIN_CIN', '128')
@@ -118,74 +118,6 @@ def test_winograd_tile_policy_and_phase2_full_tensor_parity(monkeypatch):
     monkeypatch.delenv('CTDET_CTX_W4S_MIN_CIN')
     monkeypatch.delenv('CTDET_CTX_F4_MAX_CIN')
     del fast
-    x = synth.images(2, 300, 'randn', 1234)
-    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
-    with torch.no_grad():
-        want_raw = rfbnet_ref.forward(sd, x, 300, 20, raw=True)
-        got_raw = [t.cpu() for t in net.forward_raw(x.cuda())]
-        errs = [rel_err(a, b) for a, b in zip(got_raw, want_raw)]
-        assert max(errs) < TOL, (errs, _layer_report(net, x, 300))
-        loc, conf, obj = [t.cpu() for t in net(x)]
-    for t, name in ((loc, 'p1_loc'), (conf, 'p1_conf'), (obj, 'p1_obj')):
-        a, b, _, _ = sampled(t, g, name)
-        assert rel_err(a, b) < TOL, name
-    with torch.no_grad():
-        init_conf = net(x, init=True).cpu()
-    a, b, _, _ = sampled(init_conf, g, 'p1_init_conf')
-    assert rel_err(a, b) < TOL
-    # Detect on the device outputs (reference call sequence test.py:130-131)
-    from layers.functions import Detect, PriorBox
-    from data import VOC_300
-    priors = PriorBox(VOC_300).forward().cuda()
-    boxes, scores = Detect(21, 0, VOC_300).forward(net(x), priors)
-    for t, name in ((boxes.cpu(), 'p1_boxes'), (scores.cpu(), 'p1_scores')):
-        a, b, _, _ = sampled(t, g, name)
-        assert rel_err(a, b) < TOL, name
-    # image-like input
-    xu = synth.images(1, 300, 'u8', 1234)
-    with torch.no_grad():
-        want_raw = rfbnet_ref.forward(sd, xu, 300, 20, raw=True)
-        got_raw = [t.cpu() for t in net.forward_raw(xu.cuda())]
-        assert max(rel_err(a, b) for a, b in zip(got_raw, want_raw)) < TOL      # activations: 1e-4
-        loc, conf, obj = [t.cpu() for t in net(xu)]
-    # 0..255 pixel inputs give |logit| ~ 1e2; softmax turns a 1e-5 relative logit error into
-    # up to ~|logit|*1e-5 in the probabilities, so the post-softmax goldens get 2e-3
-    for t, name in ((loc, 'p1u8_loc'), (conf, 'p1u8_conf'), (obj, 'p1u8_obj')):
-        a, b, _, _ = sampled(t, g, name)
-        assert rel_err(a, b) < (TOL if name.endswith('loc') else 2e-3), name
-
-
-@pytest.mark.parametrize('setting,C', [('transfer', 60), ('incre', 15)])
-def test_rfb300_phase2_context_transformer(golden, setting, C):
-    g = golden('rfb300_phase2_%s.npz' % setting)
-    net = _net(300, C, 2, setting)
-    x = synth.images(2, 300, 'randn', 1234)
-    with torch.no_grad():
-        loc, conf, obj = [t.cpu() for t in net(x)]
-        init_conf = net(x, init=True).cpu()
-    for t, name in ((loc, 'loc'), (conf, 'conf'), (obj, 'obj'), (init_conf, 'init_conf')):
-        a, b, _, _ = sampled(t, g, name)
-        assert rel_err(a, b) < TOL, (name, rel_err(a, b))
-    assert conf.shape[-1] == (20 if setting == 'transfer' else 20)
-
-
-def test_winograd_tile_policy_and_phase2_full_tensor_parity(monkeypatch):
-    """Networks with the Context-Transformer block (whose softmax amplifies the trunk's fp32 rounding ~1000x) run every
-    Winograd layer with at least 128 input channels on one of the two accurate bf16x3 variants: where the table picks
-    F(4x4,3x3), its three-kernel form with two accumulators (tile code 44: error vs fp64 2e-6 against 5e-6 for the fused
-    fp32 kernel), else F(2x2,3x3) on bf16x3 with two accumulators (23; F(2x2,3x3) on the fp32 MFMA where the layer has no
-    16-channel chunks); the fused F(4x4,3x3) / fp32 kernel survives only on the short channel sums (engine.ctx_tile_set,
-    ctx_f4_max_cin, ctx_w4s_min_cin); every other network takes the committed table as it is.  CTDET_CTX_TILES overrides the
-    set ('any' = the table).  Every output ELEMENT (not a sample) of the block stays within 1e-4 of the reference's CPU
-    arithmetic here (bs 2, seed 1234; tests/test_gpu_ctx_parity.py sweeps batch sizes and seeds)."""
-    net = _net(300, 60, 2, 'transfer')
-    rt = net.runtime(2)
-    for r in (rt, net.runtime(32)):
-        tiles = [st.rt.get('wino') for st in r.conv_steps() if st.rt.get('wino')]
-        assert tiles and set(tiles) <= {2, 4, 23, 44}, tiles
-        assert all(st.rt.get('wino') in (23, 44) for st in r.conv_steps() if st.rt.get('wino') and st.cin % 16 == 0 and st.cin >= 128)
-        assert all(st.cin < 128 for st in r.conv_steps() if st.rt.get('wino') == 4)
-    assert any(st.rt.get('wino') == 44 and st.cin == 512 for st in net.runtime(32).conv_steps())
     x = synth.images(2, 300, 'randn', 1234)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     with torch.no_grad():

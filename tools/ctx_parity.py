@@ -25,7 +25,7 @@ ap.add_argument('--also-threads', default='', help='comma list: evaluate the fp3
 ap.add_argument('--force-tile', default='', help='CTDET_WINO_FORCE: 23 = F(2x2,3x3) on bf16x3 with two accumulators on every Winograd layer')
 a = ap.parse_args()
 names = {'2+23': 'the shipped tile set: F(2x2,3x3) / bf16x3 with two accumulators; fused F(4x4,3x3) (CTDET_CTX_F4_TILE, default 4) up to '
-                 'CTDET_CTX_F4_MAX_CIN (256) input channels; three-kernel F(4x4,3x3) from CTDET_CTX_W4S_MIN_CIN (0 = never) input channels up',
+                 'CTDET_CTX_F4_MAX_CIN (128) input channels; three-kernel F(4x4,3x3) from CTDET_CTX_W4S_MIN_CIN (0 = never) input channels up',
          '2': 'F(2x2,3x3) / fp32 MFMA only',
          '2+4': 'fp32-MFMA Winograd kernels as the table picks them', 'any': 'the unconstrained table'}
 if a.force_tile:
