@@ -87,7 +87,7 @@ struct AttnArgs {
     float* out;
     float* save_d;      // training: aggregated context rows D = softmax(S) g, [B][P_pad][64]
     float* save_lse;    // training: log2-domain log-sum-exp of each affinity row, [B][P_pad]
-    int P, P_pad, M, M_pad, d, T, ostride, ooff, batch;
+    int P, P_pad, M, M_pad, d, T, ostride, ooff;
     float scale;
 };
 
@@ -97,17 +97,13 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
     __shared__ float objw[32 * DP];
     __shared__ float wzs[DP];
 
-    // blockIdx -> (image, query block) so that all query blocks of an image run on ONE XCD (block i is dispatched to XCD i % 8):
-    // every one of them streams the image's whole K / V (M x 64 x 12 bytes = 1.4 MB at 300, 3.8 MB at 512), and with the images'
-    // blocks spread over all eight XCDs each L2 held the stripes of six images at a time and missed on most of them (round 4 PMC:
-    // 740 MB fetched per launch against 133 MB algorithmic)
-    const int nqb = a.P_pad / QB;
-    const int b = ((int)(blockIdx.x >> 3) / nqb) * 8 + (int)(blockIdx.x & 7);
-    if (b >= a.batch) return;
-    const int qblk = (int)(blockIdx.x >> 3) % nqb;
+    // (Round 5 measured the XCD-aware numbering -- all query blocks of an image on one XCD, so that its K / V stripe stays in that
+    // L2 -- and dropped it: 1.28 ms against 1.06 at P = 11 620 / M = 1 858 / bs 32.  The kernel is bound by its vector + matrix
+    // issue time, not by the stripe re-reads, and eight images in flight instead of 32 lose the tail balance.)
+    const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = qblk * QB + wave * QW + l31;       // < P_pad by construction
+    const int q = blockIdx.x * QB + wave * QW + l31;       // < P_pad by construction
 
     for (int e = tid; e < 32 * DP; e += 256) {
         const int t = e / DP, dd = e % DP;
@@ -377,8 +373,7 @@ int forward_impl(const float* conf, const float* pool, int batch, int num_priors
     a.P = num_priors; a.P_pad = w.P_pad; a.M = num_ctx; a.M_pad = w.M_pad;
     a.d = d; a.T = prm->t; a.ostride = ostride; a.ooff = prm->fc_w ? d : 0;
     a.scale = prm->scale;
-    a.batch = batch;
-    { CT_PROF("ctx_attn_kernel", st); hipLaunchKernelGGL(ctx_attn_kernel, dim3((w.P_pad / QB) * 8 * ((batch + 7) / 8)), blk, 0, st, a); }
+    { CT_PROF("ctx_attn_kernel", st); hipLaunchKernelGGL(ctx_attn_kernel, dim3(w.P_pad / QB, batch), blk, 0, st, a); }
     CT_LAUNCH_CHECK("ctx_attn_kernel");
     return CT_OK;
 }

@@ -921,6 +921,12 @@ def apply_tuned(backend, st, batch, wino4=True):
                 want = f4                   # a fused F(4x4) entry below ctx_f4_max_cin input channels (wino_tiles put f4 into the set)
             else:
                 want = 23 if 23 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
+        elif want in WINO4F_TILES and st.cin > (getattr(backend, 'w4f_max_cin', None) or 1 << 30):
+            # the training runtime of a Context-Transformer network (TrainRuntime sets w4f_max_cin = 128): the fused bf16x3
+            # kernel has ONE accumulator, 3.4e-6 of the output range at 256 input channels and 4.6e-6 at 512 against 1.3-2.0e-6
+            # for the three-kernel form, and the block's backward amplifies that (conf.3's gradient 2.5e-4 from fp64 instead of
+            # <= 1.4e-4 at RFBNet-512 bs 8) -- its wide layers stay on the three-kernel form
+            want = 44 if st.rt.get('wino4s_ok') and 44 in allowed else 4 if 4 in allowed else 2
         elif want not in allowed:
             # a three-kernel / fused-bf16x3 F(4x4) entry without its tile in the set (CTDET_WINO_TILES=2,4) is the fused fp32 F(4x4) kernel's layer
             want = 4 if want in WINO4S_TILES + WINO4F_TILES and 4 in allowed else 2 if 2 in allowed or not allowed else allowed[0]

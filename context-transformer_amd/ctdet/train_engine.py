@@ -62,6 +62,8 @@ class TrainRuntime:
         wg4s_ws = 0             # bytes: workspace of the three-kernel Winograd weight gradients
         # CTDET_TRAIN_WINO4=0 keeps forward and data-gradient convolutions on F(2x2,3x3) where the table says F(4x4,3x3)
         wino4 = os.environ.get('CTDET_TRAIN_WINO4', '1') != '0'
+        if self.plan.ctx:
+            backend.w4f_max_cin = int(os.environ.get('CTDET_TRAIN_CTX_W4F_MAX_CIN', '128'))      # engine.apply_tuned
         for st in self.plan.steps:
             if st.kind != 'conv':
                 continue
@@ -252,6 +254,12 @@ class TrainRuntime:
                 o += (n + 63) // 64 * 64
         self.backend = backend
         Runtime._build_schedule(self)           # forward: Norm branch / heads on a side stream (CTDET_STREAMS)
+        # the forward launches of the three-kernel Winograd form share ONE V / M workspace per stream of that schedule
+        # (HipBackend.ws_pool); the launch object of a BatchNorm layer is its zstep, not the plan step
+        for i, st in enumerate(self.plan.steps):
+            if st.kind == 'conv':
+                self.state[st.name].fwd.rt['ws_key'] = self.sid[i] if self.side is not None else 0
+        backend.ws_rebuild([self.state[st.name].fwd for st in self.plan.steps if st.kind == 'conv'])
         # weight gradients on their own stream (CTDET_TRAIN_STREAMS=1 keeps everything on the caller's stream)
         self.wg_stream = torch.cuda.Stream(backend.device) if int(os.environ.get('CTDET_TRAIN_STREAMS', '2')) > 1 \
             else None
