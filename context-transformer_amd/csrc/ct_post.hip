@@ -27,6 +27,7 @@ namespace {
 
 typedef unsigned long long u64;
 constexpr int kSortThreads = 512;
+constexpr int kSelectBatch = 8;      // strided score loads in flight per thread in the select loop
 // keys a workgroup sorts in LDS (template parameter LK of select_sort_kernel): 4096 = 32 KB; 8192 = 64 KB for RFBNet-512's 32 756
 // priors, whose per-class candidate counts (~8 000 with random weights) otherwise take the bitonic network's long strides
 // through L2 (470 us of the 512 x 512 bs-32 step)
@@ -81,21 +82,27 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
 
     // ---- select (wave-aggregated append; order is irrelevant, the keys are unique) ----
     const float* sc = scores + (size_t)b * P * (T + 1) + cls;
-    for (int p0 = 0; p0 < P; p0 += kSortThreads) {
-        const int p = p0 + tid;
-        float v = 0.f;
-        bool pass = false;
-        if (p < P) {
-            v = sc[(size_t)p * (T + 1)];
-            pass = v > thresh;
+    // kSelectBatch independent loads per thread in flight before the first ballot: one load per trip made every trip wait a
+    // full memory round trip behind the LDS counter (128 trips at P = 32 756: most of the kernel's 491 us there, round 5)
+    for (int p0 = 0; p0 < P; p0 += kSortThreads * kSelectBatch) {
+        float v[kSelectBatch];
+#pragma unroll
+        for (int u = 0; u < kSelectBatch; ++u) {
+            const int p = p0 + u * kSortThreads + tid;
+            v[u] = p < P ? sc[(size_t)p * (T + 1)] : -INFINITY;
         }
-        const u64 m = __ballot(pass);
-        int basepos = 0;
-        if (lane == 0 && m) basepos = atomicAdd(&s_cnt, __popcll(m));
-        basepos = __shfl(basepos, 0);
-        if (pass) {
-            const int pos = basepos + __popcll(m & ((1ull << lane) - 1ull));
-            keys[pos] = ((u64)(~__float_as_uint(v)) << 32) | (unsigned)p;
+#pragma unroll
+        for (int u = 0; u < kSelectBatch; ++u) {
+            const int p = p0 + u * kSortThreads + tid;
+            const bool pass = v[u] > thresh;                   // padding lanes: -inf never passes (thresh may be negative)
+            const u64 m = __ballot(pass);
+            int basepos = 0;
+            if (lane == 0 && m) basepos = atomicAdd(&s_cnt, __popcll(m));
+            basepos = __shfl(basepos, 0);
+            if (pass) {
+                const int pos = basepos + __popcll(m & ((1ull << lane) - 1ull));
+                keys[pos] = ((u64)(~__float_as_uint(v[u])) << 32) | (unsigned)p;
+            }
         }
     }
     __syncthreads();

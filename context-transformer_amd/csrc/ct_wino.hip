@@ -431,7 +431,7 @@ int ctdet::pack_wino_any(const float* const* w, const int* cout, int nparts, int
         ctdet::pack_record(1, &p, sizeof(p));
         return CT_OK;
     }
-    const long total = tile == 44 ? (long)p.kblocks * ctdet::kWino4sBM * p.cin : tile == 46 ? (long)p.kblocks * KB * p.cin :
+    const long total = tile == 44 ? (long)p.kblocks * ctdet::kWino4sBM * (p.cin / 8) * 6 : tile == 46 ? (long)p.kblocks * KB * (p.cin / 8) * 6 :
                        (long)p.kblocks * p.chunks * (tile == 4 ? 512 : tile == 23 ? 2048 : ctdet::kWino2ChunkFloats);      // threads
     hipLaunchKernelGGL(wino_pack_kernel, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0,
                        ctdet::as_stream(stream), p);

@@ -177,123 +177,95 @@ __device__ __forceinline__ void winox3_pack_body(const WinoPackArgs& p, long fir
     }
 }
 
-// ct_wino4s.hip: U[point 36][cout block of 128][chunk 16 ch][sub 4][piece 3][k half 2][row 32][8 bf16] -- per transform
-// point a [cout] x [cin] GEMM operand whose (128 couts x 16 channels) blocks are 12 KB of ready-made
-// v_mfma_f32_32x32x16_bf16 fragments, copied to LDS by DMA without touching a register.  One thread = one (cout, cin)
-// filter: G g G^T in double (as wino4_pack_body), rounded to fp32 once, then the exact three-piece split.
-__device__ __forceinline__ void wino4s_pack_body(const WinoPackArgs& p, long first, long stride)
+// The two F(4x4,3x3) / bf16x3 layouts (ct_wino4s.hip: tile 44, ct_wino4f.hip: tile 46).  One thread = one (cout, 8 consecutive
+// input channels, transform row i): G g G^T in double (as wino4_pack_body), rounded to fp32 once, the exact three-piece
+// split, and per (point (i, j), piece) ONE 16-byte store -- the 8 channels are exactly the 8 bf16 a lane of
+// v_mfma_f32_32x32x16_bf16 holds, and threads with consecutive couts write consecutive 16-byte rows of a fragment.  (Until
+// round 5 a thread owned one filter and scattered 108 two-byte stores: 1.4 ms per training step, where every weight is
+// re-packed.)
+//   tile 44: U[point 36][cout block of 128][chunk 16 ch][sub 4][piece 3][k half 2][row 32][8 bf16] -- per transform point a
+//            [cout] x [cin] GEMM operand whose (128 couts x 16 channels) blocks are 12 KB of ready-made fragments (LDS-DMA)
+//   tile 46: U[cout block of 64][chunk 16 ch][wave 8][unit 9][piece 3][lane 64][8 bf16] -- wave w multiplies the points
+//            4w .. 4w+3 for both cout halves (units 2 (xi & 3) + half) and point 32 + (w >> 1) for the cout half w & 1 (unit 8)
+__device__ __forceinline__ double wino_pick6(const double (&o)[6], int i)
 {
-    const long total = (long)p.kblocks * kWino4sBM * p.cin;
-    const size_t plane = (size_t)p.kblocks * p.chunks * kWino4sChunkBytes / 2;       // bf16 elements per point
-    unsigned short* const out = reinterpret_cast<unsigned short*>(p.U);
-    for (long idx = first; idx < total; idx += stride) {
-        const int ci = (int)(idx % p.cin);
-        const int co = (int)(idx / p.cin);
-        float g[3][3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) g[i][j] = 0.f;
-        if (co < p.cout) {
-            const float* w = wino_taps(p, co, ci);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) g[i][j] = p.dgrad ? w[(2 - i) * 3 + (2 - j)] : w[i * 3 + j];
-        }
-        double t[6][3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double o[6];
-            w4::gmul6(g[0][j], g[1][j], g[2][j], o);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) t[i][j] = o[i];
-        }
-        const int cb = co / kWino4sBM, sub = (co % kWino4sBM) / 32, chunk = ci / 16, kh = (ci % 16) / 8;
-        unsigned short* base = out + ((((size_t)cb * p.chunks + chunk) * 4 + sub) * 3) * (kWino4sFragBytes / 2) +
-                               (kh * 32 + co % 32) * 8 + ci % 8;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            double o[6];
-            w4::gmul6(t[i][0], t[i][1], t[i][2], o);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const float val = (float)o[j];
-                const unsigned hb = __builtin_bit_cast(unsigned, val) & 0xFFFF0000u;
-                const float r1 = val - __builtin_bit_cast(float, hb);
-                const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-                const unsigned lb = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, mb));
-                unsigned short* q = base + (size_t)(i * 6 + j) * plane;
-                q[0] = (unsigned short)(hb >> 16);
-                q[kWino4sFragBytes / 2] = (unsigned short)(mb >> 16);
-                q[2 * (kWino4sFragBytes / 2)] = (unsigned short)(lb >> 16);
-            }
-        }
-    }
+    return i == 0 ? o[0] : i == 1 ? o[1] : i == 2 ? o[2] : i == 3 ? o[3] : i == 4 ? o[4] : o[5];
 }
 
-// ct_wino4f.hip: U[cout block of 64][chunk 16 ch][wave 8][unit 9][piece 3][lane 64][8 bf16].  Wave w multiplies the
-// transform points 4w .. 4w+3 for both cout halves (units 2 (xi & 3) + half) and point 32 + (w >> 1) for the cout half w & 1
-// (unit 8); lane (l31, hh) of a unit holds cout = 64 kb + 32 half + l31, channels 16 chunk + 8 hh .. + 7 of one bf16 piece:
-// the A operand of v_mfma_f32_32x32x16_bf16.  One thread = one (cout, cin) filter: G g G^T in double, rounded once, then
-// the exact three-piece split (as wino4s_pack_body).
-__device__ __forceinline__ void wino4f_pack_body(const WinoPackArgs& p, long first, long stride)
+template <int TILE>
+__device__ __forceinline__ void wino4x3_pack_body(const WinoPackArgs& p, long first, long stride)
 {
-    const long total = (long)p.kblocks * kWinoKB * p.cin;
-    unsigned short* const out = reinterpret_cast<unsigned short*>(p.U);
+    constexpr int BMROWS = TILE == 44 ? kWino4sBM : kWinoKB;
+    const int rows = p.kblocks * BMROWS;                 // couts incl. the zero rows of the last block
+    const int groups = p.cin / 8;
+    const long total = (long)rows * groups * 6;
+    unsigned char* const out = reinterpret_cast<unsigned char*>(p.U);
+    const size_t plane44 = (size_t)p.kblocks * p.chunks * kWino4sChunkBytes;       // bytes per point (tile 44)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     for (long idx = first; idx < total; idx += stride) {
-        const int ci = (int)(idx % p.cin);
-        const int co = (int)(idx / p.cin);
-        float g[3][3];
+        const int co = (int)(idx % rows);
+        const long rest = idx / rows;
+        const int ci8 = (int)(rest % groups);
+        const int i = (int)(rest / groups);
+        u32x4 v[6][3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 6; ++j)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) g[i][j] = 0.f;
+            for (int pc = 0; pc < 3; ++pc) v[j][pc] = u32x4{0u, 0u, 0u, 0u};
         if (co < p.cout) {
-            const float* w = wino_taps(p, co, ci);
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int e = 0; e < 8; ++e) {
+                const float* w = wino_taps(p, co, ci8 * 8 + e);
+                double t[3];                                      // row i of G g
 #pragma unroll
-                for (int j = 0; j < 3; ++j) g[i][j] = p.dgrad ? w[(2 - i) * 3 + (2 - j)] : w[i * 3 + j];
+                for (int c = 0; c < 3; ++c) {
+                    double o[6];
+                    if (p.dgrad) w4::gmul6(w[(2 - 0) * 3 + (2 - c)], w[(2 - 1) * 3 + (2 - c)], w[(2 - 2) * 3 + (2 - c)], o);
+                    else w4::gmul6(w[0 * 3 + c], w[1 * 3 + c], w[2 * 3 + c], o);
+                    t[c] = wino_pick6(o, i);
+                }
+                double o[6];                                      // (G g) G^T, row i
+                w4::gmul6(t[0], t[1], t[2], o);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float val = (float)o[j];
+                    const unsigned hb = __builtin_bit_cast(unsigned, val) & 0xFFFF0000u;
+                    const float r1 = val - __builtin_bit_cast(float, hb);
+                    const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
+                    const unsigned lb = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, mb)) & 0xFFFF0000u;
+                    const int sh = 16 * (1 - (e & 1));            // even channel: low half-word
+                    v[j][0][e >> 1] |= hb >> sh;
+                    v[j][1][e >> 1] |= mb >> sh;
+                    v[j][2][e >> 1] |= lb >> sh;
+                }
+            }
         }
-        double t[6][3];
+        const int chunk = ci8 >> 1, kh = ci8 & 1;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double o[6];
-            w4::gmul6(g[0][j], g[1][j], g[2][j], o);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) t[i][j] = o[i];
-        }
-        const int kb = co / kWinoKB, half = (co % kWinoKB) / 32, chunk = ci / 16;
-        const int ln = (co % 32) + 32 * ((ci % 16) / 8);
-        unsigned short* base = out + ((size_t)kb * p.chunks + chunk) * (kWino4fChunkBytes / 2) + ln * 8 + ci % 8;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            double o[6];
-            w4::gmul6(t[i][0], t[i][1], t[i][2], o);
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                const int xi = i * 6 + j;
+        for (int j = 0; j < 6; ++j) {
+            const int xi = i * 6 + j;
+            unsigned char* q;
+            if (TILE == 44) {
+                const int cb = co / kWino4sBM, sub = (co % kWino4sBM) / 32;
+                q = out + (size_t)xi * plane44 + ((((size_t)cb * p.chunks + chunk) * 4 + sub) * 3) * kWino4sFragBytes +
+                    (kh * 32 + co % 32) * 16;
+            } else {
+                const int kb = co / kWinoKB, half = (co % kWinoKB) / 32;
                 const int wv = xi < 32 ? xi >> 2 : 2 * (xi - 32) + half;
                 const int unit = xi < 32 ? 2 * (xi & 3) + half : 8;
-                const float val = (float)o[j];
-                const unsigned hb = __builtin_bit_cast(unsigned, val) & 0xFFFF0000u;
-                const float r1 = val - __builtin_bit_cast(float, hb);
-                const unsigned mb = __builtin_bit_cast(unsigned, r1) & 0xFFFF0000u;
-                const unsigned lb = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, mb));
-                unsigned short* q = base + (size_t)wv * (kWino4fWaveBytes / 2) + unit * (kWino4fUnitBytes / 2);
-                q[0] = (unsigned short)(hb >> 16);
-                q[512] = (unsigned short)(mb >> 16);
-                q[1024] = (unsigned short)(lb >> 16);
+                q = out + ((size_t)kb * p.chunks + chunk) * kWino4fChunkBytes + (size_t)wv * kWino4fWaveBytes +
+                    unit * kWino4fUnitBytes + (co % 32 + 32 * kh) * 16;
             }
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<u32x4*>(q + pc * 1024) = v[j][pc];
         }
     }
 }
 
 __device__ __forceinline__ void wino_pack_any(const WinoPackArgs& p, long first, long stride)
 {
-    if (p.tile == 46) wino4f_pack_body(p, first, stride);
-    else if (p.tile == 44) wino4s_pack_body(p, first, stride);
+    if (p.tile == 46) wino4x3_pack_body<46>(p, first, stride);
+    else if (p.tile == 44) wino4x3_pack_body<44>(p, first, stride);
     else if (p.tile == 23) winox3_pack_body(p, first, stride);
     else if (p.tile == 4) wino4_pack_body(p, first, stride);
     else wino2_pack_body(p, first, stride);

@@ -24,7 +24,7 @@ import os
 import torch
 
 from . import _lib, ops
-from .engine import F4_TILES, WINO4S_TILES, ConvPart, ConvStep, HipBackend, Plan, Runtime, apply_tuned, run_on_streams
+from .engine import F4_TILES, WINO4F_TILES, WINO4S_TILES, ConvPart, ConvStep, HipBackend, Plan, Runtime, apply_tuned, run_on_streams
 
 
 class _StepState:
@@ -150,6 +150,14 @@ class TrainRuntime:
                             s.dgrad_tile = 44
                             s.U_d = al((self.lib.ct_conv_wino4s_packed_bytes(zc, st.cin) // 4,))
                             w4s_ws = max(w4s_ws, self.lib.ct_conv_wino4s_workspace_bytes(C.byref(w2)))
+                        elif s.fwd.rt.get('wino') in WINO4F_TILES and os.environ.get('CTDET_TRAIN_W4F', '1') != '0' and \
+                                zc <= (getattr(backend, 'w4f_max_cin', None) or 1 << 30) and \
+                                self.lib.ct_conv_wino4f_supported(C.byref(w2)):
+                            # ... and the fused bf16x3 F(4x4,3x3) kernel (tile 46) where the forward launch runs it: the narrow
+                            # layers on the big maps, whose data gradients were 7 launches x 1.13 ms of the 37.8 ms step on the
+                            # fp32 kernel (profiles/r05_train_kernel_stats.md)
+                            s.dgrad_tile = 46
+                            s.U_d = al((self.lib.ct_conv_wino4f_packed_bytes(zc, st.cin) // 4,))
                         else:
                             sizeof = self.lib.ct_conv_wino4_packed_floats if s.dgrad_tile == 4 else self.lib.ct_conv_wino_packed_floats
                             s.U_d = al((sizeof(zc, st.cin),))
@@ -336,8 +344,8 @@ class TrainRuntime:
         ptrs = (C.c_void_p * n)(*[w for w, _ in wts])
         couts = (C.c_int * n)(*[c for _, c in wts])
         if s.dgrad_wino is not None:
-            pack = {4: self.lib.ct_conv_pack_weights_wino4_dgrad, 44: self.lib.ct_conv_pack_weights_wino4s_dgrad}.get(
-                s.dgrad_tile, self.lib.ct_conv_pack_weights_wino_dgrad)
+            pack = {4: self.lib.ct_conv_pack_weights_wino4_dgrad, 44: self.lib.ct_conv_pack_weights_wino4s_dgrad,
+                    46: self.lib.ct_conv_pack_weights_wino4f_dgrad}.get(s.dgrad_tile, self.lib.ct_conv_pack_weights_wino_dgrad)
             _lib.check(pack(ptrs, couts, n, st.cin, s.U_d.data_ptr(), self._s()), st.name + ' pack dgrad (winograd)')
         elif s.dgrad_x3 is not None:
             if getattr(self, '_recording', False):
@@ -663,6 +671,9 @@ class TrainRuntime:
                     elif s.dgrad_tile == 44:
                         _lib.check(lib.ct_conv2d_wino4s_fwd(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self.dgrad_ws4s.data_ptr(),
                                                             self.dgrad_ws4s.numel(), 1, self._s()), st.name + ' dgrad (winograd 4s)')
+                    elif s.dgrad_tile == 46:
+                        _lib.check(lib.ct_conv2d_wino4f_fwd(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self._s()),
+                                   st.name + ' dgrad (winograd 4f)')
                     else:
                         run = lib.ct_conv2d_wino4_fwd if s.dgrad_tile == 4 else lib.ct_conv2d_wino_fwd
                         _lib.check(run(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self._s()), st.name + ' dgrad (winograd)')

@@ -217,7 +217,7 @@ def test_phase2_training_step_vs_oracle_autograd(size, setting):
     assert not bad, sorted(bad.items())[:12]
 
 
-def _ctx_step_on_device_pattern(size, setting, C, B, batch_stats, seed):
+def _ctx_step_on_device_pattern(size, setting, C, B, batch_stats, seed, cpu32=False):
     """Every parameter gradient of one RFBNet + Context-Transformer training step against float64 autograd on the linear
     piece the DEVICE evaluated: the plan replayed by tests/emu_backend.py with the device's ReLU pattern and pool arg-max,
     and the Context-Transformer block (the oracle's context_block) differentiated AT the device's raw conf logits --
@@ -225,6 +225,8 @@ def _ctx_step_on_device_pattern(size, setting, C, B, batch_stats, seed):
     device's backward has to reproduce while the gradient still flows into the float64 trunk.  (The block amplifies a
     1e-6 difference of its input ~1000x, tests/ctx_cases.py; differentiating it at the float64 trunk's own logits would
     measure that amplification again, not the backward kernels.)
+    cpu32=True: the same replay once more in float32 on the CPU (torch autograd, the arithmetic the reference trains in,
+    same activation pattern and logits): fwd['grad cpu32'] = {name: ITS normalised error against the float64 gradient}.
     -> (net, {name: normalised error}, {name: reference gradient}, forward errors)"""
     from emu_backend import replay_plan_autograd
     net = _net(size, C, setting).train()
@@ -251,14 +253,16 @@ def _ctx_step_on_device_pattern(size, setting, C, B, batch_stats, seed):
            'raw conf': rel_err(raw_dev, raw64.detach().float()),
            'obj': rel_err(out[2].detach().cpu().reshape(B, -1), obj64.detach().float())}
     at = raw64 + (raw_dev.double() - raw64).detach()            # the device's point, the float64 graph
-    pooled = []
-    for st in sorted((s for s in trt.plan.steps if s.kind == 'ctxpool'), key=lambda s: s.dst_base):
-        n = st.h * st.w * st.ch
-        cut = lambda t: t[:, st.src_base:st.src_base + n].reshape(B, st.h, st.w, st.ch).permute(0, 3, 1, 2)
-        _, idx = F.max_pool2d(cut(raw_dev), st.k, st.k, ceil_mode=True, return_indices=True)
-        y = cut(at).flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
-        pooled.append(y.permute(0, 2, 3, 1).reshape(B, -1))
-    pooled = torch.cat(pooled, 1)
+    def pool_at(at):            # the pooled logits through the device's arg-max
+        pooled = []
+        for st in sorted((s for s in trt.plan.steps if s.kind == 'ctxpool'), key=lambda s: s.dst_base):
+            n = st.h * st.w * st.ch
+            cut = lambda t: t[:, st.src_base:st.src_base + n].reshape(B, st.h, st.w, st.ch).permute(0, 3, 1, 2)
+            _, idx = F.max_pool2d(cut(raw_dev), st.k, st.k, ceil_mode=True, return_indices=True)
+            y = cut(at).flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+            pooled.append(y.permute(0, 2, 3, 1).reshape(B, -1))
+        return torch.cat(pooled, 1)
+    pooled = pool_at(at)
     assert torch.equal(pooled.detach().float(), trt.bufs['pool'].view(B, -1).cpu())
     blk_sd = {n: leaf[id(p)] for n, p in named.items() if n.split('.')[0] in
               ('theta', 'phi', 'g', 'Wz', 'OBJ_Target', 'fc_base', 'scale')}
@@ -277,6 +281,15 @@ def _ctx_step_on_device_pattern(size, setting, C, B, batch_stats, seed):
         assert p.grad is not None, n
         refs[n] = leaf[id(p)].grad
         errs[n] = rel_err(p.grad.cpu().double(), refs[n])
+    if cpu32:
+        leaf32 = {id(p): sd[n].float().requires_grad_(n != 'scale') for n, p in named.items()}
+        loc32, raw32, obj32 = replay_plan_autograd(trt.plan, leaf32, x, masks, dtype=torch.float32,
+                                                   pool_inputs=lambda st: trt.bufs[st.src].cpu(), batch_stats=batch_stats)
+        at32 = raw32 + (raw_dev - raw32).detach()
+        blk32_sd = {n: leaf32[id(p)] for n, p in named.items() if n in blk_sd}
+        conf32 = rfbnet_ref.context_block(blk32_sd, at32.view(B, -1, C), pool_at(at32).view(B, -1, C), setting)
+        sum((t.reshape(B, -1) * r.reshape(B, -1)).sum() for t, r in zip((loc32, conf32, obj32), R)).backward()
+        fwd['grad cpu32'] = {n: rel_err(leaf32[id(p)].grad.double(), refs[n]) for n, p in named.items() if n in refs}
     return net, errs, refs, fwd
 
 
@@ -290,7 +303,8 @@ def test_phase2_frozen_bn_gradients_match_fp64_on_the_device_activation_pattern(
     in front of them is itself held to 1e-4 (test_ctx_block_backward_vs_float64_autograd).  See
     _ctx_step_on_device_pattern for what is compared."""
     tol = 1e-4 if size == 300 else 2e-4
-    net, errs, refs, fwd = _ctx_step_on_device_pattern(size, 'transfer', 60, B, False, 777)
+    net, errs, refs, fwd = _ctx_step_on_device_pattern(size, 'transfer', 60, B, False, 777, cpu32=size == 512)
+    cpu32 = fwd.pop('grad cpu32', {})
     for n in ('loc', 'raw conf', 'obj'):
         assert fwd[n] < 1e-4, (n, fwd)
     # the block on the device's own input: 1e-4, or what torch-CPU fp32 achieves on that input where the un-scaled logits
@@ -302,7 +316,10 @@ def test_phase2_frozen_bn_gradients_match_fp64_on_the_device_activation_pattern(
         if float(refs[n].abs().max()) < 1e-9 * gmax:        # phi.bias: softmax is shift-invariant, true gradient 0
             assert float(dict(net.named_parameters())[n].grad.abs().max()) < 1e-4 * gmax, n
             continue
-        if e >= tol:
+        # 512: 2e-4, or twice what torch-CPU float32 autograd makes of the same step where that is worse (the un-scaled logits,
+        # ~400 at 512, in front of a softmax: conf.3 / extras.3 gradients of the float32 CPU path are themselves 1-3e-4 off
+        # float64, seed-dependent: tools/ctx_grad_probe.py) -- the forward rule above, applied to the gradients
+        if e >= max(tol, 2.0 * cpu32.get(n, 0.0)):
             worst[n] = e
     assert not worst, ' '.join('%s:%.1e' % kv for kv in sorted(worst.items(), key=lambda kv: -kv[1])[:12])
 

@@ -10,14 +10,15 @@ from ctdet import ops, synth
 from ctdet.pipeline import DetectionPipeline
 from models.RFB_Net_vgg import build_net
 from layers.functions import PriorBox
-from data import VOC_300
+import data as cfgs
 
 B = int(os.environ.get('B', 32))
-net = build_net(types.SimpleNamespace(method='ours', phase=1, setting='transfer'), 300, 20)
+SIZE = int(os.environ.get('SIZE', 300))          # SIZE=512: RFBNet-512's 32 756 priors
+net = build_net(types.SimpleNamespace(method='ours', phase=1, setting='transfer'), SIZE, 20)
 net.load_state_dict(synth.fill_state_dict(net.state_dict()))
 net = net.eval().cuda(); net.device = 'cuda'
-pipe = DetectionPipeline(net, PriorBox(VOC_300).forward(), B, 20)
-x = synth.images(B, 300, 'randn', 1234).cuda()
+pipe = DetectionPipeline(net, PriorBox(getattr(cfgs, 'VOC_%d' % SIZE)).forward(), B, 20)
+x = synth.images(B, SIZE, 'randn', 1234).cuda()
 pipe.run(x)
 torch.cuda.synchronize()
 cnt = pipe.post.ws  # noqa
@@ -33,6 +34,26 @@ def t(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 print('postprocess (select+sort+nms+topk+gather): %.3f ms' % t(lambda: pipe.post.run(pipe.boxes, pipe.scores)))
+def stage_times(n=5):
+    import ctypes as C
+    from ctdet import _lib
+    lib = _lib.lib()
+    torch.cuda.synchronize()
+    _lib.check(lib.ct_profile_enable(1), 'ct_profile_enable')
+    for _ in range(n):
+        pipe.post.run(pipe.boxes, pipe.scores)
+    torch.cuda.synchronize()
+    cnt = C.c_int(0)
+    _lib.check(lib.ct_profile_collect(None, 0, C.byref(cnt)), 'ct_profile_collect')
+    recs = (_lib.ProfileRecord * max(cnt.value, 1))()
+    _lib.check(lib.ct_profile_collect(recs, cnt.value, C.byref(cnt)), 'ct_profile_collect')
+    _lib.check(lib.ct_profile_enable(0), 'ct_profile_enable')
+    agg = {}
+    for i in range(cnt.value):
+        a = agg.setdefault(recs[i].name.decode(), [0.0, 0])
+        a[0] += recs[i].ms; a[1] += 1
+    return {k: (v[0] / v[1] * 1e3, v[1] / n) for k, v in agg.items()}
+print('  stages (us per launch x launches per run): ' + '  '.join('%s %.1f x%g' % (k, us, c) for k, (us, c) in sorted(stage_times().items())))
 print('postprocess without top-k rule:            %.3f ms' % t(lambda: pipe.post.run(pipe.boxes, pipe.scores, max_per_image=0)))
 pipe.post.run(pipe.boxes, pipe.scores, max_per_image=0)
 print('kept per (img,cls) before top-k: mean %.0f max %d' % (pipe.post.out_count.float().mean().item(), int(pipe.post.out_count.max().item())))

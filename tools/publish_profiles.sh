@@ -12,7 +12,9 @@ for f in bench_full.json.log rfb300_bench.json.log rfb512_bench.json.log rfb300c
   [ -s $S/$f ] && grep -v "amdgpu.ids" $S/$f > $D/${R}_$f
 done
 [ -s $S/ctx_parity.txt ] && grep -v "amdgpu.ids" $S/ctx_parity.txt > $D/${R}_ctx_parity.txt
-python tools/prof_summary.py $S/train_stats > $D/${R}_train_kernel_stats.md 2>/dev/null || true
+# the training step's kernel table (rocprofv3 --stats of tools/train_bench.py --batch 32 --steps 10)
+python tools/prof_summary.py --stats "$(ls $S/train_stats/*kernel_stats.csv | head -1)" --tag "${R}_train" --workload 300,32,1,20 \
+    --cmd "python tools/train_bench.py --batch 32 --steps 10" --out $D > /dev/null
 # a published summary that is empty or a Python traceback is not evidence: refuse it
 bad=0
 for f in $D/${R}_*; do
