@@ -6,7 +6,9 @@
 //                       (= descending score, lower index first on ties -- the build's defined
 //                       tie order) with a bitonic network that runs in LDS for strides < 4096
 //                       and through L2 for the few larger strides, then writes the sorted
-//                       [x1,y1,x2,y2,score] rows.
+//                       [x1,y1,x2,y2,score] rows.  With the top-k rule on it sorts only the best >= 1024
+//                       candidates of a class (partial sort, see the kernel); prefix_cut_kernel flags the
+//                       segments whose cut lies further down and a second launch sorts those in full.
 //   nms_segments_kernel (ct_nms.hip) on the fixed-stride segments.
 //   topk_kernel         one workgroup per image: if more than max_per_image boxes survive,
 //                       8-bit radix select of the k-th largest score; because every segment is
@@ -58,15 +60,74 @@ __device__ __forceinline__ void lds_substages(u64* sk, int nloc, int k, int jsta
     }
 }
 
-template <int kLdsKeys>
+// Partial sort (the top-k rule's bounding pass only ever looks at a prefix): with max_per_image > 0 a workgroup sorts only
+// its best m >= min(n, kPartialMin) candidates -- every candidate at or above a cut score taken from an LDS histogram of the
+// score bits (11 bits: exponent + 3 mantissa bits; 11 more inside the crossing bin if that bin alone overflows the LDS sort
+// buffer).  seg_sorted[seg] = m rows are written, seg_count[seg] = n stays the true candidate count, the unsorted keys
+// stay in keys_ws.  prefix_cut_kernel flags a segment whose cut falls behind its sorted prefix (redo[seg] = 1); the SAME
+// kernel launched again with `redo` sorts exactly those in full.  Bit-exact either way: which rows exist never changes
+// their order or values.  (Round 5: the full 4096 / 8192 / 16384-key bitonic networks were 122 us of the 300 and 470 us
+// of the 512 pipeline with random weights; VERDICT r04 task 7.)
+constexpr int kPartialMin = 1024;
+constexpr int kHistBins = 2048;
+
+// inclusive scan over the workgroup (kSortThreads threads); s_w: 8 ints of scratch
+__device__ __forceinline__ int block_incl_scan(int v, int* s_w)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off);
+        if (lane >= off) x += y;
+    }
+    if (lane == 63) s_w[wave] = x;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += s_w[w];
+    __syncthreads();
+    return x + base;
+}
+
+// bins in DESCENDING order (d = 0 is the highest bin): the first d whose cumulative count reaches `need`.
+// -> s_out[0] = bin, s_out[1] = cumulative count through that bin, s_out[2] = count above it.  Every bin count summed must
+// be >= need.
+__device__ __forceinline__ void hist_crossing(const int* s_hist, int need, int* s_w, int* s_out)
+{
+    constexpr int PER = kHistBins / kSortThreads;
+    int c[PER], sum = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        c[u] = s_hist[kHistBins - 1 - (PER * (int)threadIdx.x + u)];
+        sum += c[u];
+    }
+    const int incl = block_incl_scan(sum, s_w);
+    int run = incl - sum;
+    if (run < need && incl >= need) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (run < need && run + c[u] >= need) {
+                s_out[0] = kHistBins - 1 - (PER * (int)threadIdx.x + u);
+                s_out[1] = run + c[u];
+                s_out[2] = run;
+            }
+            run += c[u];
+        }
+    }
+    __syncthreads();
+}
+
+template <int kLdsKeys, bool PARTIAL>
 __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
     const float* __restrict__ boxes, const float* __restrict__ scores, int batch, int P, int T, float thresh,
     int npow2_cap, u64* __restrict__ keys_ws, float* __restrict__ dets_sorted,
-    int* __restrict__ sorted_idx, int* __restrict__ seg_count)
+    int* __restrict__ sorted_idx, int* __restrict__ seg_count, int* __restrict__ seg_sorted, const int* __restrict__ redo)
 {
-    extern __shared__ __attribute__((aligned(16))) u64 sk_dyn[];      // kLdsKeys keys + the candidate counter
+    extern __shared__ __attribute__((aligned(16))) u64 sk_dyn[];      // kLdsKeys keys, [histogram,] scalars
     u64* const sk = sk_dyn;
-    int& s_cnt = *reinterpret_cast<int*>(sk_dyn + kLdsKeys);
+    int* const s_hist = reinterpret_cast<int*>(sk_dyn + kLdsKeys);
+    int* const s_sc = s_hist + (PARTIAL ? kHistBins : 0);             // [0] counter [1..3] crossing [4] counter 2; [8..15] scan
+    int& s_cnt = s_sc[0];
     // blockIdx -> (image, class) so that all classes of an image run on ONE XCD (block q is dispatched to XCD q % 8):
     // a class column of scores[b][P][T+1] is a strided read that touches every cache line of the image's score
     // array, so the T workgroups of an image share those lines through one L2 instead of fetching the array once
@@ -75,15 +136,17 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
     const int cls = 1 + (int)(blockIdx.x >> 3) % T;
     if (b >= batch) return;
     const int seg = b * T + (cls - 1);
+    if (redo && !redo[seg]) return;
     const int tid = threadIdx.x, lane = tid & 63;
     u64* keys = keys_ws + (size_t)seg * npow2_cap;
-    if (tid == 0) s_cnt = 0;
+    if (tid == 0) { s_cnt = 0; s_sc[4] = 0; }
+    if (PARTIAL)
+        for (int i = tid; i < kHistBins; i += kSortThreads) s_hist[i] = 0;
     __syncthreads();
 
     // ---- select (wave-aggregated append; order is irrelevant, the keys are unique) ----
     const float* sc = scores + (size_t)b * P * (T + 1) + cls;
-    // kSelectBatch independent loads per thread in flight before the first ballot: one load per trip made every trip wait a
-    // full memory round trip behind the LDS counter (128 trips at P = 32 756: most of the kernel's 491 us there, round 5)
+    // kSelectBatch independent loads per thread in flight before the first ballot
     for (int p0 = 0; p0 < P; p0 += kSortThreads * kSelectBatch) {
         float v[kSelectBatch];
 #pragma unroll
@@ -94,7 +157,7 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
 #pragma unroll
         for (int u = 0; u < kSelectBatch; ++u) {
             const int p = p0 + u * kSortThreads + tid;
-            const bool pass = v[u] > thresh;                   // padding lanes: -inf never passes (thresh may be negative)
+            const bool pass = v[u] > thresh;                   // padding lanes: -inf never passes
             const u64 m = __ballot(pass);
             int basepos = 0;
             if (lane == 0 && m) basepos = atomicAdd(&s_cnt, __popcll(m));
@@ -102,13 +165,90 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
             if (pass) {
                 const int pos = basepos + __popcll(m & ((1ull << lane) - 1ull));
                 keys[pos] = ((u64)(~__float_as_uint(v[u])) << 32) | (unsigned)p;
+                if (PARTIAL) atomicAdd(&s_hist[__float_as_uint(v[u]) >> 20], 1);
             }
         }
     }
     __syncthreads();
     const int n = s_cnt;
     if (tid == 0) seg_count[seg] = n;
-    if (n == 0) return;
+    if (n == 0) {
+        if (tid == 0) seg_sorted[seg] = 0;
+        return;
+    }
+
+    const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)b * P;
+    float* out = dets_sorted + (size_t)seg * P * 5;
+    int* oi = sorted_idx + (size_t)seg * P;
+    auto write_row = [&](int i, u64 key) {
+        const int p = (int)(key & 0xFFFFFFFFull);
+        const float v = __uint_as_float(~(unsigned)(key >> 32));
+        const float4 q = bx[p];
+        float* r = out + (size_t)i * 5;
+        r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w; r[4] = v;
+        oi[i] = p;
+    };
+
+    if (PARTIAL) {
+        // ---- the cut: every candidate whose score bits are >= cutbits is sorted ----
+        unsigned cutbits = 0;                       // n <= kPartialMin: everything
+        int m = n;
+        bool partial_ok = n <= kLdsKeys;
+        if (n > kPartialMin) {
+            __threadfence_block();
+            hist_crossing(s_hist, kPartialMin, s_sc + 8, s_sc + 1);
+            const int bin = s_sc[1], above = s_sc[3];
+            m = s_sc[2];
+            cutbits = (unsigned)bin << 20;
+            partial_ok = true;
+            __syncthreads();
+            if (m > kLdsKeys) {
+                // the crossing bin alone is too large: 11 more bits inside it
+                for (int i = tid; i < kHistBins; i += kSortThreads) s_hist[i] = 0;
+                __syncthreads();
+                for (int i = tid; i < n; i += kSortThreads) {
+                    const unsigned sb = ~(unsigned)(keys[i] >> 32);
+                    if ((int)(sb >> 20) == bin) atomicAdd(&s_hist[(sb >> 9) & (kHistBins - 1)], 1);
+                }
+                __syncthreads();
+                hist_crossing(s_hist, kPartialMin - above, s_sc + 8, s_sc + 1);
+                cutbits = ((unsigned)bin << 20) | ((unsigned)s_sc[1] << 9);
+                m = above + s_sc[2];
+                partial_ok = m <= kLdsKeys;
+                __syncthreads();
+            }
+        }
+        if (partial_ok) {
+            if (m < n) {
+                for (int i0 = 0; i0 < n; i0 += kSortThreads) {
+                    const int i = i0 + tid;
+                    u64 key = 0;
+                    bool pass = false;
+                    if (i < n) {
+                        key = keys[i];
+                        pass = ~(unsigned)(key >> 32) >= cutbits;
+                    }
+                    const u64 bm = __ballot(pass);
+                    int basepos = 0;
+                    if (lane == 0 && bm) basepos = atomicAdd(&s_sc[4], __popcll(bm));
+                    basepos = __shfl(basepos, 0);
+                    if (pass) sk[basepos + __popcll(bm & ((1ull << lane) - 1ull))] = key;
+                }
+            } else {
+                for (int i = tid; i < n; i += kSortThreads) sk[i] = keys[i];
+            }
+            int N = 1;
+            while (N < m) N <<= 1;
+            for (int i = m + tid; i < N; i += kSortThreads) sk[i] = ~0ull;
+            __syncthreads();
+            for (int k = 2; k <= N; k <<= 1) lds_substages(sk, N, k, k >> 1, 0);
+            for (int i = tid; i < m; i += kSortThreads) write_row(i, sk[i]);
+            if (tid == 0) seg_sorted[seg] = m;
+            return;
+        }
+        // (too many equal score bits around the cut: the full sort below)
+    }
+
     int N = 1;
     while (N < n) N <<= 1;
     for (int i = n + tid; i < N; i += kSortThreads) keys[i] = ~0ull;
@@ -151,18 +291,8 @@ __global__ __launch_bounds__(kSortThreads) void select_sort_kernel(
     __syncthreads();
 
     // ---- sorted rows ----
-    const float4* bx = reinterpret_cast<const float4*>(boxes) + (size_t)b * P;
-    float* out = dets_sorted + (size_t)seg * P * 5;
-    int* oi = sorted_idx + (size_t)seg * P;
-    for (int i = tid; i < n; i += kSortThreads) {
-        const u64 key = keys[i];
-        const int p = (int)(key & 0xFFFFFFFFull);
-        const float v = __uint_as_float(~(unsigned)(key >> 32));
-        const float4 q = bx[p];
-        float* r = out + (size_t)i * 5;
-        r[0] = q.x; r[1] = q.y; r[2] = q.z; r[3] = q.w; r[4] = v;
-        oi[i] = p;
-    }
+    for (int i = tid; i < n; i += kSortThreads) write_row(i, keys[i]);
+    if (tid == 0) seg_sorted[seg] = n;
 }
 
 // k-th largest kept score of image b (as uint bits; all scores are positive floats), or 0 when
@@ -275,21 +405,11 @@ __device__ unsigned kth_largest_kept(const float* __restrict__ dets_sorted, cons
 // k-th largest kept score t_est of the image is a LOWER bound of the final threshold: no candidate
 // below t_est can appear in the output, and the kept set above it is determined by the candidates
 // above it alone.  This kernel shortens every segment to its candidates with score >= t_est.
-__global__ __launch_bounds__(256) void prefix_cut_kernel(const float* __restrict__ dets_sorted,
-                                                         const int* __restrict__ keep,
-                                                         const int* __restrict__ keep_count,
-                                                         const int* __restrict__ seg_count, int P, int T,
-                                                         int max_per_image, int* __restrict__ seg_len_out)
+// first candidate of a descending segment with score bits < thr: 256-ary search by the whole block (256 threads), two or
+// three dependent loads instead of the 14 of a per-thread bisection over 11 620 candidates
+__device__ __forceinline__ int cut_search(const float* __restrict__ d, int hi, unsigned thr)
 {
-    __shared__ int hist[256];
-    __shared__ int s_scalars[4];
-    const int b = blockIdx.x, c = blockIdx.y;
-    const unsigned thr = kth_largest_kept(dets_sorted, keep, keep_count, P, T, b, max_per_image, hist, s_scalars);
-    // first candidate of class c with score < thr (descending order): 256-ary search by the whole block, two or
-    // three dependent loads instead of the 14 of a per-thread bisection over 11 620 candidates
-    const int seg = b * T + c;
-    const float* d = dets_sorted + (size_t)seg * P * 5;
-    int lo = 0, hi = seg_count[seg];
+    int lo = 0;
     while (hi - lo > 256) {
         const int step = (hi - lo + 255) / 256;
         const int p = lo + (int)threadIdx.x * step;
@@ -301,7 +421,42 @@ __global__ __launch_bounds__(256) void prefix_cut_kernel(const float* __restrict
     }
     const int p = lo + (int)threadIdx.x;
     const int cnt = __syncthreads_count(p < hi && __float_as_uint(d[(size_t)p * 5 + 4]) >= thr);
-    if (threadIdx.x == 0) seg_len_out[seg] = lo + cnt;
+    return lo + cnt;
+}
+
+// seg_sorted: rows select_sort_kernel wrote (a partial sort's prefix); a segment whose every sorted row passes while
+// unsorted candidates remain is flagged in redo[] (its cut lies further down): it is sorted in full and cut again
+// (recut_kernel) with the image's threshold kept in thr_img[].
+__global__ __launch_bounds__(256) void prefix_cut_kernel(const float* __restrict__ dets_sorted,
+                                                         const int* __restrict__ keep,
+                                                         const int* __restrict__ keep_count,
+                                                         const int* __restrict__ seg_count,
+                                                         const int* __restrict__ seg_sorted, int P, int T,
+                                                         int max_per_image, int* __restrict__ seg_len_out,
+                                                         int* __restrict__ redo, unsigned* __restrict__ thr_img)
+{
+    __shared__ int hist[256];
+    __shared__ int s_scalars[4];
+    const int b = blockIdx.x, c = blockIdx.y;
+    const unsigned thr = kth_largest_kept(dets_sorted, keep, keep_count, P, T, b, max_per_image, hist, s_scalars);
+    const int seg = b * T + c;
+    const int m = seg_sorted[seg];
+    const int len = cut_search(dets_sorted + (size_t)seg * P * 5, m, thr);
+    if (threadIdx.x == 0) {
+        seg_len_out[seg] = len;
+        redo[seg] = (len == m && m < seg_count[seg]) ? 1 : 0;
+        if (c == 0) thr_img[b] = thr;
+    }
+}
+
+__global__ __launch_bounds__(256) void recut_kernel(const float* __restrict__ dets_sorted, const int* __restrict__ seg_sorted,
+                                                    const int* __restrict__ redo, const unsigned* __restrict__ thr_img,
+                                                    int P, int T, int* __restrict__ seg_len_out)
+{
+    const int seg = blockIdx.x;
+    if (!redo[seg]) return;
+    const int len = cut_search(dets_sorted + (size_t)seg * P * 5, seg_sorted[seg], thr_img[seg / T]);
+    if (threadIdx.x == 0) seg_len_out[seg] = len;
 }
 
 __global__ void clamp_len_kernel(const int* __restrict__ in, int n, int cap, int* __restrict__ out)
@@ -375,6 +530,9 @@ struct PostWs {
     int* seg_count;
     int* keep_count;
     int* seg_len;      // working segment lengths (prefix pass / cut pass)
+    int* seg_sorted;   // rows written per segment (partial sort: a prefix of the candidates)
+    int* redo;         // segments whose cut fell behind their sorted prefix
+    unsigned* thr_img; // per image: the bounding pass's threshold
     size_t total;
 };
 
@@ -396,6 +554,9 @@ PostWs carve(char* base, int batch, int P, int T)
     w.seg_count = (int*)take(S * 4);
     w.keep_count = (int*)take(S * 4);
     w.seg_len = (int*)take(S * 4);
+    w.seg_sorted = (int*)take(S * 4);
+    w.redo = (int*)take(S * 4);
+    w.thr_img = (unsigned*)take((size_t)batch * 4);
     w.total = off;
     return w;
 }
@@ -424,36 +585,57 @@ extern "C" int ct_postprocess_batched(const float* boxes, const float* scores, i
     const int np2 = std::max(next_pow2(num_priors), 2);
     hipStream_t st = ctdet::as_stream(stream);
     CT_HIP(hipMemsetAsync(overflow, 0, sizeof(int), st));
+    constexpr int kPrefix = 256;          // candidates per class in the bounding pass
+    static_assert(kPrefix <= kPartialMin, "the bounding pass reads only sorted rows");
+    const bool topk_rule = max_per_image > 0 && num_priors > kPrefix;
+    constexpr size_t kLdsPartial = 4096 * 8 + kHistBins * 4 + 64, kLds4k = 4096 * 8 + 64, kLds8k = 8192 * 8 + 64;
     {
         static hipError_t attr_err = [] {
-            hipError_t e = hipFuncSetAttribute((const void*)select_sort_kernel<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 8 + 16);
+            hipError_t e = hipFuncSetAttribute((const void*)select_sort_kernel<4096, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPartial);
             if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)select_sort_kernel<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8 + 16);
+                e = hipFuncSetAttribute((const void*)select_sort_kernel<4096, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds4k);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)select_sort_kernel<8192, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8k);
             return e;
         }();
         CT_HIP(attr_err);
-        CT_PROF("select_sort_kernel", st);
-        const dim3 grid(8 * ((batch + 7) / 8) * num_fg);
+    }
+    const dim3 sort_grid(8 * ((batch + 7) / 8) * num_fg);
+    auto full_sort = [&](const int* redo) {        // every candidate of every segment (or of the flagged ones) in order
         if (num_priors > 16384)
-            hipLaunchKernelGGL(select_sort_kernel<8192>, grid, dim3(kSortThreads), 8192 * 8 + 16, st, boxes, scores, batch, num_priors,
-                               num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count);
+            hipLaunchKernelGGL((select_sort_kernel<8192, false>), sort_grid, dim3(kSortThreads), kLds8k, st, boxes, scores, batch, num_priors,
+                               num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count, w.seg_sorted, redo);
         else
-            hipLaunchKernelGGL(select_sort_kernel<4096>, grid, dim3(kSortThreads), 4096 * 8 + 16, st, boxes, scores, batch, num_priors,
-                               num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count);
+            hipLaunchKernelGGL((select_sort_kernel<4096, false>), sort_grid, dim3(kSortThreads), kLds4k, st, boxes, scores, batch, num_priors,
+                               num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count, w.seg_sorted, redo);
+    };
+    {
+        CT_PROF("select_sort_kernel", st);
+        if (topk_rule)
+            hipLaunchKernelGGL((select_sort_kernel<4096, true>), sort_grid, dim3(kSortThreads), kLdsPartial, st, boxes, scores, batch, num_priors,
+                               num_fg, conf_thresh, np2, w.keys, w.dets_sorted, w.sorted_idx, w.seg_count, w.seg_sorted, (const int*)nullptr);
+        else
+            full_sort(nullptr);
     }
     CT_LAUNCH_CHECK("select_sort_kernel");
     int rc;
-    constexpr int kPrefix = 256;          // candidates per class in the bounding pass
-    if (max_per_image > 0 && num_priors > kPrefix) {
+    if (topk_rule) {
         // pass 1: NMS of every class's best kPrefix candidates -> exact lower bound of the top-k
         // threshold -> cut every segment there (see prefix_cut_kernel); pass 2: NMS of what is left
-        { CT_PROF("clamp_len_kernel", st); hipLaunchKernelGGL(clamp_len_kernel, dim3((S + 255) / 256), dim3(256), 0, st, w.seg_count, S, kPrefix, w.seg_len); }
+        { CT_PROF("clamp_len_kernel", st); hipLaunchKernelGGL(clamp_len_kernel, dim3((S + 255) / 256), dim3(256), 0, st, w.seg_sorted, S, kPrefix, w.seg_len); }
         CT_LAUNCH_CHECK("clamp_len_kernel");
         rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_len, num_priors, S, nms_thresh, ge, w.keep, w.keep_count, st);
         if (rc != CT_OK) return rc;
         { CT_PROF("prefix_cut_kernel", st); hipLaunchKernelGGL(prefix_cut_kernel, dim3(batch, num_fg), dim3(256), 0, st, w.dets_sorted, w.keep, w.keep_count,
-                           w.seg_count, num_priors, num_fg, max_per_image, w.seg_len); }
+                           w.seg_count, w.seg_sorted, num_priors, num_fg, max_per_image, w.seg_len, w.redo, w.thr_img); }
         CT_LAUNCH_CHECK("prefix_cut_kernel");
+        {   // segments whose cut lies behind their sorted prefix (none with a trained detector's few candidates per class;
+            // with random weights only when the bounding pass keeps fewer than max_per_image boxes): workgroups of the others exit
+            CT_PROF("select_sort_redo", st);
+            full_sort(w.redo);
+            hipLaunchKernelGGL(recut_kernel, dim3(S), dim3(256), 0, st, w.dets_sorted, w.seg_sorted, w.redo, w.thr_img, num_priors, num_fg, w.seg_len);
+        }
+        CT_LAUNCH_CHECK("select_sort_redo");
         rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_len, num_priors, S, nms_thresh, ge, w.keep, w.keep_count, st);
     } else {
         rc = ctdet::nms_launch_strided(w.dets_sorted, w.seg_count, num_priors, S, nms_thresh, ge, w.keep, w.keep_count, st);

@@ -23,6 +23,7 @@
 // The price is HBM traffic (V and M live in a workspace: 354 + 236 MB for 512 -> 512 @38x38, bs 32), which is why this
 // form is for layers with >= 256 channels on maps up to 75 x 75; the fused kernels keep the rest.
 #include "ct_common.h"
+#include <type_traits>
 #include "ct_wino_pack.h"
 #include "ct_wino4_points.h"
 #include "ct_wino4_emit.h"
@@ -90,6 +91,7 @@ struct GemmArgs {
     size_t a_plane, b_plane;     // bytes per point
     size_t m_plane, m_slab;      // floats per point / per k split
     int chunks, chunks_per_split, rowblocks, colblocks, ldm;
+    int rows, cols;              // live rows (couts) / columns (tiles): 32 x 32 accumulator blocks wholly outside issue no MFMAs
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -390,67 +392,85 @@ __global__ __launch_bounds__(256, 2) void wino4s_gemm(const GemmArgs a)
     constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
     const unsigned char* const Abase = lds_raw + (2 * wr) * (3 * FRAG) + voff;
     const unsigned char* const Bbase = lds_raw + OPB + (2 * wc) * (3 * FRAG) + voff;
-    auto read_frags = [&](int buf, i32x4 (&fa)[2][3], i32x4 (&fb)[2][3]) {
-        const unsigned char* A = Abase + buf * (2 * OPB);
-        const unsigned char* B = Bbase + buf * (2 * OPB);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
+    // Remainder blocks (round 5, VERDICT r04 task 3b): the 156-cout heads fill 28 rows of their second 128-row block and a
+    // 19 x 19 map's 800 tiles 32 columns of its seventh 128-column block -- 39 % of head.0/1/2's MFMAs multiplied padding.
+    // A wave issues MFMAs only for its 32 x 32 blocks with a live row and column (the DMA, the barriers and the ring are
+    // unchanged; a workgroup is as fast as its busiest wave: half the time for the heads' second row block).  The count of
+    // live blocks per direction is a compile-time parameter of the pipeline below (four instantiations): run-time tests
+    // inside the unrolled MFMA sequence cost the dual-accumulator form 364 spilled registers.
+    const int live_r = a.rows - (cb * BM + 64 * wr), live_c = a.cols - (tb * BT + 64 * wc);
+    const bool dead = live_r <= 0 || live_c <= 0;
+    const bool on[2][2] = {{!dead, !dead && live_c > 32}, {!dead && live_r > 32, live_r > 32 && live_c > 32}};
+    auto pipeline = [&](auto ni_c, auto nj_c) {
+        constexpr int NI = decltype(ni_c)::value, NJ = decltype(nj_c)::value;
+        auto read_frags = [&](int buf, i32x4 (&fa)[2][3], i32x4 (&fb)[2][3]) {
+            const unsigned char* A = Abase + buf * (2 * OPB);
+            const unsigned char* B = Bbase + buf * (2 * OPB);
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) {
-                fa[i][pc] = *reinterpret_cast<const i32x4*>(A + (i * 3 + pc) * FRAG);
-                fb[i][pc] = *reinterpret_cast<const i32x4*>(B + (i * 3 + pc) * FRAG);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) fa[i][pc] = *reinterpret_cast<const i32x4*>(A + (i * 3 + pc) * FRAG);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j][pc] = *reinterpret_cast<const i32x4*>(B + (j * 3 + pc) * FRAG);
             }
-    };
-    auto mfmas = [&](const i32x4 (&fa)[2][3], const i32x4 (&fb)[2][3]) {
+        };
+        auto mfmas = [&](const i32x4 (&fa)[2][3], const i32x4 (&fb)[2][3]) {
+            if (NI * NJ == 1 && dead) return;           // a wave wholly outside: DMA and barriers only
 #pragma unroll
-        for (int p = 0; p < 6; ++p)
+            for (int p = 0; p < 6; ++p)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f32x16& dst = (DUAL && p < 5) ? acs[i][j] : acc[i][j];
-                    dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][PA[p]]),
-                                                                  __builtin_bit_cast(bf16x8, fb[j][PB[p]]), dst, 0, 0, 0);
-                }
-    };
-    // Software pipeline over the barrier: the fragments of step c are in registers before its MFMAs start -- they were
-    // read from LDS behind the MFMAs of step c - 1.  Top of iteration c: wait for this wave's DMA pieces of step c + 1,
-    // barrier (now step c + 1 is complete in LDS, and every wave has finished READING step c: its buffer is free for
-    // step c + 3), issue that DMA, issue the twelve fragment reads of step c + 1, then the 24 MFMAs of step c.
-    // Ring of three buffers: step c + 1 (being read), c + 2 (in flight), c + 3 (just issued).  (A ring of two with the
-    // one-accumulator register budget -- 48 KB, three workgroups per CU -- measured the same: 526 vs 469-531 us on
-    // 512 -> 512 @38x38, 3 516-3 526 vs 3 504-3 525 images/s in the pipeline; the kernel is not latency-bound.)
-    // Barriers are bare s_barrier instructions with hand-written waits: __syncthreads() carries a workgroup fence that the
-    // compiler implements as s_waitcnt vmcnt(0), which would drain the DMA queue (the steps in flight) at every step.
-    load_step(0, 0);
-    if (chunks > 1) load_step(1, 1);
-    if (chunks > 2) load_step(2, 2);
-    if (chunks > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-    else if (chunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    i32x4 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];
-    read_frags(0, fa0, fb0);
-    auto top = [&](int c) {                             // before the MFMAs of step c; returns after issuing the DMA of step c + 3
-        // outstanding DMA groups of this wave, oldest first: steps c + 1, c + 2 (those that exist); lgkmcnt(0): this wave's
-        // fragment reads of step c (issued one MFMA phase ago) are done before its buffer is handed back
-        if (c + 2 < chunks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    for (int j = 0; j < NJ; ++j) {
+                        f32x16& dst = (DUAL && p < 5) ? acs[i][j] : acc[i][j];
+                        dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][PA[p]]),
+                                                                      __builtin_bit_cast(bf16x8, fb[j][PB[p]]), dst, 0, 0, 0);
+                    }
+        };
+        // Software pipeline over the barrier: the fragments of step c are in registers before its MFMAs start -- they were
+        // read from LDS behind the MFMAs of step c - 1.  Top of iteration c: wait for this wave's DMA pieces of step c + 1,
+        // barrier (now step c + 1 is complete in LDS, and every wave has finished READING step c: its buffer is free for
+        // step c + 3), issue that DMA, issue the twelve fragment reads of step c + 1, then the 24 MFMAs of step c.
+        // Ring of three buffers: step c + 1 (being read), c + 2 (in flight), c + 3 (just issued).  (A ring of two with the
+        // one-accumulator register budget -- 48 KB, three workgroups per CU -- measured the same: 526 vs 469-531 us on
+        // 512 -> 512 @38x38, 3 516-3 526 vs 3 504-3 525 images/s in the pipeline; the kernel is not latency-bound.)
+        // Barriers are bare s_barrier instructions with hand-written waits: __syncthreads() carries a workgroup fence that the
+        // compiler implements as s_waitcnt vmcnt(0), which would drain the DMA queue (the steps in flight) at every step.
+        load_step(0, 0);
+        if (chunks > 1) load_step(1, 1);
+        if (chunks > 2) load_step(2, 2);
+        if (chunks > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+        else if (chunks > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (c + 3 < chunks) load_step(c + 3, c % 3);
+        i32x4 fa0[2][3], fb0[2][3], fa1[2][3], fb1[2][3];
+        read_frags(0, fa0, fb0);
+        auto top = [&](int c) {                             // before the MFMAs of step c; returns after issuing the DMA of step c + 3
+            // outstanding DMA groups of this wave, oldest first: steps c + 1, c + 2 (those that exist); lgkmcnt(0): this wave's
+            // fragment reads of step c (issued one MFMA phase ago) are done before its buffer is handed back
+            if (c + 2 < chunks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (c + 3 < chunks) load_step(c + 3, c % 3);
+        };
+        int c = 0;
+        for (; c + 1 < chunks; c += 2) {
+            top(c);
+            read_frags((c + 1) % 3, fa1, fb1);
+            mfmas(fa0, fb0);
+            top(c + 1);
+            if (c + 2 < chunks) read_frags((c + 2) % 3, fa0, fb0);
+            mfmas(fa1, fb1);
+        }
+        if (c < chunks) mfmas(fa0, fb0);
     };
-    int c = 0;
-    for (; c + 1 < chunks; c += 2) {
-        top(c);
-        read_frags((c + 1) % 3, fa1, fb1);
-        mfmas(fa0, fb0);
-        top(c + 1);
-        if (c + 2 < chunks) read_frags((c + 2) % 3, fa0, fb0);
-        mfmas(fa1, fb1);
-    }
-    if (c < chunks) mfmas(fa0, fb0);
+    using std::integral_constant;
+    if (live_r > 32 && live_c > 32) pipeline(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+    else if (live_r > 32) pipeline(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+    else if (live_c > 32) pipeline(integral_constant<int, 1>{}, integral_constant<int, 2>{});
+    else pipeline(integral_constant<int, 1>{}, integral_constant<int, 1>{});
 
     // M[xi][cout][tile]: register r of block (i, j) = cout 32 (2 wr + i) + (r & 3) + 8 (r >> 2) + 4 kg, tile 32 (2 wc + j) + l31
     float* const Mp = a.M + (size_t)blockIdx.y * a.m_slab + (size_t)xi * a.m_plane + (size_t)(cb * BM + 64 * wr + 4 * kg) * a.ldm +
@@ -458,12 +478,14 @@ __global__ __launch_bounds__(256, 2) void wino4s_gemm(const GemmArgs a)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            if (!on[i][j]) continue;                   // nobody reads M outside the live rows / columns
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = DUAL ? acc[i][j][r] + acs[i][j][r] : acc[i][j][r];
                 Mp[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * a.ldm + 32 * j] = v;
             }
+        }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -952,6 +974,7 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
             g.A = reinterpret_cast<const unsigned char*>(a.U); g.B = reinterpret_cast<const unsigned char*>(a.V); g.M = a.Mw;
             g.a_plane = a.u_plane; g.b_plane = a.v_plane; g.m_plane = a.m_plane; g.m_slab = 0;
             g.chunks = g.chunks_per_split = a.chunks; g.rowblocks = a.kblocks; g.colblocks = a.tblk128; g.ldm = a.Tpad;
+            g.rows = a.M; g.cols = a.NT;
             const int nwg = NXI * a.tblk128 * a.kblocks;
             if (variant == 1) hipLaunchKernelGGL(wino4s_gemm<true>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
             else hipLaunchKernelGGL(wino4s_gemm<false>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
@@ -1049,6 +1072,7 @@ extern "C" int ct_conv2d_wgrad_wino4s(const ct_conv_desc* d, const float* dz, in
         g.A = E; g.B = V; g.M = M;
         g.a_plane = s.e_plane; g.b_plane = s.v_plane; g.m_plane = s.m_plane; g.m_slab = s.m_slab;
         g.chunks = s.kchunks; g.chunks_per_split = s.cps; g.rowblocks = s.rb; g.colblocks = s.cb; g.ldm = s.cb * BT;
+        g.rows = d->cout; g.cols = d->cin;
         hipLaunchKernelGGL(wino4s_gemm<true>, dim3(NXI * s.rb * s.cb, s.splits), dim3(256), GEMM_LDS_BYTES, st, g);
         CT_LAUNCH_CHECK("wino4s_gemm (weight gradient)");
     }

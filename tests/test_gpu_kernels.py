@@ -416,6 +416,45 @@ def test_postprocess_all_pass_regime_vs_oracle():
             assert np.array_equal(allb[i][j], want[j]), (i, j)
 
 
+@pytest.mark.parametrize('regime', ['identical_boxes', 'two_levels', 'one_bin', 'few'])
+def test_postprocess_partial_sort_paths_vs_oracle(regime):
+    """ct_postprocess_batched sorts only the best >= 1024 candidates of a class when the top-k rule is on (csrc/ct_post.hip,
+    select_sort_kernel<.., true>) and re-sorts in full the segments whose cut falls behind that prefix.  The regimes force
+    each path: identical boxes -> one box kept per class, fewer than max_per_image kept in the bounding pass -> every
+    segment flagged and sorted in full; two score levels -> the cut bin alone overflows the LDS buffer even after the
+    second histogram -> full sort inside the first launch; all scores inside one histogram bin -> the 11-bit refinement;
+    few -> fewer candidates than the prefix (the trained-detector case).  Bit-exact against the oracle loop
+    (test.py:136-161), ties in ascending prior order."""
+    priors = box_ref.prior_box(box_ref.ANCHOR_CFGS['VOC_300'])
+    P, B, T = priors.shape[0], 2, 3
+    gen = torch.Generator().manual_seed(91)
+    pb = torch.cat([priors[:, :2] - priors[:, 2:] / 2, priors[:, :2] + priors[:, 2:] / 2], 1).clamp(0, 1)
+    boxes = pb[None].repeat(B, 1, 1).contiguous()
+    scores = torch.zeros(B, P, T + 1)
+    if regime == 'identical_boxes':
+        boxes[:] = torch.tensor([0.2, 0.3, 0.6, 0.7])
+        scores[:, :, 1:] = 0.02 + 0.9 * torch.rand(B, P, T, generator=gen)
+    elif regime == 'two_levels':
+        scores[:, :, 1:] = torch.where(torch.rand(B, P, T, generator=gen) < 0.5, torch.tensor(0.25), torch.tensor(0.75))
+    elif regime == 'one_bin':
+        scores[:, :, 1:] = 0.5 + 0.06 * torch.rand(B, P, T, generator=gen)
+    else:
+        for b in range(B):
+            for c in range(T):
+                idx = torch.randperm(P, generator=gen)[:300 + 100 * c]
+                scores[b, idx, 1 + c] = 0.02 + 0.9 * torch.rand(idx.numel(), generator=gen)
+    scale = torch.tensor([500., 375., 500., 375.])
+    pp = ops.PostProcessor(B, P, T, DEV, out_cap=P)
+    for topk in (200, 0):
+        pp.run(_cuda(boxes * scale), _cuda(scores), max_per_image=topk)
+        allb = pp.to_all_boxes()
+        for i in range(B):
+            want = nms_ref.postprocess_image(boxes[i].numpy(), scores[i].numpy(), (500, 375), max_per_image=topk,
+                                             nms_fn=nms_ref.nms_c)
+            for j in range(1, T + 1):
+                assert np.array_equal(allb[i][j], want[j]), (regime, topk, i, j, allb[i][j].shape, want[j].shape)
+
+
 # ------------------------------------------------------------------ context attention
 @pytest.mark.parametrize('setting,d,T', [('transfer', 60, 20), ('incre', 15, 5)])
 def test_ctx_attention_vs_oracle(setting, d, T):

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void k_write_items(i32x4* dst, int planes, int
 
 int main()
 {
+    setvbuf(stdout, nullptr, _IOLBF, 0);
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     int* sink; CK(hipMalloc(&sink, 4));
@@ -73,7 +74,7 @@ int main()
     }
     // wino4s_in of 512 -> 512 @38x38 bs 32: 108 planes of 3.28 MB (25 tile blocks x 32 chunks x 4 KB), 800 items of 4 KB per plane
     for (int planes : {108}) {
-        for (int items : {800, 3200}) {
+        for (int items : {800, 2000}) {      // 108 x 2000 x 4 KB = 885 MB of the 1 GB buffer
             const size_t plane16 = (size_t)items * 256;
             for (int wgs : {400, 512, 1024}) {
                 const double bytes = (double)planes * items * 4096;

@@ -59,6 +59,25 @@ for name in names:
         # executed matrix work: F(2x2) 16/36, F(4x4) 36/144 of the direct count; bf16x3 = six bf16 products each
         ex = 0.25 if tile == 4 else 0.25 * 6 if tile in (44, 45, 46) else (16 / 36) * (6 if tile in (23, 24) else 1)
         peak = 2500.0 if tile in (23, 24, 44, 45, 46) else 157.3
+        stages = ''
+        if os.environ.get('STAGES') and tile in (44, 45):
+            # the three kernels of the launch by the library's own profile scopes (HIP events on the launch stream)
+            import ctypes as C
+            lib = _lib.lib()
+            _lib.check(lib.ct_profile_enable(1), 'ct_profile_enable')
+            for _ in range(iters):
+                be.run_conv(st)
+            torch.cuda.synchronize()
+            cnt = C.c_int(0)
+            _lib.check(lib.ct_profile_collect(None, 0, C.byref(cnt)), 'ct_profile_collect')
+            recs = (_lib.ProfileRecord * max(cnt.value, 1))()
+            _lib.check(lib.ct_profile_collect(recs, cnt.value, C.byref(cnt)), 'ct_profile_collect')
+            _lib.check(lib.ct_profile_enable(0), 'ct_profile_enable')
+            agg = {}
+            for i in range(cnt.value):
+                a = agg.setdefault(recs[i].name.decode(), [0.0, 0])
+                a[0] += recs[i].ms; a[1] += 1
+            stages = '  [' + '  '.join('%s %.1f us' % (k.replace('wino4s_', ''), v[0] / v[1] * 1e3) for k, v in agg.items()) + ']'
         print('%-10s F%-2d %4d->%-4d @%3dx%-3d bs%-2d  %8.1f us  %6.1f TF algorithmic  %6.1f TF executed = %.3f of %.1f%s'
-              % (name, tile, Cin, Cout, H, W, B, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 * ex, fl / ms / 1e9 * ex / peak, peak, err),
+              % (name, tile, Cin, Cout, H, W, B, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 * ex, fl / ms / 1e9 * ex / peak, peak, err + stages),
               flush=True)
