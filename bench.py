@@ -305,13 +305,16 @@ def stage_rooflines(pipe, x, steps, pmc):
         a[0] += recs[i].ms * 1e-3
         a[1] += 1
     _lib.check(lib.ct_profile_enable(0), 'ct_profile_enable')
-    cand = int((pipe.scores[:, :, 1:] > pipe.conf_thresh).sum().item())      # candidates over all (image, class)
+    per_seg = (pipe.scores[:, :, 1:] > pipe.conf_thresh).sum(1)               # candidates per (image, class)
+    cand = int(per_seg.sum().item())
+    sorted_rows = int(per_seg.clamp(max=1024).sum().item())
     net = pipe.net
     work = {
         # loc 16P + conf 4CP + obj 8P in, boxes 16P + scores 4(T+1)P out per image, priors 16P once
         'detect_kernel': ('hbm', B * P * (16 + 4 * pipe.scores_in_ch + 8 + 16 + 4 * (T + 1)) + 16 * P),
-        # threshold scan of every score + 8 B key/index and 20 B row per candidate written for the sort
-        'select_sort_kernel': ('hbm', B * P * (T + 1) * 4 + cand * 28),
+        # threshold scan of every score, an 8 B key per candidate written and read back, and a 20 B row + 4 B index for the
+        # candidates that are sorted: the best >= 1024 of a class under the top-k rule (csrc/ct_post.hip, partial sort)
+        'select_sort_kernel': ('hbm', B * P * (T + 1) * 4 + cand * 16 + sorted_rows * 24),
         # 20 B row in + 4 B kept index out per candidate (SURVEY 8d "20N in + 4N out"), both NMS passes share it
         'nms_segments_kernel': ('hbm', cand * 24),
     }
