@@ -543,6 +543,48 @@ __global__ __launch_bounds__(256) void maxpool2d_bwd_kernel(const float* __restr
     }
 }
 
+// The same for planes that fit in LDS (pool5: 3x3 / stride 1 on 19x19 or 32x32 -- 81 global reads per element in the kernel
+// above, 492 us of the bs-32 training step): workgroup = one plane; the plane goes to LDS once, every window's first maximum
+// is found once (its flat index), every element then sums dy over the <= k*k windows that name it.  Same tie rule, same sum
+// order (windows in row-major order) as the kernel above.
+constexpr int kPoolPlaneMax = 4096;
+__global__ __launch_bounds__(256) void maxpool2d_bwd_plane_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  float* __restrict__ dx, int H, int W, int OH, int OW,
+                                                                  int k, int stride, int pad, int accumulate)
+{
+    __shared__ float xs[kPoolPlaneMax];
+    __shared__ int am[kPoolPlaneMax];
+    const long pl = blockIdx.x;
+    const float* xp = x + pl * (long)H * W;
+    const float* gp = dy + pl * (long)OH * OW;
+    float* dp = dx + pl * (long)H * W;
+    for (int i = threadIdx.x; i < H * W; i += 256) xs[i] = xp[i];
+    __syncthreads();
+    for (int o = threadIdx.x; o < OH * OW; o += 256) {
+        const int oh = o / OW, ow = o - oh * OW;
+        const int h0 = oh * stride - pad, w0 = ow * stride - pad;
+        float m = -INFINITY;
+        int mi = -1;
+        for (int hh = max(h0, 0); hh < min(h0 + k, H); ++hh)
+            for (int ww = max(w0, 0); ww < min(w0 + k, W); ++ww) {
+                const float v = xs[hh * W + ww];
+                if (v > m) { m = v; mi = hh * W + ww; }
+            }
+        am[o] = mi;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+        const int h = i / W, w = i - h * W;
+        float g = 0.f;
+        const int oh_lo = max(0, (h + pad - k + stride) / stride), oh_hi = min(OH - 1, (h + pad) / stride);
+        const int ow_lo = max(0, (w + pad - k + stride) / stride), ow_hi = min(OW - 1, (w + pad) / stride);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow)
+                if (am[oh * OW + ow] == i) g += gp[oh * OW + ow];
+        dp[i] = accumulate ? dp[i] + g : g;
+    }
+}
+
 // MaxPool2d(2, 2) (floor or ceil mode): the windows do not overlap, so one thread owns one window -- reads its
 // (up to) 2x2 inputs, finds the first maximum in row-major order (strict >, as the gather kernel above) and
 // writes all four gradients; input rows/columns no window covers (floor mode, odd extent) get zeros.
@@ -866,6 +908,12 @@ extern "C" int ct_maxpool2d_bwd(const float* x, const float* dy, float* dx, long
         hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3((unsigned)planes), dim3(256), 0, ctdet::as_stream(stream), x,
                            dy, dx, h, w, oh, ow, accumulate);
         CT_LAUNCH_CHECK("maxpool2x2_bwd_kernel");
+        return CT_OK;
+    }
+    if (h * w <= kPoolPlaneMax && oh * ow <= kPoolPlaneMax && planes <= 0x7FFFFFFFL) {
+        hipLaunchKernelGGL(maxpool2d_bwd_plane_kernel, dim3((unsigned)planes), dim3(256), 0, ctdet::as_stream(stream), x, dy, dx,
+                           h, w, oh, ow, k, stride, pad, accumulate);
+        CT_LAUNCH_CHECK("maxpool2d_bwd_plane_kernel");
         return CT_OK;
     }
     hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0,

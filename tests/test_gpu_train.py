@@ -124,7 +124,8 @@ def test_pool_and_bias_backward():
     lib = _lib.lib()
     gen = torch.Generator().manual_seed(5)
     for (H, W, k, s, p, ceil) in [(30, 30, 2, 2, 0, False), (15, 15, 2, 2, 0, True), (15, 13, 2, 2, 0, False),
-                                  (75, 75, 2, 2, 0, True), (9, 9, 3, 1, 1, False)]:
+                                  (75, 75, 2, 2, 0, True), (9, 9, 3, 1, 1, False), (19, 19, 3, 1, 1, False), (32, 32, 3, 1, 1, False),
+                                  (19, 19, 3, 3, 0, True), (70, 66, 3, 1, 1, False)]:      # last: larger than an LDS plane
         x = torch.randn(2, 3, H, W, generator=gen)
         x[0, 0, :4, :4] = 1.5                       # ties inside windows
         x = x.requires_grad_(True)
