@@ -256,7 +256,10 @@ __global__ __launch_bounds__(NT) void conv_bf16_nhwc(const Bf16Args a)
             if (nload < s1) { load_step(nload); ++nload; dma_buf = dma_buf + 1 == NBUF ? 0 : dma_buf + 1; }
         if (PF == 2 && nload - s0 == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // bare barriers in this loop: __syncthreads() carries a workgroup fence, which the compiler emits as s_waitcnt vmcnt(0)
+        // -- it drained the DMA ring at every k-step and made the counted wait above meaningless (rounds 3-4 ran that way)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         const int xa = (((wm0 + l31) / RL) % SPR) * 16, xb = (((wn0 + l31) / RL) % SPR) * 16;
         int buf = 0;
         for (int step = s0; step < s1; ++step) {
@@ -286,9 +289,10 @@ __global__ __launch_bounds__(NT) void conv_bf16_nhwc(const Bf16Args a)
                                                                             acc[i][j], 0, 0, 0);
             }
             // the next step's pieces must have landed; with two steps in flight the newest step's may still fly
-            if (PF == 2 && more && nload - step > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (PF == 2 && more && nload - step > 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             buf = buf + 1 == NBUF ? 0 : buf + 1;
         }
     } else {

@@ -295,7 +295,15 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
             }
         }
         if (LOAD) end_load();
-        __syncthreads();
+        // A bare barrier behind the LDS counter only: __syncthreads() carries a workgroup fence that the compiler turns into
+        // s_waitcnt vmcnt(0), i.e. a wait for the global loads this step has just issued for the tile two steps ahead (the
+        // staging registers are private, only the LDS tiles are shared, and the compiler still waits for a register's own
+        // load before its split).  Measured in round 5: no difference on any layer (the loads of a step land within it);
+        // a second set of staging registers (loads three tiles ahead) was 10-25 % SLOWER on the layers that cannot fill the
+        // chip -- their ~0.7 us per 12-MFMA step is not a memory round trip.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
 
     // prologue: tile s0 -> LDS buffer 0, tile s0 + 1 -> staging registers
