@@ -268,9 +268,11 @@ class TrainRuntime:
             if st.kind == 'conv':
                 self.state[st.name].fwd.rt['ws_key'] = self.sid[i] if self.side is not None else 0
         backend.ws_rebuild([self.state[st.name].fwd for st in self.plan.steps if st.kind == 'conv'])
-        # weight gradients on their own stream (CTDET_TRAIN_STREAMS=1 keeps everything on the caller's stream)
-        self.wg_stream = torch.cuda.Stream(backend.device) if int(os.environ.get('CTDET_TRAIN_STREAMS', '2')) > 1 \
-            else None
+        # weight gradients beside the data-gradient chain (CTDET_TRAIN_STREAMS=1 keeps everything on the caller's stream).  The
+        # stream is the forward pass's side stream: the two are never busy at the same time, and a training step with ONE side
+        # stream can be captured as a hipGraph (a second one crashes hipStreamEndCapture on ROCm 7.2)
+        self.wg_stream = (self.side if self.side is not None else torch.cuda.Stream(backend.device)) \
+            if int(os.environ.get('CTDET_TRAIN_STREAMS', '2')) > 1 else None
         for s_ in self.state.values():
             s_.ev_dz = torch.cuda.Event()
         self._bns = [p.bn for st in self.plan.steps if st.kind == 'conv' for p in st.parts if p.bn is not None]
