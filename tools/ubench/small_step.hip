@@ -92,6 +92,42 @@ __global__ __launch_bounds__(256) void kp(const i32x4* g, float* out, unsigned l
     if (tid == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// Eight waves per workgroup, the work of a step divided between the two waves of a SIMD: six MFMAs, six fragment reads, three
+// LDS writes and six global loads each (the two k-groups of a 32-channel step on different waves).
+__global__ __launch_bounds__(512) void k8(const i32x4* g, float* out, unsigned long long* clk, int steps)
+{
+    __shared__ i32x4 lds[4096];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 4096; i += 512) lds[i] = g[i & 1023];
+    __syncthreads();
+    f32x16 a0, a1;
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+    i32x4 f[6];
+    for (int i = 0; i < 6; ++i) f[i] = lds[(tid + 64 * i) & 4095];
+    i32x4 pre[6];
+    const i32x4* gp = g + (blockIdx.x * 512 + tid) % 1024;
+    for (int i = 0; i < 6; ++i) pre[i] = gp[i * 1024];
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int s = 0; s < steps; ++s) {
+        for (int i = 0; i < 6; ++i) f[i] = lds[(tid + 64 * i + s) & 4095];
+        for (int i = 0; i < 6; ++i) {
+            f32x16& d = i < 5 ? a0 : a1;
+            d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f[i]), __builtin_bit_cast(bf16x8, f[(i + 1) % 6]), d, 0, 0, 0);
+        }
+        for (int i = 0; i < 3; ++i) lds[(tid + 512 * i + 7 * s) & 4095] = pre[i] + pre[(i + 3) % 6];
+        for (int i = 0; i < 6; ++i) pre[i] = gp[((i + s) & 63) * 1024];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sum = 0.f;
+    for (int r = 0; r < 16; ++r) sum += a0[r] + a1[r];
+    for (int i = 0; i < 6; ++i) sum += (float)pre[i].x;
+    out[blockIdx.x * 512 + tid] = sum;
+    if (tid == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 template <int MODE>
 void run(const i32x4* g, float* out, unsigned long long* clk, int wgs, const char* what)
 {
@@ -135,6 +171,21 @@ int main()
             unsigned long long h[2];
             hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
             printf("%-58s %4d WGs: %.3f us per step, %.0f shader ticks per step\n", "the same, software-pipelined over the barrier (3 buffers)", wgs,
+                   ms * 1e3 / steps, (double)h[0] / steps);
+        }
+        {
+            const int steps = 4000;
+            hipLaunchKernelGGL(k8, dim3(wgs), dim3(512), 0, 0, g, out, clk, steps);
+            hipDeviceSynchronize();
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k8, dim3(wgs), dim3(512), 0, 0, g, out, clk, steps);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms = -1.f; hipEventElapsedTime(&ms, e0, e1);
+            unsigned long long h[2] = {0, 0};
+            hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+            printf("%-58s %4d WGs: %.3f us per step, %.0f shader ticks per step\n", "the same work on eight waves (two per SIMD, half each)", wgs,
                    ms * 1e3 / steps, (double)h[0] / steps);
         }
     }
