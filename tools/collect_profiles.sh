@@ -49,7 +49,7 @@ timeout 200 python tools/res_probe.py > "$O/res_probe.txt" 2>&1
 [ -n "${QUICK:-}" ] || { timeout 300 python tools/wino_accuracy.py > "$O/wino_accuracy.txt" 2>&1; }
 # the shipped Context-Transformer policy: error budget + sweep against the fp32 CPU path at 8 and 128 reference threads (the policy
 # comparison itself is tools/ctx_policy2.sh / ctx_policy3.sh: its own GPU call, published as profiles/<tag>_ctx_policy.txt)
-[ -n "${QUICK:-}" ] || { timeout 1500 python tools/ctx_parity.py --budget --sweep --policies 2+23 --also-threads 128 > "$O/ctx_parity.txt" 2>&1; }
+[ -n "${QUICK:-}${SKIP_CTX_PARITY:-}" ] || { timeout 1500 python tools/ctx_parity.py --budget --sweep --policies 2+23 --also-threads 128 > "$O/ctx_parity.txt" 2>&1; }
 timeout 300 python bench.py --train --steps 5 --warmup 2 > "$O/bench_train.json.log" 2> "$O/bench_train.err"
 [ -n "${QUICK:-}" ] || { timeout 300 python bench.py --gpus 2 --share-devices --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > "$O/bench_2rank_rehearsal.json.log" 2> "$O/bench_2rank_rehearsal.err"; }
 [ -n "${QUICK:-}" ] || { timeout 300 python bench.py --train --gpus 2 --share-devices --steps 3 --warmup 1 > "$O/bench_train_2rank_rehearsal.json.log" 2> "$O/bench_train_2rank_rehearsal.err"; }
