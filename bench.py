@@ -68,12 +68,19 @@ PEAK_HBM_GBS = 8000.0               # HBM3E spec (6.3 TB/s achievable, MI355X_MI
 # st.rt['wino'] codes 23 / 24 are F(2x2,3x3) on the bf16 pipe (csrc/ct_wino_x3.hip): every
 # transform-domain multiplication is six bf16 MFMA products (bf16x3), priced against the bf16 MFMA peak
 WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0, 23: 16.0 / 36.0, 24: 16.0 / 36.0, 44: 36.0 / 144.0, 45: 36.0 / 144.0,
-                       46: 36.0 / 144.0}
-# 44 / 45: one conv launch = three kernels (csrc/ct_wino4s.hip: wino4s_in, wino4s_gemm<dual>, wino4s_out)
+                       46: 36.0 / 144.0, 47: 36.0 / 144.0, 48: 36.0 / 144.0}
+# 44 / 45: one conv launch = three kernels (csrc/ct_wino4s.hip: wino4s_in, wino4s_gemm<dual>, wino4s_out); 47: the same on the
+# f16x2 operand form (csrc/ct_f16x2.h: absmax pass, wino4s_in<h2>, wino4h_gemm, wino4s_out<h2>); 48: the fused kernel on f16x2
 WINOGRAD_KERNEL = {2: 'wino_f2x2_3x3_f32', 4: 'wino_f4x4_3x3_f32', 23: 'wino_f2x2_3x3_x3', 24: 'wino_f2x2_3x3_x3q',
-                   44: 'wino4s(in+gemm+out)', 45: 'wino4sq(in+gemm+out)', 46: 'wino_f4x4_3x3_x3'}
-WINOGRAD_X3 = (23, 24, 44, 45, 46)       # 46: F(4x4,3x3) fused on bf16x3 (csrc/ct_wino4f.hip)
-WINOGRAD_F4 = (4, 44, 45, 46)
+                   44: 'wino4s(in+gemm+out)', 45: 'wino4sq(in+gemm+out)', 46: 'wino_f4x4_3x3_x3',
+                   47: 'wino4s_h2(absmax+in+gemm+out)', 48: 'wino_f4x4_3x3_h2'}
+WINOGRAD_X3 = (23, 24, 44, 45, 46, 47, 48)       # on the 16-bit matrix pipe; 46: F(4x4,3x3) fused on bf16x3 (csrc/ct_wino4f.hip)
+WINOGRAD_F4 = (4, 44, 45, 46, 47, 48)
+WINOGRAD_H2 = (47, 48)                   # f16x2: two binary16 pieces, THREE piece products per multiply-add (bf16x3: six)
+
+
+def piece_products(wino):
+    return 3.0 if wino in WINOGRAD_H2 else 6.0
 
 
 def _lib_config_name(cfg):
@@ -218,7 +225,7 @@ def conv_roofline(rt, batch, pmc, pick=None):
         if bf16:
             name, mult, pk = 'conv_bf16_nhwc', 1.0, PEAK_BF16_MFMA_TFLOPS
         elif wino in WINOGRAD_X3:
-            name, mult, pk = WINOGRAD_KERNEL[wino], WINOGRAD_MULT_RATIO[wino] * 6.0, PEAK_BF16_MFMA_TFLOPS
+            name, mult, pk = WINOGRAD_KERNEL[wino], WINOGRAD_MULT_RATIO[wino] * piece_products(wino), PEAK_BF16_MFMA_TFLOPS
         elif wino:
             name, mult, pk = WINOGRAD_KERNEL[wino], WINOGRAD_MULT_RATIO[wino], PEAK_F32_MFMA_TFLOPS
         elif x3 is not None:
@@ -254,7 +261,7 @@ def conv_roofline(rt, batch, pmc, pick=None):
         'flops_definition': 'multiply-adds x2 executed on the matrix pipe per launch' +
                             (' = direct-convolution flops x %s (Winograd F(%dx%d,3x3), output-tile padding not counted)%s'
                              % ('36/144' if wino in WINOGRAD_F4 else '16/36', 4 if wino in WINOGRAD_F4 else 2, 4 if wino in WINOGRAD_F4 else 2,
-                                ' x 6 (bf16x3 split, bf16 MFMA pipe)' if wino in WINOGRAD_X3 else '') if wino else
+                                (' x 3 (f16x2 split, f16 MFMA pipe)' if wino in WINOGRAD_H2 else ' x 6 (bf16x3 split, bf16 MFMA pipe)' if wino in WINOGRAD_X3 else '')) if wino else
                              ' = direct-convolution flops x 6 (bf16x3 split, bf16 MFMA pipe)' if name.startswith('conv_x3') else ''),
         'algorithmic_flops_per_launch': round(f / n),
         'algorithmic_achieved': round(f / t / 1e12, 2),
@@ -318,7 +325,7 @@ def stage_rooflines(pipe, x, steps, pmc):
         # 20 B row in + 4 B kept index out per candidate (SURVEY 8d "20N in + 4N out"), both NMS passes share it
         'nms_segments_kernel': ('hbm', cand * 24),
     }
-    w4s = [st for st in pipe.rt.conv_steps() if int(st.rt.get('wino') or 0) in (44, 45)]
+    w4s = [st for st in pipe.rt.conv_steps() if int(st.rt.get('wino') or 0) in (44, 45, 47)]
     if w4s:
         # the three kernels of the F(4x4,3x3) / bf16x3 layers, summed over the layers of a step (csrc/ct_wino4s.hip):
         # tiles padded to 128, couts to 128; V = 36 points x 3 bf16 pieces, M = 36 points x fp32; dilated layers (pad = dilation)
@@ -328,9 +335,10 @@ def stage_rooflines(pipe, x, steps, pmc):
             dl = st.dil              # dilated layers: dl x dl sub-lattices of ceil(oh / dl) x ceil(ow / dl) pixels, tiled like images
             tiles = B * dl * dl * ((-(-st.oh // dl) + 3) // 4) * ((-(-st.ow // dl) + 3) // 4)
             tpad, mpad = -(-tiles // 128) * 128, -(-st.cout // 128) * 128
-            gf += 36.0 * tiles * st.cin * st.cout * 2 * 6          # useful work: the layer's own tiles and couts
-            gfp += 36.0 * tpad * st.cin * mpad * 2 * 6             # what the 128 x 128 blocks execute
-            ib += 4.0 * B * st.cin * st.h * st.w + 6.0 * 36 * tpad * st.cin
+            pp = piece_products(int(st.rt['wino']))          # piece products per multiply-add (f16x2: 3, V = two 2-byte pieces; bf16x3: 6, three pieces)
+            gf += 36.0 * tiles * st.cin * st.cout * 2 * pp         # useful work: the layer's own tiles and couts
+            gfp += 36.0 * tpad * st.cin * mpad * 2 * pp            # what the 128 x 128 blocks execute
+            ib += 4.0 * B * st.cin * st.h * st.w + (4.0 if pp == 3.0 else 6.0) * 36 * tpad * st.cin
             ob += 4.0 * 36 * tiles * st.cout + 4.0 * B * st.cout * st.oh * st.ow
         work['wino4s_gemm'] = ('mfma_bf16', gf)
         gemm_padded = gfp

@@ -27,6 +27,7 @@
 #include "ct_wino_pack.h"
 #include "ct_wino4_points.h"
 #include "ct_wino4_emit.h"
+#include "ct_f16x2.h"
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
@@ -52,6 +53,15 @@ constexpr int NBUF = 3;                     // LDS ring: two k-steps in flight
 constexpr int GEMM_LDS_BYTES = NBUF * 2 * OPB;         // 72 KB: two workgroups per CU
 constexpr int PT_STRIDE = CC * TB;          // wino4s_in: floats per point in LDS, V[point][channel 16][tile 32]
 constexpr int IN_LDS_BYTES = NXI * PT_STRIDE * 4;      // 72 KB
+// The f16x2 operand form (variant 3, round 6): two binary16 pieces per value instead of three bfloat16 ones, three piece
+// products instead of six (see the section "f16x2" below)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int HP = 2;                                  // pieces per value
+constexpr int OPBH = 4 * HP * FRAG;                    // one operand block of a 16-channel k-group: [sub 4][piece 2][1 KB] = 8 KB
+constexpr int AMAX_SLOTS = ctdet::kWino4hAmaxSlots;    // partial maxima of |input| (one per workgroup of wino4h_absmax)
+constexpr int HDR_BYTES = ctdet::kWino4hHeaderBytes;   // workspace header: [AMAX_SLOTS] partial maxima, then word 0 = eV
 
 struct Wino4sArgs {
     const float* in;
@@ -78,6 +88,11 @@ struct Wino4sArgs {
     size_t m_plane;          // floats per point
     int chunks_per_wg;       // wino4s_in: blockIdx.y owns chunks [y * chunks_per_wg, ...)
     int dil;                 // > 1: dilated layer, tiles live on the dil x dil sub-lattices (wino4s_in_dil)
+    // f16x2 form only: V is stored scaled by 2^eV, U by 2^eU (powers of two from the operands' maxima, so that no binary16
+    // piece overflows and the small pieces keep their bits); wino4s_out multiplies M by 2^-(eU + eV)
+    unsigned* hdr;           // workspace header: [AMAX_SLOTS] partial maxima of |input| as bit patterns, hdr[AMAX_SLOTS] = eV
+    int amax_n;              // live entries of hdr
+    const int* eU;           // the exponent the weight packing chose (trailer of the packed weights)
 };
 
 // 36 GEMMs  M[xi][row][col] = sum_k A[xi][row][k] B[xi][col][k], both operands as 12 KB fragment blocks
@@ -116,12 +131,56 @@ __device__ __forceinline__ int pack_hi(unsigned e0, unsigned e1)      // [bf16 e
     return (int)__builtin_amdgcn_perm(e1, e0, 0x07060302u);
 }
 
+// The operand fragments of eight channels of one (point, 32-tile block): bf16x3 = three 16-byte pieces (hi, mid, lo by
+// truncation), f16x2 = two (hi, lo by rounding) of the values scaled by vscale = 2^eV.
+template <bool H2>
+__device__ __forceinline__ void split_store(const float (&raw)[8], unsigned char* dst, float vscale)
+{
+    if constexpr (H2) {
+        i32x4 fb[2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            int hi, lo;
+            ctdet::h2::split2(raw[2 * q] * vscale, raw[2 * q + 1] * vscale, hi, lo);
+            fb[0][q] = hi;
+            fb[1][q] = lo;
+        }
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) *reinterpret_cast<i32x4*>(dst + pc * FRAG) = fb[pc];
+    } else {
+        i32x4 fb[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            unsigned h0, m0, l0, h1, m1, l1;
+            split3(raw[2 * q], h0, m0, l0);
+            split3(raw[2 * q + 1], h1, m1, l1);
+            fb[0][q] = pack_hi(h0, h1);
+            fb[1][q] = pack_hi(m0, m1);
+            fb[2][q] = pack_hi(l0, l1);
+        }
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<i32x4*>(dst + pc * FRAG) = fb[pc];
+    }
+}
+
+// f16x2: the scale of this launch's V from the partial maxima of |input| the absmax pass left in the workspace header
+// (every workgroup computes the same value; workgroup (0, 0) records the exponent for wino4s_out)
+__device__ __forceinline__ float h2_input_scale(const Wino4sArgs& a)
+{
+    __shared__ unsigned red[4];
+    const unsigned m = ctdet::h2::block_max_of(a.hdr, a.amax_n, red);
+    const int e = ctdet::h2::exponent_for(m, ctdet::h2::kGrowthBtB);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.hdr[AMAX_SLOTS] = (unsigned)e;
+    return __builtin_ldexpf(1.f, e);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. input transform + split.  Workgroup = (32 tiles, a run of 16-channel chunks), 256 threads.  Per chunk every thread
 // loads two 6x6 patches (tile = lane & 31, channels 4 wave + h and 4 wave + 2 + h; twelve 12-byte buffer loads each,
 // out-of-map rows / columns read as zero), applies B^T d B in registers and writes the 36 values lane-linearly to LDS
 // V[point][channel][tile]; then wave w splits the points 9w .. 9w+8 -- a lane reads its 8 channels of a point, splits
 // them into three pieces and stores 16 bytes of each: one 1 KB fragment per (point, piece) and wave instruction.
+template <bool H2>
 __global__ __launch_bounds__(256, 2) void wino4s_in(const Wino4sArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -132,6 +191,9 @@ __global__ __launch_bounds__(256, 2) void wino4s_in(const Wino4sArgs a)
     const int HW = a.H * a.W;
     const int c_begin = blockIdx.y * a.chunks_per_wg, c_end = min(a.chunks, c_begin + a.chunks_per_wg);
     if (c_begin >= c_end) return;
+    constexpr int PF = (H2 ? HP : 3) * FRAG, OPBX = 4 * PF;       // bytes of a sub-block's pieces / of a chunk's operand block
+    float vscale = 1.f;
+    if constexpr (H2) vscale = h2_input_scale(a);
 
     int voffr[6];
     bool mc[6], lp;
@@ -198,8 +260,8 @@ __global__ __launch_bounds__(256, 2) void wino4s_in(const Wino4sArgs a)
     };
     const float* const vr_base = lds + (8 * h) * TB + l31;
     // destination of this workgroup's fragments inside a point's plane: (128-tile block, chunk, sub-block, piece)
-    unsigned char* const vdst = reinterpret_cast<unsigned char*>(a.V) + (size_t)(tblk >> 2) * a.chunks * OPB +
-                                (tblk & 3) * (3 * FRAG) + lane * 16;
+    unsigned char* const vdst = reinterpret_cast<unsigned char*>(a.V) + (size_t)(tblk >> 2) * a.chunks * OPBX +
+                                (tblk & 3) * PF + lane * 16;
 
     Half x0h, y0h, x1h, y1h;
     load_patch(c_begin, 0, x0h, y0h);
@@ -219,19 +281,7 @@ __global__ __launch_bounds__(256, 2) void wino4s_in(const Wino4sArgs a)
             float raw[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) raw[e] = ptr[e * TB];
-            i32x4 fb[3];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned h0, m0, l0, h1, m1, l1;
-                split3(raw[2 * q], h0, m0, l0);
-                split3(raw[2 * q + 1], h1, m1, l1);
-                fb[0][q] = pack_hi(h0, h1);
-                fb[1][q] = pack_hi(m0, m1);
-                fb[2][q] = pack_hi(l0, l1);
-            }
-            unsigned char* dst = vdst + (size_t)xi * a.v_plane + (size_t)c * OPB;
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<i32x4*>(dst + pc * FRAG) = fb[pc];
+            split_store<H2>(raw, vdst + (size_t)xi * a.v_plane + (size_t)c * OPBX, vscale);
         }
         __syncthreads();
     }
@@ -246,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void wino4s_in(const Wino4sArgs a)
 // sub-lattices of 4x4 / 3x4 / 3x3 pixels = one tile each: 2.5x fewer multiplications than the direct kernel in spite of the
 // 63 % tile fill.  Only the two transform kernels know about it; V, the GEMMs and M are as for d = 1.  Patches are 36 scalar
 // loads (stride d), no software prefetch: these layers are small.
+template <bool H2>
 __global__ __launch_bounds__(256, 2) void wino4s_in_dil(const Wino4sArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -255,6 +306,9 @@ __global__ __launch_bounds__(256, 2) void wino4s_in_dil(const Wino4sArgs a)
     const int HW = a.H * a.W, d = a.dil;
     const int c_begin = blockIdx.y * a.chunks_per_wg, c_end = min(a.chunks, c_begin + a.chunks_per_wg);
     if (c_begin >= c_end) return;
+    constexpr int PF = (H2 ? HP : 3) * FRAG, OPBX = 4 * PF;
+    float vscale = 1.f;
+    if constexpr (H2) vscale = h2_input_scale(a);
     int rowoff[6], coloff[6];
     {
         const int T = tblk * TB + l31;
@@ -278,8 +332,8 @@ __global__ __launch_bounds__(256, 2) void wino4s_in_dil(const Wino4sArgs a)
     const int chan_base = 4 * wave * HW * 4;
     float* const vw_base = lds + wave * 128 + lane;
     const float* const vr_base = lds + (8 * h) * TB + l31;
-    unsigned char* const vdst = reinterpret_cast<unsigned char*>(a.V) + (size_t)(tblk >> 2) * a.chunks * OPB +
-                                (tblk & 3) * (3 * FRAG) + lane * 16;
+    unsigned char* const vdst = reinterpret_cast<unsigned char*>(a.V) + (size_t)(tblk >> 2) * a.chunks * OPBX +
+                                (tblk & 3) * PF + lane * 16;
     for (int c = c_begin; c < c_end; ++c) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -314,19 +368,7 @@ __global__ __launch_bounds__(256, 2) void wino4s_in_dil(const Wino4sArgs a)
             float raw[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) raw[e] = ptr[e * TB];
-            i32x4 fb[3];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                unsigned h0, m0, l0, h1, m1, l1;
-                split3(raw[2 * q], h0, m0, l0);
-                split3(raw[2 * q + 1], h1, m1, l1);
-                fb[0][q] = pack_hi(h0, h1);
-                fb[1][q] = pack_hi(m0, m1);
-                fb[2][q] = pack_hi(l0, l1);
-            }
-            unsigned char* dst = vdst + (size_t)xi * a.v_plane + (size_t)c * OPB;
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) *reinterpret_cast<i32x4*>(dst + pc * FRAG) = fb[pc];
+            split_store<H2>(raw, vdst + (size_t)xi * a.v_plane + (size_t)c * OPBX, vscale);
         }
         __syncthreads();
     }
@@ -489,8 +531,215 @@ __global__ __launch_bounds__(256, 2) void wino4s_gemm(const GemmArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// f16x2 (round 6; ct_f16x2.h).  Every matrix kernel of this library sits on the same plateau -- the pipe gives ~1.0 PFLOP/s to
+// any loop that also moves its operands ("law 3") -- so the lever left is FEWER matrix instructions per
+// multiply-add.  Two binary16 pieces per value and three piece products (hi.hi, hi.lo, lo.hi) carry the same 22-24 bits as
+// three bfloat16 pieces and six products: half the MFMAs, two thirds of the V / U bytes, 2 instead of 5.5 VALU instructions
+// per split value in wino4s_in, same error against fp64 (tests/test_gpu_wino.py::test_wino_rounding_error_vs_fp64).
+//   0. wino4h_absmax  max |x| of the layer's input slice -> one partial maximum per workgroup in the workspace header (when the
+//                     producer of the input did not leave it: ct_conv_desc.in_absmax);
+//   1. wino4s_in<true>   V 2^eV as two pieces, eV from that maximum (no hi piece above 2^15, ct_f16x2.h);
+//   2. wino4h_gemm       below: the bf16x3 pipeline with 8 KB operand blocks per 16-channel k-group, KG groups per barrier;
+//   3. wino4s_out<true>  M 2^-(eU + eV), then as before.
+// Operand blocks: [point][block of 128 rows][k-group of 16][sub 4][piece 2][k half 2][row 32][8 f16].
+
+// max |x| over the [cin * H * W] floats of every image's channel slice; items of 4096 floats, one partial maximum per workgroup
+__global__ __launch_bounds__(256) void wino4h_absmax(const float* __restrict__ in, int batch, long per_image, long img_stride,
+                                                     int vec_ok, unsigned* __restrict__ partial)
+{
+    __shared__ unsigned red[4];
+    const int ipi = (int)((per_image + 4095) / 4096);
+    const long nitems = (long)batch * ipi;
+    unsigned m = 0;
+    for (long it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int n = (int)(it / ipi), sgm = (int)(it - (long)n * ipi);
+        const float* base = in + (size_t)n * img_stride;
+        const long e0 = (long)sgm * 4096;
+        if (vec_ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long e = e0 + (long)(r * 256 + threadIdx.x) * 4;
+                if (e < per_image) {                           // per_image % 4 == 0 (cin % 16 == 0)
+                    const i32x4 v = *reinterpret_cast<const i32x4*>(base + e);
+                    const unsigned a0 = (unsigned)v.x & 0x7FFFFFFFu, a1 = (unsigned)v.y & 0x7FFFFFFFu;
+                    const unsigned a2 = (unsigned)v.z & 0x7FFFFFFFu, a3 = (unsigned)v.w & 0x7FFFFFFFu;
+                    const unsigned b0 = a0 > a1 ? a0 : a1, b1 = a2 > a3 ? a2 : a3, b = b0 > b1 ? b0 : b1;
+                    m = b > m ? b : m;
+                }
+            }
+        } else {
+            for (int r = 0; r < 16; ++r) {
+                const long e = e0 + r * 256 + threadIdx.x;
+                if (e < per_image) {
+                    const unsigned a0 = __builtin_bit_cast(unsigned, base[e]) & 0x7FFFFFFFu;
+                    m = a0 > m ? a0 : m;
+                }
+            }
+        }
+    }
+    m = ctdet::h2::wave_max(m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned ab = red[0] > red[1] ? red[0] : red[1], cd = red[2] > red[3] ? red[2] : red[3];
+        partial[blockIdx.x] = ab > cd ? ab : cd;
+    }
+}
+
+// Workgroup = one point xi, 128 couts x 128 tiles, 2 x 2 waves of 64 x 64, as wino4s_gemm.  A step = KG k-groups of 16 channels
+// (KG x 16 KB in LDS: [group][A 8 KB][B 8 KB]), ring of NB steps.  The pipeline runs over k-GROUPS: the fragments of group q + 1
+// are read behind the MFMAs of group q; where q + 1 opens a new step the wave first waits for its DMA pieces of that step and
+// its own reads of the step just finished, then the barrier (the finished step's buffer is free: the DMA of step + NB goes
+// there).  DUAL: the hi.hi products in their own accumulator (the two small products, <= 2^-11 of them, in the other).
+template <bool DUAL, int KG, int NB>
+__global__ __launch_bounds__(256, 2) void wino4h_gemm(const GemmArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kg = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 1, wc = wave >> 1;
+    int wg;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid & 7, local = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    }
+    const int cb = wg % a.rowblocks;
+    const int rest = wg / a.rowblocks;
+    const int tb = rest % a.colblocks;
+    const int xi = rest / a.colblocks;
+    const unsigned strip = (unsigned)a.chunks * OPBH;
+    const int groups = a.chunks;                       // forward only: one k split
+    const int steps = groups / KG;                     // the host picks KG = 1 when groups is odd
+    const __amdgpu_buffer_rsrc_t rU = make_rsrc(a.A + (size_t)xi * a.a_plane + (size_t)cb * strip, strip);
+    const __amdgpu_buffer_rsrc_t rV = make_rsrc(a.B + (size_t)xi * a.b_plane + (size_t)tb * strip, strip);
+
+    f32x16 acc[2][2], acs[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; acs[i][j][r] = 0.f; }
+
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int voff = lane * 16;
+    constexpr int GB = 2 * OPBH;                       // LDS bytes of one k-group: A block, B block
+    constexpr int SB = KG * GB;                        // ... of one step
+    constexpr int PIECES = KG * 2 * HP;                // DMA instructions per step and wave
+    auto load_step = [&](int st, int buf) {
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+            unsigned char* Ad = lds_raw + buf * SB + g * GB + wave * (HP * FRAG);
+            unsigned char* Bd = Ad + OPBH;
+            const int soff = (st * KG + g) * OPBH + wave * (HP * FRAG);
+            (void)Ad; (void)Bd; (void)soff;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int pc = 0; pc < HP; ++pc) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rU, (lds_ptr)(Ad + pc * FRAG), 16, voff, soff + pc * FRAG, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (lds_ptr)(Bd + pc * FRAG), 16, voff, soff + pc * FRAG, 0, 0);
+            }
+#endif
+        }
+    };
+    const unsigned char* const Abase = lds_raw + (2 * wr) * (HP * FRAG) + voff;
+    const unsigned char* const Bbase = lds_raw + OPBH + (2 * wc) * (HP * FRAG) + voff;
+    const int live_r = a.rows - (cb * BM + 64 * wr), live_c = a.cols - (tb * BT + 64 * wc);
+    const bool dead = live_r <= 0 || live_c <= 0;
+    const bool on[2][2] = {{!dead, !dead && live_c > 32}, {!dead && live_r > 32, live_r > 32 && live_c > 32}};
+    auto pipeline = [&](auto ni_c, auto nj_c) {
+        constexpr int NI = decltype(ni_c)::value, NJ = decltype(nj_c)::value;
+        auto read_frags = [&](int q, i32x4 (&fa)[2][HP], i32x4 (&fb)[2][HP]) {
+            const int off = ((q / KG) % NB) * SB + (q % KG) * GB;
+            const unsigned char* A = Abase + off;
+            const unsigned char* B = Bbase + off;
+#pragma unroll
+            for (int pc = 0; pc < HP; ++pc) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) fa[i][pc] = *reinterpret_cast<const i32x4*>(A + (i * HP + pc) * FRAG);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) fb[j][pc] = *reinterpret_cast<const i32x4*>(B + (j * HP + pc) * FRAG);
+            }
+        };
+        // the three piece products, small ones first: (lo, hi) (hi, lo) (hi, hi)   [A piece, B piece]
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+        auto mfmas = [&](const i32x4 (&fa)[2][HP], const i32x4 (&fb)[2][HP]) {
+            if (NI * NJ == 1 && dead) return;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        f32x16& dst = (DUAL && p < 2) ? acs[i][j] : acc[i][j];
+                        dst = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[i][PA[p]]),
+                                                                     __builtin_bit_cast(f16x8, fb[j][PB[p]]), dst, 0, 0, 0);
+                    }
+        };
+        const int pre = steps < NB ? steps : NB;
+        for (int st = 0; st < pre; ++st) load_step(st, st);
+        // wait for step 0: the pre - 1 later steps may stay in flight
+        if (pre >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PIECES > 63 ? 63 : 3 * PIECES) : "memory");
+        else if (pre == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+        else if (pre == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        i32x4 fa0[2][HP], fb0[2][HP], fa1[2][HP], fb1[2][HP];
+        read_frags(0, fa0, fb0);
+        // before the MFMAs of group q: make group q + 1 readable
+        auto top = [&](int q) {
+            if ((q + 1) % KG != 0) return;                 // same step: its buffer is complete since the step was opened
+            const int s1 = (q + 1) / KG;                   // the step being opened; step s1 - 1 has been read by this wave
+            if (s1 < steps) {
+                // DMA groups of this wave issued after step s1: steps s1 + 1 .. min(steps - 1, s1 - 2 + NB)
+                const int later = min(steps - 1 - s1, NB - 2);
+                if (later >= 3) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(3 * PIECES > 63 ? 63 : 3 * PIECES) : "memory");
+                else if (later == 2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PIECES) : "memory");
+                else if (later == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(PIECES) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (s1 - 1 + NB < steps) load_step(s1 - 1 + NB, (s1 - 1) % NB);
+            }
+        };
+        int q = 0;
+        for (; q + 1 < groups; q += 2) {
+            top(q);
+            read_frags(q + 1, fa1, fb1);
+            mfmas(fa0, fb0);
+            top(q + 1);
+            if (q + 2 < groups) read_frags(q + 2, fa0, fb0);
+            mfmas(fa1, fb1);
+        }
+        if (q < groups) mfmas(fa0, fb0);
+    };
+    using std::integral_constant;
+    if (live_r > 32 && live_c > 32) pipeline(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+    else if (live_r > 32) pipeline(integral_constant<int, 2>{}, integral_constant<int, 1>{});
+    else if (live_c > 32) pipeline(integral_constant<int, 1>{}, integral_constant<int, 2>{});
+    else pipeline(integral_constant<int, 1>{}, integral_constant<int, 1>{});
+
+    float* const Mp = a.M + (size_t)xi * a.m_plane + (size_t)(cb * BM + 64 * wr + 4 * kg) * a.ldm + tb * BT + 64 * wc + l31;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!on[i][j]) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = DUAL ? acc[i][j][r] + acs[i][j][r] : acc[i][j][r];
+                Mp[(size_t)(32 * i + (r & 3) + 8 * (r >> 2)) * a.ldm + 32 * j] = v;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 3. output transform + epilogue.  Thread = one (cout, tile): 36 coalesced loads (lanes = 64 consecutive tiles of a
 // cout row), y = A^T M A, the epilogue of ct_wino4.hip.
+template <bool H2>
 __global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
 {
     const int T = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -502,6 +751,13 @@ __global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) m[i][j] = __builtin_nontemporal_load(src + (size_t)(i * 6 + j) * a.m_plane);
+    if constexpr (H2) {              // the f16x2 operands were scaled by 2^eU, 2^eV: exact powers of two, undone here
+        const int e = -(*a.eU + (int)a.hdr[AMAX_SLOTS]);
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[i][j] = __builtin_ldexpf(m[i][j], e);
+    }
     // A^T M A in double, rounded once: this kernel waits for HBM, the fp32 chain of ct_wino4.hip rounds ~10 times per output
     double t[6][4];
 #pragma unroll
@@ -779,6 +1035,83 @@ __global__ __launch_bounds__(256) void wino4s_wgrad_finish(const float* __restri
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// f16x2 weights: U = G g G^T in double (as the bf16x3 packing), times 2^eU, as two binary16 pieces in the GEMM operand order
+// [point 36][cout block of 128][k-group 16 ch][sub 4][piece 2][k half 2][row 32][8 f16]; eU from max |g| over the layer
+// (wino4h_wmax, one atomic per wave into the trailer behind the packed weights; the packing kernel records eU there).
+__global__ __launch_bounds__(256) void wino4h_wmax(const ctdet::WinoPackArgs p, unsigned* trailer)
+{
+    unsigned m = 0;
+    for (int part = 0; part < p.nparts; ++part) {
+        const long n = (long)(p.mbeg[part + 1] - p.mbeg[part]) * p.cin_fwd * 9;
+        const float* w = p.w[part];
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+            const unsigned a = __builtin_bit_cast(unsigned, w[i]) & 0x7FFFFFFFu;
+            m = a > m ? a : m;
+        }
+    }
+    m = ctdet::h2::wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(trailer, m);
+}
+
+// one thread = one (cout, 8 consecutive input channels, transform row i): six 16-byte stores per piece
+__global__ __launch_bounds__(256) void wino4h_pack(const ctdet::WinoPackArgs p, unsigned* trailer)
+{
+    const int eU = ctdet::h2::exponent_for(trailer[0], ctdet::h2::kGrowthGG);
+    if (blockIdx.x == 0 && threadIdx.x == 0) trailer[1] = (unsigned)eU;
+    const int rows = p.kblocks * BM;
+    const int groups8 = p.cin / 8;
+    const long total = (long)rows * groups8 * 6;
+    unsigned char* const out = reinterpret_cast<unsigned char*>(p.U);
+    const size_t plane = (size_t)p.kblocks * p.chunks * OPBH;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+        const int co = (int)(idx % rows);
+        const long rest = idx / rows;
+        const int ci8 = (int)(rest % groups8);
+        const int i = (int)(rest / groups8);
+        u32x4 v[6][2];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) v[j][pc] = u32x4{0u, 0u, 0u, 0u};
+        if (co < p.cout) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float* w = ctdet::wino_taps(p, co, ci8 * 8 + e);
+                double t[3];                                      // row i of G g
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    double o[6];
+                    if (p.dgrad) ctdet::w4::gmul6(w[(2 - 0) * 3 + (2 - c)], w[(2 - 1) * 3 + (2 - c)], w[(2 - 2) * 3 + (2 - c)], o);
+                    else ctdet::w4::gmul6(w[0 * 3 + c], w[1 * 3 + c], w[2 * 3 + c], o);
+                    t[c] = ctdet::wino_pick6(o, i);
+                }
+                double o[6];                                      // (G g) G^T, row i
+                ctdet::w4::gmul6(t[0], t[1], t[2], o);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double us = __builtin_ldexp(o[j], eU);
+                    const _Float16 hi = (_Float16)(float)us;
+                    const _Float16 lo = (_Float16)(float)(us - (double)(float)hi);
+                    const int sh = 16 * (e & 1);                  // even channel: low half-word
+                    v[j][0][e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, hi) << sh;
+                    v[j][1][e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, lo) << sh;
+                }
+            }
+        }
+        const int chunk = ci8 >> 1, kh = ci8 & 1;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int xi = i * 6 + j;
+            const int cb = co / BM, sub = (co % BM) / 32;
+            unsigned char* q = out + (size_t)xi * plane + ((((size_t)cb * p.chunks + chunk) * 4 + sub) * HP) * FRAG + (kh * 32 + co % 32) * 16;
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) *reinterpret_cast<u32x4*>(q + pc * FRAG) = v[j][pc];
+        }
+    }
+}
+
 struct WgSizes { int TY, TX, NT, tblk32, kchunks, rb, cb, splits, cps; size_t e_plane, v_plane, m_plane, m_slab, e_bytes, v_bytes, m_bytes; };
 
 WgSizes wg_sizes_of(int batch, int oh, int ow, int cin, int cout, int dil)
@@ -826,7 +1159,7 @@ bool wino4s_ok(const ct_conv_desc* d)
 
 struct Sizes { int TY, TX, NT, Tpad, kblocks, chunks; size_t v_plane, m_plane, v_bytes, m_bytes; };
 
-Sizes sizes_of(int batch, int oh, int ow, int cin, int cout, int dil)
+Sizes sizes_of(int batch, int oh, int ow, int cin, int cout, int dil, int opb = OPB)
 {
     Sizes s{};
     s.TY = ((oh + dil - 1) / dil + 3) / 4; s.TX = ((ow + dil - 1) / dil + 3) / 4;      // per sub-lattice (dil = 1: the map)
@@ -834,7 +1167,7 @@ Sizes sizes_of(int batch, int oh, int ow, int cin, int cout, int dil)
     s.Tpad = (s.NT + BT - 1) / BT * BT;
     s.kblocks = (cout + BM - 1) / BM;
     s.chunks = cin / CC;
-    s.v_plane = (size_t)(s.Tpad / BT) * s.chunks * OPB;
+    s.v_plane = (size_t)(s.Tpad / BT) * s.chunks * opb;
     s.m_plane = (size_t)s.kblocks * BM * s.Tpad;
     s.v_bytes = ctdet::align_up(s.v_plane * NXI, 256);
     s.m_bytes = s.m_plane * NXI * 4;
@@ -855,7 +1188,61 @@ extern "C" size_t ct_conv_wino4s_workspace_bytes(const ct_conv_desc* d)
 {
     if (!d || !wino4s_ok(d) || d->batch <= 0 || d->cout <= 0) return 0;
     const Sizes s = sizes_of(d->batch, d->oh, d->ow, d->cin, d->cout, d->dil);
-    return s.v_bytes + s.m_bytes;
+    return HDR_BYTES + s.v_bytes + s.m_bytes;       // any variant (the f16x2 form: header + a V two thirds the size)
+}
+
+extern "C" size_t ct_conv_wino4s_h2_packed_bytes(int cin, int cout)
+{
+    if (cin <= 0 || cout <= 0 || cin % CC) return 0;
+    return (size_t)NXI * ((cout + BM - 1) / BM) * (cin / CC) * OPBH + ctdet::kWino4hTrailerBytes;
+}
+
+static int pack_h2(const float* const* w, const int* cout, int nparts, int cin, int dgrad, void* upacked, ct_stream_t stream,
+                   const char* who)
+{
+    CT_REQUIRE(w && cout && upacked && nparts >= 1 && nparts <= 6, "%s: bad argument", who);
+    CT_REQUIRE(!ctdet::pack_recording(), "%s: the f16x2 packing takes the layer's maximum first and cannot be recorded (ct_pack_record_begin)", who);
+    ctdet::WinoPackArgs p{};
+    int tot = 0;
+    for (int i = 0; i < nparts; ++i) {
+        CT_REQUIRE(w[i] && cout[i] > 0, "%s: part %d", who, i);
+        p.w[i] = w[i];
+        p.mbeg[i] = tot;
+        tot += cout[i];
+    }
+    p.mbeg[nparts] = tot;
+    p.nparts = nparts;
+    p.dgrad = dgrad;
+    p.tile = 47;
+    p.cin_fwd = cin;
+    p.cin = dgrad ? tot : cin;
+    p.cout = dgrad ? cin : tot;
+    CT_REQUIRE(p.cin > 0 && p.cin % CC == 0, "%s: %d input channels, must be a multiple of %d", who, p.cin, CC);
+    p.chunks = p.cin / CC;
+    p.kblocks = (p.cout + BM - 1) / BM;
+    p.U = static_cast<float*>(upacked);
+    hipStream_t st = ctdet::as_stream(stream);
+    unsigned* trailer = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(upacked) + (size_t)NXI * p.kblocks * p.chunks * OPBH);
+    CT_HIP(hipMemsetAsync(trailer, 0, ctdet::kWino4hTrailerBytes, st));
+    const long nw = (long)tot * cin * 9;
+    hipLaunchKernelGGL(wino4h_wmax, dim3((int)std::min<long>((nw + 255) / 256, 1024)), dim3(256), 0, st, p, trailer);
+    CT_LAUNCH_CHECK("wino4h_wmax");
+    const long total = (long)p.kblocks * BM * (p.cin / 8) * 6;
+    hipLaunchKernelGGL(wino4h_pack, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, p, trailer);
+    CT_LAUNCH_CHECK("wino4h_pack");
+    return CT_OK;
+}
+
+extern "C" int ct_conv_pack_weights_wino4s_h2(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                              ct_stream_t stream)
+{
+    return pack_h2(w, cout, nparts, cin, 0, upacked, stream, "ct_conv_pack_weights_wino4s_h2");
+}
+
+extern "C" int ct_conv_pack_weights_wino4s_h2_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                                    ct_stream_t stream)
+{
+    return pack_h2(w, cout, nparts, cin, 1, upacked, stream, "ct_conv_pack_weights_wino4s_h2_dgrad");
 }
 
 extern "C" int ct_conv_pack_weights_wino4s(const float* const* w, const int* cout, int nparts, int cin,
@@ -880,7 +1267,8 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
         return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wino4s_fwd: needs 3x3 stride 1 pad = dilation (dilated: plain NCHW output), cin %% 16 == 0 "
                            "(got %dx%d s%d d%d p%d cin=%d nseg=%d)", d->kh, d->kw, d->stride, d->dil,
                            d->pad_h, d->cin, d->nseg);
-    CT_REQUIRE(variant == 1 || variant == 2, "ct_conv2d_wino4s_fwd: variant %d (1 = two accumulators, 2 = one)", variant);
+    CT_REQUIRE(variant >= 1 && variant <= 3, "ct_conv2d_wino4s_fwd: variant %d (1 = bf16x3 two accumulators, 2 = bf16x3 one, 3 = f16x2 two accumulators)", variant);
+    const bool h2 = variant == 3;
     CT_REQUIRE(d->batch > 0 && d->cout > 0, "ct_conv2d_wino4s_fwd: bad shape");
     CT_REQUIRE(write_full || pool_out, "ct_conv2d_wino4s_pool_fwd: nothing to write");
     CT_REQUIRE(d->dil == 1 || !pool_out, "ct_conv2d_wino4s_pool_fwd: fused pooling on a dilated layer");
@@ -903,10 +1291,11 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
     const long long img_res_bytes = d->res ? (long long)d->res_ctot * d->oh * d->ow * 4 : 0;
     CT_REQUIRE(img_out_bytes < kMaxBufBytes && img_res_bytes < kMaxBufBytes, "ct_conv2d_wino4s_fwd: one image exceeds 2 GiB");
     const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / std::max(img_in_bytes, std::max(img_out_bytes, img_res_bytes)));
+    const size_t hdr_bytes = h2 ? (size_t)HDR_BYTES : 0;
     {
-        const Sizes s = sizes_of(std::min(d->batch, max_chunk), d->oh, d->ow, d->cin, d->cout, d->dil);
-        CT_REQUIRE(workspace_bytes >= s.v_bytes + s.m_bytes, "ct_conv2d_wino4s_fwd: workspace of %zu bytes, needs %zu "
-                   "(ct_conv_wino4s_workspace_bytes)", workspace_bytes, s.v_bytes + s.m_bytes);
+        const Sizes s = sizes_of(std::min(d->batch, max_chunk), d->oh, d->ow, d->cin, d->cout, d->dil, h2 ? OPBH : OPB);
+        CT_REQUIRE(workspace_bytes >= hdr_bytes + s.v_bytes + s.m_bytes, "ct_conv2d_wino4s_fwd: workspace of %zu bytes, needs %zu "
+                   "(ct_conv_wino4s_workspace_bytes)", workspace_bytes, hdr_bytes + s.v_bytes + s.m_bytes);
         CT_REQUIRE((size_t)s.chunks * OPB < (size_t)kMaxBufBytes, "ct_conv2d_wino4s_fwd: too many input channels");
     }
     hipStream_t st = ctdet::as_stream(stream);
@@ -914,20 +1303,23 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
         std::call_once(once, [] {
-            attr_err = hipFuncSetAttribute((const void*)wino4s_in, hipFuncAttributeMaxDynamicSharedMemorySize, IN_LDS_BYTES);
-            if (attr_err == hipSuccess)
-                attr_err = hipFuncSetAttribute((const void*)wino4s_in_dil, hipFuncAttributeMaxDynamicSharedMemorySize, IN_LDS_BYTES);
-            if (attr_err == hipSuccess)
-                attr_err = hipFuncSetAttribute((const void*)wino4s_gemm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-            if (attr_err == hipSuccess)
-                attr_err = hipFuncSetAttribute((const void*)wino4s_gemm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+            const std::pair<const void*, int> fs[] = {
+                {(const void*)wino4s_in<false>, IN_LDS_BYTES}, {(const void*)wino4s_in<true>, IN_LDS_BYTES},
+                {(const void*)wino4s_in_dil<false>, IN_LDS_BYTES}, {(const void*)wino4s_in_dil<true>, IN_LDS_BYTES},
+                {(const void*)wino4s_gemm<true>, GEMM_LDS_BYTES}, {(const void*)wino4s_gemm<false>, GEMM_LDS_BYTES},
+                {(const void*)wino4h_gemm<true, 1, 4>, 4 * 2 * OPBH}, {(const void*)wino4h_gemm<true, 1, 5>, 5 * 2 * OPBH},
+                {(const void*)wino4h_gemm<true, 2, 2>, 2 * 2 * 2 * OPBH}};
+            for (const auto& f : fs)
+                if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f.first, hipFuncAttributeMaxDynamicSharedMemorySize, f.second);
         });
         CT_HIP(attr_err);
     }
+    // f16x2: k-groups per barrier / ring depth of the GEMM pipeline (measurement switch; default below)
+    static const int h2_pipe = [] { const char* e = std::getenv("CTDET_W4H_PIPE"); return e ? std::atoi(e) : 22; }();
     const int OHW = d->oh * d->ow;
     for (int b0 = 0; b0 < d->batch; b0 += max_chunk) {
         const int nb = std::min(max_chunk, d->batch - b0);
-        const Sizes s = sizes_of(nb, d->oh, d->ow, d->cin, d->cout, d->dil);
+        const Sizes s = sizes_of(nb, d->oh, d->ow, d->cin, d->cout, d->dil, h2 ? OPBH : OPB);
         Wino4sArgs a{};
         a.in = d->in + (size_t)b0 * d->in_ctot * d->h * d->w;
         a.U = static_cast<const unsigned short*>(upacked);
@@ -953,19 +1345,39 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
         a.pool_ctot = pool_ctot; a.pool_coff = pool_coff; a.pool_oh = pool_oh; a.pool_ow = pool_ow;
         a.write_full = write_full;
         a.dil = d->dil;
-        a.V = static_cast<unsigned short*>(workspace);
-        a.Mw = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + s.v_bytes);
+        a.V = reinterpret_cast<unsigned short*>(static_cast<unsigned char*>(workspace) + hdr_bytes);
+        a.Mw = reinterpret_cast<float*>(static_cast<unsigned char*>(workspace) + hdr_bytes + s.v_bytes);
         a.v_plane = s.v_plane;
-        a.u_plane = (size_t)s.kblocks * s.chunks * OPB;
+        a.u_plane = (size_t)s.kblocks * s.chunks * (h2 ? OPBH : OPB);
         a.m_plane = s.m_plane;
+        if (h2) {
+            a.hdr = static_cast<unsigned*>(workspace);
+            a.eU = reinterpret_cast<const int*>(static_cast<const unsigned char*>(upacked) + (size_t)NXI * a.u_plane) + 1;
+            // max |x| of the input slice: one partial maximum per workgroup, no atomics
+            const long per_image = (long)d->cin * d->h * d->w;
+            const long img_stride = (long)d->in_ctot * d->h * d->w;
+            const float* base = a.in + (size_t)d->in_coff * d->h * d->w;
+            const bool vec_ok = ((d->h * d->w) % 4 == 0 || (d->in_ctot % 4 == 0 && d->in_coff % 4 == 0)) &&
+                                reinterpret_cast<uintptr_t>(base) % 16 == 0;
+            const long items = (long)nb * ((per_image + 4095) / 4096);
+            a.amax_n = (int)std::min<long>(items, AMAX_SLOTS);
+            CT_PROF("wino4h_absmax", st);
+            hipLaunchKernelGGL(wino4h_absmax, dim3(a.amax_n), dim3(256), 0, st, base, nb, per_image, img_stride, vec_ok ? 1 : 0, a.hdr);
+            CT_LAUNCH_CHECK("wino4h_absmax");
+        }
         // transform: ~2048 workgroups (four rounds of two per CU) unless the layer has fewer (tile block, chunk) pairs
         const long pairs = (long)a.tblk32 * a.chunks;
         a.chunks_per_wg = (int)std::max<long>(1, std::min<long>(a.chunks, pairs / 2048));
         const int ygroups = (a.chunks + a.chunks_per_wg - 1) / a.chunks_per_wg;
         {
             CT_PROF("wino4s_in", st);
-            if (a.dil > 1) hipLaunchKernelGGL(wino4s_in_dil, dim3(a.tblk32, ygroups), dim3(256), IN_LDS_BYTES, st, a);
-            else hipLaunchKernelGGL(wino4s_in, dim3(a.tblk32, ygroups), dim3(256), IN_LDS_BYTES, st, a);
+            if (h2) {
+                if (a.dil > 1) hipLaunchKernelGGL(wino4s_in_dil<true>, dim3(a.tblk32, ygroups), dim3(256), IN_LDS_BYTES, st, a);
+                else hipLaunchKernelGGL(wino4s_in<true>, dim3(a.tblk32, ygroups), dim3(256), IN_LDS_BYTES, st, a);
+            } else {
+                if (a.dil > 1) hipLaunchKernelGGL(wino4s_in_dil<false>, dim3(a.tblk32, ygroups), dim3(256), IN_LDS_BYTES, st, a);
+                else hipLaunchKernelGGL(wino4s_in<false>, dim3(a.tblk32, ygroups), dim3(256), IN_LDS_BYTES, st, a);
+            }
             CT_LAUNCH_CHECK("wino4s_in");
         }
         {
@@ -976,13 +1388,19 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
             g.chunks = g.chunks_per_split = a.chunks; g.rowblocks = a.kblocks; g.colblocks = a.tblk128; g.ldm = a.Tpad;
             g.rows = a.M; g.cols = a.NT;
             const int nwg = NXI * a.tblk128 * a.kblocks;
-            if (variant == 1) hipLaunchKernelGGL(wino4s_gemm<true>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
+            if (h2) {
+                const int pipe = (a.chunks & 1) && h2_pipe == 22 ? 14 : h2_pipe;       // two k-groups per barrier need an even count
+                if (pipe == 22) hipLaunchKernelGGL((wino4h_gemm<true, 2, 2>), dim3(nwg), dim3(256), 2 * 2 * 2 * OPBH, st, g);
+                else if (pipe == 15) hipLaunchKernelGGL((wino4h_gemm<true, 1, 5>), dim3(nwg), dim3(256), 5 * 2 * OPBH, st, g);
+                else hipLaunchKernelGGL((wino4h_gemm<true, 1, 4>), dim3(nwg), dim3(256), 4 * 2 * OPBH, st, g);
+            } else if (variant == 1) hipLaunchKernelGGL(wino4s_gemm<true>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
             else hipLaunchKernelGGL(wino4s_gemm<false>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
             CT_LAUNCH_CHECK("wino4s_gemm");
         }
         {
             CT_PROF("wino4s_out", st);
-            hipLaunchKernelGGL(wino4s_out, dim3((a.NT + 63) / 64, (a.M + 3) / 4), dim3(256), 0, st, a);
+            if (h2) hipLaunchKernelGGL(wino4s_out<true>, dim3((a.NT + 63) / 64, (a.M + 3) / 4), dim3(256), 0, st, a);
+            else hipLaunchKernelGGL(wino4s_out<false>, dim3((a.NT + 63) / 64, (a.M + 3) / 4), dim3(256), 0, st, a);
             CT_LAUNCH_CHECK("wino4s_out");
         }
     }

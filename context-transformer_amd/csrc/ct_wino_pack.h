@@ -30,6 +30,13 @@ constexpr int kWino4sBM = 128;                      // ct_wino4s.hip: output cha
 constexpr int kWino4sFragBytes = 1024;              // one MFMA operand fragment: [k half 2][row 32][8 bf16]
 constexpr int kWino4sChunkBytes = 4 * 3 * kWino4sFragBytes;   // [sub 4][piece 3] of one (128-row block, 16-channel chunk)
 
+// the f16x2 operand form of the same kernels (ct_f16x2.h; variant 3 of ct_conv2d_wino4s_fwd): two binary16 pieces, and a 256-byte
+// trailer behind the packed weights with { bit pattern of max |g|, exponent eU } (the weights are stored as U 2^eU)
+constexpr int kWino4hChunkBytes = 4 * 2 * kWino4sFragBytes;   // [sub 4][piece 2] of one (128-row block, 16-channel chunk)
+constexpr int kWino4hTrailerBytes = 256;
+constexpr int kWino4hAmaxSlots = 1024;                        // workspace header: partial maxima of |input|, one per absmax workgroup
+constexpr int kWino4hHeaderBytes = 2 * kWino4hAmaxSlots * 4;  // ... followed by the exponent eV the input transform chose
+
 // ct_wino4f.hip (fused F(4x4,3x3) on bf16x3): per (cout block of 64, 16-channel chunk) eight wave regions of nine 3 KB
 // "units" = (transform point, cout half), each [piece 3][lane 64][8 bf16]
 constexpr int kWino4fUnitBytes = 3 * 1024;

@@ -142,6 +142,9 @@ SIGNATURES = {
     'ct_conv_wino4s_workspace_bytes': (_Z, [C.POINTER(ConvDesc)]),
     'ct_conv_pack_weights_wino4s': (_I, [_P, _P, _I, _I, _P, _P]),
     'ct_conv_pack_weights_wino4s_dgrad': (_I, [_P, _P, _I, _I, _P, _P]),
+    'ct_conv_wino4s_h2_packed_bytes': (_Z, [_I, _I]),
+    'ct_conv_pack_weights_wino4s_h2': (_I, [_P, _P, _I, _I, _P, _P]),
+    'ct_conv_pack_weights_wino4s_h2_dgrad': (_I, [_P, _P, _I, _I, _P, _P]),
     'ct_conv2d_wino4s_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _Z, _I, _P]),
     'ct_conv2d_wino4s_pool_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _Z, _I, _P, _I, _I, _I, _I, _I, _P]),
     'ct_conv_wino4f_supported': (_I, [C.POINTER(ConvDesc)]),

@@ -351,17 +351,20 @@ WINOXQ = -5        # ... one accumulator, four-wave workgroups (two per CU)
 WINO4S = -6        # ... F(4x4,3x3) as transform / bf16x3 GEMM / transform kernels, two accumulators (csrc/ct_wino4s.hip)
 WINO4SQ = -7       # ... one accumulator
 WINO4F = -8        # ... F(4x4,3x3) fused on bf16x3, one 64-cout block per workgroup (csrc/ct_wino4f.hip): the narrow layers on big maps
+WINO4H = -9        # ... the three-kernel form on the f16x2 operand form (two binary16 pieces, three products; csrc/ct_f16x2.h)
 # st.rt['wino'] values: 2, 4 = the fp32-MFMA kernels' tile sizes; F(2x2,3x3) on bf16x3: 23 = two accumulators (eight
 # waves), 24 = one accumulator in the four-wave / two-workgroups-per-CU form
 # 44 / 45 = F(4x4,3x3) in the three-kernel form with the GEMMs on bf16x3 (two / one accumulator); 46 = F(4x4,3x3) fused on bf16x3
-WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXQ: 24, WINO4S: 44, WINO4SQ: 45, WINO4F: 46}
-WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 24: 'winoxq', 44: 'wino4s', 45: 'wino4sq', 46: 'wino4f'}
+# 47 = the three-kernel form with its GEMMs on f16x2 (two binary16 pieces, three products, two accumulators)
+WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXQ: 24, WINO4S: 44, WINO4SQ: 45, WINO4F: 46, WINO4H: 47}
+WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 24: 'winoxq', 44: 'wino4s', 45: 'wino4sq', 46: 'wino4f', 47: 'wino4h'}
 WINOX_TILES = (23, 24)
 WINOX_VARIANT = {23: 1, 24: 2}               # the `variant` argument of ct_conv2d_wino_x3_fwd
-WINO4S_TILES = (44, 45)
-WINO4S_VARIANT = {44: 1, 45: 2}              # the `variant` argument of ct_conv2d_wino4s_fwd
+WINO4S_TILES = (44, 45, 47)
+WINO4S_VARIANT = {44: 1, 45: 2, 47: 3}       # the `variant` argument of ct_conv2d_wino4s_fwd
+WINO4H_TILES = (47,)                         # ... whose weights come from ct_conv_pack_weights_wino4s_h2
 WINO4F_TILES = (46,)
-F4_TILES = (4, 44, 45, 46)                   # every variant with F(4x4,3x3)'s rounding (accuracy policies treat them alike)
+F4_TILES = (4, 44, 45, 46, 47)               # every variant with F(4x4,3x3)'s rounding (accuracy policies treat them alike)
 
 
 class HipBackend:
@@ -495,13 +498,16 @@ class HipBackend:
             raise _lib.CtdetError('%s: geometry has no Winograd path' % st.name)
         rt['x3'] = None
         if tile not in (2, 4) + WINOX_TILES + WINO4S_TILES + WINO4F_TILES:
-            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23, 24, 44, 45 or 46)' % (st.name, tile))
+            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23, 24, 44, 45, 46 or 47)' % (st.name, tile))
         if tile not in WINO4S_TILES:
             rt.pop('ws4s_bytes', None)
         if tile in WINO4S_TILES:
             if not rt.get('wino4s_ok'):
                 raise _lib.CtdetError('%s: geometry has no three-kernel Winograd path (cin %% 16)' % st.name)
-            if 'U4S' not in rt:
+            if tile in WINO4H_TILES:
+                if 'U4H' not in rt:
+                    rt['U4H'] = self.alloc((self.lib.ct_conv_wino4s_h2_packed_bytes(st.cin, st.cout),), torch.uint8)
+            elif 'U4S' not in rt:
                 rt['U4S'] = self.alloc((self.lib.ct_conv_wino4s_packed_bytes(st.cin, st.cout),), torch.uint8)
             rt['ws4s_bytes'] = self.lib.ct_conv_wino4s_workspace_bytes(C.byref(rt['desc']))
             self.ws_reserve(rt.get('ws_key', 0), rt['ws4s_bytes'])
@@ -534,6 +540,10 @@ class HipBackend:
         if st.rt['wino'] in WINOX_TILES:
             _lib.check(self.lib.ct_conv_pack_weights_wino_x3(ptrs, couts, n, st.cin, st.rt['UX'].data_ptr(), self._stream()),
                        'ct_conv_pack_weights_wino_x3')
+            return
+        if st.rt['wino'] in WINO4H_TILES:
+            _lib.check(self.lib.ct_conv_pack_weights_wino4s_h2(ptrs, couts, n, st.cin, st.rt['U4H'].data_ptr(), self._stream()),
+                       'ct_conv_pack_weights_wino4s_h2')
             return
         if st.rt['wino'] in WINO4S_TILES:
             _lib.check(self.lib.ct_conv_pack_weights_wino4s(ptrs, couts, n, st.cin, st.rt['U4S'].data_ptr(), self._stream()),
@@ -606,7 +616,8 @@ class HipBackend:
     def run_conv(self, st):
         tile = st.rt.get('wino')
         if tile in WINO4S_TILES:         # F(4x4,3x3): transform / bf16x3 GEMM / transform (csrc/ct_wino4s.hip)
-            lib, U, ws, var = self.lib, st.rt['U4S'].data_ptr(), self.ws_pool[st.rt.get('ws_key', 0)], WINO4S_VARIANT[tile]
+            lib, U, ws, var = self.lib, st.rt['U4H' if tile in WINO4H_TILES else 'U4S'].data_ptr(), \
+                self.ws_pool[st.rt.get('ws_key', 0)], WINO4S_VARIANT[tile]
             pool = st.rt.get('pool')
             if pool is not None:
                 t, poh, pow_, full = pool
@@ -791,6 +802,8 @@ def wino_tiles(backend=None, st=None):
     ctx_w4s_min_cin input channels up, see apply_tuned)."""
     env = os.environ.get('CTDET_WINO_TILES')
     tiles = tuple(int(t) for t in (env or '2,4,44,46').split(',') if t)
+    if env is None and getattr(backend, 'h2', False):
+        tiles = tiles + H2_OF_TILE_VALUES
     allowed = getattr(backend, 'wino_tile_set', None)
     if allowed is not None:             # a runtime's accuracy policy: its set, narrowed by an explicit CTDET_WINO_TILES
         tiles = tuple(t for t in allowed if env is None or t in tiles)
@@ -807,6 +820,18 @@ def wino_tiles(backend=None, st=None):
     if st is not None and not st.rt.get('wino_ok'):          # dilated 3x3: only the three-kernel form
         tiles = tuple(t for t in tiles if t in WINO4S_TILES)
     return tiles
+
+
+# bf16x3 tile -> the same kernel on the f16x2 operand form (csrc/ct_f16x2.h: two binary16 pieces, three products)
+H2_OF_TILE = {44: 47}
+H2_OF_TILE_VALUES = tuple(H2_OF_TILE.values())
+
+
+def operand_form_h2(net):
+    """Whether an inference runtime runs its bf16x3 Winograd table entries on the f16x2 operand form (CTDET_H2, default on;
+    off for the networks with an accuracy policy, whose sweeps were made on bf16x3: ctx_tile_set).  Same error against
+    fp64 per layer (tests/test_gpu_wino.py::test_wino_rounding_error_vs_fp64), half the matrix instructions."""
+    return os.environ.get('CTDET_H2', '1') != '0' and ctx_tile_set(net) is None
 
 
 CTX_TILES_DEFAULT = '2,23'
@@ -930,6 +955,8 @@ def apply_tuned(backend, st, batch, wino4=True):
         elif want not in allowed:
             # a three-kernel / fused-bf16x3 F(4x4) entry without its tile in the set (CTDET_WINO_TILES=2,4) is the fused fp32 F(4x4) kernel's layer
             want = 4 if want in WINO4S_TILES + WINO4F_TILES and 4 in allowed else 2 if 2 in allowed or not allowed else allowed[0]
+        if getattr(backend, 'h2', False) and H2_OF_TILE.get(want) in allowed:
+            want = H2_OF_TILE[want]         # the same kernel on the f16x2 operand form (operand_form_h2)
         backend.enable_wino(st, tile=want)
         return True
     if isinstance(cfg, str) and cfg.startswith('x3:'):
@@ -996,6 +1023,7 @@ class Runtime:
         # live autotune only for shapes the table does not know (CTDET_TUNE=0 disables, =2 forces)
         mode = os.environ.get('CTDET_TUNE', '1') if tune is None else ('1' if tune else '0')
         backend.wino_tile_set = ctx_tile_set(net)
+        backend.h2 = operand_form_h2(net)
         backend.wino4_max_cin = ctx_f4_max_cin(net)
         backend.ctx_w4s_min_cin = ctx_w4s_min_cin(net)
         self.tuned = False

@@ -336,14 +336,26 @@ int ct_conv2d_wino_x3_pool_fwd(const ct_conv_desc* desc, const void* upacked, in
  * the loop); an output-transform kernel applies A^T M A and the epilogue.  V and M live in the caller's `workspace`
  * (ct_conv_wino4s_workspace_bytes(desc) bytes: 13.5 bytes per (output pixel, input channel) + 9 per (output pixel,
  * output channel); launches on different streams need different workspaces).  Weights: ct_conv_pack_weights_wino4s
- * (ct_conv_wino4s_packed_bytes bytes).  variant 1: the hi.hi products in their own accumulator; 2: one accumulator. */
+ * (ct_conv_wino4s_packed_bytes bytes).  variant 1: the hi.hi products in their own accumulator; 2: one accumulator.
+ * variant 3 (round 6): the "f16x2" operand form -- every transform-domain value as TWO binary16 pieces (hi = rne16(x 2^e),
+ * lo = rne16(x 2^e - hi)) and a multiply-add as the THREE piece products hi.hi, hi.lo, lo.hi on the f16 matrix pipe, the hi.hi
+ * products in their own accumulator: the same 22-24 bits as three bfloat16 pieces / six products (same error against fp64), half
+ * the matrix instructions, 9 instead of 13.5 bytes of V per (output pixel, input channel).  The power-of-two scales 2^e come from
+ * the operands' own maxima (an absmax pass over the input slice in front of the input transform; max |g| of the layer at
+ * packing time), so no binary16 piece overflows for any data; the output transform undoes them exactly.  Weights for variant 3:
+ * ct_conv_pack_weights_wino4s_h2 (ct_conv_wino4s_h2_packed_bytes bytes; not recordable by ct_pack_record_begin). */
 int ct_conv_wino4s_supported(const ct_conv_desc* desc);
 size_t ct_conv_wino4s_packed_bytes(int cin, int cout);
+size_t ct_conv_wino4s_h2_packed_bytes(int cin, int cout);
 size_t ct_conv_wino4s_workspace_bytes(const ct_conv_desc* desc);
 int ct_conv_pack_weights_wino4s(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
                                 ct_stream_t stream);
 int ct_conv_pack_weights_wino4s_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
                                       ct_stream_t stream);
+int ct_conv_pack_weights_wino4s_h2(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                   ct_stream_t stream);
+int ct_conv_pack_weights_wino4s_h2_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                         ct_stream_t stream);
 int ct_conv2d_wino4s_fwd(const ct_conv_desc* desc, const void* upacked, void* workspace, size_t workspace_bytes,
                          int variant, ct_stream_t stream);
 int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* desc, const void* upacked, void* workspace, size_t workspace_bytes,

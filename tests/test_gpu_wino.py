@@ -15,9 +15,10 @@ from test_gpu_kernels import _bn, _ref_conv, _run_conv
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 W = engine.WINO
-VARIANTS = [engine.WINO, engine.WINO4, engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ, engine.WINO4F]
-VIDS = ['f2x2', 'f4x4', 'f2x2_x3', 'f2x2_x3q', 'f4x4_s', 'f4x4_sq', 'f4x4_f']
-X3V = (engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ, engine.WINO4F)         # cin must be a multiple of 16 (one bf16 MFMA k-group)
+VARIANTS = [engine.WINO, engine.WINO4, engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ, engine.WINO4F, engine.WINO4H]
+VIDS = ['f2x2', 'f4x4', 'f2x2_x3', 'f2x2_x3q', 'f4x4_s', 'f4x4_sq', 'f4x4_f', 'f4x4_h']
+X3V = (engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ, engine.WINO4F, engine.WINO4H)         # cin must be a multiple of 16 (one MFMA k-group)
+S3V = (engine.WINO4S, engine.WINO4SQ, engine.WINO4H)                                     # the three-kernel forms (dilated layers too)
 
 
 def _cin(W, cin):
@@ -54,7 +55,7 @@ DIL_CASES = [  # name, B, Cin, H, W, Cout, dilation -- conv6 (d 6 @19x19) and th
 ]
 
 
-@pytest.mark.parametrize('W', [engine.WINO4S, engine.WINO4SQ], ids=['f4x4_s', 'f4x4_sq'])
+@pytest.mark.parametrize('W', list(S3V), ids=['f4x4_s', 'f4x4_sq', 'f4x4_h'])
 @pytest.mark.parametrize('case', DIL_CASES, ids=[c[0] for c in DIL_CASES])
 def test_wino4s_dilated_layers(case, W):
     """Dilated 3x3 layers (pad = dilation) on the three-kernel form: the d x d sub-lattices are tiled like small images
@@ -104,7 +105,7 @@ def test_wino_rejects_other_geometries(W):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1, 16, 9, 9, generator=g)
     # the three-kernel form takes dilated layers with pad = dilation (test_wino4s_dilated_layers); pad != dilation stays out
-    dilated = (3, 1, 1, 2, 16) if W in (engine.WINO4S, engine.WINO4SQ) else (3, 1, 2, 2, 16)
+    dilated = (3, 1, 1, 2, 16) if W in S3V else (3, 1, 2, 2, 16)
     for (k, stride, pad, dil, cin) in ((3, 2, 1, 1, 16), dilated, (1, 1, 0, 1, 16), (3, 1, 0, 1, 16)):
         w = torch.randn(8, cin, k, k, generator=g)
         with pytest.raises(_lib.CtdetError):
@@ -202,7 +203,8 @@ def test_conv_input_above_2gib_is_chunked(use_wino):
 
 
 @pytest.mark.parametrize('W,bound', [(engine.WINO, 3e-6), (engine.WINO4, 5e-5), (engine.WINOX, 1e-6), (engine.WINOXQ, 2e-6),
-                                     (engine.WINO4S, 6e-6), (engine.WINO4SQ, 1.2e-5), (engine.WINO4F, 1.2e-5)], ids=VIDS)
+                                     (engine.WINO4S, 6e-6), (engine.WINO4SQ, 1.2e-5), (engine.WINO4F, 1.2e-5), (engine.WINO4H, 6e-6)],
+                         ids=VIDS)
 def test_wino_rounding_error_vs_fp64(W, bound):
     """The transform-domain rounding of each variant on the deepest VGG shape (512 input channels, post-ReLU input):
     max error over the output range against an fp64 convolution.  Measured 1e-6 for F(2x2,3x3) and 2e-5 for

@@ -39,7 +39,7 @@ for name in names:
     if os.environ.get('CHECK', '1') != '0' and B * Cin * H * W <= 64 << 20:
         ref = torch.relu(torch.nn.functional.conv2d(bufs['x'].double(), w.double(), b.double(), padding=1))
     for tile in [int(t) for t in os.environ.get('TILES', '2,4,23,24,44,45,46').split(',')]:
-        if tile in (23, 24, 44, 45, 46) and Cin % 16:
+        if tile in (23, 24, 44, 45, 46, 47, 48) and Cin % 16:
             continue
         be.enable_wino(st, tile=tile)
         bufs['y'].fill_(float('nan'))
@@ -57,10 +57,11 @@ for name in names:
         ms = e0.elapsed_time(e1) / iters
         fl = st.flops(B)
         # executed matrix work: F(2x2) 16/36, F(4x4) 36/144 of the direct count; bf16x3 = six bf16 products each
-        ex = 0.25 if tile == 4 else 0.25 * 6 if tile in (44, 45, 46) else (16 / 36) * (6 if tile in (23, 24) else 1)
-        peak = 2500.0 if tile in (23, 24, 44, 45, 46) else 157.3
+        # f16x2 (47, 48): three f16 products each
+        ex = 0.25 if tile == 4 else 0.25 * 6 if tile in (44, 45, 46) else 0.25 * 3 if tile in (47, 48) else (16 / 36) * (6 if tile in (23, 24) else 1)
+        peak = 2500.0 if tile in (23, 24, 44, 45, 46, 47, 48) else 157.3
         stages = ''
-        if os.environ.get('STAGES') and tile in (44, 45):
+        if os.environ.get('STAGES') and tile in (44, 45, 47):
             # the three kernels of the launch by the library's own profile scopes (HIP events on the launch stream)
             import ctypes as C
             lib = _lib.lib()
@@ -77,7 +78,7 @@ for name in names:
             for i in range(cnt.value):
                 a = agg.setdefault(recs[i].name.decode(), [0.0, 0])
                 a[0] += recs[i].ms; a[1] += 1
-            stages = '  [' + '  '.join('%s %.1f us' % (k.replace('wino4s_', ''), v[0] / v[1] * 1e3) for k, v in agg.items()) + ']'
+            stages = '  [' + '  '.join('%s %.1f us' % (k.replace('wino4s_', '').replace('wino4h_', ''), v[0] / v[1] * 1e3) for k, v in agg.items()) + ']'
         print('%-10s F%-2d %4d->%-4d @%3dx%-3d bs%-2d  %8.1f us  %6.1f TF algorithmic  %6.1f TF executed = %.3f of %.1f%s'
               % (name, tile, Cin, Cout, H, W, B, ms * 1e3, fl / ms / 1e9, fl / ms / 1e9 * ex, fl / ms / 1e9 * ex / peak, peak, err + stages),
               flush=True)
