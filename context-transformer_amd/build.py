@@ -64,7 +64,7 @@ def _compile(src, flags, force):
     path = os.path.join(CSRC, src)
     deps = [path, os.path.join(REPO, 'include', 'ctdet.h'), os.path.join(CSRC, 'ct_common.h'),
             os.path.join(CSRC, 'ct_attn_common.h'), os.path.join(CSRC, 'ct_wino_pack.h'),
-            os.path.join(CSRC, 'ct_wino4_points.h'), os.path.join(CSRC, 'ct_wino4_emit.h'), __file__]
+            os.path.join(CSRC, 'ct_wino4_points.h'), os.path.join(CSRC, 'ct_wino4_emit.h'), os.path.join(CSRC, 'ct_f16x2.h'), __file__]
     if force or any(_newer(d, obj) for d in deps):
         cmd = [hipcc()] + COMMON + flags + os.environ.get('CTDET_EXTRA_FLAGS', '').split() + ['-x', 'hip', '-c', path, '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -24,6 +24,7 @@
 // k ordering: k = ci*KH*KW + tap (the natural [cout][cin][kh][kw] order); a k-step covers
 // CPB whole input channels so the row -> (channel, tap) split is a compile-time constant.
 #include "ct_common.h"
+#include "ct_f16x2.h"
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
@@ -61,6 +62,7 @@ struct ConvArgs {
     int transposed;
     int ksplit, steps_per_split;    // > 1: blockIdx.y owns k-steps [y*sps, (y+1)*sps) and writes its raw sums to ws
     float* ws;                      // [ksplit][M][Npix] partial sums, reduced in fixed order by conv_splitk_epilogue
+    unsigned* out_amax;             // conv_valu3x3_f32 only: ct_conv_desc.out_absmax (max |y| of what the launch stores), or null
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -389,6 +391,8 @@ __global__ __launch_bounds__(256) void conv_valu3x3_f32(const ConvArgs a)
     cfloat* const sc = (cfloat*)a.scale;
     cfloat* const sh = (cfloat*)a.shift;
     cfloat* const lo = (cfloat*)a.lo;
+    float amax_run = 0.f;                     // a.out_amax: the thread's maximum of |v| over what it stores
+    const bool track = a.out_amax != nullptr;
     for (int co0 = 0; co0 < a.M; co0 += 8) {
         f32x2 acc[PPT][4];
 #pragma unroll
@@ -449,10 +453,14 @@ __global__ __launch_bounds__(256) void conv_valu3x3_f32(const ConvArgs a)
             for (int p = 0; p < PPT; ++p) {
                 float v = (j & 1 ? acc[p][j >> 1].y : acc[p][j >> 1].x) * scv + shv;
                 v = v < lov ? lov : v;                  // NaN propagates
-                if (live[p]) op[p][(size_t)co * a.OHW] = v;
+                if (live[p]) {
+                    op[p][(size_t)co * a.OHW] = v;
+                    if (track) ctdet::h2::track_absmax(amax_run, v);
+                }
             }
         }
     }
+    if (track) ctdet::h2::wave_atomic_absmax(a.out_amax, blockIdx.x, amax_run);       // one atomic per wave
 }
 
 // epilogue of a split-K convolution: sum of the slabs in split order, then the same arithmetic as the fused one
@@ -780,6 +788,7 @@ extern "C" int ct_conv2d_fwd(const ct_conv_desc* d, ct_stream_t stream)
         a.stride = d->stride; a.pad_h = d->pad_h; a.pad_w = d->pad_w; a.dil = d->dil;
         a.OW = d->ow; a.OHW = d->oh * d->ow; a.Npix = d->batch * a.OHW;
         a.out_ctot = d->out_ctot; a.out_coff = d->out_coff; a.relu = d->relu;
+        a.out_amax = d->out_absmax;
         static const int ppt = getenv("CTDET_VALU_PPT") ? atoi(getenv("CTDET_VALU_PPT")) : 2;
         if (ppt == 1)
             hipLaunchKernelGGL((conv_valu3x3_f32<3, 1>), dim3((a.Npix + 255) / 256), dim3(256), 0, ctdet::as_stream(stream), a);

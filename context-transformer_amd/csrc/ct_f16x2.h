@@ -65,13 +65,22 @@ __device__ __forceinline__ unsigned wave_max(unsigned m)
     return m;
 }
 
+// A "slot" (ct_conv_desc.in_absmax / out_absmax, CT_ABSMAX_SLOT_BYTES): sixteen words, one per 128-byte line
+constexpr int kSlotLines = 16, kSlotStride = 32;
+
+// the maximum a slot holds, computed by one wave (every lane gets it)
+__device__ __forceinline__ unsigned slot_max(const unsigned* __restrict__ slot)
+{
+    return wave_max(slot[(threadIdx.x & (kSlotLines - 1)) * kSlotStride]);
+}
+
 // Every thread of a 256-thread workgroup gets the maximum of partial[0 .. n): the consumer side of an absmax pass whose
 // workgroups each left one partial maximum (no atomics, no zero-initialisation, the same value in every launch).
-__device__ __forceinline__ unsigned block_max_of(const unsigned* __restrict__ partial, int n, unsigned* red /* LDS [4] */)
+__device__ __forceinline__ unsigned block_max_of(const unsigned* __restrict__ partial, int n, int stride, unsigned* red /* LDS [4] */)
 {
     unsigned m = 0;
     for (int i = threadIdx.x; i < n; i += 256) {
-        const unsigned v = partial[i];
+        const unsigned v = partial[(size_t)i * stride];
         m = v > m ? v : m;
     }
     m = wave_max(m);
@@ -84,10 +93,17 @@ __device__ __forceinline__ unsigned block_max_of(const unsigned* __restrict__ pa
 
 // The producer side where a kernel's epilogue knows the values it stores: wave maximum of |v| (bit pattern), one atomic per
 // wave into a scalar the runtime zeroes once per step.
-__device__ __forceinline__ void wave_atomic_absmax(unsigned* dst, float v_absmax_candidate)
+__device__ __forceinline__ void wave_atomic_absmax(unsigned* slot, unsigned line, float v_absmax_candidate)
 {
     const unsigned m = wave_max(__builtin_bit_cast(unsigned, v_absmax_candidate) & 0x7FFFFFFFu);
-    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(dst, m);
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(slot + (line & (kSlotLines - 1)) * kSlotStride, m);
+}
+
+// running maximum of |v| in a thread (NaN sticks: the unsigned order puts it above everything)
+__device__ __forceinline__ void track_absmax(float& run, float v)
+{
+    const unsigned a = __builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu, r = __builtin_bit_cast(unsigned, run);
+    run = __builtin_bit_cast(float, a > r ? a : r);
 }
 
 }  // namespace h2

@@ -2,6 +2,7 @@
 // and ct_wino4s.hip (three-kernel bf16x3 form) apply the same arithmetic to their output-transformed sums.  Internal header.
 #pragma once
 #include "ct_common.h"
+#include "ct_f16x2.h"
 
 namespace ctdet {
 namespace w4 {
@@ -11,15 +12,18 @@ constexpr int kEmitInvalidOff = 0x7FFFFFF0;
 
 // y = A^T M A of one tile.  *scale + shift, residual, ReLU / per-channel floor (NaN propagates), the four 2x2 pooling
 // windows a 4x4 tile holds, NCHW or head-scatter stores.  Args: any record with the epilogue fields of Wino4Args.
+// ymul: a factor folded into the per-channel scale (the f16x2 kernels' 2^-(eU + eV): exact).  track / amax_run: the thread's
+// running maximum of |v| over everything this call stores (ct_conv_desc.out_absmax; the caller folds it into the slot once, at
+// the end of the kernel) -- a reference and a flag, not a nullable pointer, so that the value stays in a register.
 template <class Args>
 __device__ __forceinline__ void emit_tile4(const Args& a, const __amdgpu_buffer_rsrc_t rout,
                                            const __amdgpu_buffer_rsrc_t rres, const int n, const int ty, const int tx,
-                                           const int co, const float (&y)[4][4])
+                                           const int co, const float (&y)[4][4], const float ymul, const bool track, float& amax_run)
 {
     const int OH = a.H, OW = a.W;                      // pad 1, stride 1: same spatial size
     const int oy = 4 * ty, ox = 4 * tx;
     const bool c1 = ox + 1 < OW, c2 = ox + 2 < OW, c3 = ox + 3 < OW;
-    float sc = a.scale[co], sh = a.shift[co];
+    float sc = a.scale[co] * ymul, sh = a.shift[co];
     float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
     // The three per-channel values are needed by every row below, and every row sits behind its own `yy >= OH` test: left
     // alone, the compiler waits for these loads at the first use in EACH row block with s_waitcnt vmcnt(0) -- which from the
@@ -46,6 +50,12 @@ __device__ __forceinline__ void emit_tile4(const Args& a, const __amdgpu_buffer_
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = v[j] < lo ? lo : v[j];      // NaN propagates
+        if (track) {
+            ctdet::h2::track_absmax(amax_run, v[0]);
+            if (c1) ctdet::h2::track_absmax(amax_run, v[1]);
+            if (c2) ctdet::h2::track_absmax(amax_run, v[2]);
+            if (c3) ctdet::h2::track_absmax(amax_run, v[3]);
+        }
         pl[i >> 1][0] = fmaxf(pl[i >> 1][0], c1 ? fmaxf(v[0], v[1]) : v[0]);
         if (c2) pl[i >> 1][1] = fmaxf(pl[i >> 1][1], c3 ? fmaxf(v[2], v[3]) : v[2]);
         if (!a.write_full) continue;
@@ -88,6 +98,15 @@ __device__ __forceinline__ void emit_tile4(const Args& a, const __amdgpu_buffer_
                     a.pool_out[(((size_t)n * a.pool_ctot + a.pool_coff + co) * a.pool_oh + py) * a.pool_ow + px] = pl[pi][pj];
             }
     }
+}
+
+template <class Args>
+__device__ __forceinline__ void emit_tile4(const Args& a, const __amdgpu_buffer_rsrc_t rout,
+                                           const __amdgpu_buffer_rsrc_t rres, const int n, const int ty, const int tx,
+                                           const int co, const float (&y)[4][4])
+{
+    float unused = 0.f;
+    emit_tile4(a, rout, rres, n, ty, tx, co, y, 1.f, false, unused);
 }
 
 }  // namespace w4

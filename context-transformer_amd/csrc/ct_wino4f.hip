@@ -30,13 +30,16 @@
 #include "ct_wino_pack.h"
 #include "ct_wino4_points.h"
 #include "ct_wino4_emit.h"
+#include "ct_f16x2.h"
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <mutex>
 
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -59,9 +62,13 @@ constexpr int STAGE_BYTES = 8 * STAGE_WAVE_BYTES;          // 72 KB
 constexpr int MXI = 32 * 32;                // output staging M[point][cout 32][tile 32]
 constexpr int W4F_LDS_BYTES = NXI * MXI * 4;               // 144 KB = V + patch stage
 static_assert(V_BYTES + STAGE_BYTES == W4F_LDS_BYTES, "LDS plan");
-constexpr int UNIT_BYTES = ctdet::kWino4fUnitBytes;
-constexpr int U_WAVE_BYTES = ctdet::kWino4fWaveBytes;
-constexpr int U_CHUNK_BYTES = ctdet::kWino4fChunkBytes;
+// U "units" = (transform point, cout half) of a wave: bf16x3 [piece 3][lane 64][16 B], f16x2 (H2, ct_f16x2.h) [piece 2][lane 64][16 B]
+template <bool H2> struct ULayout {
+    static constexpr int NP = H2 ? 2 : 3;                                   // pieces per value
+    static constexpr int UNIT = H2 ? ctdet::kWino4fhUnitBytes : ctdet::kWino4fUnitBytes;
+    static constexpr int WAVE = H2 ? ctdet::kWino4fhWaveBytes : ctdet::kWino4fWaveBytes;
+    static constexpr int CHUNK = H2 ? ctdet::kWino4fhChunkBytes : ctdet::kWino4fChunkBytes;
+};
 
 struct Wino4fArgs {
     const float* in;
@@ -82,6 +89,11 @@ struct Wino4fArgs {
     int pool_ctot, pool_coff, pool_oh, pool_ow, write_full;
     int nseg;                // > 0: channels-last scatter into the flattened head buffers (ct_out_segment)
     ct_out_segment seg[3];
+    // f16x2 form (H2): V is split as V 2^eV with eV from the producer's maximum of |input| (ct_conv_desc.in_absmax), U arrives as
+    // U 2^eU (eU in the trailer of the packed weights); the epilogue's per-channel scale takes 2^-(eU + eV)
+    const unsigned* in_amax;
+    const int* eU;
+    unsigned* out_amax;      // any form: ct_conv_desc.out_absmax, max |y| of what the launch stores, or null
 };
 
 // The epilogue's view of the arguments (ct_wino4_emit.h is a template over any record with these members).  The persistent
@@ -144,10 +156,12 @@ __device__ unsigned long long* g_w4f_trace = nullptr;
 // PLAIN: no residual, no per-channel floor, no head scatter (a.res == a.lo == nullptr, a.nseg == 0): what the narrow trunk layers
 // this kernel exists for use (bias + ReLU, optionally the fused 2x2 max-pool) -- the epilogue then needs a third of the scalar
 // registers and none of those branches.
-template <bool SEG, bool PLAIN>
+template <bool SEG, bool PLAIN, bool H2>
 __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
 {
     const Wino4fArgs& a = a_in;
+    typedef ULayout<H2> UL;
+    constexpr int NP = UL::NP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     float* const lds = reinterpret_cast<float*>(lds_raw);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
@@ -227,32 +241,54 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
     const float* const vr = lds + (8 * h) * TB + l31;          // B fragment: channels 8h .. 8h+7 of tile l31
 
     // ---- A fragments: unit u of this wave = 3 KB [piece 3][lane 64][16 B]
-    const int u_voff = wave * U_WAVE_BYTES + lane * 16;
+    const int u_voff = wave * UL::WAVE + lane * 16;
+    // f16x2: the scale of V from the maximum the input's producer left, the epilogue factor from both exponents
+    float vscale = 1.f, ymul = 1.f;
+    if constexpr (H2) {
+        const int eV = ctdet::h2::exponent_for(ctdet::h2::slot_max(a.in_amax), ctdet::h2::kGrowthBtB);
+        vscale = __builtin_ldexpf(1.f, eV);
+        ymul = __builtin_ldexpf(1.f, -(eV + *a.eU));
+    }
+    float amax_run = 0.f;
     auto read_raw = [&](int xi, float (&raw)[8]) {
         const float* p = vr + xi * PT_STRIDE;
 #pragma unroll
         for (int e = 0; e < 8; ++e) raw[e] = p[e * TB];
     };
-    auto split_all = [&](const float (&raw)[8], i32x4 (&fb)[3]) {
+    auto split_all = [&](const float (&raw)[8], i32x4 (&fb)[NP]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            unsigned h0, m0, l0, h1, m1, l1;
-            split3(raw[2 * q], h0, m0, l0);
-            split3(raw[2 * q + 1], h1, m1, l1);
-            fb[0][q] = pack_hi(h0, h1);
-            fb[1][q] = pack_hi(m0, m1);
-            fb[2][q] = pack_hi(l0, l1);
+            if constexpr (H2) {
+                int hi, lo;
+                ctdet::h2::split2(raw[2 * q] * vscale, raw[2 * q + 1] * vscale, hi, lo);
+                fb[0][q] = hi;
+                fb[1][q] = lo;
+            } else {
+                unsigned h0, m0, l0, h1, m1, l1;
+                split3(raw[2 * q], h0, m0, l0);
+                split3(raw[2 * q + 1], h1, m1, l1);
+                fb[0][q] = pack_hi(h0, h1);
+                fb[1][q] = pack_hi(m0, m1);
+                fb[2][q] = pack_hi(l0, l1);
+            }
         }
     };
     const int xi0 = 4 * wave, xi_half = 32 + (wave >> 1);
 
-    // the six piece products, smallest first: (mid, mid), (lo, hi), (hi, lo), (mid, hi), (hi, mid), (hi, hi)   [A piece, B piece]
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+    // the piece products, smallest first   [A piece, B piece]: bf16x3 (mid, mid), (lo, hi), (hi, lo), (mid, hi), (hi, mid), (hi, hi);
+    // f16x2 (lo, hi), (hi, lo), (hi, hi)
+    constexpr int NPROD = H2 ? 3 : 6;
+    constexpr int PA[6] = {H2 ? 1 : 1, H2 ? 0 : 2, 0, 1, 0, 0}, PB[6] = {H2 ? 0 : 1, H2 ? 1 : 0, H2 ? 0 : 2, 0, 1, 0};
 #define W4F_UNIT(X, UA, FB)                                                                                          \
     do {                                                                                                             \
-        _Pragma("unroll") for (int t_ = 0; t_ < 6; ++t_)                                                             \
-            acc[X] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, UA[PA[t_]]),                 \
-                                                             __builtin_bit_cast(bf16x8, FB[PB[t_]]), acc[X], 0, 0, 0); \
+        _Pragma("unroll") for (int t_ = 0; t_ < NPROD; ++t_) {                                                       \
+            if constexpr (H2)                                                                                        \
+                acc[X] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, UA[PA[t_]]),               \
+                                                                __builtin_bit_cast(f16x8, FB[PB[t_]]), acc[X], 0, 0, 0); \
+            else                                                                                                     \
+                acc[X] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, UA[PA[t_]]),             \
+                                                                 __builtin_bit_cast(bf16x8, FB[PB[t_]]), acc[X], 0, 0, 0); \
+        }                                                                                                            \
     } while (0)
 
     int vb = next_valid(blockIdx.x);
@@ -260,7 +296,7 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
     setup_addr(vb);
     setup_masks();
     dma_patch(0);
-    i32x4 ua0[3], ua1[3], ua2[3];
+    i32x4 ua0[NP], ua1[NP], ua2[NP];
     bool u_ahead = false;                     // ua0 / ua1 already hold (are receiving) units 0, 1 of this item's first chunk
     while (vb < nitems) {
         W4F_STAMP(0);
@@ -268,12 +304,12 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
         const int tb0 = item_tblk(vb) * TB;
         const int vb_next = next_valid(vb + gridDim.x);
         const int u_kb = kb * a.chunks;
-        auto load_u_of = [&](int ukb, int c, int unit, i32x4 (&dst)[3]) {
-            const int soff = (ukb + c) * U_CHUNK_BYTES + unit * UNIT_BYTES;
+        auto load_u_of = [&](int ukb, int c, int unit, i32x4 (&dst)[NP]) {
+            const int soff = (ukb + c) * UL::CHUNK + unit * UL::UNIT;
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) dst[pc] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, soff + pc * 1024, 0);
+            for (int pc = 0; pc < NP; ++pc) dst[pc] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, soff + pc * 1024, 0);
         };
-        auto load_u = [&](int c, int unit, i32x4 (&dst)[3]) { load_u_of(u_kb, c, unit, dst); };
+        auto load_u = [&](int c, int unit, i32x4 (&dst)[NP]) { load_u_of(u_kb, c, unit, dst); };
         f32x16 acc[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j)
@@ -351,7 +387,7 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
             // scratch per lane at 256 registers and is slower.)
             {
                 float raw[8];
-                i32x4 fbA[3], fbB[3];
+                i32x4 fbA[NP], fbB[NP];
                 read_raw(xi0, raw);
                 split_all(raw, fbA);
                 // point 0
@@ -475,7 +511,7 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
                     float y[4][4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) at4(z[i], y[i]);
-                    ctdet::w4::emit_tile4(ep, rout, rres, n, ty, tx, co, y);
+                    ctdet::w4::emit_tile4(ep, rout, rres, n, ty, tx, co, y, ymul, H2 && e.out_amax != nullptr, amax_run);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -487,6 +523,20 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
         vb = vb_next;
     }
 #undef W4F_UNIT
+    if constexpr (H2) {
+        // ct_conv_desc.out_absmax: one atomic per wave and launch (the pointer re-read from the kernel arguments like the epilogue's
+        // record, so that it is not carried through the main loops).  Only the f16x2 instantiations track it: the bf16x3 ones are at
+        // the register limit (one more live value costs them scratch), and a network runs one form or the other.
+        unsigned* slot = a_in.out_amax;
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const __attribute__((address_space(4))) unsigned long long* kernarg_qwords;
+        kernarg_qwords kq = (kernarg_qwords)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kq));
+        static_assert(offsetof(Wino4fArgs, out_amax) % 8 == 0, "pointer field alignment");
+        slot = reinterpret_cast<unsigned*>(kq[offsetof(Wino4fArgs, out_amax) / 8]);
+#endif
+        if (slot) ctdet::h2::wave_atomic_absmax(slot, blockIdx.x + wave, amax_run);
+    }
 }
 
 bool wino4f_ok(const ct_conv_desc* d)
@@ -511,7 +561,7 @@ extern "C" int ct_wino4f_set_trace(unsigned long long* buf)      // device buffe
 extern "C" size_t ct_conv_wino4f_packed_bytes(int cin, int cout)
 {
     if (cin <= 0 || cout <= 0 || cin % CC) return 0;
-    return (size_t)((cout + KB - 1) / KB) * (cin / CC) * U_CHUNK_BYTES;
+    return (size_t)((cout + KB - 1) / KB) * (cin / CC) * ctdet::kWino4fChunkBytes;
 }
 
 extern "C" int ct_conv_pack_weights_wino4f(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
@@ -526,10 +576,47 @@ extern "C" int ct_conv_pack_weights_wino4f_dgrad(const float* const* w, const in
     return ctdet::pack_wino_any(w, cout, nparts, cin, 1, 46, (float*)upacked, stream, "ct_conv_pack_weights_wino4f_dgrad");
 }
 
+extern "C" size_t ct_conv_wino4f_h2_packed_bytes(int cin, int cout)
+{
+    if (cin <= 0 || cout <= 0 || cin % CC) return 0;
+    return ctdet::wino_h2_trailer_offset(cin, cout, 48) + ctdet::kWino4hTrailerBytes;
+}
+
+extern "C" int ct_conv_pack_weights_wino4f_h2(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                              ct_stream_t stream)
+{
+    return ctdet::pack_wino_h2(w, cout, nparts, cin, 0, 48, upacked, stream, "ct_conv_pack_weights_wino4f_h2");
+}
+
+extern "C" int ct_conv_pack_weights_wino4f_h2_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                                    ct_stream_t stream)
+{
+    return ctdet::pack_wino_h2(w, cout, nparts, cin, 1, 48, upacked, stream, "ct_conv_pack_weights_wino4f_h2_dgrad");
+}
+
+static int wino4f_launch(const ct_conv_desc* d, const void* upacked, int variant, float* pool_out, int pool_ctot,
+                         int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
+
 extern "C" int ct_conv2d_wino4f_pool_fwd(const ct_conv_desc* d, const void* upacked, float* pool_out, int pool_ctot,
                                          int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream)
 {
+    return wino4f_launch(d, upacked, 1, pool_out, pool_ctot, pool_coff, pool_oh, pool_ow, write_full, stream);
+}
+
+extern "C" int ct_conv2d_wino4f_pool_fwd_v(const ct_conv_desc* d, const void* upacked, int variant, float* pool_out, int pool_ctot,
+                                           int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream)
+{
+    return wino4f_launch(d, upacked, variant, pool_out, pool_ctot, pool_coff, pool_oh, pool_ow, write_full, stream);
+}
+
+static int wino4f_launch(const ct_conv_desc* d, const void* upacked, int variant, float* pool_out, int pool_ctot,
+                         int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream)
+{
     const char* who = "ct_conv2d_wino4f_fwd";
+    CT_REQUIRE(variant == 1 || variant == 2, "%s: variant %d (1 = bf16x3, 2 = f16x2)", who, variant);
+    const bool h2 = variant == 2;
+    CT_REQUIRE(!h2 || (d && d->in_absmax), "%s: the f16x2 form needs the maximum of |input| (ct_conv_desc.in_absmax: the producer's "
+               "out_absmax slot, or ct_absmax_f32)", who);
     CT_REQUIRE(d && upacked, "%s: null pointer", who);
     CT_REQUIRE(d->in && (d->out || d->nseg > 0) && d->scale && d->shift, "%s: null tensor", who);
     if (!wino4f_ok(d))
@@ -556,7 +643,7 @@ extern "C" int ct_conv2d_wino4f_pool_fwd(const ct_conv_desc* d, const void* upac
     const long long img_out_bytes = d->nseg ? 4 : (long long)d->out_ctot * d->oh * d->ow * 4;
     const long long img_res_bytes = d->res ? (long long)d->res_ctot * d->oh * d->ow * 4 : 0;
     CT_REQUIRE(img_out_bytes < kMaxBufBytes && img_res_bytes < kMaxBufBytes, "%s: one image exceeds 2 GiB", who);
-    const size_t u_bytes = ct_conv_wino4f_packed_bytes(d->cin, d->cout);
+    const size_t u_bytes = h2 ? ctdet::wino_h2_trailer_offset(d->cin, d->cout, 48) : ct_conv_wino4f_packed_bytes(d->cin, d->cout);
     CT_REQUIRE(u_bytes < (size_t)kMaxBufBytes, "%s: packed weights exceed 2 GiB", who);
     const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / std::max(img_in_bytes, std::max(img_out_bytes, img_res_bytes)));
     hipStream_t st = ctdet::as_stream(stream);
@@ -564,8 +651,9 @@ extern "C" int ct_conv2d_wino4f_pool_fwd(const ct_conv_desc* d, const void* upac
         static std::once_flag once;
         static hipError_t attr_err = hipSuccess;
         std::call_once(once, [] {
-            const void* fs[] = {(const void*)wino_f4x4_3x3_x3<false, false>, (const void*)wino_f4x4_3x3_x3<false, true>,
-                                (const void*)wino_f4x4_3x3_x3<true, false>};
+            const void* fs[] = {(const void*)wino_f4x4_3x3_x3<false, false, false>, (const void*)wino_f4x4_3x3_x3<false, true, false>,
+                                (const void*)wino_f4x4_3x3_x3<true, false, false>, (const void*)wino_f4x4_3x3_x3<false, false, true>,
+                                (const void*)wino_f4x4_3x3_x3<false, true, true>, (const void*)wino_f4x4_3x3_x3<true, false, true>};
             for (const void* f : fs)
                 if (attr_err == hipSuccess) attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, W4F_LDS_BYTES);
         });
@@ -600,6 +688,9 @@ extern "C" int ct_conv2d_wino4f_pool_fwd(const ct_conv_desc* d, const void* upac
         a.pool_out = pool_out ? pool_out + (size_t)b0 * pool_ctot * pool_oh * pool_ow : nullptr;
         a.pool_ctot = pool_ctot; a.pool_coff = pool_coff; a.pool_oh = pool_oh; a.pool_ow = pool_ow;
         a.write_full = write_full;
+        a.in_amax = d->in_absmax;
+        a.out_amax = d->out_absmax;
+        a.eU = h2 ? reinterpret_cast<const int*>(static_cast<const unsigned char*>(upacked) + u_bytes) + 1 : nullptr;
         a.kblocks = (d->cout + KB - 1) / KB;
         // 8 XCD-local sequences of (tile block group, cout block); sequences past the last tile block exit at once
         const int groups = (a.tile_blocks + 7) / 8;
@@ -611,11 +702,17 @@ extern "C" int ct_conv2d_wino4f_pool_fwd(const ct_conv_desc* d, const void* upac
                 n = 256;
             return std::max(8, n / 8 * 8);
         }();
-        CT_PROF("wino_f4x4_3x3_x3", st);
+        CT_PROF(h2 ? "wino_f4x4_3x3_h2" : "wino_f4x4_3x3_x3", st);
         const dim3 grid(std::min(items, cus));
-        if (a.nseg > 0) hipLaunchKernelGGL((wino_f4x4_3x3_x3<true, false>), grid, dim3(512), W4F_LDS_BYTES, st, a);
-        else if (!a.res && !a.lo) hipLaunchKernelGGL((wino_f4x4_3x3_x3<false, true>), grid, dim3(512), W4F_LDS_BYTES, st, a);
-        else hipLaunchKernelGGL((wino_f4x4_3x3_x3<false, false>), grid, dim3(512), W4F_LDS_BYTES, st, a);
+        if (h2) {
+            if (a.nseg > 0) hipLaunchKernelGGL((wino_f4x4_3x3_x3<true, false, true>), grid, dim3(512), W4F_LDS_BYTES, st, a);
+            else if (!a.res && !a.lo) hipLaunchKernelGGL((wino_f4x4_3x3_x3<false, true, true>), grid, dim3(512), W4F_LDS_BYTES, st, a);
+            else hipLaunchKernelGGL((wino_f4x4_3x3_x3<false, false, true>), grid, dim3(512), W4F_LDS_BYTES, st, a);
+        } else {
+            if (a.nseg > 0) hipLaunchKernelGGL((wino_f4x4_3x3_x3<true, false, false>), grid, dim3(512), W4F_LDS_BYTES, st, a);
+            else if (!a.res && !a.lo) hipLaunchKernelGGL((wino_f4x4_3x3_x3<false, true, false>), grid, dim3(512), W4F_LDS_BYTES, st, a);
+            else hipLaunchKernelGGL((wino_f4x4_3x3_x3<false, false, false>), grid, dim3(512), W4F_LDS_BYTES, st, a);
+        }
         CT_LAUNCH_CHECK("wino_f4x4_3x3_x3");
     }
     return CT_OK;

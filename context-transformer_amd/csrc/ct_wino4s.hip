@@ -91,8 +91,10 @@ struct Wino4sArgs {
     // f16x2 form only: V is stored scaled by 2^eV, U by 2^eU (powers of two from the operands' maxima, so that no binary16
     // piece overflows and the small pieces keep their bits); wino4s_out multiplies M by 2^-(eU + eV)
     unsigned* hdr;           // workspace header: [AMAX_SLOTS] partial maxima of |input| as bit patterns, hdr[AMAX_SLOTS] = eV
-    int amax_n;              // live entries of hdr
+    const unsigned* amax;    // where the maxima of |input| are: hdr (own absmax pass) or the producer's slot (ct_conv_desc.in_absmax)
+    int amax_n, amax_stride; // ... how many words, how far apart
     const int* eU;           // the exponent the weight packing chose (trailer of the packed weights)
+    unsigned* out_amax;      // any variant: ct_conv_desc.out_absmax (max |y| of what wino4s_out stores), or null
 };
 
 // 36 GEMMs  M[xi][row][col] = sum_k A[xi][row][k] B[xi][col][k], both operands as 12 KB fragment blocks
@@ -168,7 +170,7 @@ __device__ __forceinline__ void split_store(const float (&raw)[8], unsigned char
 __device__ __forceinline__ float h2_input_scale(const Wino4sArgs& a)
 {
     __shared__ unsigned red[4];
-    const unsigned m = ctdet::h2::block_max_of(a.hdr, a.amax_n, red);
+    const unsigned m = ctdet::h2::block_max_of(a.amax, a.amax_n, a.amax_stride, red);
     const int e = ctdet::h2::exponent_for(m, ctdet::h2::kGrowthBtB);
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.hdr[AMAX_SLOTS] = (unsigned)e;
     return __builtin_ldexpf(1.f, e);
@@ -586,6 +588,38 @@ __global__ __launch_bounds__(256) void wino4h_absmax(const float* __restrict__ i
     }
 }
 
+// ct_absmax_f32: the same pass for callers outside this file, folded into a slot by atomic max (the caller zeroes the slot)
+__global__ __launch_bounds__(256) void absmax_slot_kernel(const float* __restrict__ in, int batch, long per_image, long img_stride,
+                                                          int vec_ok, unsigned* __restrict__ slot)
+{
+    const int ipi = (int)((per_image + 4095) / 4096);
+    const long nitems = (long)batch * ipi;
+    unsigned m = 0;
+    for (long it = blockIdx.x; it < nitems; it += gridDim.x) {
+        const int n = (int)(it / ipi), sgm = (int)(it - (long)n * ipi);
+        const float* base = in + (size_t)n * img_stride;
+        const long e0 = (long)sgm * 4096;
+        for (int r = 0; r < (vec_ok ? 4 : 16); ++r) {
+            const long e = vec_ok ? e0 + (long)(r * 256 + threadIdx.x) * 4 : e0 + r * 256 + threadIdx.x;
+            if (e >= per_image) continue;
+            if (vec_ok && e + 3 < per_image) {
+                const i32x4 v = *reinterpret_cast<const i32x4*>(base + e);
+                const unsigned a0 = (unsigned)v.x & 0x7FFFFFFFu, a1 = (unsigned)v.y & 0x7FFFFFFFu;
+                const unsigned a2 = (unsigned)v.z & 0x7FFFFFFFu, a3 = (unsigned)v.w & 0x7FFFFFFFu;
+                const unsigned b0 = a0 > a1 ? a0 : a1, b1 = a2 > a3 ? a2 : a3, b = b0 > b1 ? b0 : b1;
+                m = b > m ? b : m;
+            } else {
+                for (int t = 0; t < (vec_ok ? 4 : 1); ++t)
+                    if (e + t < per_image) {
+                        const unsigned a0 = __builtin_bit_cast(unsigned, base[e + t]) & 0x7FFFFFFFu;
+                        m = a0 > m ? a0 : m;
+                    }
+            }
+        }
+    }
+    ctdet::h2::wave_atomic_absmax(slot, blockIdx.x, __builtin_bit_cast(float, m));
+}
+
 // Workgroup = one point xi, 128 couts x 128 tiles, 2 x 2 waves of 64 x 64, as wino4s_gemm.  A step = KG k-groups of 16 channels
 // (KG x 16 KB in LDS: [group][A 8 KB][B 8 KB]), ring of NB steps.  The pipeline runs over k-GROUPS: the fragments of group q + 1
 // are read behind the MFMAs of group q; where q + 1 opens a new step the wave first waits for its DMA pieces of that step and
@@ -740,24 +774,31 @@ __global__ __launch_bounds__(256, 2) void wino4h_gemm(const GemmArgs a)
 // 3. output transform + epilogue.  Thread = one (cout, tile): 36 coalesced loads (lanes = 64 consecutive tiles of a
 // cout row), y = A^T M A, the epilogue of ct_wino4.hip.
 template <bool H2>
+__device__ __forceinline__ void wino4s_out_one(const Wino4sArgs& a, int T, int co, bool track, float& amax_run);
+
+template <bool H2>
 __global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
 {
     const int T = blockIdx.x * 64 + (threadIdx.x & 63);
     const int co = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (T >= a.NT || co >= a.M) return;
+    float amax_run = 0.f;            // max |y| of what this thread stores (a.out_amax)
+    if (T < a.NT && co < a.M) wino4s_out_one<H2>(a, T, co, a.out_amax != nullptr, amax_run);
+    // every lane of the wave arrives here (no early exit above): one atomic per wave
+    if (a.out_amax) ctdet::h2::wave_atomic_absmax(a.out_amax, blockIdx.x + blockIdx.y, amax_run);
+}
+
+template <bool H2>
+__device__ __forceinline__ void wino4s_out_one(const Wino4sArgs& a, const int T, const int co, const bool track, float& amax_run)
+{
     const float* src = a.Mw + (size_t)co * a.Tpad + T;
     float m[6][6];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) m[i][j] = __builtin_nontemporal_load(src + (size_t)(i * 6 + j) * a.m_plane);
-    if constexpr (H2) {              // the f16x2 operands were scaled by 2^eU, 2^eV: exact powers of two, undone here
-        const int e = -(*a.eU + (int)a.hdr[AMAX_SLOTS]);
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int j = 0; j < 6; ++j) m[i][j] = __builtin_ldexpf(m[i][j], e);
-    }
+    // f16x2: the operands were scaled by 2^eU, 2^eV (exact powers of two); folded into the per-channel scale of the epilogue
+    float ymul = 1.f;
+    if constexpr (H2) ymul = __builtin_ldexpf(1.f, -(*a.eU + (int)a.hdr[AMAX_SLOTS]));
     // A^T M A in double, rounded once: this kernel waits for HBM, the fp32 chain of ct_wino4.hip rounds ~10 times per output
     double t[6][4];
 #pragma unroll
@@ -784,7 +825,7 @@ __global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
         const int sx = q % d; q /= d;
         const int sy = q % d;
         const int n = q / d;
-        const float sc = a.scale[co], sh = a.shift[co];
+        const float sc = a.scale[co] * ymul, sh = a.shift[co];
         const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
         float* const plane = a.out + ((size_t)n * a.out_ctot + a.out_coff + co) * a.H * a.W;
 #pragma unroll
@@ -795,8 +836,10 @@ __global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
             for (int c = 0; c < 4; ++c) {
                 const int xx = sx + d * (4 * tx + c);
                 if (xx >= a.W) continue;
-                const float v = y[r][c] * sc + sh;
-                plane[(size_t)yy * a.W + xx] = v < lo ? lo : v;
+                float v = y[r][c] * sc + sh;
+                v = v < lo ? lo : v;
+                plane[(size_t)yy * a.W + xx] = v;
+                if (track) ctdet::h2::track_absmax(amax_run, v);
             }
         }
         return;
@@ -806,7 +849,7 @@ __global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
     const int ty = rem / a.TX, tx = rem - ty * a.TX;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res_bytes);
-    ctdet::w4::emit_tile4(a, rout, rres, n, ty, tx, co, y);
+    ctdet::w4::emit_tile4(a, rout, rres, n, ty, tx, co, y, ymul, track, amax_run);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1059,7 +1102,8 @@ __global__ __launch_bounds__(256) void wino4h_pack(const ctdet::WinoPackArgs p, 
 {
     const int eU = ctdet::h2::exponent_for(trailer[0], ctdet::h2::kGrowthGG);
     if (blockIdx.x == 0 && threadIdx.x == 0) trailer[1] = (unsigned)eU;
-    const int rows = p.kblocks * BM;
+    const bool fused = p.tile == 48;                   // ct_wino4f.hip's unit order (64-cout blocks) instead of the GEMM operand's
+    const int rows = p.kblocks * (fused ? ctdet::kWinoKB : BM);
     const int groups8 = p.cin / 8;
     const long total = (long)rows * groups8 * 6;
     unsigned char* const out = reinterpret_cast<unsigned char*>(p.U);
@@ -1104,8 +1148,17 @@ __global__ __launch_bounds__(256) void wino4h_pack(const ctdet::WinoPackArgs p, 
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             const int xi = i * 6 + j;
-            const int cb = co / BM, sub = (co % BM) / 32;
-            unsigned char* q = out + (size_t)xi * plane + ((((size_t)cb * p.chunks + chunk) * 4 + sub) * HP) * FRAG + (kh * 32 + co % 32) * 16;
+            unsigned char* q;
+            if (fused) {
+                const int kb = co / ctdet::kWinoKB, half = (co % ctdet::kWinoKB) / 32;
+                const int wv = xi < 32 ? xi >> 2 : 2 * (xi - 32) + half;
+                const int unit = xi < 32 ? 2 * (xi & 3) + half : 8;
+                q = out + ((size_t)kb * p.chunks + chunk) * ctdet::kWino4fhChunkBytes + (size_t)wv * ctdet::kWino4fhWaveBytes +
+                    unit * ctdet::kWino4fhUnitBytes + (co % 32 + 32 * kh) * 16;
+            } else {
+                const int cb = co / BM, sub = (co % BM) / 32;
+                q = out + (size_t)xi * plane + ((((size_t)cb * p.chunks + chunk) * 4 + sub) * HP) * FRAG + (kh * 32 + co % 32) * 16;
+            }
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) *reinterpret_cast<u32x4*>(q + pc * FRAG) = v[j][pc];
         }
@@ -1191,14 +1244,31 @@ extern "C" size_t ct_conv_wino4s_workspace_bytes(const ct_conv_desc* d)
     return HDR_BYTES + s.v_bytes + s.m_bytes;       // any variant (the f16x2 form: header + a V two thirds the size)
 }
 
+extern "C" int ct_absmax_f32(const float* in, int batch, long long per_image, long long img_stride, unsigned* slot, ct_stream_t stream)
+{
+    CT_REQUIRE(in && slot && batch > 0 && per_image > 0 && img_stride >= per_image, "ct_absmax_f32: bad argument");
+    const bool vec_ok = per_image % 4 == 0 && img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(in) % 16 == 0;
+    const long items = (long)batch * ((per_image + 4095) / 4096);
+    hipLaunchKernelGGL(absmax_slot_kernel, dim3((int)std::min<long>(items, 1024)), dim3(256), 0, ctdet::as_stream(stream), in, batch,
+                       (long)per_image, (long)img_stride, vec_ok ? 1 : 0, slot);
+    CT_LAUNCH_CHECK("absmax_slot_kernel");
+    return CT_OK;
+}
+
 extern "C" size_t ct_conv_wino4s_h2_packed_bytes(int cin, int cout)
 {
     if (cin <= 0 || cout <= 0 || cin % CC) return 0;
-    return (size_t)NXI * ((cout + BM - 1) / BM) * (cin / CC) * OPBH + ctdet::kWino4hTrailerBytes;
+    return ctdet::wino_h2_trailer_offset(cin, cout, 47) + ctdet::kWino4hTrailerBytes;
 }
 
-static int pack_h2(const float* const* w, const int* cout, int nparts, int cin, int dgrad, void* upacked, ct_stream_t stream,
-                   const char* who)
+size_t ctdet::wino_h2_trailer_offset(int cin, int cout, int tile)
+{
+    return tile == 48 ? (size_t)((cout + ctdet::kWinoKB - 1) / ctdet::kWinoKB) * (cin / CC) * ctdet::kWino4fhChunkBytes
+                      : (size_t)NXI * ((cout + BM - 1) / BM) * (cin / CC) * OPBH;
+}
+
+int ctdet::pack_wino_h2(const float* const* w, const int* cout, int nparts, int cin, int dgrad, int tile, void* upacked,
+                        ct_stream_t stream, const char* who)
 {
     CT_REQUIRE(w && cout && upacked && nparts >= 1 && nparts <= 6, "%s: bad argument", who);
     CT_REQUIRE(!ctdet::pack_recording(), "%s: the f16x2 packing takes the layer's maximum first and cannot be recorded (ct_pack_record_begin)", who);
@@ -1213,21 +1283,22 @@ static int pack_h2(const float* const* w, const int* cout, int nparts, int cin, 
     p.mbeg[nparts] = tot;
     p.nparts = nparts;
     p.dgrad = dgrad;
-    p.tile = 47;
+    p.tile = tile;
     p.cin_fwd = cin;
     p.cin = dgrad ? tot : cin;
     p.cout = dgrad ? cin : tot;
     CT_REQUIRE(p.cin > 0 && p.cin % CC == 0, "%s: %d input channels, must be a multiple of %d", who, p.cin, CC);
     p.chunks = p.cin / CC;
-    p.kblocks = (p.cout + BM - 1) / BM;
+    const int rowblock = tile == 48 ? ctdet::kWinoKB : BM;
+    p.kblocks = (p.cout + rowblock - 1) / rowblock;
     p.U = static_cast<float*>(upacked);
     hipStream_t st = ctdet::as_stream(stream);
-    unsigned* trailer = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(upacked) + (size_t)NXI * p.kblocks * p.chunks * OPBH);
+    unsigned* trailer = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(upacked) + ctdet::wino_h2_trailer_offset(p.cin, p.cout, tile));
     CT_HIP(hipMemsetAsync(trailer, 0, ctdet::kWino4hTrailerBytes, st));
     const long nw = (long)tot * cin * 9;
     hipLaunchKernelGGL(wino4h_wmax, dim3((int)std::min<long>((nw + 255) / 256, 1024)), dim3(256), 0, st, p, trailer);
     CT_LAUNCH_CHECK("wino4h_wmax");
-    const long total = (long)p.kblocks * BM * (p.cin / 8) * 6;
+    const long total = (long)p.kblocks * rowblock * (p.cin / 8) * 6;
     hipLaunchKernelGGL(wino4h_pack, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, p, trailer);
     CT_LAUNCH_CHECK("wino4h_pack");
     return CT_OK;
@@ -1236,13 +1307,13 @@ static int pack_h2(const float* const* w, const int* cout, int nparts, int cin, 
 extern "C" int ct_conv_pack_weights_wino4s_h2(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
                                               ct_stream_t stream)
 {
-    return pack_h2(w, cout, nparts, cin, 0, upacked, stream, "ct_conv_pack_weights_wino4s_h2");
+    return ctdet::pack_wino_h2(w, cout, nparts, cin, 0, 47, upacked, stream, "ct_conv_pack_weights_wino4s_h2");
 }
 
 extern "C" int ct_conv_pack_weights_wino4s_h2_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
                                                     ct_stream_t stream)
 {
-    return pack_h2(w, cout, nparts, cin, 1, upacked, stream, "ct_conv_pack_weights_wino4s_h2_dgrad");
+    return ctdet::pack_wino_h2(w, cout, nparts, cin, 1, 47, upacked, stream, "ct_conv_pack_weights_wino4s_h2_dgrad");
 }
 
 extern "C" int ct_conv_pack_weights_wino4s(const float* const* w, const int* cout, int nparts, int cin,
@@ -1360,11 +1431,17 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
             const bool vec_ok = ((d->h * d->w) % 4 == 0 || (d->in_ctot % 4 == 0 && d->in_coff % 4 == 0)) &&
                                 reinterpret_cast<uintptr_t>(base) % 16 == 0;
             const long items = (long)nb * ((per_image + 4095) / 4096);
-            a.amax_n = (int)std::min<long>(items, AMAX_SLOTS);
-            CT_PROF("wino4h_absmax", st);
-            hipLaunchKernelGGL(wino4h_absmax, dim3(a.amax_n), dim3(256), 0, st, base, nb, per_image, img_stride, vec_ok ? 1 : 0, a.hdr);
-            CT_LAUNCH_CHECK("wino4h_absmax");
+            if (d->in_absmax) {              // the producer of the input left its maximum (an upper bound over the slice)
+                a.amax = d->in_absmax; a.amax_n = ctdet::h2::kSlotLines; a.amax_stride = ctdet::h2::kSlotStride;
+            } else {
+                a.amax = a.hdr; a.amax_stride = 1;
+                a.amax_n = (int)std::min<long>(items, AMAX_SLOTS);
+                CT_PROF("wino4h_absmax", st);
+                hipLaunchKernelGGL(wino4h_absmax, dim3(a.amax_n), dim3(256), 0, st, base, nb, per_image, img_stride, vec_ok ? 1 : 0, a.hdr);
+                CT_LAUNCH_CHECK("wino4h_absmax");
+            }
         }
+        a.out_amax = d->out_absmax;
         // transform: ~2048 workgroups (four rounds of two per CU) unless the layer has fewer (tile block, chunk) pairs
         const long pairs = (long)a.tblk32 * a.chunks;
         a.chunks_per_wg = (int)std::max<long>(1, std::min<long>(a.chunks, pairs / 2048));

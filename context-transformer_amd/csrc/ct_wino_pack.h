@@ -37,6 +37,11 @@ constexpr int kWino4hTrailerBytes = 256;
 constexpr int kWino4hAmaxSlots = 1024;                        // workspace header: partial maxima of |input|, one per absmax workgroup
 constexpr int kWino4hHeaderBytes = 2 * kWino4hAmaxSlots * 4;  // ... followed by the exponent eV the input transform chose
 
+// ct_wino4f.hip on f16x2 (tile 48): units of [piece 2][lane 64][8 f16] = 2 KB, same wave / unit numbering as tile 46, same trailer
+constexpr int kWino4fhUnitBytes = 2 * 1024;
+constexpr int kWino4fhWaveBytes = 9 * kWino4fhUnitBytes;
+constexpr int kWino4fhChunkBytes = 8 * kWino4fhWaveBytes;
+
 // ct_wino4f.hip (fused F(4x4,3x3) on bf16x3): per (cout block of 64, 16-channel chunk) eight wave regions of nine 3 KB
 // "units" = (transform point, cout half), each [piece 3][lane 64][8 bf16]
 constexpr int kWino4fUnitBytes = 3 * 1024;
@@ -277,6 +282,12 @@ __device__ __forceinline__ void wino_pack_any(const WinoPackArgs& p, long first,
     else if (p.tile == 4) wino4_pack_body(p, first, stride);
     else wino2_pack_body(p, first, stride);
 }
+
+// the f16x2 layouts (tile 47: GEMM operand of ct_wino4s.hip variant 3; 48: per-wave units of ct_wino4f.hip variant 2): max |g| pass,
+// then the packing proper (csrc/ct_wino4s.hip); not recordable
+int pack_wino_h2(const float* const* w, const int* cout, int nparts, int cin, int dgrad, int tile, void* upacked, ct_stream_t stream,
+                 const char* who);
+size_t wino_h2_trailer_offset(int cin, int cout, int tile);
 
 // fills and validates a record; launches it, or appends it to the open recording (ct_pack_record_begin)
 int pack_wino_any(const float* const* w, const int* cout, int nparts, int cin, int dgrad, int tile, float* upacked,

@@ -38,7 +38,11 @@ class ConvDesc(C.Structure):
         ('config', C.c_int),
         ('transposed', C.c_int),
         ('ksplit', C.c_int), ('ksplit_ws', C.c_void_p), ('ksplit_ws_floats', C.c_longlong),
+        ('in_absmax', C.c_void_p), ('out_absmax', C.c_void_p),
     ]
+
+
+ABSMAX_SLOT_BYTES = 2048        # CT_ABSMAX_SLOT_BYTES
 
 
 class ProfileRecord(C.Structure):
@@ -151,6 +155,10 @@ SIGNATURES = {
     'ct_conv_wino4f_packed_bytes': (_Z, [_I, _I]),
     'ct_conv_pack_weights_wino4f': (_I, [_P, _P, _I, _I, _P, _P]),
     'ct_conv_pack_weights_wino4f_dgrad': (_I, [_P, _P, _I, _I, _P, _P]),
+    'ct_conv_wino4f_h2_packed_bytes': (_Z, [_I, _I]),
+    'ct_conv_pack_weights_wino4f_h2': (_I, [_P, _P, _I, _I, _P, _P]),
+    'ct_conv_pack_weights_wino4f_h2_dgrad': (_I, [_P, _P, _I, _I, _P, _P]),
+    'ct_conv2d_wino4f_pool_fwd_v': (_I, [C.POINTER(ConvDesc), _P, _I, _P, _I, _I, _I, _I, _I, _P]),
     'ct_conv2d_wino4f_fwd': (_I, [C.POINTER(ConvDesc), _P, _P]),
     'ct_conv2d_wino4f_pool_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P]),
     'ct_conv_wino4_supported': (_I, [C.POINTER(ConvDesc)]),
@@ -160,6 +168,7 @@ SIGNATURES = {
     'ct_conv2d_wino4_fwd': (_I, [C.POINTER(ConvDesc), _P, _P]),
     'ct_conv2d_wino4_pool_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P]),
     'ct_conv2d_fwd': (_I, [C.POINTER(ConvDesc), _P]),
+    'ct_absmax_f32': (_I, [_P, _I, _LL, _LL, _P, _P]),
     'ct_conv_x3_num_configs': (_I, []),
     'ct_conv_x3_config_name': (C.c_char_p, [_I]),
     'ct_conv_x3_config_bk': (_I, [_I]),

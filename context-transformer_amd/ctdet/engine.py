@@ -352,19 +352,25 @@ WINO4S = -6        # ... F(4x4,3x3) as transform / bf16x3 GEMM / transform kerne
 WINO4SQ = -7       # ... one accumulator
 WINO4F = -8        # ... F(4x4,3x3) fused on bf16x3, one 64-cout block per workgroup (csrc/ct_wino4f.hip): the narrow layers on big maps
 WINO4H = -9        # ... the three-kernel form on the f16x2 operand form (two binary16 pieces, three products; csrc/ct_f16x2.h)
+WINO4FH = -10      # ... the fused kernel on the f16x2 operand form
 # st.rt['wino'] values: 2, 4 = the fp32-MFMA kernels' tile sizes; F(2x2,3x3) on bf16x3: 23 = two accumulators (eight
 # waves), 24 = one accumulator in the four-wave / two-workgroups-per-CU form
 # 44 / 45 = F(4x4,3x3) in the three-kernel form with the GEMMs on bf16x3 (two / one accumulator); 46 = F(4x4,3x3) fused on bf16x3
 # 47 = the three-kernel form with its GEMMs on f16x2 (two binary16 pieces, three products, two accumulators)
-WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXQ: 24, WINO4S: 44, WINO4SQ: 45, WINO4F: 46, WINO4H: 47}
-WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 24: 'winoxq', 44: 'wino4s', 45: 'wino4sq', 46: 'wino4f', 47: 'wino4h'}
+# 48 = the fused F(4x4,3x3) kernel on f16x2
+WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXQ: 24, WINO4S: 44, WINO4SQ: 45, WINO4F: 46, WINO4H: 47, WINO4FH: 48}
+WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 24: 'winoxq', 44: 'wino4s', 45: 'wino4sq', 46: 'wino4f', 47: 'wino4h', 48: 'wino4fh'}
 WINOX_TILES = (23, 24)
 WINOX_VARIANT = {23: 1, 24: 2}               # the `variant` argument of ct_conv2d_wino_x3_fwd
 WINO4S_TILES = (44, 45, 47)
 WINO4S_VARIANT = {44: 1, 45: 2, 47: 3}       # the `variant` argument of ct_conv2d_wino4s_fwd
 WINO4H_TILES = (47,)                         # ... whose weights come from ct_conv_pack_weights_wino4s_h2
-WINO4F_TILES = (46,)
-F4_TILES = (4, 44, 45, 46, 47)               # every variant with F(4x4,3x3)'s rounding (accuracy policies treat them alike)
+WINO4F_TILES = (46, 48)
+WINO4F_VARIANT = {46: 1, 48: 2}              # the `variant` argument of ct_conv2d_wino4f_pool_fwd_v
+WINO4FH_TILES = (48,)                        # ... whose weights come from ct_conv_pack_weights_wino4f_h2 and which needs desc.in_absmax
+H2_TILES = (47, 48)                          # the f16x2 operand form: consumers of a maximum of |input| (ct_conv_desc.in_absmax)
+TRACK_TILES = (44, 45, 47, 48)               # kernels that fold max |output| into ct_conv_desc.out_absmax (+ the 'valu' image layer)
+F4_TILES = (4, 44, 45, 46, 47, 48)           # every variant with F(4x4,3x3)'s rounding (accuracy policies treat them alike)
 
 
 class HipBackend:
@@ -380,6 +386,24 @@ class HipBackend:
         # index the Runtime gave the step, 0 before there is a schedule).  Per-layer buffers were ~6 GB per RFBNet-300
         # runtime at bs 32 and > 10 GB for RFBNet-512.
         self.ws_pool = {}
+        # "slots" for maxima of |activation| (ct_conv_desc.in_absmax / out_absmax, include/ctdet.h): rows of one tensor that a
+        # runtime zeroes once per step (zero_slots)
+        self.slot_pool = None
+        self.slots_used = 0
+
+    def new_slot(self):
+        """Device pointer of a fresh CT_ABSMAX_SLOT_BYTES slot."""
+        words = _lib.ABSMAX_SLOT_BYTES // 4
+        if self.slot_pool is None:
+            self.slot_pool = torch.zeros((256, words), device=self.device, dtype=torch.int32)
+        if self.slots_used >= self.slot_pool.shape[0]:
+            raise _lib.CtdetError('out of absmax slots')
+        self.slots_used += 1
+        return self.slot_pool[self.slots_used - 1].data_ptr()
+
+    def zero_slots(self):
+        if self.slot_pool is not None and self.slots_used:
+            self.slot_pool[:self.slots_used].zero_()
 
     def ws_reserve(self, key, nbytes):
         t = self.ws_pool.get(key)
@@ -498,7 +522,7 @@ class HipBackend:
             raise _lib.CtdetError('%s: geometry has no Winograd path' % st.name)
         rt['x3'] = None
         if tile not in (2, 4) + WINOX_TILES + WINO4S_TILES + WINO4F_TILES:
-            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23, 24, 44, 45, 46 or 47)' % (st.name, tile))
+            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23, 24, 44, 45, 46, 47 or 48)' % (st.name, tile))
         if tile not in WINO4S_TILES:
             rt.pop('ws4s_bytes', None)
         if tile in WINO4S_TILES:
@@ -514,7 +538,10 @@ class HipBackend:
         elif tile in WINO4F_TILES:
             if not rt.get('wino4f_ok'):
                 raise _lib.CtdetError('%s: geometry has no fused F(4x4,3x3) bf16x3 path (cin %% 16)' % st.name)
-            if 'U4F' not in rt:
+            if tile in WINO4FH_TILES:
+                if 'U4FH' not in rt:
+                    rt['U4FH'] = self.alloc((self.lib.ct_conv_wino4f_h2_packed_bytes(st.cin, st.cout),), torch.uint8)
+            elif 'U4F' not in rt:
                 rt['U4F'] = self.alloc((self.lib.ct_conv_wino4f_packed_bytes(st.cin, st.cout),), torch.uint8)
         elif tile in WINOX_TILES:
             if not rt.get('winox_ok'):
@@ -548,6 +575,10 @@ class HipBackend:
         if st.rt['wino'] in WINO4S_TILES:
             _lib.check(self.lib.ct_conv_pack_weights_wino4s(ptrs, couts, n, st.cin, st.rt['U4S'].data_ptr(), self._stream()),
                        'ct_conv_pack_weights_wino4s')
+            return
+        if st.rt['wino'] in WINO4FH_TILES:
+            _lib.check(self.lib.ct_conv_pack_weights_wino4f_h2(ptrs, couts, n, st.cin, st.rt['U4FH'].data_ptr(), self._stream()),
+                       'ct_conv_pack_weights_wino4f_h2')
             return
         if st.rt['wino'] in WINO4F_TILES:
             _lib.check(self.lib.ct_conv_pack_weights_wino4f(ptrs, couts, n, st.cin, st.rt['U4F'].data_ptr(), self._stream()),
@@ -613,8 +644,23 @@ class HipBackend:
                         v.append((t.data_ptr(), t._version))
         return v
 
+    def _own_absmax(self, st):
+        """A consumer of ct_conv_desc.in_absmax whose input has no producer-side maximum (a layer run on its own, an input some
+        other kernel wrote): a private slot, zeroed and filled by ct_absmax_f32 in front of the launch."""
+        rt, d = st.rt, st.rt['desc']
+        if rt.get('amax_own') is None:
+            rt['amax_own'] = torch.zeros(_lib.ABSMAX_SLOT_BYTES // 4, device=self.device, dtype=torch.int32)
+            d.in_absmax = rt['amax_own'].data_ptr()
+        rt['amax_own'].zero_()
+        hw = d.h * d.w
+        base = d.in_ + 4 * d.in_coff * hw
+        _lib.check(self.lib.ct_absmax_f32(base, d.batch, d.cin * hw, d.in_ctot * hw, rt['amax_own'].data_ptr(), self._stream()),
+                   'ct_absmax_f32')
+
     def run_conv(self, st):
         tile = st.rt.get('wino')
+        if tile in WINO4FH_TILES and (not st.rt['desc'].in_absmax or st.rt.get('amax_own') is not None):
+            self._own_absmax(st)
         if tile in WINO4S_TILES:         # F(4x4,3x3): transform / bf16x3 GEMM / transform (csrc/ct_wino4s.hip)
             lib, U, ws, var = self.lib, st.rt['U4H' if tile in WINO4H_TILES else 'U4S'].data_ptr(), \
                 self.ws_pool[st.rt.get('ws_key', 0)], WINO4S_VARIANT[tile]
@@ -629,14 +675,14 @@ class HipBackend:
                        st.name)
             return
         if tile in WINO4F_TILES:         # F(4x4,3x3) fused on the bf16 matrix pipe (csrc/ct_wino4f.hip)
-            lib, U = self.lib, st.rt['U4F'].data_ptr()
+            lib, U, var = self.lib, st.rt['U4FH' if tile in WINO4FH_TILES else 'U4F'].data_ptr(), WINO4F_VARIANT[tile]
             pool = st.rt.get('pool')
             if pool is not None:
                 t, poh, pow_, full = pool
-                _lib.check(lib.ct_conv2d_wino4f_pool_fwd(C.byref(st.rt['desc']), U, t.data_ptr(), t.shape[1], 0, poh, pow_,
-                                                         int(full), self._stream()), st.name)
+                _lib.check(lib.ct_conv2d_wino4f_pool_fwd_v(C.byref(st.rt['desc']), U, var, t.data_ptr(), t.shape[1], 0, poh, pow_,
+                                                           int(full), self._stream()), st.name)
                 return
-            _lib.check(lib.ct_conv2d_wino4f_fwd(C.byref(st.rt['desc']), U, self._stream()), st.name)
+            _lib.check(lib.ct_conv2d_wino4f_pool_fwd_v(C.byref(st.rt['desc']), U, var, None, 0, 0, 0, 0, 1, self._stream()), st.name)
             return
         if tile in WINOX_TILES:          # F(2x2,3x3) on the bf16 matrix pipe (csrc/ct_wino_x3.hip)
             lib, U, dual = self.lib, st.rt['UX'].data_ptr(), WINOX_VARIANT[tile]
@@ -823,7 +869,7 @@ def wino_tiles(backend=None, st=None):
 
 
 # bf16x3 tile -> the same kernel on the f16x2 operand form (csrc/ct_f16x2.h: two binary16 pieces, three products)
-H2_OF_TILE = {44: 47}
+H2_OF_TILE = {44: 47, 46: 48}
 H2_OF_TILE_VALUES = tuple(H2_OF_TILE.values())
 
 
@@ -1045,6 +1091,7 @@ class Runtime:
         self._mark_exclusive()
         self._build_schedule()
         self._share_workspaces()
+        self._wire_absmax()
 
     def _fuse_pools(self):
         """MaxPool2d(2, 2) directly behind a Winograd conv: the 2x2 output tile is the pooling window, so
@@ -1154,6 +1201,63 @@ class Runtime:
         self.side = self.sides[0]
         self.ev = {j: torch.cuda.Event() for j in self.signal}
 
+    def _wire_absmax(self):
+        """Maxima of |activation| for the f16x2 kernels (ct_conv_desc.in_absmax / out_absmax, csrc/ct_f16x2.h).  A buffer that an
+        f16x2 layer reads gets a slot when EVERY step that writes it can fold the maximum of what it stores into one (the
+        F(4x4,3x3) epilogue of tiles 44 / 45 / 47 / 48, the image layer's vector-ALU kernel); a max-pool's output shares the slot
+        of its input (pooled values are a subset), whether the pool runs as a step or inside its producer.  Consumers whose
+        buffer has no slot take the maximum themselves (tile 47: an absmax pass inside the launch; tile 48: ct_absmax_f32 in
+        front of it, HipBackend._own_absmax).  The slots are zeroed once per step (run_loaded)."""
+        be = self.backend
+        if not hasattr(be, 'new_slot'):
+            return
+        steps = self.plan.steps
+        for st in self.conv_steps():
+            st.rt['desc'].in_absmax = None
+            st.rt['desc'].out_absmax = None
+            st.rt.pop('amax_own', None)
+        if not any(st.rt.get('wino') in H2_TILES for st in self.conv_steps()):
+            return
+
+        def tracks(st):
+            if st.kind != 'conv' or st.segs:
+                return False
+            if st.rt.get('wino') in TRACK_TILES:
+                return True
+            d = st.rt['desc']          # the image layer, when its config NAMES the vector-ALU kernel (config 0 leaves the choice to the library)
+            name = be.lib.ct_conv_config_name(d.config - 1).decode() if d.config > 0 else ''
+            return not st.rt.get('wino') and st.rt.get('x3') is None and name == 'valu' 
+        root = {}                          # pooled buffer -> the buffer whose maximum bounds it
+        for ps in steps:
+            if ps.kind == 'pool':
+                root[ps.dst] = ps.src
+
+        def root_of(b):
+            while b in root:
+                b = root[b]
+            return b
+        writers = {}
+        for st in steps:
+            if st.kind == 'conv':
+                for b in ([sg.dst for sg in st.segs] if st.segs else [st.dst]):
+                    writers.setdefault(b, []).append(st)
+            elif st.kind != 'pool':
+                writers.setdefault(st.dst, []).append(st)
+        slots = {}
+        be.slots_used = 0
+        for st in self.conv_steps():
+            if st.rt.get('wino') not in H2_TILES:
+                continue
+            b = root_of(st.src)
+            ws = writers.get(b, [])
+            if ws and all(tracks(w) for w in ws):
+                if b not in slots:
+                    slots[b] = be.new_slot()
+                    for w in ws:
+                        w.rt['desc'].out_absmax = slots[b]
+                st.rt['desc'].in_absmax = slots[b]
+        self.amax_slots = slots
+
     def _share_workspaces(self):
         """One three-kernel-Winograd workspace per stream of the schedule (HipBackend.ws_pool) instead of one per layer."""
         if not hasattr(self.backend, 'ws_rebuild'):
@@ -1230,6 +1334,8 @@ class Runtime:
 
     def run_loaded(self):
         """The launches of the backbone on the input buffer (no allocation, no host synchronisation: capturable)."""
+        if getattr(self.backend, 'zero_slots', None) is not None:
+            self.backend.zero_slots()       # the maxima of |activation| the f16x2 layers take their scales from (_wire_absmax)
         run_on_streams(self, self._run_step)
         return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
 

@@ -238,7 +238,23 @@ typedef struct ct_conv_desc {
     int ksplit;
     float* ksplit_ws;
     long long ksplit_ws_floats;
+    /* Maxima of |activation| for the f16x2 operand form (csrc/ct_f16x2.h: binary16 pieces need a power-of-two scale per
+     * tensor, taken from the tensor's maximum).  Both optional (NULL = off) and both "slots" of CT_ABSMAX_SLOT_BYTES bytes of
+     * device memory that the caller zeroes once per step: the bit pattern of max |x| lives in word 32 * i of the slot,
+     * i = 0 .. 15 (sixteen cache lines, so that a launch's atomics do not queue on one).
+     *   in_absmax   an upper bound of |x| over the input slice, left there by whoever produced the input (any kernel of this
+     *               library run with out_absmax, or ct_absmax_f32); kernels that need the maximum and do not get it take it
+     *               themselves in an extra pass (ct_conv2d_wino4s_fwd variant 3) or refuse (ct_conv2d_wino4f_fwd variant 2);
+     *   out_absmax  the launch folds max |y| of everything it stores into this slot (atomic max): honoured by the F(4x4,3x3)
+     *               kernels' shared epilogue (ct_conv2d_wino4_fwd, _wino4s_fwd, _wino4f_fwd) and by the 3-channel image layer
+     *               of ct_conv2d_fwd (config "valu"); ignored by the other kernels. */
+    const unsigned* in_absmax;
+    unsigned* out_absmax;
 } ct_conv_desc;
+#define CT_ABSMAX_SLOT_BYTES 2048
+/* max |x| over the channel slices [batch][per_image floats] (images img_stride floats apart) folded into `slot` (atomic max;
+ * the caller zeroes the slot once per step). */
+int ct_absmax_f32(const float* in, int batch, long long per_image, long long img_stride, unsigned* slot, ct_stream_t stream);
 
 /* Rows of the packed weight matrix for a (cin, kh, kw) filter: k_pad. */
 int ct_conv_kpad(int cin, int kh, int kw);
@@ -378,6 +394,17 @@ int ct_conv_pack_weights_wino4f_dgrad(const float* const* w, const int* cout, in
 int ct_conv2d_wino4f_fwd(const ct_conv_desc* desc, const void* upacked, ct_stream_t stream);
 int ct_conv2d_wino4f_pool_fwd(const ct_conv_desc* desc, const void* upacked, float* pool_out, int pool_ctot, int pool_coff,
                               int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
+/* The same kernel on the f16x2 operand form (variant 2; variant 1 = bf16x3 = ct_conv2d_wino4f_pool_fwd): two binary16 pieces per
+ * transform-domain value, three piece products (csrc/ct_f16x2.h, see ct_conv2d_wino4s_fwd variant 3) -- 27 instead of 54 MFMAs and
+ * 120 instead of 220 split instructions per wave and 16-channel chunk.  Needs desc->in_absmax (the fused kernel cannot take the
+ * input's maximum itself) and weights from ct_conv_pack_weights_wino4f_h2 (ct_conv_wino4f_h2_packed_bytes bytes); pool_out == NULL
+ * and write_full == 1 for a plain launch.  Honours desc->out_absmax. */
+size_t ct_conv_wino4f_h2_packed_bytes(int cin, int cout);
+int ct_conv_pack_weights_wino4f_h2(const float* const* w, const int* cout, int nparts, int cin, void* upacked, ct_stream_t stream);
+int ct_conv_pack_weights_wino4f_h2_dgrad(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
+                                         ct_stream_t stream);
+int ct_conv2d_wino4f_pool_fwd_v(const ct_conv_desc* desc, const void* upacked, int variant, float* pool_out, int pool_ctot,
+                                int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream);
 
 /* ---- "bf16x3": the fp32 convolution of ct_conv2d_fwd on the bf16 matrix pipe (csrc/ct_conv_x3.hip) ----
  * Same layers (models/RFB_Net_vgg.py:7-22 BasicConv, the plain Conv2d layers, the multibox heads :238-248), the same

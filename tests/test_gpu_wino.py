@@ -15,9 +15,10 @@ from test_gpu_kernels import _bn, _ref_conv, _run_conv
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 W = engine.WINO
-VARIANTS = [engine.WINO, engine.WINO4, engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ, engine.WINO4F, engine.WINO4H]
-VIDS = ['f2x2', 'f4x4', 'f2x2_x3', 'f2x2_x3q', 'f4x4_s', 'f4x4_sq', 'f4x4_f', 'f4x4_h']
-X3V = (engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ, engine.WINO4F, engine.WINO4H)         # cin must be a multiple of 16 (one MFMA k-group)
+VARIANTS = [engine.WINO, engine.WINO4, engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ, engine.WINO4F, engine.WINO4H,
+            engine.WINO4FH]
+VIDS = ['f2x2', 'f4x4', 'f2x2_x3', 'f2x2_x3q', 'f4x4_s', 'f4x4_sq', 'f4x4_f', 'f4x4_h', 'f4x4_fh']
+X3V = (engine.WINOX, engine.WINOXQ, engine.WINO4S, engine.WINO4SQ, engine.WINO4F, engine.WINO4H, engine.WINO4FH)         # cin must be a multiple of 16 (one MFMA k-group)
 S3V = (engine.WINO4S, engine.WINO4SQ, engine.WINO4H)                                     # the three-kernel forms (dilated layers too)
 
 
@@ -203,7 +204,8 @@ def test_conv_input_above_2gib_is_chunked(use_wino):
 
 
 @pytest.mark.parametrize('W,bound', [(engine.WINO, 3e-6), (engine.WINO4, 5e-5), (engine.WINOX, 1e-6), (engine.WINOXQ, 2e-6),
-                                     (engine.WINO4S, 6e-6), (engine.WINO4SQ, 1.2e-5), (engine.WINO4F, 1.2e-5), (engine.WINO4H, 6e-6)],
+                                     (engine.WINO4S, 6e-6), (engine.WINO4SQ, 1.2e-5), (engine.WINO4F, 1.2e-5), (engine.WINO4H, 6e-6),
+                                     (engine.WINO4FH, 1.2e-5)],
                          ids=VIDS)
 def test_wino_rounding_error_vs_fp64(W, bound):
     """The transform-domain rounding of each variant on the deepest VGG shape (512 input channels, post-ReLU input):

