@@ -22,7 +22,12 @@ for name in sys.argv[1:] or ['base.2', 'base.7']:
     st = engine.ConvStep(name, [engine.ConvPart(w, b, None, True)], Cin, 3, 3, 1, 1, 1, 1, 'x', 0, H, W, 'y', 0)
     bufs = {'x': torch.randn(B, Cin, H, W, device=DEV), 'y': torch.empty(B, Cout, H, W, device=DEV)}
     be.prepare_conv(st, bufs, B)
-    be.enable_wino(st, tile=46)
+    tile = int(os.environ.get('TILE', '46'))            # 46: bf16x3, 48: f16x2 (needs the maximum of |input|, taken once here)
+    be.enable_wino(st, tile=tile)
+    if tile == 48:
+        slot = torch.zeros(_lib.ABSMAX_SLOT_BYTES // 4, device=DEV, dtype=torch.int32)
+        _lib.check(be.lib.ct_absmax_f32(bufs['x'].data_ptr(), B, Cin * H * W, Cin * H * W, slot.data_ptr(), be._stream()), 'ct_absmax_f32')
+        st.rt['desc'].in_absmax = slot.data_ptr()
     for _ in range(3):
         be.run_conv(st)
     tiles = B * ((H + 3) // 4) * ((W + 3) // 4)
