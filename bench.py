@@ -229,8 +229,10 @@ def conv_roofline(rt, batch, pmc, pick=None):
         elif wino:
             name, mult, pk = WINOGRAD_KERNEL[wino], WINOGRAD_MULT_RATIO[wino], PEAK_F32_MFMA_TFLOPS
         elif x3 is not None:
-            # bf16x3: six bf16 MFMA products per fp32 multiply-add, on the bf16 pipe
-            name, mult, pk = 'conv_x3_f32<%dx%d,%s>' % (st.kh, st.kw, x3_names[x3][3:]), 6.0, PEAK_BF16_MFMA_TFLOPS
+            # bf16x3: six bf16 MFMA products per fp32 multiply-add, on the bf16 pipe; f16x2 ('h2:' configurations): three f16 products
+            h2 = x3_names[x3].startswith('h2:')
+            name, mult, pk = 'conv_%s_f32<%dx%d,%s>' % ('h2' if h2 else 'x3', st.kh, st.kw, x3_names[x3][3:]), 3.0 if h2 else 6.0, \
+                PEAK_BF16_MFMA_TFLOPS
         else:
             cname = lib.ct_conv_config_name(cfg - 1).decode() if cfg > 0 else 'auto'
             name = st.rt.get('kernel_name') or 'conv_igemm_f32<%dx%d,%s>' % (st.kh, st.kw, cname)

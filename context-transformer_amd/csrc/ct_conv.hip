@@ -391,7 +391,9 @@ __global__ __launch_bounds__(256) void conv_valu3x3_f32(const ConvArgs a)
     cfloat* const sc = (cfloat*)a.scale;
     cfloat* const sh = (cfloat*)a.shift;
     cfloat* const lo = (cfloat*)a.lo;
-    float amax_run = 0.f;                     // a.out_amax: the thread's maximum of |v| over what it stores
+    float amax_run[PPT];                      // a.out_amax: the thread's maxima of |v| over what it stores, per pixel (= per image)
+#pragma unroll
+    for (int p = 0; p < PPT; ++p) amax_run[p] = 0.f;
     const bool track = a.out_amax != nullptr;
     for (int co0 = 0; co0 < a.M; co0 += 8) {
         f32x2 acc[PPT][4];
@@ -455,12 +457,18 @@ __global__ __launch_bounds__(256) void conv_valu3x3_f32(const ConvArgs a)
                 v = v < lov ? lov : v;                  // NaN propagates
                 if (live[p]) {
                     op[p][(size_t)co * a.OHW] = v;
-                    if (track) ctdet::h2::track_absmax(amax_run, v);
+                    if (track) ctdet::h2::track_absmax(amax_run[p], v);
                 }
             }
         }
     }
-    if (track) ctdet::h2::wave_atomic_absmax(a.out_amax, blockIdx.x, amax_run);       // one atomic per wave
+    if (track) {                              // one atomic per image present in the wave (every lane arrives here)
+#pragma unroll
+        for (int p = 0; p < PPT; ++p) {
+            const int P = (blockIdx.x * PPT + p) * 256 + threadIdx.x;
+            ctdet::h2::flush_absmax(a.out_amax, live[p] ? P / a.OHW : -1, amax_run[p]);
+        }
+    }
 }
 
 // epilogue of a split-K convolution: sum of the slabs in split order, then the same arithmetic as the fused one

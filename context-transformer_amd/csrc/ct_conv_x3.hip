@@ -25,6 +25,7 @@
 //   LDS double buffered, one barrier per k-step; the loads of step s+1 are issued before the MFMAs of step s.
 // Small maps use the same deterministic slab split-K as ct_conv2d_fwd (desc->ksplit).
 #include "ct_common.h"
+#include "ct_f16x2.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -36,6 +37,7 @@
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
@@ -64,6 +66,12 @@ struct X3Args {
     int ksplit, steps_per_split, nsteps;
     int transposed;                 // data gradient: `in` = dY, output pixel = input pixel of the forward convolution
     float* ws;
+    // f16x2 form (H2 instantiations, ct_f16x2.h): activations are split as x 2^eX with eX from the producer's maximum of |input|
+    // (ct_conv_desc.in_absmax), the weights arrive as w 2^eW (eW in the trailer of the split weights); the epilogue's per-channel
+    // scale takes 2^-(eX + eW)
+    const unsigned* in_amax;
+    const int* eW;
+    unsigned* out_amax;             // ct_conv_desc.out_absmax: max |y| of what the launch stores, or null (any form)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -95,17 +103,22 @@ __device__ __forceinline__ int pack_hi(unsigned e0, unsigned e1)
 // every MFMA, and the compiler's scheduler keeps that interleaving (pinning the slots with sched_barrier measured
 // 10-40 % SLOWER here, as cdna_hip_programming.md warns for 32-cycle MFMAs); first / last steps are peeled (STORE /
 // LOAD flags) so no branch cuts the block.
-template <int BM, int BN, int BK, bool DUAL>
+// H2: the f16x2 operand form (csrc/ct_f16x2.h): two binary16 pieces per operand, the three products (lo, hi), (hi, lo), (hi, hi) on
+//   v_mfma_f32_32x32x16_f16 -- half the MFMAs, two thirds of the LDS traffic and of the weight bytes, 2 instead of 5.5 vector
+//   instructions per split activation; DUAL then keeps (hi, hi) apart from the two small products.
+template <int BM, int BN, int BK, bool DUAL, bool H2>
 __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
 {
+    constexpr int NP = H2 ? 2 : 3;              // pieces per operand
+    constexpr int NPROD = H2 ? 3 : 6;           // piece products per multiply-add
     constexpr int OCT = BK / 8;                 // k-octets per k-step
     constexpr int NH = BK / 16;                 // MFMA k-groups per k-step
     constexpr int WM = BM / 2, WN = BN / 2;     // wave tile (2 x 2 waves)
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int A_PIECE = OCT * BM * 16;      // bytes of one piece of the A tile
     constexpr int B_PIECE = OCT * BN * 16;
-    constexpr int A_BYTES = 3 * A_PIECE, B_BYTES = 3 * B_PIECE;
-    constexpr int NA = (3 * OCT * BM + 255) / 256;          // 16-byte rows of A per thread and k-step
+    constexpr int A_BYTES = NP * A_PIECE, B_BYTES = NP * B_PIECE;
+    constexpr int NA = (NP * OCT * BM + 255) / 256;         // 16-byte rows of A per thread and k-step
     constexpr int OSTR = 256 / BN;                          // octet stride between a thread's gathers
     constexpr int GPT = OCT / OSTR;                         // k-octets gathered per thread and k-step
     static_assert(256 % BN == 0 && OCT % OSTR == 0 && GPT >= 1, "B staging: every thread gathers GPT whole octets");
@@ -136,13 +149,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
     const int bp = tid % BN;
     const int oct0 = __builtin_amdgcn_readfirstlane(tid / BN);       // first k-octet of this thread; next: + OSTR
     const int HW = a.H * a.W;
-    int img_base, ih0, iw0;
+    int img_base, ih0, iw0, bp_image;
     bool pvalid;
     {
         const int P = n0 + bp;
         pvalid = P < a.Npix;
         const int Pc = pvalid ? P : 0;
         const int n = Pc / a.OHW;
+        bp_image = n;
         const int s = Pc - n * a.OHW;
         const int oh = s / a.OW, ow = s - oh * a.OW;
         // forward: (oh, ow) reads ih = oh*stride - pad + kh*dil.  transposed (this "output" pixel is the forward conv's
@@ -157,18 +171,23 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
         int f = tid + 256 * j;
-        if (f >= 3 * OCT * BM) f %= (3 * OCT * BM);      // surplus lanes duplicate an element (same data, same slot)
+        if (f >= NP * OCT * BM) f %= (NP * OCT * BM);    // surplus lanes duplicate an element (same data, same slot)
         const int row = f % BM, po = f / BM;             // po = piece * OCT + octet
         const int col = m0 + row;
         a_voff[j] = col < a.M_pad ? (po * a.M_pad + col) * 16 : kInvalidOff;
         a_lds[j] = po * (BM * 16) + row * 16;
     }
-    const int a_step_bytes = 3 * OCT * a.M_pad * 16;
+    const int a_step_bytes = NP * OCT * a.M_pad * 16;
+    // f16x2: this thread's gathered activations are split as x 2^eX with eX from the maximum of |input| of ITS pixel's image
+    // (ct_f16x2.h: per image, so that an image's results do not depend on its batch mates)
+    float vscale = 1.f;
+    if constexpr (H2) vscale = __builtin_ldexpf(1.f, ctdet::h2::image_exponent(a.in_amax, bp_image, ctdet::h2::kGrowthNone));
     const int chan_bytes = HW * 4;
 
     i32x4 areg[NA];
     float breg[GPT][8];
-    unsigned sh[GPT][8], sm[GPT][8], sl[GPT][8];      // split pieces of the tile being stored
+    unsigned sh[GPT][8], sm[GPT][8], sl[GPT][8];      // split pieces of the tile being stored (bf16x3)
+    int ph[GPT][4], pl[GPT][4];                       // ... packed pairs of hi / lo pieces (f16x2)
 
     // ---- loader state: (channel group, tap) of the NEXT tile to load, advanced tap-fastest so the BK channels of a
     // group stay in cache over the filter taps; everything wave-uniform lives in SGPRs
@@ -216,24 +235,37 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
         *reinterpret_cast<i32x4*>(lds + buf * (A_BYTES + B_BYTES) + a_lds[j]) = areg[j];
     };
     auto store_b = [&](int g, int piece, int buf) {
-        const unsigned(&v)[8] = piece == 0 ? sh[g] : piece == 1 ? sm[g] : sl[g];
         i32x4 pk;
+        if constexpr (H2) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pk[q] = pack_hi(v[2 * q], v[2 * q + 1]);
+            for (int q = 0; q < 4; ++q) pk[q] = piece == 0 ? ph[g][q] : pl[g][q];
+        } else {
+            const unsigned(&v)[8] = piece == 0 ? sh[g] : piece == 1 ? sm[g] : sl[g];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pk[q] = pack_hi(v[2 * q], v[2 * q + 1]);
+        }
         *reinterpret_cast<i32x4*>(lds + buf * (A_BYTES + B_BYTES) + A_BYTES + piece * B_PIECE +
                                   ((oct0 + g * OSTR) * BN + bp) * 16) = pk;
     };
-    // side work of a k-step as a list of items: A rows, then per gathered octet 8 x (split + reload) and 3 x (pack + write)
-    constexpr int NW = NA + GPT * 11;
+    // side work of a k-step as a list of items: A rows, then per gathered octet 8 x (split + reload) and NP x (pack + write);
+    // f16x2 splits a PAIR (r, r + 1) at the even item, before either register is reloaded
+    constexpr int IPG = 8 + NP;
+    constexpr int NW = NA + GPT * IPG;
     auto side_item = [&](int w, int buf, auto store_c, auto load_c) {
         constexpr bool STORE = decltype(store_c)::value, LOAD = decltype(load_c)::value;
         if (w < NA) {
             if (STORE) store_a(w, buf);
             if (LOAD) load_a(w);
         } else {
-            const int g = (w - NA) / 11, r = (w - NA) % 11;
+            const int g = (w - NA) / IPG, r = (w - NA) % IPG;
             if (r < 8) {
-                if (STORE) split3(breg[g][r], sh[g][r], sm[g][r], sl[g][r]);
+                if (STORE) {
+                    if constexpr (H2) {
+                        if ((r & 1) == 0) ctdet::h2::split2(breg[g][r] * vscale, breg[g][r + 1] * vscale, ph[g][r >> 1], pl[g][r >> 1]);
+                    } else {
+                        split3(breg[g][r], sh[g][r], sm[g][r], sl[g][r]);
+                    }
+                }
                 if (LOAD) load_b(g, r);
             } else if (STORE) {
                 store_b(g, r - 8, buf);
@@ -253,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
                 if (DUAL) acs[i][j][r] = 0.f;
             }
 
-    constexpr int NMF = NH * 6 * TM * TN;                     // MFMAs per k-step and wave
+    constexpr int NMF = NH * NPROD * TM * TN;                 // MFMAs per k-step and wave
     constexpr int WPS = (NW + NMF - 2) / (NMF - 1);           // side items per MFMA slot (the last slot stays free)
     using T_ = std::true_type;
     using F_ = std::false_type;
@@ -262,11 +294,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
         constexpr bool LOAD = decltype(load_c)::value;
         const unsigned char* A = lds + buf * (A_BYTES + B_BYTES) + (wm0 + l31) * 16;
         const unsigned char* B = lds + buf * (A_BYTES + B_BYTES) + A_BYTES + (wn0 + l31) * 16;
-        i32x4 fa[NH][3][TM], fb[NH][3][TN];
+        i32x4 fa[NH][NP][TM], fb[NH][NP][TN];
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NP; ++p) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
                     fa[h][p][i] = *reinterpret_cast<const i32x4*>(A + p * A_PIECE + (2 * h + hsel) * (BM * 16) + i * 512);
@@ -275,19 +307,18 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
                     fb[h][p][j] = *reinterpret_cast<const i32x4*>(B + p * B_PIECE + (2 * h + hsel) * (BN * 16) + j * 512);
             }
         if (LOAD) begin_load();
-        // smallest products first: (mid, mid), (lo, hi), (hi, lo), (mid, hi), (hi, mid), then (hi, hi)
-        constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+        // smallest products first: bf16x3 (mid, mid), (lo, hi), (hi, lo), (mid, hi), (hi, mid), then (hi, hi); f16x2 (lo, hi), (hi, lo), (hi, hi)
+        constexpr int PA[6] = {1, H2 ? 0 : 2, 0, 1, 0, 0}, PB[6] = {H2 ? 0 : 1, H2 ? 1 : 0, H2 ? 0 : 2, 0, 1, 0};
 #pragma unroll
         for (int s = 0; s < NMF; ++s) {
-            const int h = s / (6 * TM * TN), t = (s / (TM * TN)) % 6, i = (s / TN) % TM, j = s % TN;
-            if (DUAL && t < 5)
-                acs[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[h][PA[t]][i]),
-                                                                    __builtin_bit_cast(bf16x8, fb[h][PB[t]][j]),
-                                                                    acs[i][j], 0, 0, 0);
+            const int h = s / (NPROD * TM * TN), t = (s / (TM * TN)) % NPROD, i = (s / TN) % TM, j = s % TN;
+            f32x16& dst = (DUAL && t < NPROD - 1) ? acs[i][j] : acc[i][j];
+            if constexpr (H2)
+                dst = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[h][PA[t]][i]),
+                                                             __builtin_bit_cast(f16x8, fb[h][PB[t]][j]), dst, 0, 0, 0);
             else
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[h][PA[t]][i]),
-                                                                    __builtin_bit_cast(bf16x8, fb[h][PB[t]][j]),
-                                                                    acc[i][j], 0, 0, 0);
+                dst = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[h][PA[t]][i]),
+                                                              __builtin_bit_cast(bf16x8, fb[h][PB[t]][j]), dst, 0, 0, 0);
 #pragma unroll
             for (int q = 0; q < WPS; ++q) {
                 const int w = s * WPS + q;
@@ -363,62 +394,93 @@ __global__ __launch_bounds__(256, 2) void conv_x3_f32(const X3Args a)
         ev[2 * BM + i] = !in ? 0.f : a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
     }
     __syncthreads();
+    const bool track = a.out_amax != nullptr;
+    int eW = 0;
+    if constexpr (H2) eW = *a.eW;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int P = n0 + wn0 + j * 32 + l31;
-        if (P >= a.Npix) continue;
-        const int n = P / a.OHW;
-        const int s = P - n * a.OHW;
-        float* const orow = a.nseg == 0 ? a.out + ((size_t)n * a.out_ctot + a.out_coff) * a.OHW + s : nullptr;
-        const float* const rrow = a.res ? a.res + ((size_t)n * a.res_ctot + a.res_coff) * a.OHW + s : nullptr;
+        const bool live = P < a.Npix;
+        const int n = live ? P / a.OHW : -1;
+        float amax_run = 0.f;                       // a.out_amax: the thread's maximum of |v| over what it stores for pixel P's image
+        if (live) {
+            const int s = P - n * a.OHW;
+            // f16x2: the sums carry 2^(eX[image] + eW); undone with an exact power of two in front of the per-channel scale
+            float ymul = 1.f;
+            if constexpr (H2) ymul = __builtin_ldexpf(1.f, -(eW + ctdet::h2::image_exponent(a.in_amax, n, ctdet::h2::kGrowthNone)));
+            float* const orow = a.nseg == 0 ? a.out + ((size_t)n * a.out_ctot + a.out_coff) * a.OHW + s : nullptr;
+            const float* const rrow = a.res ? a.res + ((size_t)n * a.res_ctot + a.res_coff) * a.OHW + s : nullptr;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            // the residual values of the whole 32 x 32 block first, sixteen loads in flight: taken one by one between the
-            // stores (which they may alias, so the compiler keeps the order) every load waited a full round trip behind the
-            // previous store -- the RFB blocks' ConvLinear layers ran at 0.6 of the rate of the same GEMM without a shortcut
-            float rv[16];
-            if (rrow) {
+            for (int i = 0; i < TM; ++i) {
+                // the residual values of the whole 32 x 32 block first, sixteen loads in flight: taken one by one between the
+                // stores (which they may alias, so the compiler keeps the order) every load waited a full round trip behind the
+                // previous store -- the RFB blocks' ConvLinear layers ran at 0.6 of the rate of the same GEMM without a shortcut
+                float rv[16];
+                if (rrow) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                        rv[r] = co < a.M ? rrow[(size_t)co * a.OHW] : 0.f;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int co = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-                    rv[r] = co < a.M ? rrow[(size_t)co * a.OHW] : 0.f;
-                }
-            }
+                    const int cl = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;      // cout inside the tile
+                    const int co = m0 + cl;
+                    if (co >= a.M) continue;
+                    float v = (H2 ? acc[i][j][r] * ymul : acc[i][j][r]) * ev[cl] + ev[BM + cl];
+                    if (rrow) v = v * a.res_scale + rv[r];
+                    { const float fl = ev[2 * BM + cl]; v = v < fl ? fl : v; }      // NaN propagates (torch.relu / no clamp)
+                    if (track) ctdet::h2::track_absmax(amax_run, v);
+                    if (a.nseg == 0) {
+                        orow[(size_t)co * a.OHW] = v;
+                    } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cl = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;      // cout inside the tile
-                const int co = m0 + cl;
-                if (co >= a.M) continue;
-                float v = acc[i][j][r] * ev[cl] + ev[BM + cl];
-                if (rrow) v = v * a.res_scale + rv[r];
-                { const float fl = ev[2 * BM + cl]; v = v < fl ? fl : v; }      // NaN propagates (torch.relu / no clamp)
-                if (a.nseg == 0) {
-                    orow[(size_t)co * a.OHW] = v;
-                } else {
-#pragma unroll
-                    for (int g = 0; g < 3; ++g)
-                        if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
-                            a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
-                                         (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
+                        for (int g = 0; g < 3; ++g)
+                            if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
+                                a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                             (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
+                    }
                 }
             }
         }
+        // ct_conv_desc.out_absmax: every lane arrives here; one atomic per image present in the wave
+        if (track) ctdet::h2::flush_absmax(a.out_amax, n, amax_run);
     }
 }
 
-// sum of the split-K slabs in split order, then the fused epilogue
+__device__ __forceinline__ void x3_splitk_one(const X3Args& a, int idx, int total, bool track, float& amax_run, int& n_out);
+
+// sum of the split-K slabs in split order, then the fused epilogue (f16x2 launches: the slabs hold the scaled sums)
 __global__ __launch_bounds__(256) void conv_x3_splitk_epilogue(const X3Args a)
 {
     const int total = a.M * a.Npix;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const bool track = a.out_amax != nullptr;
+    const int rounds = (total + gridDim.x * 256 - 1) / (gridDim.x * 256);       // the same trip count for every lane (flush below)
+    for (int it = 0; it < rounds; ++it) {
+        const int idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        float amax_run = 0.f;
+        int n = -1;
+        if (idx < total) x3_splitk_one(a, idx, total, track, amax_run, n);
+        if (track) ctdet::h2::flush_absmax(a.out_amax, n, amax_run);
+    }
+}
+
+__device__ __forceinline__ void x3_splitk_one(const X3Args& a, const int idx, const int total, const bool track, float& amax_run, int& n_out)
+{
+    {
         const int co = idx / a.Npix, P = idx - co * a.Npix;
         const int n = P / a.OHW, s = P - n * a.OHW;
+        n_out = n;
+        float ymul = 1.f;       // f16x2 launches: the slabs hold sums scaled by 2^(eX[image] + eW)
+        if (a.eW) ymul = __builtin_ldexpf(1.f, -(*a.eW + ctdet::h2::image_exponent(a.in_amax, n, ctdet::h2::kGrowthNone)));
         float sum = a.ws[idx];
         for (int k = 1; k < a.ksplit; ++k) sum += a.ws[(size_t)k * total + idx];
-        float v = sum * a.scale[co] + a.shift[co];
+        float v = (sum * ymul) * a.scale[co] + a.shift[co];
         if (a.res) v = v * a.res_scale + a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
         if (a.lo) { const float fl = a.lo[co]; v = v < fl ? fl : v; }      // NaN propagates
         else if (a.relu) v = v < 0.f ? 0.f : v;
+        if (track) ctdet::h2::track_absmax(amax_run, v);
         if (a.nseg == 0) {
             a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
         } else {
@@ -438,6 +500,9 @@ struct X3PackArgs {
     int nparts, cin, khw, bk, m_pad, cgroups;
     int dgrad;                // rows m = forward INPUT channels, k-channels = forward OUTPUT channels (concatenated parts)
     unsigned short* out;
+    // f16x2 layout: [step][piece 2][octet][m_pad][8 f16] of w 2^eW, eW from max |w| over the layer (trailer[0] = its bit pattern,
+    // filled by x3h_wmax_kernel; the packing records trailer[1] = eW)
+    unsigned* trailer;        // null: bf16x3
 };
 
 __device__ __forceinline__ void x3_pack_body(const X3PackArgs& p, long first, long stride)
@@ -458,8 +523,10 @@ __device__ __forceinline__ void x3_pack_body(const X3PackArgs& p, long first, lo
                 if (i < p.nparts && m >= p.mbeg[i] && m < p.mbeg[i + 1]) { src = p.w[i]; mm = m - p.mbeg[i]; }
         }
         const long step = (long)cg * p.khw + tap;
-        unsigned short* base = p.out + (((step * 3) * oct + o) * (long)p.m_pad + m) * 8;
+        const int np = p.trailer ? 2 : 3;
+        unsigned short* base = p.out + (((step * np) * oct + o) * (long)p.m_pad + m) * 8;
         const long piece_stride = (long)oct * p.m_pad * 8;
+        const int eW = p.trailer ? ctdet::h2::exponent_for(p.trailer[0], ctdet::h2::kGrowthNone) : 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int ci = cg * p.bk + o * 8 + e;
@@ -472,6 +539,14 @@ __device__ __forceinline__ void x3_pack_body(const X3PackArgs& p, long first, lo
                     if (i < p.nparts && ci >= p.mbeg[i] && ci < p.mbeg[i + 1])
                         v = p.w[i][((size_t)(ci - p.mbeg[i]) * p.cin + m) * p.khw + tap];
             }
+            if (p.trailer) {
+                const float vs = __builtin_ldexpf(v, eW);
+                const _Float16 hi = (_Float16)vs;
+                const _Float16 lo = (_Float16)(vs - (float)hi);
+                base[e] = __builtin_bit_cast(unsigned short, hi);
+                base[piece_stride + e] = __builtin_bit_cast(unsigned short, lo);
+                continue;
+            }
             unsigned h, mid, l;
             split3(v, h, mid, l);
             base[e] = (unsigned short)(h >> 16);
@@ -479,6 +554,23 @@ __device__ __forceinline__ void x3_pack_body(const X3PackArgs& p, long first, lo
             base[2 * piece_stride + e] = (unsigned short)(l >> 16);
         }
     }
+    if (p.trailer && first == 0) p.trailer[1] = (unsigned)ctdet::h2::exponent_for(p.trailer[0], ctdet::h2::kGrowthNone);
+}
+
+// max |w| over the parts of a layer -> trailer[0] (atomic max; the caller zeroes the trailer)
+__global__ __launch_bounds__(256) void x3h_wmax_kernel(const X3PackArgs p)
+{
+    unsigned m = 0;
+    for (int part = 0; part < p.nparts; ++part) {
+        const long n = (long)(p.mbeg[part + 1] - p.mbeg[part]) * p.cin * p.khw;
+        const float* w = p.w[part];
+        for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+            const unsigned a = __builtin_bit_cast(unsigned, w[i]) & 0x7FFFFFFFu;
+            m = a > m ? a : m;
+        }
+    }
+    m = ctdet::h2::wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(p.trailer, m);
 }
 
 __global__ void x3_pack_kernel(const X3PackArgs p)
@@ -496,12 +588,16 @@ __global__ void x3_pack_batched_kernel(const X3PackArgs* __restrict__ items)
 struct X3Cfg {
     int bm, bn, bk, dual;
     const char* name;
+    int h2;                   // 1: the f16x2 operand form (weights from ct_conv_pack_weights_x3h, needs ct_conv_desc.in_absmax)
 };
 // name: x3:<BM>x<BN>k<BK>[d]   d = dual accumulators -- the configurations the engine may select (accuracy gate);
 // the single-accumulator forms are kept for the comparison in tests/test_gpu_x3.py and tools/x3_probe.py
 const X3Cfg kX3[] = {
     {128, 128, 16, 1, "x3:128x128k16d"}, {64, 128, 16, 1, "x3:64x128k16d"}, {128, 64, 32, 1, "x3:128x64k32d"},
     {64, 64, 32, 1, "x3:64x64k32d"},     {128, 128, 16, 0, "x3:128x128k16"}, {64, 128, 16, 0, "x3:64x128k16"},
+    // the same tiles on f16x2 ("h2:..."): the engine maps a table entry x3:<tile> to h2:<tile> where the runtime uses that form
+    {128, 128, 16, 1, "h2:128x128k16d", 1}, {64, 128, 16, 1, "h2:64x128k16d", 1}, {128, 64, 32, 1, "h2:128x64k32d", 1},
+    {64, 64, 32, 1, "h2:64x64k32d", 1},
 };
 constexpr int kNumX3 = sizeof(kX3) / sizeof(kX3[0]);
 
@@ -526,14 +622,18 @@ hipError_t launch_x3(K kernel, size_t smem, const X3Args& a, hipStream_t st)
 hipError_t launch_cfg(int cfg, const X3Args& a, hipStream_t st)
 {
     switch (cfg) {
-#define X3_CASE(idx, BM, BN, BK, DU) \
-    case idx: return launch_x3(conv_x3_f32<BM, BN, BK, DU>, (size_t)2 * 3 * (BK / 8) * (BM + BN) * 16, a, st);
-        X3_CASE(0, 128, 128, 16, true)
-        X3_CASE(1, 64, 128, 16, true)
-        X3_CASE(2, 128, 64, 32, true)
-        X3_CASE(3, 64, 64, 32, true)
-        X3_CASE(4, 128, 128, 16, false)
-        X3_CASE(5, 64, 128, 16, false)
+#define X3_CASE(idx, BM, BN, BK, DU, H2) \
+    case idx: return launch_x3(conv_x3_f32<BM, BN, BK, DU, H2>, (size_t)2 * (H2 ? 2 : 3) * (BK / 8) * (BM + BN) * 16, a, st);
+        X3_CASE(0, 128, 128, 16, true, false)
+        X3_CASE(1, 64, 128, 16, true, false)
+        X3_CASE(2, 128, 64, 32, true, false)
+        X3_CASE(3, 64, 64, 32, true, false)
+        X3_CASE(4, 128, 128, 16, false, false)
+        X3_CASE(5, 64, 128, 16, false, false)
+        X3_CASE(6, 128, 128, 16, true, true)
+        X3_CASE(7, 64, 128, 16, true, true)
+        X3_CASE(8, 128, 64, 32, true, true)
+        X3_CASE(9, 64, 64, 32, true, true)
 #undef X3_CASE
         default: return hipErrorInvalidValue;
     }
@@ -546,6 +646,18 @@ extern "C" int ct_conv_x3_num_configs(void) { return kNumX3; }
 extern "C" const char* ct_conv_x3_config_name(int i) { return (i >= 0 && i < kNumX3) ? kX3[i].name : "?"; }
 
 extern "C" int ct_conv_x3_config_bk(int i) { return (i >= 0 && i < kNumX3) ? kX3[i].bk : -1; }
+
+extern "C" int ct_conv_x3_config_h2(int i) { return (i >= 0 && i < kNumX3) ? kX3[i].h2 : -1; }
+
+constexpr int kX3hTrailerBytes = 256;
+
+// bytes of the f16x2 split weights for k-steps of bk channels, trailer { max |w| bits, eW } included
+extern "C" size_t ct_conv_x3h_packed_bytes(int cin, int cout, int kh, int kw, int bk)
+{
+    if (bk != 16 && bk != 32) return 0;
+    const size_t cgroups = (size_t)(cin + bk - 1) / bk;
+    return cgroups * kh * kw * 2 * (size_t)bk * ct_conv_mpad(cout) * 2 + kX3hTrailerBytes;
+}
 
 // bytes of the split weights for k-steps of bk (16 or 32) channels
 extern "C" size_t ct_conv_x3_packed_bytes(int cin, int cout, int kh, int kw, int bk)
@@ -630,6 +742,26 @@ extern "C" int ct_conv_pack_weights_x3(const float* const* w, const int* cout, i
     return x3_pack_impl(w, cout, nparts, cin, kh, kw, bk, wx3, 0, stream);
 }
 
+// f16x2: max |w| first, then the split of w 2^eW (forward layout only; three launches, not recordable)
+extern "C" int ct_conv_pack_weights_x3h(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
+                                        int bk, void* wx3, ct_stream_t stream)
+{
+    X3PackArgs p{};
+    if (int rc = x3_pack_fill(w, cout, nparts, cin, kh, kw, bk, wx3, 0, p)) return rc;
+    hipStream_t st = ctdet::as_stream(stream);
+    int mtot = p.mbeg[nparts];
+    p.trailer = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(wx3) + ct_conv_x3h_packed_bytes(cin, mtot, kh, kw, bk) -
+                                            kX3hTrailerBytes);
+    CT_HIP(hipMemsetAsync(p.trailer, 0, kX3hTrailerBytes, st));
+    const long nw = (long)mtot * cin * kh * kw;
+    hipLaunchKernelGGL(x3h_wmax_kernel, dim3((unsigned)std::min<long>((nw + 255) / 256, 1024)), dim3(256), 0, st, p);
+    CT_LAUNCH_CHECK("x3h_wmax_kernel");
+    const long rows = (long)p.cgroups * p.khw * (bk / 8) * p.m_pad;
+    hipLaunchKernelGGL(x3_pack_kernel, dim3((unsigned)std::min<long>((rows + 255) / 256, 4096)), dim3(256), 0, st, p);
+    CT_LAUNCH_CHECK("x3_pack_kernel");
+    return CT_OK;
+}
+
 extern "C" int ct_conv_pack_weights_x3_dgrad(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw,
                                              int bk, void* wx3, ct_stream_t stream)
 {
@@ -665,11 +797,16 @@ extern "C" int ct_conv2d_x3_fwd(const ct_conv_desc* d, const void* wx3, int conf
         for (int g = 0; g < d->nseg; ++g) CT_REQUIRE(d->seg[g].ptr, "ct_conv2d_x3_fwd: null segment");
     }
     const int bm = kX3[config].bm, bn = kX3[config].bn, bk = kX3[config].bk;
+    const bool h2 = kX3[config].h2 != 0;
+    CT_REQUIRE(!h2 || d->in_absmax, "ct_conv2d_x3_fwd: the f16x2 configurations need the maximum of |input| (ct_conv_desc.in_absmax: "
+               "the producer's out_absmax slot, or ct_absmax_f32)");
+    CT_REQUIRE(!h2 || !d->transposed, "ct_conv2d_x3_fwd: the f16x2 configurations are forward-only");
     if (d->cin % bk != 0)
         return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_x3_fwd: cin=%d is not a multiple of the k-step (%d channels)",
                            d->cin, bk);
     const int m_pad = ct_conv_mpad(d->cout);
-    const size_t wbytes = ct_conv_x3_packed_bytes(d->cin, d->cout, d->kh, d->kw, bk);
+    const size_t wbytes = h2 ? ct_conv_x3h_packed_bytes(d->cin, d->cout, d->kh, d->kw, bk) - kX3hTrailerBytes
+                             : ct_conv_x3_packed_bytes(d->cin, d->cout, d->kh, d->kw, bk);
     CT_REQUIRE((long long)wbytes < kMaxBufBytes, "ct_conv2d_x3_fwd: weights too large");
     const long long img_in_bytes = (long long)d->in_ctot * d->h * d->w * 4;
     CT_REQUIRE(img_in_bytes < kMaxBufBytes, "ct_conv2d_x3_fwd: one image exceeds 2 GiB");
@@ -713,6 +850,9 @@ extern "C" int ct_conv2d_x3_fwd(const ct_conv_desc* d, const void* wx3, int conf
         a.res_scale = d->res_scale;
         a.relu = d->relu;
         a.transposed = d->transposed;
+        a.in_amax = d->in_absmax ? d->in_absmax + (size_t)b0 * ctdet::h2::kLineWords : nullptr;
+        a.eW = h2 ? reinterpret_cast<const int*>(static_cast<const unsigned char*>(wx3) + wbytes) + 1 : nullptr;
+        a.out_amax = d->out_absmax ? d->out_absmax + (size_t)b0 * ctdet::h2::kLineWords : nullptr;
         a.nseg = d->nseg;
         for (int g = 0; g < d->nseg; ++g) {
             a.seg[g] = d->seg[g];

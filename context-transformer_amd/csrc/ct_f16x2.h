@@ -65,38 +65,15 @@ __device__ __forceinline__ unsigned wave_max(unsigned m)
     return m;
 }
 
-// A "slot" (ct_conv_desc.in_absmax / out_absmax, CT_ABSMAX_SLOT_BYTES): sixteen words, one per 128-byte line
-constexpr int kSlotLines = 16, kSlotStride = 32;
+// Maxima of |activation| travel PER IMAGE (ct_conv_desc.in_absmax / out_absmax): `batch` lines of CT_ABSMAX_LINE_BYTES, the bit
+// pattern of image n's maximum in the first word of line n.  Per image and not per batch so that what a kernel computes for an
+// image never depends on the other images of its batch (the subnormal lo pieces make the split depend on the exponent in the
+// last bits; the harness tests require detections that are bit-identical whatever the batch composition).
+constexpr int kLineWords = 32;
 
-// the maximum a slot holds, computed by one wave (every lane gets it)
-__device__ __forceinline__ unsigned slot_max(const unsigned* __restrict__ slot)
+__device__ __forceinline__ int image_exponent(const unsigned* __restrict__ lines, int n, int growth_log2)
 {
-    return wave_max(slot[(threadIdx.x & (kSlotLines - 1)) * kSlotStride]);
-}
-
-// Every thread of a 256-thread workgroup gets the maximum of partial[0 .. n): the consumer side of an absmax pass whose
-// workgroups each left one partial maximum (no atomics, no zero-initialisation, the same value in every launch).
-__device__ __forceinline__ unsigned block_max_of(const unsigned* __restrict__ partial, int n, int stride, unsigned* red /* LDS [4] */)
-{
-    unsigned m = 0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const unsigned v = partial[(size_t)i * stride];
-        m = v > m ? v : m;
-    }
-    m = wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    const unsigned a = red[0], b = red[1], c = red[2], d = red[3];
-    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
-    return ab > cd ? ab : cd;
-}
-
-// The producer side where a kernel's epilogue knows the values it stores: wave maximum of |v| (bit pattern), one atomic per
-// wave into a scalar the runtime zeroes once per step.
-__device__ __forceinline__ void wave_atomic_absmax(unsigned* slot, unsigned line, float v_absmax_candidate)
-{
-    const unsigned m = wave_max(__builtin_bit_cast(unsigned, v_absmax_candidate) & 0x7FFFFFFFu);
-    if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(slot + (line & (kSlotLines - 1)) * kSlotStride, m);
+    return exponent_for(lines[(size_t)n * kLineWords], growth_log2);
 }
 
 // running maximum of |v| in a thread (NaN sticks: the unsigned order puts it above everything)
@@ -104,6 +81,23 @@ __device__ __forceinline__ void track_absmax(float& run, float v)
 {
     const unsigned a = __builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu, r = __builtin_bit_cast(unsigned, run);
     run = __builtin_bit_cast(float, a > r ? a : r);
+}
+
+// The producer side: every lane of a wave brings (image n, maximum of |v| over what it stored for that image; n < 0 = nothing);
+// one atomic max per distinct image in the wave (one or two on the large maps).  Must be called by all lanes of the wave.
+__device__ __forceinline__ void flush_absmax(unsigned* __restrict__ lines, int n, float run)
+{
+    const unsigned m = __builtin_bit_cast(unsigned, run) & 0x7FFFFFFFu;
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(n >= 0 && m != 0u);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int n0 = __shfl(n, leader, 64);
+        const bool mine = n == n0 && ((todo >> lane) & 1ull);
+        const unsigned mm = wave_max(mine ? m : 0u);
+        if (lane == leader) atomicMax(lines + (size_t)n0 * kLineWords, mm);
+        todo &= ~__ballot(mine);
+    }
 }
 
 }  // namespace h2

@@ -242,13 +242,9 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
 
     // ---- A fragments: unit u of this wave = 3 KB [piece 3][lane 64][16 B]
     const int u_voff = wave * UL::WAVE + lane * 16;
-    // f16x2: the scale of V from the maximum the input's producer left, the epilogue factor from both exponents
-    float vscale = 1.f, ymul = 1.f;
-    if constexpr (H2) {
-        const int eV = ctdet::h2::exponent_for(ctdet::h2::slot_max(a.in_amax), ctdet::h2::kGrowthBtB);
-        vscale = __builtin_ldexpf(1.f, eV);
-        ymul = __builtin_ldexpf(1.f, -(eV + *a.eU));
-    }
+    // f16x2: V is split as V 2^eV with eV PER IMAGE from the maximum the input's producer left for that image (ct_f16x2.h: an image's
+    // results never depend on its batch mates); this lane's tile of the current item decides (transform and split roles: tile l31)
+    float vscale = 1.f;
     float amax_run = 0.f;
     auto read_raw = [&](int xi, float (&raw)[8]) {
         const float* p = vr + xi * PT_STRIDE;
@@ -297,12 +293,25 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
     setup_masks();
     dma_patch(0);
     i32x4 ua0[NP], ua1[NP], ua2[NP];
+    // f16x2: the maximum of |input| of the image this lane's tile (tile l31 of the item) belongs to.  For a follow-up item the load
+    // leaves with the first U units, in front of the previous item's last stores (a wait for it must not wait for those stores)
+    unsigned amax_bits = 0;
+    bool amax_ahead = false;
+    auto load_amax = [&](int tb_first) {
+        const int Tl = tb_first + l31;
+        const int nl = Tl < a.NT ? Tl / (a.TY * a.TX) : 0;
+        return a.in_amax[(size_t)nl * ctdet::h2::kLineWords];
+    };
     bool u_ahead = false;                     // ua0 / ua1 already hold (are receiving) units 0, 1 of this item's first chunk
     while (vb < nitems) {
         W4F_STAMP(0);
         const int kb = item_kb(vb);
         const int tb0 = item_tblk(vb) * TB;
         const int vb_next = next_valid(vb + gridDim.x);
+        if constexpr (H2) {               // needed by the first phase M
+            if (!amax_ahead) amax_bits = load_amax(tb0);
+            vscale = __builtin_ldexpf(1.f, ctdet::h2::exponent_for(amax_bits, ctdet::h2::kGrowthBtB));
+        }
         const int u_kb = kb * a.chunks;
         auto load_u_of = [&](int ukb, int c, int unit, i32x4 (&dst)[NP]) {
             const int soff = (ukb + c) * UL::CHUNK + unit * UL::UNIT;
@@ -466,6 +475,8 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
         const int o_kk = tid >> 5, o_tl = tid & 31;
         const int o_T = tb0 + o_tl;
         const int o_n = o_T / (a.TY * a.TX);
+        float ymul = 1.f;                 // f16x2: 2^-(eU + eV[image of this thread's tile]) into the per-channel scale
+        if constexpr (H2) ymul = __builtin_ldexpf(1.f, -(*e.eU + ctdet::h2::image_exponent(e.in_amax, o_T < a.NT ? o_n : 0, ctdet::h2::kGrowthBtB)));
         const int o_rem = o_T - o_n * (a.TY * a.TX);
         const int o_ty = o_rem / a.TX, o_tx = o_rem - o_ty * a.TX;
 #pragma unroll
@@ -491,7 +502,9 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
                     const int ukb_next = item_kb(vb_next) * a.chunks;
                     load_u_of(ukb_next, 0, 0, ua0);
                     load_u_of(ukb_next, 0, 1, ua1);
+                    if constexpr (H2) amax_bits = load_amax(item_tblk(vb_next) * TB);
                 }
+                if constexpr (H2) amax_ahead = u_ahead;
             }
             {
                 const int co = kb * KB + 16 * q + o_kk;
@@ -520,23 +533,15 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
             if (q == 1) W4F_STAMP(3);
         }
         W4F_STAMP(4);
+        if constexpr (H2) {               // ct_conv_desc.out_absmax: this item's maxima, one atomic per image present in the wave
+            if (e.out_amax) {
+                ctdet::h2::flush_absmax(e.out_amax, o_T < a.NT ? o_n : -1, amax_run);
+                amax_run = 0.f;
+            }
+        }
         vb = vb_next;
     }
 #undef W4F_UNIT
-    if constexpr (H2) {
-        // ct_conv_desc.out_absmax: one atomic per wave and launch (the pointer re-read from the kernel arguments like the epilogue's
-        // record, so that it is not carried through the main loops).  Only the f16x2 instantiations track it: the bf16x3 ones are at
-        // the register limit (one more live value costs them scratch), and a network runs one form or the other.
-        unsigned* slot = a_in.out_amax;
-#if defined(__HIP_DEVICE_COMPILE__)
-        typedef const __attribute__((address_space(4))) unsigned long long* kernarg_qwords;
-        kernarg_qwords kq = (kernarg_qwords)__builtin_amdgcn_kernarg_segment_ptr();
-        asm volatile("" : "+s"(kq));
-        static_assert(offsetof(Wino4fArgs, out_amax) % 8 == 0, "pointer field alignment");
-        slot = reinterpret_cast<unsigned*>(kq[offsetof(Wino4fArgs, out_amax) / 8]);
-#endif
-        if (slot) ctdet::h2::wave_atomic_absmax(slot, blockIdx.x + wave, amax_run);
-    }
 }
 
 bool wino4f_ok(const ct_conv_desc* d)
@@ -688,8 +693,8 @@ static int wino4f_launch(const ct_conv_desc* d, const void* upacked, int variant
         a.pool_out = pool_out ? pool_out + (size_t)b0 * pool_ctot * pool_oh * pool_ow : nullptr;
         a.pool_ctot = pool_ctot; a.pool_coff = pool_coff; a.pool_oh = pool_oh; a.pool_ow = pool_ow;
         a.write_full = write_full;
-        a.in_amax = d->in_absmax;
-        a.out_amax = d->out_absmax;
+        a.in_amax = d->in_absmax ? d->in_absmax + (size_t)b0 * ctdet::h2::kLineWords : nullptr;
+        a.out_amax = d->out_absmax ? d->out_absmax + (size_t)b0 * ctdet::h2::kLineWords : nullptr;
         a.eU = h2 ? reinterpret_cast<const int*>(static_cast<const unsigned char*>(upacked) + u_bytes) + 1 : nullptr;
         a.kblocks = (d->cout + KB - 1) / KB;
         // 8 XCD-local sequences of (tile block group, cout block); sequences past the last tile block exit at once

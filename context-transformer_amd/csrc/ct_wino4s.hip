@@ -60,8 +60,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int HP = 2;                                  // pieces per value
 constexpr int OPBH = 4 * HP * FRAG;                    // one operand block of a 16-channel k-group: [sub 4][piece 2][1 KB] = 8 KB
-constexpr int AMAX_SLOTS = ctdet::kWino4hAmaxSlots;    // partial maxima of |input| (one per workgroup of wino4h_absmax)
-constexpr int HDR_BYTES = ctdet::kWino4hHeaderBytes;   // workspace header: [AMAX_SLOTS] partial maxima, then word 0 = eV
+constexpr int LINE_BYTES = ctdet::h2::kLineWords * 4;  // one image's maximum of |input| (CT_ABSMAX_LINE_BYTES)
 
 struct Wino4sArgs {
     const float* in;
@@ -90,11 +89,11 @@ struct Wino4sArgs {
     int dil;                 // > 1: dilated layer, tiles live on the dil x dil sub-lattices (wino4s_in_dil)
     // f16x2 form only: V is stored scaled by 2^eV, U by 2^eU (powers of two from the operands' maxima, so that no binary16
     // piece overflows and the small pieces keep their bits); wino4s_out multiplies M by 2^-(eU + eV)
-    unsigned* hdr;           // workspace header: [AMAX_SLOTS] partial maxima of |input| as bit patterns, hdr[AMAX_SLOTS] = eV
-    const unsigned* amax;    // where the maxima of |input| are: hdr (own absmax pass) or the producer's slot (ct_conv_desc.in_absmax)
-    int amax_n, amax_stride; // ... how many words, how far apart
+    const unsigned* amax;    // per-image maxima of |input| (ct_f16x2.h): the producer's lines (ct_conv_desc.in_absmax) or, after an
+                             // absmax pass of its own, the workspace header
     const int* eU;           // the exponent the weight packing chose (trailer of the packed weights)
-    unsigned* out_amax;      // any variant: ct_conv_desc.out_absmax (max |y| of what wino4s_out stores), or null
+    unsigned* out_amax;      // any variant: ct_conv_desc.out_absmax (per-image max |y| of what wino4s_out stores), or null
+    int batch;               // images of this launch (lines of amax / out_amax)
 };
 
 // 36 GEMMs  M[xi][row][col] = sum_k A[xi][row][k] B[xi][col][k], both operands as 12 KB fragment blocks
@@ -165,17 +164,6 @@ __device__ __forceinline__ void split_store(const float (&raw)[8], unsigned char
     }
 }
 
-// f16x2: the scale of this launch's V from the partial maxima of |input| the absmax pass left in the workspace header
-// (every workgroup computes the same value; workgroup (0, 0) records the exponent for wino4s_out)
-__device__ __forceinline__ float h2_input_scale(const Wino4sArgs& a)
-{
-    __shared__ unsigned red[4];
-    const unsigned m = ctdet::h2::block_max_of(a.amax, a.amax_n, a.amax_stride, red);
-    const int e = ctdet::h2::exponent_for(m, ctdet::h2::kGrowthBtB);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.hdr[AMAX_SLOTS] = (unsigned)e;
-    return __builtin_ldexpf(1.f, e);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
 // 1. input transform + split.  Workgroup = (32 tiles, a run of 16-channel chunks), 256 threads.  Per chunk every thread
 // loads two 6x6 patches (tile = lane & 31, channels 4 wave + h and 4 wave + 2 + h; twelve 12-byte buffer loads each,
@@ -194,8 +182,7 @@ __global__ __launch_bounds__(256, 2) void wino4s_in(const Wino4sArgs a)
     const int c_begin = blockIdx.y * a.chunks_per_wg, c_end = min(a.chunks, c_begin + a.chunks_per_wg);
     if (c_begin >= c_end) return;
     constexpr int PF = (H2 ? HP : 3) * FRAG, OPBX = 4 * PF;       // bytes of a sub-block's pieces / of a chunk's operand block
-    float vscale = 1.f;
-    if constexpr (H2) vscale = h2_input_scale(a);
+    float vscale = 1.f;          // f16x2: 2^eV of the image this lane's tile belongs to (transform role and split role: tile tb0 + l31)
 
     int voffr[6];
     bool mc[6], lp;
@@ -204,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void wino4s_in(const Wino4sArgs a)
         const int T = tb0 + l31;
         const bool live = T < a.NT;
         const int n = T / (a.TY * a.TX);
+        if constexpr (H2) vscale = __builtin_ldexpf(1.f, ctdet::h2::image_exponent(a.amax, live ? n : 0, ctdet::h2::kGrowthBtB));
         const int rem = T - n * (a.TY * a.TX);
         const int ty = rem / a.TX, tx = rem - ty * a.TX;
         const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
@@ -310,7 +298,6 @@ __global__ __launch_bounds__(256, 2) void wino4s_in_dil(const Wino4sArgs a)
     if (c_begin >= c_end) return;
     constexpr int PF = (H2 ? HP : 3) * FRAG, OPBX = 4 * PF;
     float vscale = 1.f;
-    if constexpr (H2) vscale = h2_input_scale(a);
     int rowoff[6], coloff[6];
     {
         const int T = tblk * TB + l31;
@@ -322,6 +309,7 @@ __global__ __launch_bounds__(256, 2) void wino4s_in_dil(const Wino4sArgs a)
         const int sx = q % d; q /= d;
         const int sy = q % d;
         const int n = q / d;
+        if constexpr (H2) vscale = __builtin_ldexpf(1.f, ctdet::h2::image_exponent(a.amax, live ? n : 0, ctdet::h2::kGrowthBtB));
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int y = sy + d * (4 * ty - 1 + i), x = sx + d * (4 * tx - 1 + i);
@@ -538,67 +526,25 @@ __global__ __launch_bounds__(256, 2) void wino4s_gemm(const GemmArgs a)
 // multiply-add.  Two binary16 pieces per value and three piece products (hi.hi, hi.lo, lo.hi) carry the same 22-24 bits as
 // three bfloat16 pieces and six products: half the MFMAs, two thirds of the V / U bytes, 2 instead of 5.5 VALU instructions
 // per split value in wino4s_in, same error against fp64 (tests/test_gpu_wino.py::test_wino_rounding_error_vs_fp64).
-//   0. wino4h_absmax  max |x| of the layer's input slice -> one partial maximum per workgroup in the workspace header (when the
-//                     producer of the input did not leave it: ct_conv_desc.in_absmax);
-//   1. wino4s_in<true>   V 2^eV as two pieces, eV from that maximum (no hi piece above 2^15, ct_f16x2.h);
+//   0. absmax_lines_kernel  max |x| of every image's input slice -> the workspace header (when the producer of the input did not
+//                     leave the maxima: ct_conv_desc.in_absmax);
+//   1. wino4s_in<true>   V 2^eV as two pieces, eV PER IMAGE from that maximum (no hi piece above 2^15, ct_f16x2.h);
 //   2. wino4h_gemm       below: the bf16x3 pipeline with 8 KB operand blocks per 16-channel k-group, KG groups per barrier;
-//   3. wino4s_out<true>  M 2^-(eU + eV), then as before.
+//   3. wino4s_out<true>  M 2^-(eU + eV[image]), then as before.
 // Operand blocks: [point][block of 128 rows][k-group of 16][sub 4][piece 2][k half 2][row 32][8 f16].
 
-// max |x| over the [cin * H * W] floats of every image's channel slice; items of 4096 floats, one partial maximum per workgroup
-__global__ __launch_bounds__(256) void wino4h_absmax(const float* __restrict__ in, int batch, long per_image, long img_stride,
-                                                     int vec_ok, unsigned* __restrict__ partial)
+// max |x| over the [per_image] floats of every image's channel slice, folded into the image's line (atomic max, one per wave and
+// item of 4096 floats; the caller zeroes the lines): ct_absmax_f32 and the absmax pass of ct_conv2d_wino4s_fwd variant 3
+__global__ __launch_bounds__(256) void absmax_lines_kernel(const float* __restrict__ in, int batch, long per_image, long img_stride,
+                                                           int vec_ok, unsigned* __restrict__ lines)
 {
-    __shared__ unsigned red[4];
     const int ipi = (int)((per_image + 4095) / 4096);
     const long nitems = (long)batch * ipi;
-    unsigned m = 0;
     for (long it = blockIdx.x; it < nitems; it += gridDim.x) {
         const int n = (int)(it / ipi), sgm = (int)(it - (long)n * ipi);
         const float* base = in + (size_t)n * img_stride;
         const long e0 = (long)sgm * 4096;
-        if (vec_ok) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const long e = e0 + (long)(r * 256 + threadIdx.x) * 4;
-                if (e < per_image) {                           // per_image % 4 == 0 (cin % 16 == 0)
-                    const i32x4 v = *reinterpret_cast<const i32x4*>(base + e);
-                    const unsigned a0 = (unsigned)v.x & 0x7FFFFFFFu, a1 = (unsigned)v.y & 0x7FFFFFFFu;
-                    const unsigned a2 = (unsigned)v.z & 0x7FFFFFFFu, a3 = (unsigned)v.w & 0x7FFFFFFFu;
-                    const unsigned b0 = a0 > a1 ? a0 : a1, b1 = a2 > a3 ? a2 : a3, b = b0 > b1 ? b0 : b1;
-                    m = b > m ? b : m;
-                }
-            }
-        } else {
-            for (int r = 0; r < 16; ++r) {
-                const long e = e0 + r * 256 + threadIdx.x;
-                if (e < per_image) {
-                    const unsigned a0 = __builtin_bit_cast(unsigned, base[e]) & 0x7FFFFFFFu;
-                    m = a0 > m ? a0 : m;
-                }
-            }
-        }
-    }
-    m = ctdet::h2::wave_max(m);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned ab = red[0] > red[1] ? red[0] : red[1], cd = red[2] > red[3] ? red[2] : red[3];
-        partial[blockIdx.x] = ab > cd ? ab : cd;
-    }
-}
-
-// ct_absmax_f32: the same pass for callers outside this file, folded into a slot by atomic max (the caller zeroes the slot)
-__global__ __launch_bounds__(256) void absmax_slot_kernel(const float* __restrict__ in, int batch, long per_image, long img_stride,
-                                                          int vec_ok, unsigned* __restrict__ slot)
-{
-    const int ipi = (int)((per_image + 4095) / 4096);
-    const long nitems = (long)batch * ipi;
-    unsigned m = 0;
-    for (long it = blockIdx.x; it < nitems; it += gridDim.x) {
-        const int n = (int)(it / ipi), sgm = (int)(it - (long)n * ipi);
-        const float* base = in + (size_t)n * img_stride;
-        const long e0 = (long)sgm * 4096;
+        unsigned m = 0;
         for (int r = 0; r < (vec_ok ? 4 : 16); ++r) {
             const long e = vec_ok ? e0 + (long)(r * 256 + threadIdx.x) * 4 : e0 + r * 256 + threadIdx.x;
             if (e >= per_image) continue;
@@ -616,8 +562,9 @@ __global__ __launch_bounds__(256) void absmax_slot_kernel(const float* __restric
                     }
             }
         }
+        m = ctdet::h2::wave_max(m);
+        if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(lines + (size_t)n * ctdet::h2::kLineWords, m);
     }
-    ctdet::h2::wave_atomic_absmax(slot, blockIdx.x, __builtin_bit_cast(float, m));
 }
 
 // Workgroup = one point xi, 128 couts x 128 tiles, 2 x 2 waves of 64 x 64, as wino4s_gemm.  A step = KG k-groups of 16 channels
@@ -774,7 +721,7 @@ __global__ __launch_bounds__(256, 2) void wino4h_gemm(const GemmArgs a)
 // 3. output transform + epilogue.  Thread = one (cout, tile): 36 coalesced loads (lanes = 64 consecutive tiles of a
 // cout row), y = A^T M A, the epilogue of ct_wino4.hip.
 template <bool H2>
-__device__ __forceinline__ void wino4s_out_one(const Wino4sArgs& a, int T, int co, bool track, float& amax_run);
+__device__ __forceinline__ void wino4s_out_one(const Wino4sArgs& a, int T, int co, bool track, float& amax_run, int& img);
 
 template <bool H2>
 __global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
@@ -782,13 +729,14 @@ __global__ __launch_bounds__(256) void wino4s_out(const Wino4sArgs a)
     const int T = blockIdx.x * 64 + (threadIdx.x & 63);
     const int co = blockIdx.y * 4 + (threadIdx.x >> 6);
     float amax_run = 0.f;            // max |y| of what this thread stores (a.out_amax)
-    if (T < a.NT && co < a.M) wino4s_out_one<H2>(a, T, co, a.out_amax != nullptr, amax_run);
-    // every lane of the wave arrives here (no early exit above): one atomic per wave
-    if (a.out_amax) ctdet::h2::wave_atomic_absmax(a.out_amax, blockIdx.x + blockIdx.y, amax_run);
+    int img = -1;                    // ... and the image it belongs to
+    if (T < a.NT && co < a.M) wino4s_out_one<H2>(a, T, co, a.out_amax != nullptr, amax_run, img);
+    // every lane of the wave arrives here (no early exit above): one atomic per image present in the wave
+    if (a.out_amax) ctdet::h2::flush_absmax(a.out_amax, img, amax_run);
 }
 
 template <bool H2>
-__device__ __forceinline__ void wino4s_out_one(const Wino4sArgs& a, const int T, const int co, const bool track, float& amax_run)
+__device__ __forceinline__ void wino4s_out_one(const Wino4sArgs& a, const int T, const int co, const bool track, float& amax_run, int& img)
 {
     const float* src = a.Mw + (size_t)co * a.Tpad + T;
     float m[6][6];
@@ -796,9 +744,8 @@ __device__ __forceinline__ void wino4s_out_one(const Wino4sArgs& a, const int T,
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < 6; ++j) m[i][j] = __builtin_nontemporal_load(src + (size_t)(i * 6 + j) * a.m_plane);
-    // f16x2: the operands were scaled by 2^eU, 2^eV (exact powers of two); folded into the per-channel scale of the epilogue
+    // f16x2: the operands were scaled by 2^eU, 2^eV[image] (exact powers of two); folded into the per-channel scale of the epilogue
     float ymul = 1.f;
-    if constexpr (H2) ymul = __builtin_ldexpf(1.f, -(*a.eU + (int)a.hdr[AMAX_SLOTS]));
     // A^T M A in double, rounded once: this kernel waits for HBM, the fp32 chain of ct_wino4.hip rounds ~10 times per output
     double t[6][4];
 #pragma unroll
@@ -825,6 +772,8 @@ __device__ __forceinline__ void wino4s_out_one(const Wino4sArgs& a, const int T,
         const int sx = q % d; q /= d;
         const int sy = q % d;
         const int n = q / d;
+        img = n;
+        if constexpr (H2) ymul = __builtin_ldexpf(1.f, -(*a.eU + ctdet::h2::image_exponent(a.amax, n, ctdet::h2::kGrowthBtB)));
         const float sc = a.scale[co] * ymul, sh = a.shift[co];
         const float lo = a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
         float* const plane = a.out + ((size_t)n * a.out_ctot + a.out_coff + co) * a.H * a.W;
@@ -845,6 +794,8 @@ __device__ __forceinline__ void wino4s_out_one(const Wino4sArgs& a, const int T,
         return;
     }
     const int n = T / (a.TY * a.TX);
+    img = n;
+    if constexpr (H2) ymul = __builtin_ldexpf(1.f, -(*a.eU + ctdet::h2::image_exponent(a.amax, n, ctdet::h2::kGrowthBtB)));
     const int rem = T - n * (a.TY * a.TX);
     const int ty = rem / a.TX, tx = rem - ty * a.TX;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
@@ -1241,17 +1192,18 @@ extern "C" size_t ct_conv_wino4s_workspace_bytes(const ct_conv_desc* d)
 {
     if (!d || !wino4s_ok(d) || d->batch <= 0 || d->cout <= 0) return 0;
     const Sizes s = sizes_of(d->batch, d->oh, d->ow, d->cin, d->cout, d->dil);
-    return HDR_BYTES + s.v_bytes + s.m_bytes;       // any variant (the f16x2 form: header + a V two thirds the size)
+    // any variant (the f16x2 form: a header of one line per image for the maxima of |input| + a V two thirds the size)
+    return ctdet::align_up((size_t)d->batch * LINE_BYTES, 256) + s.v_bytes + s.m_bytes;
 }
 
-extern "C" int ct_absmax_f32(const float* in, int batch, long long per_image, long long img_stride, unsigned* slot, ct_stream_t stream)
+extern "C" int ct_absmax_f32(const float* in, int batch, long long per_image, long long img_stride, unsigned* lines, ct_stream_t stream)
 {
-    CT_REQUIRE(in && slot && batch > 0 && per_image > 0 && img_stride >= per_image, "ct_absmax_f32: bad argument");
+    CT_REQUIRE(in && lines && batch > 0 && per_image > 0 && img_stride >= per_image, "ct_absmax_f32: bad argument");
     const bool vec_ok = per_image % 4 == 0 && img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(in) % 16 == 0;
     const long items = (long)batch * ((per_image + 4095) / 4096);
-    hipLaunchKernelGGL(absmax_slot_kernel, dim3((int)std::min<long>(items, 1024)), dim3(256), 0, ctdet::as_stream(stream), in, batch,
-                       (long)per_image, (long)img_stride, vec_ok ? 1 : 0, slot);
-    CT_LAUNCH_CHECK("absmax_slot_kernel");
+    hipLaunchKernelGGL(absmax_lines_kernel, dim3((int)std::min<long>(items, 2048)), dim3(256), 0, ctdet::as_stream(stream), in, batch,
+                       (long)per_image, (long)img_stride, vec_ok ? 1 : 0, lines);
+    CT_LAUNCH_CHECK("absmax_lines_kernel");
     return CT_OK;
 }
 
@@ -1362,7 +1314,7 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
     const long long img_res_bytes = d->res ? (long long)d->res_ctot * d->oh * d->ow * 4 : 0;
     CT_REQUIRE(img_out_bytes < kMaxBufBytes && img_res_bytes < kMaxBufBytes, "ct_conv2d_wino4s_fwd: one image exceeds 2 GiB");
     const int max_chunk = (int)std::max<long long>(1, kMaxBufBytes / std::max(img_in_bytes, std::max(img_out_bytes, img_res_bytes)));
-    const size_t hdr_bytes = h2 ? (size_t)HDR_BYTES : 0;
+    const size_t hdr_bytes = h2 ? ctdet::align_up((size_t)std::min(d->batch, max_chunk) * LINE_BYTES, 256) : 0;
     {
         const Sizes s = sizes_of(std::min(d->batch, max_chunk), d->oh, d->ow, d->cin, d->cout, d->dil, h2 ? OPBH : OPB);
         CT_REQUIRE(workspace_bytes >= hdr_bytes + s.v_bytes + s.m_bytes, "ct_conv2d_wino4s_fwd: workspace of %zu bytes, needs %zu "
@@ -1421,27 +1373,27 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
         a.v_plane = s.v_plane;
         a.u_plane = (size_t)s.kblocks * s.chunks * (h2 ? OPBH : OPB);
         a.m_plane = s.m_plane;
+        a.batch = nb;
         if (h2) {
-            a.hdr = static_cast<unsigned*>(workspace);
             a.eU = reinterpret_cast<const int*>(static_cast<const unsigned char*>(upacked) + (size_t)NXI * a.u_plane) + 1;
-            // max |x| of the input slice: one partial maximum per workgroup, no atomics
-            const long per_image = (long)d->cin * d->h * d->w;
-            const long img_stride = (long)d->in_ctot * d->h * d->w;
-            const float* base = a.in + (size_t)d->in_coff * d->h * d->w;
-            const bool vec_ok = ((d->h * d->w) % 4 == 0 || (d->in_ctot % 4 == 0 && d->in_coff % 4 == 0)) &&
-                                reinterpret_cast<uintptr_t>(base) % 16 == 0;
-            const long items = (long)nb * ((per_image + 4095) / 4096);
-            if (d->in_absmax) {              // the producer of the input left its maximum (an upper bound over the slice)
-                a.amax = d->in_absmax; a.amax_n = ctdet::h2::kSlotLines; a.amax_stride = ctdet::h2::kSlotStride;
-            } else {
-                a.amax = a.hdr; a.amax_stride = 1;
-                a.amax_n = (int)std::min<long>(items, AMAX_SLOTS);
+            if (d->in_absmax) {              // the producer of the input left the maxima (upper bounds over the slice, per image)
+                a.amax = d->in_absmax + (size_t)b0 * ctdet::h2::kLineWords;
+            } else {                         // an absmax pass of its own into the workspace header
+                unsigned* hdr = static_cast<unsigned*>(workspace);
+                a.amax = hdr;
+                const long per_image = (long)d->cin * d->h * d->w;
+                const long img_stride = (long)d->in_ctot * d->h * d->w;
+                const float* base = a.in + (size_t)d->in_coff * d->h * d->w;
+                const bool vec_ok = per_image % 4 == 0 && img_stride % 4 == 0 && reinterpret_cast<uintptr_t>(base) % 16 == 0;
+                const long items = (long)nb * ((per_image + 4095) / 4096);
                 CT_PROF("wino4h_absmax", st);
-                hipLaunchKernelGGL(wino4h_absmax, dim3(a.amax_n), dim3(256), 0, st, base, nb, per_image, img_stride, vec_ok ? 1 : 0, a.hdr);
-                CT_LAUNCH_CHECK("wino4h_absmax");
+                CT_HIP(hipMemsetAsync(hdr, 0, hdr_bytes, st));
+                hipLaunchKernelGGL(absmax_lines_kernel, dim3((int)std::min<long>(items, 2048)), dim3(256), 0, st, base, nb, per_image,
+                                   img_stride, vec_ok ? 1 : 0, hdr);
+                CT_LAUNCH_CHECK("absmax_lines_kernel");
             }
         }
-        a.out_amax = d->out_absmax;
+        a.out_amax = d->out_absmax ? d->out_absmax + (size_t)b0 * ctdet::h2::kLineWords : nullptr;
         // transform: ~2048 workgroups (four rounds of two per CU) unless the layer has fewer (tile block, chunk) pairs
         const long pairs = (long)a.tblk32 * a.chunks;
         a.chunks_per_wg = (int)std::max<long>(1, std::min<long>(a.chunks, pairs / 2048));

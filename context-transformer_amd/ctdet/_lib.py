@@ -42,7 +42,7 @@ class ConvDesc(C.Structure):
     ]
 
 
-ABSMAX_SLOT_BYTES = 2048        # CT_ABSMAX_SLOT_BYTES
+ABSMAX_LINE_BYTES = 128         # CT_ABSMAX_LINE_BYTES: one line per image in ct_conv_desc.in_absmax / out_absmax
 
 
 class ProfileRecord(C.Structure):
@@ -172,7 +172,10 @@ SIGNATURES = {
     'ct_conv_x3_num_configs': (_I, []),
     'ct_conv_x3_config_name': (C.c_char_p, [_I]),
     'ct_conv_x3_config_bk': (_I, [_I]),
+    'ct_conv_x3_config_h2': (_I, [_I]),
     'ct_conv_x3_packed_bytes': (_Z, [_I, _I, _I, _I, _I]),
+    'ct_conv_x3h_packed_bytes': (_Z, [_I, _I, _I, _I, _I]),
+    'ct_conv_pack_weights_x3h': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'ct_conv_pack_weights_x3': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'ct_conv_pack_weights_x3_dgrad': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'ct_conv2d_x3_fwd': (_I, [C.POINTER(ConvDesc), _P, _I, _P]),

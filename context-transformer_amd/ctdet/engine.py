@@ -386,16 +386,19 @@ class HipBackend:
         # index the Runtime gave the step, 0 before there is a schedule).  Per-layer buffers were ~6 GB per RFBNet-300
         # runtime at bs 32 and > 10 GB for RFBNet-512.
         self.ws_pool = {}
-        # "slots" for maxima of |activation| (ct_conv_desc.in_absmax / out_absmax, include/ctdet.h): rows of one tensor that a
-        # runtime zeroes once per step (zero_slots)
+        # "slots" for the per-image maxima of |activation| (ct_conv_desc.in_absmax / out_absmax, include/ctdet.h: one line per
+        # image): rows of one tensor that a runtime zeroes once per step (zero_slots)
         self.slot_pool = None
         self.slots_used = 0
+        self.kernel_epoch = 0          # bumped whenever a step changes kernels (enable_wino / enable_x3): a Runtime re-wires its slots
 
-    def new_slot(self):
-        """Device pointer of a fresh CT_ABSMAX_SLOT_BYTES slot."""
-        words = _lib.ABSMAX_SLOT_BYTES // 4
-        if self.slot_pool is None:
-            self.slot_pool = torch.zeros((256, words), device=self.device, dtype=torch.int32)
+    def new_slot(self, batch):
+        """Device pointer of a fresh slot of `batch` lines of CT_ABSMAX_LINE_BYTES."""
+        words = batch * _lib.ABSMAX_LINE_BYTES // 4
+        if self.slot_pool is None or self.slot_pool.shape[1] < words:
+            if self.slots_used:
+                raise _lib.CtdetError('absmax slots were handed out for a smaller batch')
+            self.slot_pool = torch.zeros((128, words), device=self.device, dtype=torch.int32)
         if self.slots_used >= self.slot_pool.shape[0]:
             raise _lib.CtdetError('out of absmax slots')
         self.slots_used += 1
@@ -509,6 +512,7 @@ class HipBackend:
         tile 4 = F(4x4,3x3), 23 / 24 = F(2x2,3x3) on the bf16 matrix pipe (cin % 16 == 0) with two accumulators / in the
         four-wave form.  st.rt['wino'] holds the code in use."""
         rt = st.rt
+        self.kernel_epoch += 1
         if not on:
             rt['wino'] = False
             rt.pop('ws4s_bytes', None)      # the three-kernel form's V / M workspace need (ws_rebuild shrinks the pool)
@@ -649,7 +653,7 @@ class HipBackend:
         other kernel wrote): a private slot, zeroed and filled by ct_absmax_f32 in front of the launch."""
         rt, d = st.rt, st.rt['desc']
         if rt.get('amax_own') is None:
-            rt['amax_own'] = torch.zeros(_lib.ABSMAX_SLOT_BYTES // 4, device=self.device, dtype=torch.int32)
+            rt['amax_own'] = torch.zeros(d.batch * _lib.ABSMAX_LINE_BYTES // 4, device=self.device, dtype=torch.int32)
             d.in_absmax = rt['amax_own'].data_ptr()
         rt['amax_own'].zero_()
         hw = d.h * d.w
@@ -659,7 +663,8 @@ class HipBackend:
 
     def run_conv(self, st):
         tile = st.rt.get('wino')
-        if tile in WINO4FH_TILES and (not st.rt['desc'].in_absmax or st.rt.get('amax_own') is not None):
+        needs_max = tile in WINO4FH_TILES or (not tile and st.rt.get('x3') is not None and self.x3_h2(st.rt['x3']))
+        if needs_max and (not st.rt['desc'].in_absmax or st.rt.get('amax_own') is not None):
             self._own_absmax(st)
         if tile in WINO4S_TILES:         # F(4x4,3x3): transform / bf16x3 GEMM / transform (csrc/ct_wino4s.hip)
             lib, U, ws, var = self.lib, st.rt['U4H' if tile in WINO4H_TILES else 'U4S'].data_ptr(), \
@@ -709,7 +714,7 @@ class HipBackend:
             return
         x3 = st.rt.get('x3')
         if x3 is not None:               # fp32 convolution on the bf16 matrix pipe (bf16x3 split, csrc/ct_conv_x3.hip)
-            _lib.check(self.lib.ct_conv2d_x3_fwd(C.byref(st.rt['desc']), st.rt['wx3'][self.x3_bk(x3)].data_ptr(), x3,
+            _lib.check(self.lib.ct_conv2d_x3_fwd(C.byref(st.rt['desc']), st.rt['wx3'][(self.x3_bk(x3), self.x3_h2(x3))].data_ptr(), x3,
                                                  self._stream()), st.name)
             return
         _lib.check(self.lib.ct_conv2d_fwd(C.byref(st.rt['desc']), self._stream()), st.name)
@@ -718,12 +723,17 @@ class HipBackend:
     def x3_bk(self, cfg):
         return self.lib.ct_conv_x3_config_bk(cfg)
 
+    def x3_h2(self, cfg):
+        """Whether bf16x3-kernel config `cfg` is one of the f16x2 twins ('h2:<tile>', csrc/ct_f16x2.h)."""
+        return bool(self.lib.ct_conv_x3_config_h2(cfg))
+
     def x3_names(self):
         return [self.lib.ct_conv_x3_config_name(i).decode() for i in range(self.lib.ct_conv_x3_num_configs())]
 
     def enable_x3(self, st, cfg):
         """Route this conv through the bf16x3 kernel with tile config `cfg` (None = back to ct_conv2d_fwd)."""
         rt = st.rt
+        self.kernel_epoch += 1
         if cfg is None:
             rt['x3'] = None
             if rt.get('wpk_stale'):
@@ -734,9 +744,10 @@ class HipBackend:
         if bk <= 0:
             raise _lib.CtdetError('%s: bf16x3 config %r' % (st.name, cfg))
         rt.setdefault('wx3', {})
-        if bk not in rt['wx3']:
-            nbytes = self.lib.ct_conv_x3_packed_bytes(st.cin, st.cout, st.kh, st.kw, bk)
-            rt['wx3'][bk] = self.alloc((nbytes,), torch.uint8)
+        h2 = self.x3_h2(cfg)
+        if (bk, h2) not in rt['wx3']:
+            size = self.lib.ct_conv_x3h_packed_bytes if h2 else self.lib.ct_conv_x3_packed_bytes
+            rt['wx3'][(bk, h2)] = self.alloc((size(st.cin, st.cout, st.kh, st.kw, bk),), torch.uint8)
         rt['x3'] = cfg
         self._pack_x3(st)
 
@@ -744,9 +755,10 @@ class HipBackend:
         n = len(st.parts)
         ptrs = (C.c_void_p * n)(*[p.weight.detach().data_ptr() for p in st.parts])
         couts = (C.c_int * n)(*[p.cout for p in st.parts])
-        bk = self.x3_bk(st.rt['x3'])
-        _lib.check(self.lib.ct_conv_pack_weights_x3(ptrs, couts, n, st.cin, st.kh, st.kw, bk,
-                                                    st.rt['wx3'][bk].data_ptr(), self._stream()), 'ct_conv_pack_weights_x3')
+        bk, h2 = self.x3_bk(st.rt['x3']), self.x3_h2(st.rt['x3'])
+        pack = self.lib.ct_conv_pack_weights_x3h if h2 else self.lib.ct_conv_pack_weights_x3
+        _lib.check(pack(ptrs, couts, n, st.cin, st.kh, st.kw, bk, st.rt['wx3'][(bk, h2)].data_ptr(), self._stream()),
+                   'ct_conv_pack_weights_x3h' if h2 else 'ct_conv_pack_weights_x3')
 
     def run_pool(self, st, bufs, batch):
         _lib.check(self.lib.ct_maxpool2d_fwd(bufs[st.src].data_ptr(), bufs[st.dst].data_ptr(), batch * st.ch,
@@ -800,7 +812,7 @@ class HipBackend:
         best_x3 = None
         if x3_allowed(st):
             for cfg in range(self.lib.ct_conv_x3_num_configs()):
-                if st.cin % self.x3_bk(cfg) or not self.x3_names()[cfg].endswith('d'):
+                if st.cin % self.x3_bk(cfg) or not self.x3_names()[cfg].endswith('d') or self.x3_h2(cfg):   # (the table holds the bf16x3 names)
                     times.append(float('inf'))      # k-step does not divide cin / single accumulator (accuracy gate)
                     continue
                 self.enable_x3(st, cfg)
@@ -1008,7 +1020,9 @@ def apply_tuned(backend, st, batch, wino4=True):
     if isinstance(cfg, str) and cfg.startswith('x3:'):
         xn = backend.x3_names()
         if cfg in xn and x3_allowed(st) and st.cin % backend.x3_bk(xn.index(cfg)) == 0:     # the k-step must divide cin
-            backend.enable_x3(st, xn.index(cfg))
+            twin = 'h2:' + cfg[3:]              # the same tile on the f16x2 operand form (operand_form_h2)
+            use = twin if getattr(backend, 'h2', False) and twin in xn and os.environ.get('CTDET_H2_X3', '1') != '0' else cfg
+            backend.enable_x3(st, xn.index(use))
             return True
         cfg = tune_table().get(st.tune_key(batch) + '|f32')       # the best fp32-MFMA tile, recorded next to it
     if cfg == 'valu' and not (st.cin == 3 and (st.kh, st.kw, st.stride, st.dil) == (3, 3, 1, 1) and st.res is None):
@@ -1211,12 +1225,15 @@ class Runtime:
         be = self.backend
         if not hasattr(be, 'new_slot'):
             return
+        self._wired_epoch = be.kernel_epoch
         steps = self.plan.steps
         for st in self.conv_steps():
             st.rt['desc'].in_absmax = None
             st.rt['desc'].out_absmax = None
             st.rt.pop('amax_own', None)
-        if not any(st.rt.get('wino') in H2_TILES for st in self.conv_steps()):
+        def consumes(st):
+            return st.rt.get('wino') in H2_TILES or (not st.rt.get('wino') and st.rt.get('x3') is not None and be.x3_h2(st.rt['x3']))
+        if not any(consumes(st) for st in self.conv_steps()):
             return
 
         def tracks(st):
@@ -1224,6 +1241,8 @@ class Runtime:
                 return False
             if st.rt.get('wino') in TRACK_TILES:
                 return True
+            if not st.rt.get('wino') and st.rt.get('x3') is not None:
+                return True                # ct_conv2d_x3_fwd, either operand form (split-K launches: in the finishing kernel)
             d = st.rt['desc']          # the image layer, when its config NAMES the vector-ALU kernel (config 0 leaves the choice to the library)
             name = be.lib.ct_conv_config_name(d.config - 1).decode() if d.config > 0 else ''
             return not st.rt.get('wino') and st.rt.get('x3') is None and name == 'valu' 
@@ -1245,14 +1264,15 @@ class Runtime:
                 writers.setdefault(st.dst, []).append(st)
         slots = {}
         be.slots_used = 0
+        self._wired_epoch = be.kernel_epoch
         for st in self.conv_steps():
-            if st.rt.get('wino') not in H2_TILES:
+            if not consumes(st):
                 continue
             b = root_of(st.src)
             ws = writers.get(b, [])
             if ws and all(tracks(w) for w in ws):
                 if b not in slots:
-                    slots[b] = be.new_slot()
+                    slots[b] = be.new_slot(self.batch)
                     for w in ws:
                         w.rt['desc'].out_absmax = slots[b]
                 st.rt['desc'].in_absmax = slots[b]
@@ -1335,6 +1355,8 @@ class Runtime:
     def run_loaded(self):
         """The launches of the backbone on the input buffer (no allocation, no host synchronisation: capturable)."""
         if getattr(self.backend, 'zero_slots', None) is not None:
+            if getattr(self, '_wired_epoch', None) != self.backend.kernel_epoch:
+                self._wire_absmax()         # a step changed kernels since the slots were wired (tuner, tools): producers may have stopped tracking
             self.backend.zero_slots()       # the maxima of |activation| the f16x2 layers take their scales from (_wire_absmax)
         run_on_streams(self, self._run_step)
         return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']

@@ -238,23 +238,25 @@ typedef struct ct_conv_desc {
     int ksplit;
     float* ksplit_ws;
     long long ksplit_ws_floats;
-    /* Maxima of |activation| for the f16x2 operand form (csrc/ct_f16x2.h: binary16 pieces need a power-of-two scale per
-     * tensor, taken from the tensor's maximum).  Both optional (NULL = off) and both "slots" of CT_ABSMAX_SLOT_BYTES bytes of
-     * device memory that the caller zeroes once per step: the bit pattern of max |x| lives in word 32 * i of the slot,
-     * i = 0 .. 15 (sixteen cache lines, so that a launch's atomics do not queue on one).
-     *   in_absmax   an upper bound of |x| over the input slice, left there by whoever produced the input (any kernel of this
-     *               library run with out_absmax, or ct_absmax_f32); kernels that need the maximum and do not get it take it
-     *               themselves in an extra pass (ct_conv2d_wino4s_fwd variant 3) or refuse (ct_conv2d_wino4f_fwd variant 2);
-     *   out_absmax  the launch folds max |y| of everything it stores into this slot (atomic max): honoured by the F(4x4,3x3)
-     *               kernels' shared epilogue (ct_conv2d_wino4_fwd, _wino4s_fwd, _wino4f_fwd) and by the 3-channel image layer
-     *               of ct_conv2d_fwd (config "valu"); ignored by the other kernels. */
+    /* Maxima of |activation| for the f16x2 operand form (csrc/ct_f16x2.h: binary16 pieces need a power-of-two scale, taken from
+     * the tensor's maximum).  Both optional (NULL = off), both arrays of `batch` LINES of CT_ABSMAX_LINE_BYTES bytes of device
+     * memory that the caller zeroes once per step: the bit pattern of max |x| of image n lives in the first word of line n.  PER
+     * IMAGE, so that what a kernel computes for an image never depends on the other images of its batch.
+     *   in_absmax   per image an upper bound of |x| over the input slice, left there by whoever produced the input (any kernel of
+     *               this library run with out_absmax, or ct_absmax_f32); kernels that need the maxima and do not get them take
+     *               them themselves in an extra pass (ct_conv2d_wino4s_fwd variant 3) or refuse (ct_conv2d_wino4f_pool_fwd_v
+     *               variant 2, the "h2:" configurations of ct_conv2d_x3_fwd);
+     *   out_absmax  the launch folds max |y| of everything it stores for image n into line n (atomic max): honoured by the shared
+     *               epilogue of ct_conv2d_wino4s_fwd (every variant) and of the f16x2 variant of ct_conv2d_wino4f_pool_fwd_v, by
+     *               ct_conv2d_x3_fwd (every configuration; split-K launches: in the finishing kernel) and by the 3-channel image
+     *               layer of ct_conv2d_fwd (config "valu"); ignored by the other kernels. */
     const unsigned* in_absmax;
     unsigned* out_absmax;
 } ct_conv_desc;
-#define CT_ABSMAX_SLOT_BYTES 2048
-/* max |x| over the channel slices [batch][per_image floats] (images img_stride floats apart) folded into `slot` (atomic max;
- * the caller zeroes the slot once per step). */
-int ct_absmax_f32(const float* in, int batch, long long per_image, long long img_stride, unsigned* slot, ct_stream_t stream);
+#define CT_ABSMAX_LINE_BYTES 128
+/* max |x| over the channel slice [per_image floats] of every image (images img_stride floats apart), folded into `lines`
+ * (batch lines, atomic max; the caller zeroes them once per step). */
+int ct_absmax_f32(const float* in, int batch, long long per_image, long long img_stride, unsigned* lines, ct_stream_t stream);
 
 /* Rows of the packed weight matrix for a (cin, kh, kw) filter: k_pad. */
 int ct_conv_kpad(int cin, int kh, int kw);
@@ -427,6 +429,14 @@ int ct_conv_pack_weights_x3(const float* const* w, const int* cout, int nparts, 
 int ct_conv_pack_weights_x3_dgrad(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk,
                                   void* wx3, ct_stream_t stream);
 int ct_conv2d_x3_fwd(const ct_conv_desc* desc, const void* wx3, int config, ct_stream_t stream);
+/* The f16x2 operand form of the same kernel (csrc/ct_f16x2.h; see ct_conv2d_wino4s_fwd variant 3): configurations named
+ * "h2:<tile>" (ct_conv_x3_config_h2(i) == 1) take weights from ct_conv_pack_weights_x3h (ct_conv_x3h_packed_bytes bytes: two
+ * binary16 pieces of w 2^eW and a trailer with eW) and need desc->in_absmax; forward only.  Every configuration honours
+ * desc->out_absmax (split-K launches: in their finishing kernel). */
+int ct_conv_x3_config_h2(int i);
+size_t ct_conv_x3h_packed_bytes(int cin, int cout, int kh, int kw, int bk);
+int ct_conv_pack_weights_x3h(const float* const* w, const int* cout, int nparts, int cin, int kh, int kw, int bk, void* wx3,
+                             ct_stream_t stream);
 /* All weight splits of a training step (train.py:222-229 updates every weight every step) in ONE launch: the arguments
  * never change between steps, so build the list once -- ct_conv_x3_pack_item fills one item of
  * ct_conv_x3_pack_item_bytes() bytes in HOST memory from the arguments of ct_conv_pack_weights_x3 (dgrad = 0) or

@@ -339,3 +339,24 @@ def test_autotune_times_every_variant_and_keeps_a_correct_one(monkeypatch):
     be.run_conv(st)
     torch.cuda.synchronize()
     assert rel_err(bufs['y'].cpu(), _ref_conv(x, [(w, b, None, True)], 1, 1, 1)) < TOL
+
+
+@pytest.mark.parametrize('W', [engine.WINO4H, engine.WINO4FH], ids=['f4x4_h', 'f4x4_fh'])
+def test_f16x2_results_do_not_depend_on_batch_mates(W):
+    """The f16x2 forms scale their operands by a power of two taken from a maximum of |input| (csrc/ct_f16x2.h); the subnormal lo
+    pieces make the split depend on that exponent in the last bits, so the maximum is PER IMAGE: an image convolved alone and
+    next to an image 4 096 times larger (another exponent for a batch-wide maximum) gives the same bits.  What the harness
+    tests rely on (detections independent of batch composition and position)."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 64, 38, 38, generator=g).relu()
+    x[1] *= 4096.0
+    x[2] *= 1.0 / 1024
+    w = torch.randn(96, 64, 3, 3, generator=g) * 0.05
+    b = torch.rand(96, generator=g) - 0.5
+    together = _run_conv(x, [(w, b, None, True)], 1, 1, 1, config=W)
+    for n in range(3):
+        alone = _run_conv(x[n:n + 1], [(w, b, None, True)], 1, 1, 1, config=W)
+        assert torch.equal(alone[0], together[n]), n
+    want = _ref_conv(x, [(w, b, None, True)], 1, 1, 1)
+    for n in range(3):                      # each image at ITS scale (a batch-wide scale would lose the small image's low bits)
+        assert rel_err(together[n], want[n]) < TOL, n

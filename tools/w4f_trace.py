@@ -25,7 +25,7 @@ for name in sys.argv[1:] or ['base.2', 'base.7']:
     tile = int(os.environ.get('TILE', '46'))            # 46: bf16x3, 48: f16x2 (needs the maximum of |input|, taken once here)
     be.enable_wino(st, tile=tile)
     if tile == 48:
-        slot = torch.zeros(_lib.ABSMAX_SLOT_BYTES // 4, device=DEV, dtype=torch.int32)
+        slot = torch.zeros(B * _lib.ABSMAX_LINE_BYTES // 4, device=DEV, dtype=torch.int32)
         _lib.check(be.lib.ct_absmax_f32(bufs['x'].data_ptr(), B, Cin * H * W, Cin * H * W, slot.data_ptr(), be._stream()), 'ct_absmax_f32')
         st.rt['desc'].in_absmax = slot.data_ptr()
     for _ in range(3):

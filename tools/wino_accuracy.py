@@ -38,6 +38,16 @@ for phase, C, kind in ((1, 20, 'randn'), (1, 20, 'u8'), (2, 60, 'randn')):
 
     report('(the fp32 CPU path itself)', 0, [t.double() for t in ref32])
     rt = net.runtime(a.batch)
+    with torch.no_grad():
+        got = [t.double().cpu() for t in net.forward_raw(x.cuda())]
+    if got is not None:          # what the runtime ships: the committed table, f16x2 operand forms where operand_form_h2 says so
+        from ctdet import engine as _eng
+        kinds = {}
+        for st in rt.conv_steps():
+            k = _eng.WINO_NAME.get(st.rt.get('wino')) or (rt.backend.x3_names()[st.rt['x3']][:2] if st.rt.get('x3') is not None else 'fp32')
+            kinds[k] = kinds.get(k, 0) + 1
+        report('the shipped table (CTDET_H2=%s): %s' % (os.environ.get('CTDET_H2', '1'), ' '.join('%s %d' % kv for kv in sorted(kinds.items()))),
+               len(rt.conv_steps()), got)
     # the layers the committed table routes through a Winograd kernel and that have the fused kernels' geometry (3x3, stride 1,
     # dilation 1): the dilated layers only exist on the three-kernel form (tile 44) and keep it in every row
     fused = [st for st in rt.conv_steps() if st.rt.get('wino') and st.rt.get('wino_ok')]

@@ -47,7 +47,7 @@ for name in names:
         if tile in (47, 48) and os.environ.get('PRE_AMAX', '1') != '0':
             # the f16x2 kernels take their input scale from a maximum of |input|: in a network the producer of the input leaves it
             # (ct_conv_desc.out_absmax -> in_absmax); here it is taken ONCE, outside the timed launches (PRE_AMAX=0: inside them)
-            slot = torch.zeros(_lib.ABSMAX_SLOT_BYTES // 4, device=DEV, dtype=torch.int32)
+            slot = torch.zeros(B * _lib.ABSMAX_LINE_BYTES // 4, device=DEV, dtype=torch.int32)
             _lib.check(be.lib.ct_absmax_f32(bufs['x'].data_ptr(), B, Cin * H * W, Cin * H * W, slot.data_ptr(), be._stream()), 'ct_absmax_f32')
             st.rt['desc'].in_absmax = slot.data_ptr()
             st.rt['slot_keepalive'] = slot
