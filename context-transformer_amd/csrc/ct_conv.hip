@@ -62,7 +62,7 @@ struct ConvArgs {
     int transposed;
     int ksplit, steps_per_split;    // > 1: blockIdx.y owns k-steps [y*sps, (y+1)*sps) and writes its raw sums to ws
     float* ws;                      // [ksplit][M][Npix] partial sums, reduced in fixed order by conv_splitk_epilogue
-    unsigned* out_amax;             // conv_valu3x3_f32 only: ct_conv_desc.out_absmax (max |y| of what the launch stores), or null
+    unsigned* out_amax;             // ct_conv_desc.out_absmax (per-image max |y| of what the launch stores), or null
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes)
@@ -310,35 +310,41 @@ __global__ __launch_bounds__(256, MINW) void conv_igemm_f32(const ConvArgs a)
         ev[2 * BM + i] = !in ? 0.f : a.lo ? a.lo[co] : (a.relu ? 0.f : -INFINITY);
     }
     __syncthreads();
+    const bool track = a.out_amax != nullptr;       // ct_conv_desc.out_absmax: per-image maxima of |v| of what the launch stores
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int P = n0 + wn0 + j * 32 + l31;
-        if (P >= a.Npix) continue;
-        const int n = P / a.OHW;
-        const int s = P - n * a.OHW;
+        const bool live = P < a.Npix;
+        const int n = live ? P / a.OHW : -1;
+        float amax_run = 0.f;
+        if (live) {
+            const int s = P - n * a.OHW;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
+            for (int i = 0; i < TM; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int cl = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-                const int co = m0 + cl;
-                if (co >= a.M) continue;
-                float v = acc[i][j][r] * ev[cl] + ev[BM + cl];
-                if (a.res)
-                    v = v * a.res_scale +
-                        a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
-                { const float fl = ev[2 * BM + cl]; v = v < fl ? fl : v; }      // NaN propagates (torch.relu / no clamp)
-                if (a.nseg == 0) {
-                    a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
-                } else {
+                for (int r = 0; r < 16; ++r) {
+                    const int cl = wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                    const int co = m0 + cl;
+                    if (co >= a.M) continue;
+                    float v = acc[i][j][r] * ev[cl] + ev[BM + cl];
+                    if (a.res)
+                        v = v * a.res_scale +
+                            a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
+                    { const float fl = ev[2 * BM + cl]; v = v < fl ? fl : v; }      // NaN propagates (torch.relu / no clamp)
+                    if (track) ctdet::h2::track_absmax(amax_run, v);
+                    if (a.nseg == 0) {
+                        a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
+                    } else {
 #pragma unroll
-                    for (int g = 0; g < 3; ++g)
-                        if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
-                            a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
-                                         (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
+                        for (int g = 0; g < 3; ++g)
+                            if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
+                                a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                             (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
+                    }
                 }
             }
         }
+        if (track) ctdet::h2::flush_absmax(a.out_amax, n, amax_run);      // every lane arrives here
     }
 }
 
@@ -475,24 +481,34 @@ __global__ __launch_bounds__(256) void conv_valu3x3_f32(const ConvArgs a)
 __global__ __launch_bounds__(256) void conv_splitk_epilogue(const ConvArgs a)
 {
     const int total = a.M * a.Npix;
-    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
-        const int co = idx / a.Npix, P = idx - co * a.Npix;
-        const int n = P / a.OHW, s = P - n * a.OHW;
-        float sum = a.ws[idx];
-        for (int k = 1; k < a.ksplit; ++k) sum += a.ws[(size_t)k * total + idx];
-        float v = sum * a.scale[co] + a.shift[co];
-        if (a.res) v = v * a.res_scale + a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
-        if (a.lo) { const float fl = a.lo[co]; v = v < fl ? fl : v; }      // NaN propagates
-        else if (a.relu) v = v < 0.f ? 0.f : v;
-        if (a.nseg == 0) {
-            a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
-        } else {
+    const bool track = a.out_amax != nullptr;
+    const int rounds = (total + gridDim.x * 256 - 1) / (gridDim.x * 256);       // the same trip count for every lane (flush below)
+    for (int it = 0; it < rounds; ++it) {
+        const int idx = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        float amax_run = 0.f;
+        int img = -1;
+        if (idx < total) {
+            const int co = idx / a.Npix, P = idx - co * a.Npix;
+            const int n = P / a.OHW, s = P - n * a.OHW;
+            img = n;
+            float sum = a.ws[idx];
+            for (int k = 1; k < a.ksplit; ++k) sum += a.ws[(size_t)k * total + idx];
+            float v = sum * a.scale[co] + a.shift[co];
+            if (a.res) v = v * a.res_scale + a.res[((size_t)n * a.res_ctot + a.res_coff + co) * a.OHW + s];
+            if (a.lo) { const float fl = a.lo[co]; v = v < fl ? fl : v; }      // NaN propagates
+            else if (a.relu) v = v < 0.f ? 0.f : v;
+            if (track) ctdet::h2::track_absmax(amax_run, v);
+            if (a.nseg == 0) {
+                a.out[((size_t)n * a.out_ctot + a.out_coff + co) * a.OHW + s] = v;
+            } else {
 #pragma unroll
-            for (int g = 0; g < 3; ++g)
-                if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
-                    a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
-                                 (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
+                for (int g = 0; g < 3; ++g)
+                    if (g < a.nseg && co >= a.seg[g].co_begin && co < a.seg[g].co_end)
+                        a.seg[g].ptr[(size_t)n * a.seg[g].img_stride + a.seg[g].base +
+                                     (size_t)s * a.seg[g].pix_stride + (co - a.seg[g].co_begin)] = v;
+            }
         }
+        if (track) ctdet::h2::flush_absmax(a.out_amax, img, amax_run);
     }
 }
 
@@ -842,6 +858,7 @@ extern "C" int ct_conv2d_fwd(const ct_conv_desc* d, ct_stream_t stream)
         a.res_coff = d->res_coff;
         a.res_scale = d->res_scale;
         a.relu = d->relu;
+        a.out_amax = (d->out_absmax && !d->transposed) ? d->out_absmax + (size_t)b0 * ctdet::h2::kLineWords : nullptr;
         a.nseg = d->nseg;
         for (int g = 0; g < d->nseg; ++g) {
             a.seg[g] = d->seg[g];

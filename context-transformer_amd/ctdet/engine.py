@@ -664,7 +664,7 @@ class HipBackend:
     def run_conv(self, st):
         tile = st.rt.get('wino')
         needs_max = tile in WINO4FH_TILES or (not tile and st.rt.get('x3') is not None and self.x3_h2(st.rt['x3']))
-        if needs_max and (not st.rt['desc'].in_absmax or st.rt.get('amax_own') is not None):
+        if needs_max and (not st.rt['desc'].in_absmax or (st.rt.get('amax_own') is not None and not st.rt.get('amax_frozen'))):
             self._own_absmax(st)
         if tile in WINO4S_TILES:         # F(4x4,3x3): transform / bf16x3 GEMM / transform (csrc/ct_wino4s.hip)
             lib, U, ws, var = self.lib, st.rt['U4H' if tile in WINO4H_TILES else 'U4S'].data_ptr(), \
@@ -775,7 +775,14 @@ class HipBackend:
     def _time_conv(self, st, iters=3, rounds=2):
         """ms per launch: the better of `rounds` timed bursts of `iters` launches after one warm-up launch.  Short
         launches get longer bursts (>= ~1 ms of device time): three 30 us launches are inside the timer's noise, and a
-        flipped choice lands in the committed table."""
+        flipped choice lands in the committed table.  A kernel on the f16x2 operand form is timed with the maxima of |input| in
+        place (taken once here, as its producer would have left them in a network), not with an absmax pass per launch."""
+        tile = st.rt.get('wino')
+        if tile in H2_TILES or (not tile and st.rt.get('x3') is not None and self.x3_h2(st.rt['x3'])):
+            if not st.rt['desc'].in_absmax or st.rt.get('amax_own') is not None:
+                st.rt['amax_frozen'] = False
+                self._own_absmax(st)
+                st.rt['amax_frozen'] = True
         self.run_conv(st)
         torch.cuda.synchronize(self.device)
         best = float('inf')
@@ -885,11 +892,23 @@ H2_OF_TILE = {44: 47, 46: 48}
 H2_OF_TILE_VALUES = tuple(H2_OF_TILE.values())
 
 
-def operand_form_h2(net):
-    """Whether an inference runtime runs its bf16x3 Winograd table entries on the f16x2 operand form (CTDET_H2, default on;
-    off for the networks with an accuracy policy, whose sweeps were made on bf16x3: ctx_tile_set).  Same error against
-    fp64 per layer (tests/test_gpu_wino.py::test_wino_rounding_error_vs_fp64), half the matrix instructions."""
-    return os.environ.get('CTDET_H2', '1') != '0' and ctx_tile_set(net) is None
+H2_MIN_PIXELS = 8 * 300 * 300
+
+
+def operand_form_h2(net, batch=None):
+    """Whether an inference runtime runs its bf16x3 table entries on the f16x2 operand form (csrc/ct_f16x2.h: two binary16
+    pieces, three products; same error against fp64 per layer, tests/test_gpu_wino.py::test_wino_rounding_error_vs_fp64, half
+    the matrix instructions).  CTDET_H2: '1' (default) = from batch x size^2 >= 8 x 300^2 up, '2' = always, '0' = never; never for
+    the networks with an accuracy policy, whose sweeps were made on bf16x3 (ctx_tile_set).  Why a threshold: an f16x2 launch
+    waits for its input's maxima when it starts and folds its own in when it ends -- a few us per launch that the launch-bound
+    small batches do not get back (same-box, images/s bf16x3 -> f16x2: RFBNet-300 bs 4 2 065 -> 1 830, bs 8 2 850 -> 2 990,
+    bs 16 3 450 -> 3 945, bs 32 4 005 -> 4 655; RFBNet-512 bs 4 1 120 -> 1 126, bs 8 1 340 -> 1 438, bs 32 1 608 -> 1 805;
+    profiles/r06_ab_batches.txt)."""
+    mode = os.environ.get('CTDET_H2', '1')
+    if mode == '0' or ctx_tile_set(net) is not None:
+        return False
+    size = int(getattr(net, 'size', 300) or 300)
+    return mode == '2' or batch is None or batch * size * size >= H2_MIN_PIXELS
 
 
 CTX_TILES_DEFAULT = '2,23'
@@ -970,6 +989,10 @@ def apply_tuned(backend, st, batch, wino4=True):
     most accurate allowed variant: F(2x2) on bf16x3 with two accumulators where the layer has 16-channel chunks, else
     F(2x2) on the fp32 MFMA."""
     cfg = tune_table().get(st.tune_key(batch))
+    if getattr(backend, 'h2', False):
+        # a runtime on the f16x2 operand forms: where the forms' different speed-ups change which KERNEL FAMILY wins a shape
+        # (tools/tune_convs.py --h2), the table holds that choice under '<key>|h2' (same names: mapped to the f16x2 twins below)
+        cfg = tune_table().get(st.tune_key(batch) + '|h2', cfg)
     names = [backend.lib.ct_conv_config_name(i).decode() for i in range(backend.lib.ct_conv_num_configs())]
     codes = {v: k for k, v in WINO_NAME.items()}
     usable = cfg in codes and (st.rt.get('wino_ok') or (codes[cfg] in WINO4S_TILES and st.rt.get('wino4s_ok'))) and \
@@ -1017,11 +1040,19 @@ def apply_tuned(backend, st, batch, wino4=True):
             want = H2_OF_TILE[want]         # the same kernel on the f16x2 operand form (operand_form_h2)
         backend.enable_wino(st, tile=want)
         return True
+    if isinstance(cfg, str) and cfg.startswith('h2:'):
+        # the f16x2 twin of a direct-kernel tile: only from a '<key>|h2' entry (tools/tune_convs.py --h2 times it against the
+        # bf16x3 tile per shape: it wins from batch 8-16 up, not on the launch-bound small batches)
+        xn = backend.x3_names()
+        if getattr(backend, 'h2', False) and cfg in xn and x3_allowed(st) and st.cin % backend.x3_bk(xn.index(cfg)) == 0 and \
+                os.environ.get('CTDET_H2_X3', '1') != '0':
+            backend.enable_x3(st, xn.index(cfg))
+            return True
+        cfg = 'x3:' + cfg[3:]
     if isinstance(cfg, str) and cfg.startswith('x3:'):
         xn = backend.x3_names()
         if cfg in xn and x3_allowed(st) and st.cin % backend.x3_bk(xn.index(cfg)) == 0:     # the k-step must divide cin
-            twin = 'h2:' + cfg[3:]              # the same tile on the f16x2 operand form (operand_form_h2)
-            use = twin if getattr(backend, 'h2', False) and twin in xn and os.environ.get('CTDET_H2_X3', '1') != '0' else cfg
+            use = cfg
             backend.enable_x3(st, xn.index(use))
             return True
         cfg = tune_table().get(st.tune_key(batch) + '|f32')       # the best fp32-MFMA tile, recorded next to it
@@ -1083,7 +1114,7 @@ class Runtime:
         # live autotune only for shapes the table does not know (CTDET_TUNE=0 disables, =2 forces)
         mode = os.environ.get('CTDET_TUNE', '1') if tune is None else ('1' if tune else '0')
         backend.wino_tile_set = ctx_tile_set(net)
-        backend.h2 = operand_form_h2(net)
+        backend.h2 = operand_form_h2(net, batch)
         backend.wino4_max_cin = ctx_f4_max_cin(net)
         backend.ctx_w4s_min_cin = ctx_w4s_min_cin(net)
         self.tuned = False
@@ -1216,36 +1247,24 @@ class Runtime:
         self.ev = {j: torch.cuda.Event() for j in self.signal}
 
     def _wire_absmax(self):
-        """Maxima of |activation| for the f16x2 kernels (ct_conv_desc.in_absmax / out_absmax, csrc/ct_f16x2.h).  A buffer that an
-        f16x2 layer reads gets a slot when EVERY step that writes it can fold the maximum of what it stores into one (the
-        F(4x4,3x3) epilogue of tiles 44 / 45 / 47 / 48, the image layer's vector-ALU kernel); a max-pool's output shares the slot
-        of its input (pooled values are a subset), whether the pool runs as a step or inside its producer.  Consumers whose
-        buffer has no slot take the maximum themselves (tile 47: an absmax pass inside the launch; tile 48: ct_absmax_f32 in
-        front of it, HipBackend._own_absmax).  The slots are zeroed once per step (run_loaded)."""
+        """Per-image maxima of |activation| for the f16x2 kernels (ct_conv_desc.in_absmax / out_absmax, csrc/ct_f16x2.h).  A buffer
+        that an f16x2 layer reads gets a slot (one line per image) when EVERY step that writes it folds the maxima of what it
+        stores into one: every forward convolution kernel does, except the fused Winograd kernels on fp32 / bf16x3; a max-pool's
+        output shares the slot of its input (pooled values are a subset), whether the pool runs as a step or inside its producer.
+        An f16x2 consumer whose buffer has no slot runs the bf16x3 twin of its kernel (tile 47 takes the maxima itself, inside its
+        launch).  The slots are zeroed once per step (run_loaded)."""
         be = self.backend
         if not hasattr(be, 'new_slot'):
             return
-        self._wired_epoch = be.kernel_epoch
         steps = self.plan.steps
-        for st in self.conv_steps():
-            st.rt['desc'].in_absmax = None
-            st.rt['desc'].out_absmax = None
-            st.rt.pop('amax_own', None)
+
         def consumes(st):
             return st.rt.get('wino') in H2_TILES or (not st.rt.get('wino') and st.rt.get('x3') is not None and be.x3_h2(st.rt['x3']))
-        if not any(consumes(st) for st in self.conv_steps()):
-            return
 
         def tracks(st):
             if st.kind != 'conv' or st.segs:
                 return False
-            if st.rt.get('wino') in TRACK_TILES:
-                return True
-            if not st.rt.get('wino') and st.rt.get('x3') is not None:
-                return True                # ct_conv2d_x3_fwd, either operand form (split-K launches: in the finishing kernel)
-            d = st.rt['desc']          # the image layer, when its config NAMES the vector-ALU kernel (config 0 leaves the choice to the library)
-            name = be.lib.ct_conv_config_name(d.config - 1).decode() if d.config > 0 else ''
-            return not st.rt.get('wino') and st.rt.get('x3') is None and name == 'valu' 
+            return st.rt.get('wino') in TRACK_TILES if st.rt.get('wino') else True
         root = {}                          # pooled buffer -> the buffer whose maximum bounds it
         for ps in steps:
             if ps.kind == 'pool':
@@ -1262,20 +1281,36 @@ class Runtime:
                     writers.setdefault(b, []).append(st)
             elif st.kind != 'pool':
                 writers.setdefault(st.dst, []).append(st)
-        slots = {}
-        be.slots_used = 0
+        while True:
+            for st in self.conv_steps():
+                st.rt['desc'].in_absmax = None
+                st.rt['desc'].out_absmax = None
+                st.rt.pop('amax_own', None)
+                st.rt.pop('amax_frozen', None)
+            slots, fallback = {}, []
+            be.slots_used = 0
+            for st in self.conv_steps():
+                if not consumes(st):
+                    continue
+                b = root_of(st.src)
+                ws = writers.get(b, [])
+                if ws and all(tracks(w) for w in ws):
+                    if b not in slots:
+                        slots[b] = be.new_slot(self.batch)
+                        for w in ws:
+                            w.rt['desc'].out_absmax = slots[b]
+                    st.rt['desc'].in_absmax = slots[b]
+                elif st.rt.get('wino') != 47:
+                    fallback.append(st)
+            if not fallback:
+                break
+            for st in fallback:            # (a layer that leaves the f16x2 form may stop tracking: wire again)
+                if st.rt.get('wino') == 48:
+                    be.enable_wino(st, tile=46)
+                else:
+                    xn = be.x3_names()
+                    be.enable_x3(st, xn.index('x3:' + xn[st.rt['x3']][3:]))
         self._wired_epoch = be.kernel_epoch
-        for st in self.conv_steps():
-            if not consumes(st):
-                continue
-            b = root_of(st.src)
-            ws = writers.get(b, [])
-            if ws and all(tracks(w) for w in ws):
-                if b not in slots:
-                    slots[b] = be.new_slot(self.batch)
-                    for w in ws:
-                        w.rt['desc'].out_absmax = slots[b]
-                st.rt['desc'].in_absmax = slots[b]
         self.amax_slots = slots
 
     def _share_workspaces(self):

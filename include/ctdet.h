@@ -248,8 +248,8 @@ typedef struct ct_conv_desc {
      *               variant 2, the "h2:" configurations of ct_conv2d_x3_fwd);
      *   out_absmax  the launch folds max |y| of everything it stores for image n into line n (atomic max): honoured by the shared
      *               epilogue of ct_conv2d_wino4s_fwd (every variant) and of the f16x2 variant of ct_conv2d_wino4f_pool_fwd_v, by
-     *               ct_conv2d_x3_fwd (every configuration; split-K launches: in the finishing kernel) and by the 3-channel image
-     *               layer of ct_conv2d_fwd (config "valu"); ignored by the other kernels. */
+     *               ct_conv2d_x3_fwd and ct_conv2d_fwd (every configuration; split-K launches: in the finishing kernel); ignored
+     *               by the other kernels (the fp32 / bf16x3 fused Winograd kernels, the bf16 path) and by data-gradient launches. */
     const unsigned* in_absmax;
     unsigned* out_absmax;
 } ct_conv_desc;
