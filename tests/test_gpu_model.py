@@ -80,7 +80,7 @@ def test_rfb300_phase1_vs_oracle_and_golden(golden):
         assert rel_err(a, b) < (TOL if name.endswith('loc') else 2e-3), name
 
 
-@pytest.mark.parametrize('size,batch', [(300, 2), (512, 1)])
+@pytest.mark.parametrize('size,batch', [(300, 2), (512, 4)])
 def test_f16x2_operand_forms_whole_network(monkeypatch, size, batch):
     """The whole network on the f16x2 operand forms (csrc/ct_f16x2.h; CTDET_H2=2 forces what batch x size^2 >= 8 x 300^2 selects by
     default, engine.operand_form_h2): raw outputs against the CPU oracle at 1e-4, the per-image maxima wired from producer to
@@ -88,25 +88,27 @@ def test_f16x2_operand_forms_whole_network(monkeypatch, size, batch):
     from ctdet import engine
     monkeypatch.setenv('CTDET_H2', '2')
     net = _net(size, 20)
-    x = synth.images(batch + 1, size, 'randn', 4321)
-    x[batch] *= 37.0                                       # a batch mate with other maxima
+    x = synth.images(batch, size, 'randn', 4321)
+    x[batch - 1] *= 37.0                                   # a batch mate with other maxima
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     with torch.no_grad():
         want = rfbnet_ref.forward(sd, x, size, 20, raw=True)
         got = [t.cpu().clone() for t in net.forward_raw(x.cuda())]
-    rt = net.runtime(batch + 1)
+    rt = net.runtime(batch)
     assert rt.backend.h2
     kinds = [st.rt.get('wino') for st in rt.conv_steps()]
     assert any(k in engine.H2_TILES for k in kinds), kinds
     assert not any(k == 46 for k in kinds) and rt.amax_slots, kinds       # every f16x2 consumer got its producer's maxima
     assert all(st.rt.get('amax_own') is None for st in rt.conv_steps())
     for g_, w_ in zip(got, want):
-        for n in range(batch + 1):
+        for n in range(batch):
             assert rel_err(g_[n], w_[n]) < TOL, n
+    x2 = x.clone()
+    x2[batch - 1] = synth.images(1, size, 'randn', 99)[0] * 0.01          # another mate, other maxima again
     with torch.no_grad():
-        alone = [t.cpu() for t in net.forward_raw(x[:batch].cuda())]
-    for a_, g_ in zip(alone, got):
-        assert torch.equal(a_, g_[:batch])
+        other = [t.cpu() for t in net.forward_raw(x2.cuda())]
+    for a_, g_ in zip(other, got):
+        assert torch.equal(a_[:batch - 1], g_[:batch - 1])
 
 
 @pytest.mark.parametrize('setting,C', [('transfer', 60), ('incre', 15)])
