@@ -1118,12 +1118,16 @@ class Runtime:
         backend.wino4_max_cin = ctx_f4_max_cin(net)
         backend.ctx_w4s_min_cin = ctx_w4s_min_cin(net)
         self.tuned = False
+        self.live_tuned = []
         self.event_log = None        # set to a list to collect (step, start_event, end_event) per conv
         if getattr(backend, 'tune_conv', None) is not None:
             missing = [st for st in self.conv_steps() if mode == '2' or not apply_tuned(backend, st, batch)]
             if missing and mode != '0':
                 self.autotune(missing)
             self.tuned = not missing or mode != '0'
+            # shapes the committed table does not serve: timed live (mode 1 / 2) or left to the library's heuristic (mode 0) --
+            # either way a tile choice no parity test pinned at that shape (bench.py refuses a headline with any)
+            self.live_tuned = [st.tune_key(batch) for st in missing]
             # CTDET_WINO_FORCE = tile code (experiments, tools/ctx_parity.py): every layer that runs on a Winograd kernel
             # and has the geometry for it is moved to that variant
             force = int(os.environ.get('CTDET_WINO_FORCE', '0') or 0)

@@ -30,13 +30,16 @@ def test_bench_line_contract():
     r = d['roofline']
     # the dominant kernel's own pipe: fp32 MFMA, or the bf16 MFMA for a bf16x3 kernel (six bf16 products per fp32 multiply-add)
     assert r['bound'] == 'mfma' and r['unit'] == 'TFLOP/s'
-    # bf16x3 kernels: direct, fused Winograd F(2x2), or the GEMM kernel of the three-kernel F(4x4) form
-    on_bf16 = r['kernel'].startswith('conv_x3_f32') or '_x3' in r['kernel'] or r['kernel'].startswith('wino4s')
+    # kernels on the 16-bit matrix pipe: bf16x3 (direct, fused Winograd, the GEMM kernel of the three-kernel F(4x4) form) or the
+    # f16x2 twins of the same kernels (three piece products instead of six)
+    on_h2 = r['kernel'].startswith('conv_h2_f32') or '_h2' in r['kernel']
+    on_bf16 = on_h2 or r['kernel'].startswith('conv_x3_f32') or '_x3' in r['kernel'] or r['kernel'].startswith('wino4s')
     assert r['peak'] == (2500.0 if on_bf16 else 157.3)
     assert 0.0 < r['frac'] <= 1.0 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
-    if r['kernel'].startswith('conv_x3_f32'):
-        assert abs(r['flops_per_launch'] / r['algorithmic_flops_per_launch'] - 6.0) < 1e-6
-    assert 'arith' in d and 'bf16x3' in d['arith']
+    if r['kernel'].startswith('conv_x3_f32') or r['kernel'].startswith('conv_h2_f32'):
+        assert abs(r['flops_per_launch'] / r['algorithmic_flops_per_launch'] - (3.0 if on_h2 else 6.0)) < 1e-6
+    assert 'arith' in d and 'bf16x3' in d['arith'] and 'f16x2' in d['arith']
+    assert d['config']['operand_form'] in ('f16x2', 'bf16x3') and d['config']['live_tuned_layers']['count'] == 0
     assert len(d['per_rank_ms_per_step']) == 1 and d['dist']['rccl_ranks'] == 1
     if r['kernel'] == 'wino4s_gemm':
         # a three-kernel launch dominates: kernel-level fields = its matrix kernel, launch-level ones kept beside them
@@ -45,7 +48,7 @@ def test_bench_line_contract():
         assert 0 < r['stages']['wino4s_in']['frac'] < 1 and 0 < r['stages']['wino4s_out']['frac'] < 1
     elif r['kernel'].startswith('wino'):
         assert r['winograd_mult_ratio'] in (round(16 / 36, 4), 0.25)
-        assert abs(r['flops_per_launch'] / r['algorithmic_flops_per_launch'] - r['winograd_mult_ratio'] * (6 if on_bf16 else 1)) < 1e-3
+        assert abs(r['flops_per_launch'] / r['algorithmic_flops_per_launch'] - r['winograd_mult_ratio'] * (3 if on_h2 else 6 if on_bf16 else 1)) < 1e-3
         assert r['algorithmic_frac'] > r['frac']
     st = r['stages']
     for k in ('detect_kernel', 'select_sort_kernel', 'nms_segments_kernel'):
