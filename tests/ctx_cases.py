@@ -80,9 +80,9 @@ def sweep_case(net, size, C, setting, batch, seed, kind, sd32=None, sd64=None, e
 
 def verdict(r, tol=1e-4):
     """'ok': every element of the block's output within tol of the reference's fp32 CPU arithmetic; else 'FAIL'.  north_star's
-    contract, flat: no second clause (rounds 2-4 accepted cases above 1e-4 that were within 1e-4 of fp64; the shipped tile
-    policy -- engine.ctx_f4_max_cin / ctx_w4s_min_cin -- now holds 1e-4 against the CPU path in all nine sweep cases, with the
-    CPU reference at 8 and at 128 threads: profiles/r05_ctx_policy.txt).  What makes this a narrow pass, for the record: the
+    contract, flat: no second clause (rounds 2-4 accepted cases above 1e-4 that were within 1e-4 of fp64; the shipped kernel
+    policy -- engine.ctx_policy -- holds 1e-4 against the CPU path in all nine sweep cases, with the CPU reference at 8 and at
+    128 threads: profiles/r06_ctx_policy.txt; round 5's: profiles/r05_ctx_policy.txt).  What makes this a narrow pass, for the record: the
     block multiplies a perturbation of its input by ~1000 (budget below), the reference's own fp32 CPU path sits 4.8..7.2e-5
     from an fp64 evaluation and moves inside that band with the host's thread count (torch's CPU convolutions split their
     sums by thread: tests/conftest.py pins 8 threads, the count tools/gen_goldens.py captured the goldens with)."""

@@ -7,11 +7,12 @@ What is asserted (tools/ctx_parity.py --budget, profiles/r04_ctx_parity.txt):
   * the block's own arithmetic on an identical input: 1e-4 (measured 1.0e-5; torch-CPU fp32's is 1.6e-5);
   * the composite: 1e-4 vs the CPU fp32 path, every element, no second clause (ctx_cases.verdict; the fp64 block amplifies a
     perturbation of its input ~1000x, the CPU path itself is 4.8..7.2e-5 from fp64 and moves inside that band with the host's
-    thread count; conftest.py pins 8 threads; the shipped tile policy also holds at 128: profiles/r05_ctx_policy.txt).
+    thread count; conftest.py pins 8 threads) -- against the reference at 8 threads AND, same device output, at 128
+    (profiles/r06_ctx_policy.txt: the sweep that chose the shipped policy).
 Inputs are 'randn' (SURVEY 8d (i)).  On image-like 'u8' inputs (8d (ii), |x| ~ 128) the logits are ~1e4 and the
 block is chaotic in fp32: torch-CPU fp32 itself is 1e-3 .. 1e-1 away from fp64 there, so no fp32 implementation has a
-parity to meet; that case only checks the block's input.  The shipped Winograd tile policy (engine.ctx_tile_set: F(2x2,3x3) on
-bf16x3 with two accumulators; the fused F(4x4,3x3) / fp32 kernel up to 128 input channels) runs here."""
+parity to meet; that case only checks the block's input.  The shipped kernel policy (engine.ctx_policy 'h2': the committed table
+with its F(4x4,3x3) entries on the f16x2 operand form, direct layers on bf16x3 with two accumulators) runs here."""
 import pytest
 import torch
 
@@ -30,9 +31,12 @@ def net300():
 @pytest.mark.parametrize('seed', [1234, 7, 99])
 def test_phase2_parity_sweep(net300, batch, seed):
     net, sd32, sd64 = net300
-    r = cc.sweep_case(net, 300, 60, 'transfer', batch, seed, 'randn', sd32, sd64)
+    r = cc.sweep_case(net, 300, 60, 'transfer', batch, seed, 'randn', sd32, sd64, extra_threads=(128,))
     assert r['loc_gpu_cpu32'] < 1e-4 and r['obj_gpu_cpu32'] < 1e-4 and r['rawconf_gpu_cpu32'] < 1e-4, r
     assert cc.verdict(r) == 'ok', r
+    # the same device output against the fp32 CPU reference evaluated with 128 threads (torch's CPU convolutions split their sums
+    # by thread: another, equally valid fp32 reference)
+    assert r['gpu_cpu32@128'] <= 1e-4, r
 
 
 def test_phase2_parity_512_at_the_per_gpu_batch_of_configs3():

@@ -126,29 +126,22 @@ def test_rfb300_phase2_context_transformer(golden, setting, C):
 
 
 def test_winograd_tile_policy_and_phase2_full_tensor_parity(monkeypatch):
-    """Networks with the Context-Transformer block (whose softmax amplifies the trunk's fp32 rounding ~1000x) run their
-    Winograd layers on F(2x2,3x3) / bf16x3 with two accumulators (tile code 23; F(2x2,3x3) on the fp32 MFMA where the layer has no
-    16-channel chunks); a fused F(4x4,3x3) kernel survives only up to 128 input channels, where the table picks one
-    (engine.ctx_tile_set, ctx_f4_max_cin, ctx_f4_tile); the three-kernel form (tile 44) is opt-in (ctx_w4s_min_cin).  Every other
-    network takes the committed table as it is.  CTDET_CTX_TILES overrides the set ('any' = the table).  Every output ELEMENT
-    (not a sample) of the block stays within 1e-4 of the reference's CPU arithmetic here (bs 2, seed 1234;
-    tests/test_gpu_ctx_parity.py sweeps batch sizes and seeds)."""
+    """Networks with the Context-Transformer block (whose softmax amplifies the trunk's fp32 rounding ~1000x) have a measured
+    kernel policy (engine.ctx_policy / ctx_tile_set / operand_form_h2).  Shipped (round 6, 'h2'): the committed table with its
+    F(4x4,3x3) entries on the f16x2 operand form at every batch size, the direct layers on bf16x3.  CTDET_CTX_TILES=2,23 is round
+    5's tile-set policy: F(2x2,3x3) / bf16x3 with two accumulators (tile 23), a fused F(4x4,3x3) kernel only up to 128 input
+    channels (ctx_f4_max_cin, ctx_f4_tile), the three-kernel form opt-in (ctx_w4s_min_cin); 'any' = what every other network
+    runs.  Every output ELEMENT (not a sample) of the block stays within 1e-4 of the reference's CPU arithmetic here (bs 2, seed
+    1234; tests/test_gpu_ctx_parity.py sweeps batch sizes and seeds)."""
+    from ctdet import engine
     net = _net(300, 60, 2, 'transfer')
     rt = net.runtime(2)
     for r in (rt, net.runtime(32)):
+        assert r.backend.h2 and not r.backend.h2_direct and r.backend.wino_tile_set is None
         tiles = [st.rt.get('wino') for st in r.conv_steps() if st.rt.get('wino')]
-        assert tiles and set(tiles) <= {2, 4, 23, 46}, tiles
-        assert all(st.rt.get('wino') == 23 for st in r.conv_steps() if st.rt.get('wino') and st.cin % 16 == 0 and st.cin > 128)
-        assert all(st.cin <= 128 for st in r.conv_steps() if st.rt.get('wino') in (4, 46))
-    assert any(st.rt.get('wino') == 23 and st.cin == 512 for st in net.runtime(32).conv_steps())
-    # the opt-in fast policy of round 4: three-kernel F(4x4) from 128 input channels up
-    monkeypatch.setenv('CTDET_CTX_W4S_MIN_CIN', '128')
-    monkeypatch.setenv('CTDET_CTX_F4_MAX_CIN', '128')
-    fast = _net(300, 60, 2, 'transfer').runtime(32)
-    assert any(st.rt.get('wino') == 44 and st.cin == 512 for st in fast.conv_steps())
-    monkeypatch.delenv('CTDET_CTX_W4S_MIN_CIN')
-    monkeypatch.delenv('CTDET_CTX_F4_MAX_CIN')
-    del fast
+        assert tiles and not set(tiles) & {44, 45, 46}, tiles             # every bf16x3 F(4x4) entry runs its f16x2 twin
+        assert not any(st.rt.get('x3') is not None and r.backend.x3_h2(st.rt['x3']) for st in r.conv_steps())
+    assert any(st.rt.get('wino') == 47 and st.cin == 512 for st in net.runtime(32).conv_steps())
     x = synth.images(2, 300, 'randn', 1234)
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     with torch.no_grad():
@@ -156,6 +149,27 @@ def test_winograd_tile_policy_and_phase2_full_tensor_parity(monkeypatch):
         got = [t.cpu() for t in net.forward_raw(x.cuda())]
     for a, b, name in zip(got, want, ('loc', 'conf', 'obj')):
         assert rel_err(a.reshape(b.shape), b) < TOL, (name, rel_err(a.reshape(b.shape), b))
+    # round 5's tile-set policy
+    monkeypatch.setenv('CTDET_CTX_TILES', '2,23')
+    old = _net(300, 60, 2, 'transfer')
+    for r in (old.runtime(2), old.runtime(32)):
+        assert not r.backend.h2
+        tiles = [st.rt.get('wino') for st in r.conv_steps() if st.rt.get('wino')]
+        assert tiles and set(tiles) <= {2, 4, 23, 46}, tiles
+        assert all(st.rt.get('wino') == 23 for st in r.conv_steps() if st.rt.get('wino') and st.cin % 16 == 0 and st.cin > 128)
+        assert all(st.cin <= 128 for st in r.conv_steps() if st.rt.get('wino') in (4, 46))
+    assert any(st.rt.get('wino') == 23 and st.cin == 512 for st in old.runtime(32).conv_steps())
+    with torch.no_grad():
+        got = [t.cpu() for t in old.forward_raw(x.cuda())]
+    for a, b, name in zip(got, want, ('loc', 'conf', 'obj')):
+        assert rel_err(a.reshape(b.shape), b) < TOL, (name, rel_err(a.reshape(b.shape), b))
+    del old
+    # ... and its opt-in fast variant of round 4: three-kernel F(4x4) from 128 input channels up
+    monkeypatch.setenv('CTDET_CTX_W4S_MIN_CIN', '128')
+    monkeypatch.setenv('CTDET_CTX_F4_MAX_CIN', '128')
+    fast = _net(300, 60, 2, 'transfer').runtime(32)
+    assert any(st.rt.get('wino') == 44 and st.cin == 512 for st in fast.conv_steps())
+    del fast
     monkeypatch.setenv('CTDET_CTX_F4_MAX_CIN', '0')
     monkeypatch.setenv('CTDET_CTX_W4S_MIN_CIN', '0')
     monkeypatch.setenv('CTDET_CTX_TILES', '2')

@@ -17,15 +17,16 @@ torch.set_num_threads(int(os.environ.get('CTDET_REF_THREADS', '8')))
 
 ap = argparse.ArgumentParser()
 ap.add_argument('--budget', action='store_true'); ap.add_argument('--sweep', action='store_true')
-ap.add_argument('--policies', default='2+23'); ap.add_argument('--batches', default='2,8,32')
+ap.add_argument('--policies', default='h2'); ap.add_argument('--batches', default='2,8,32')
 ap.add_argument('--seeds', default='1234,7,99'); ap.add_argument('--kinds', default='randn,u8')
 ap.add_argument('--size', type=int, default=300); ap.add_argument('--budget-batch', type=int, default=8)
 ap.add_argument('--f4-max-cin', default='', help='CTDET_CTX_F4_MAX_CIN: F(4x4)/fp32 allowed on layers with at most this many input channels')
 ap.add_argument('--also-threads', default='', help='comma list: evaluate the fp32 CPU reference again at these thread counts (same device output)')
 ap.add_argument('--force-tile', default='', help='CTDET_WINO_FORCE: 23 = F(2x2,3x3) on bf16x3 with two accumulators on every Winograd layer')
 a = ap.parse_args()
-names = {'2+23': 'the shipped tile set: F(2x2,3x3) / bf16x3 with two accumulators; fused F(4x4,3x3) (CTDET_CTX_F4_TILE, default 4) up to '
+names = {'2+23': 'round 5\'s tile set: F(2x2,3x3) / bf16x3 with two accumulators; fused F(4x4,3x3) (CTDET_CTX_F4_TILE, default 4) up to '
                  'CTDET_CTX_F4_MAX_CIN (128) input channels; three-kernel F(4x4,3x3) from CTDET_CTX_W4S_MIN_CIN (0 = never) input channels up',
+         'h2': 'the shipped policy (round 6): the committed table, F(4x4,3x3) entries on the f16x2 operand form, direct layers on bf16x3',
          '2': 'F(2x2,3x3) / fp32 MFMA only',
          '2+4': 'fp32-MFMA Winograd kernels as the table picks them', 'any': 'the unconstrained table'}
 if a.force_tile:
