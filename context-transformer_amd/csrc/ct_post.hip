@@ -590,15 +590,20 @@ extern "C" int ct_postprocess_batched(const float* boxes, const float* scores, i
     const bool topk_rule = max_per_image > 0 && num_priors > kPrefix;
     constexpr size_t kLdsPartial = 4096 * 8 + kHistBins * 4 + 64, kLds4k = 4096 * 8 + 64, kLds8k = 8192 * 8 + 64;
     {
+        // per instantiation, and the 8 192-key one (64 KB + 64 B of dynamic LDS) only for the launches that need it: a part whose
+        // LDS cannot hold it still runs every network with at most 16 384 priors
         static hipError_t attr_err = [] {
             hipError_t e = hipFuncSetAttribute((const void*)select_sort_kernel<4096, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPartial);
             if (e == hipSuccess)
                 e = hipFuncSetAttribute((const void*)select_sort_kernel<4096, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds4k);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute((const void*)select_sort_kernel<8192, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kLds8k);
             return e;
         }();
         CT_HIP(attr_err);
+        if (num_priors > 16384) {
+            static hipError_t attr8k = hipFuncSetAttribute((const void*)select_sort_kernel<8192, false>,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, kLds8k);
+            CT_HIP(attr8k);
+        }
     }
     const dim3 sort_grid(8 * ((batch + 7) / 8) * num_fg);
     auto full_sort = [&](const int* redo) {        // every candidate of every segment (or of the flagged ones) in order

@@ -450,6 +450,9 @@ __global__ __launch_bounds__(512) void wino_f4x4_3x3_x3(const Wino4fArgs a_in)
             kernarg_words kp = (kernarg_words)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(kp));
             static_assert(sizeof(Wino4fArgs) % 4 == 0, "argument record in words");
+            // the record is the kernel's FIRST AND ONLY explicit argument, at offset 0 of the kernel-argument segment (by-value
+            // aggregates are placed at their natural alignment): a second parameter in front of it would silently shift these words
+            static_assert(alignof(Wino4fArgs) <= 8, "argument record at offset 0 of the kernarg segment");
             int words[sizeof(Wino4fArgs) / 4];
 #pragma unroll
             for (int i = 0; i < (int)(sizeof(Wino4fArgs) / 4); ++i) words[i] = kp[i];
@@ -553,7 +556,18 @@ bool wino4f_ok(const ct_conv_desc* d)
 
 }  // namespace
 
-extern "C" int ct_conv_wino4f_supported(const ct_conv_desc* d) { return d && wino4f_ok(d) ? 1 : 0; }
+extern "C" int ct_conv_wino4f_supported(const ct_conv_desc* d)
+{
+    // the kernel needs 144 KB of LDS per workgroup: not a geometry question, but a part without it cannot run any geometry
+    static const bool lds_ok = [] {
+        int dev = 0, bytes = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&bytes, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess)
+            return true;                      // no device to ask (the CPU-side symbol checks): geometry decides
+        return bytes >= W4F_LDS_BYTES;
+    }();
+    return d && lds_ok && wino4f_ok(d) ? 1 : 0;
+}
 
 #ifdef CTDET_W4F_TRACE
 extern "C" int ct_wino4f_set_trace(unsigned long long* buf)      // device buffer of 8 words per workgroup, or null

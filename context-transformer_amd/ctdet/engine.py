@@ -386,6 +386,7 @@ class HipBackend:
         # index the Runtime gave the step, 0 before there is a schedule).  Per-layer buffers were ~6 GB per RFBNet-300
         # runtime at bs 32 and > 10 GB for RFBNet-512.
         self.ws_pool = {}
+        self.ws_generation = 0
         # "slots" for the per-image maxima of |activation| (ct_conv_desc.in_absmax / out_absmax, include/ctdet.h: one line per
         # image): rows of one tensor that a runtime zeroes once per step (zero_slots)
         self.slot_pool = None
@@ -408,10 +409,19 @@ class HipBackend:
         if self.slot_pool is not None and self.slots_used:
             self.slot_pool[:self.slots_used].zero_()
 
+    def _ws_drop(self, key):
+        """Give a workspace back.  Launches on the side streams may still be using it (it was allocated on the caller's stream,
+        so the caching allocator would hand the block out again at once), and a captured hipGraph holds its raw pointer: wait
+        for the device, and bump the generation a DetectionPipeline keys its graph on."""
+        if self.ws_pool.get(key) is not None:
+            torch.cuda.synchronize(self.device)
+            self.ws_generation += 1
+        self.ws_pool[key] = None
+
     def ws_reserve(self, key, nbytes):
         t = self.ws_pool.get(key)
         if t is None or t.numel() < nbytes:
-            self.ws_pool[key] = None            # drop the old buffer before allocating the larger one
+            self._ws_drop(key)                  # drop the old buffer before allocating the larger one
             self.ws_pool[key] = self.alloc((nbytes,), torch.uint8)
 
     def ws_rebuild(self, steps):
@@ -423,7 +433,7 @@ class HipBackend:
                 need[k] = max(need.get(k, 0), st.rt.get('ws4s_bytes', 0))
         for k in list(self.ws_pool):
             if k not in need or self.ws_pool[k] is None or self.ws_pool[k].numel() != need[k]:
-                self.ws_pool[k] = None
+                self._ws_drop(k)
         for k, n in need.items():
             if self.ws_pool.get(k) is None:
                 self.ws_pool[k] = self.alloc((n,), torch.uint8)
@@ -874,6 +884,8 @@ def wino_tiles(backend=None, st=None):
         tiles = tuple(t for t in allowed if env is None or t in tiles)
         cap = getattr(backend, 'wino4_max_cin', None)
         f4 = ctx_f4_tile()
+        if cap and st is not None and st.cin <= cap and f4 in WINO4F_TILES and not st.rt.get('wino4f_ok'):
+            f4 = 4                      # the fused bf16x3 kernel needs 16-channel chunks: such layers keep the fp32 fused kernel
         if cap and st is not None and st.cin <= cap and f4 not in tiles and (env is None or str(f4) in env.split(',')):
             tiles = tiles + (f4,)       # short channel sums: F(4x4) costs little accuracy there
     if st is not None and not st.rt.get('winox_ok'):
@@ -1150,8 +1162,9 @@ class Runtime:
             force = int(os.environ.get('CTDET_WINO_FORCE', '0') or 0)
             for st in (self.conv_steps() if force else ()):
                 # dilated layers only exist on the three-kernel form: they keep it unless that is what is being forced
-                geo = st.rt.get('wino4s_ok') if force in WINO4S_TILES else st.rt.get('wino_ok')
-                if st.rt.get('wino') and geo and (st.rt.get('winox_ok') or force in (2, 4) + WINO4S_TILES):
+                geo = st.rt.get('wino4s_ok') if force in WINO4S_TILES else st.rt.get('wino4f_ok') if force in WINO4F_TILES else \
+                    st.rt.get('wino_ok')
+                if st.rt.get('wino') and geo and (st.rt.get('winox_ok') or force in (2, 4) + WINO4S_TILES + WINO4F_TILES):
                     backend.enable_wino(st, tile=force)
         self._fuse_pools()
         self._mark_exclusive()
@@ -1411,11 +1424,16 @@ class Runtime:
     def run_loaded(self):
         """The launches of the backbone on the input buffer (no allocation, no host synchronisation: capturable)."""
         if getattr(self.backend, 'zero_slots', None) is not None:
-            if getattr(self, '_wired_epoch', None) != self.backend.kernel_epoch:
-                self._wire_absmax()         # a step changed kernels since the slots were wired (tuner, tools): producers may have stopped tracking
+            self.ensure_wired()
             self.backend.zero_slots()       # the maxima of |activation| the f16x2 layers take their scales from (_wire_absmax)
         run_on_streams(self, self._run_step)
         return self.bufs['loc'], self.bufs['conf'], self.bufs['obj']
+
+    def ensure_wired(self):
+        """Re-wire the maxima slots when a step changed kernels since they were wired (tuner, tools): a producer may have stopped
+        tracking.  Allocates: a DetectionPipeline calls it before it captures or replays a hipGraph."""
+        if getattr(self.backend, 'new_slot', None) is not None and getattr(self, '_wired_epoch', None) != self.backend.kernel_epoch:
+            self._wire_absmax()
 
     def run_backbone(self, x):
         """x [B,3,S,S] on the device -> raw (loc [B,P*4], conf [B,P*C], obj [B,P*2]) buffers (views)."""

@@ -101,7 +101,13 @@ class DetectionPipeline:
             self.set_image_wh(image_wh)
         rt = self.rt
         rt.load_input(x)                            # shape check, weight refresh, copy into the plan's input buffer
-        key = (self.conf_thresh, self.nms_thresh, self.ge, self.max_per_image, rt.event_log is None) + self._net_key()
+        if hasattr(rt, 'ensure_wired'):
+            rt.ensure_wired()
+        be = rt.backend
+        # (kernel_epoch: a step changed kernels; ws_generation: a three-kernel-Winograd workspace was re-allocated -- either way
+        # a captured graph holds stale launches / pointers)
+        key = (self.conf_thresh, self.nms_thresh, self.ge, self.max_per_image, rt.event_log is None,
+               getattr(be, 'kernel_epoch', 0), getattr(be, 'ws_generation', 0)) + self._net_key()
         if self.use_graph and rt.event_log is None:
             if self._graph is not None and self._graph_key == key:
                 self._graph.replay()

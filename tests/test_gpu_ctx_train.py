@@ -318,8 +318,9 @@ def test_phase2_frozen_bn_gradients_match_fp64_on_the_device_activation_pattern(
             continue
         # 512: 2e-4, or twice what torch-CPU float32 autograd makes of the same step where that is worse (the un-scaled logits,
         # ~400 at 512, in front of a softmax: conf.3 / extras.3 gradients of the float32 CPU path are themselves 1-3e-4 off
-        # float64, seed-dependent: tools/ctx_grad_probe.py) -- the forward rule above, applied to the gradients
-        if e >= max(tol, 2.0 * cpu32.get(n, 0.0)):
+        # float64, seed-dependent: tools/ctx_grad_probe.py) -- the forward rule above, applied to the gradients; with an absolute
+        # ceiling, so that a noisy CPU reference cannot hide a real regression
+        if e >= min(4e-4, max(tol, 2.0 * cpu32.get(n, 0.0))):
             worst[n] = e
     assert not worst, ' '.join('%s:%.1e' % kv for kv in sorted(worst.items(), key=lambda kv: -kv[1])[:12])
 
