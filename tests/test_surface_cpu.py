@@ -208,6 +208,16 @@ def test_committed_tune_table_is_consistent():
             assert val not in wino, (key, val)
             assert key.rsplit('|', 1)[0] in table, key
             continue
+        if key.endswith('|h2'):
+            # the choice of a runtime on the f16x2 operand forms where it differs from the bf16x3 one (tools/tune_convs.py --h2):
+            # an F(4x4,3x3) family by its bf16x3 name (mapped to the f16x2 twin at plan time), or an f16x2 tile of the direct kernel
+            base = key.rsplit('|', 1)[0]
+            assert base in table and (val in ('wino4s', 'wino4f') or re.fullmatch(r'h2:\d+x\d+k\d+d', val)), (key, val)
+            if val.startswith('h2:'):
+                assert table[base] == 'x3:' + val[3:], (key, val, table[base])
+            elif int(re.search(r'_d(\d+)_', base).group(1)) > 1:
+                assert val == 'wino4s', (key, val)
+            continue
         m = re.match(r'(\d+)x(\d+)_s(\d+)_d(\d+)_c(\d+)_m(\d+)_(\d+)x(\d+)_b(\d+)', key)
         assert m, key
         kh, kw, stride, dil, cin = (int(m.group(i)) for i in (1, 2, 3, 4, 5))
