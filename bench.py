@@ -525,6 +525,26 @@ def train_config(size, num_fg, phase, setting, batch, dev, steps=4, warmup=2, ra
     return res
 
 
+XGMI_LINK_GBS = 153.0        # one xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU)
+
+
+def allreduce_model(grad_bytes, bucket_bytes, world):
+    """What the gradient all-reduce of a step should cost on an 8-GPU MI355X node, so that the first run on one can be read against a
+    prediction: a ring all-reduce moves 2 (N - 1) / N of the buffer through every GPU; xGMI is point-to-point, so one ring is
+    bound by ONE link per hop (153 GB/s), and RCCL can run up to seven rings (one per link) -- the two bounds below, per bucket and
+    per step, at an assumed 70 % of link rate."""
+    n = max(2, int(world))
+    moved = 2.0 * (n - 1) / n
+    eff = 0.7
+    def ms(nbytes, links):
+        return round(moved * nbytes / (links * XGMI_LINK_GBS * 1e9 * eff) * 1e3, 3)
+    return {'ranks': n, 'bytes_through_each_gpu': int(moved * grad_bytes),
+            'ms_per_step_one_ring': ms(grad_bytes, 1), 'ms_per_step_seven_rings': ms(grad_bytes, 7),
+            'ms_per_bucket_one_ring': ms(bucket_bytes, 1), 'ms_per_bucket_seven_rings': ms(bucket_bytes, 7),
+            'assumptions': 'ring all-reduce, xGMI %.0f GB/s per link and direction, %.0f %% of it achieved; one ring = one link per '
+                           'hop, seven rings = every link of the fully connected node' % (XGMI_LINK_GBS, eff * 100)}
+
+
 def free_port():
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
         sk.bind(('127.0.0.1', 0))
@@ -668,6 +688,8 @@ def main():
                               'backward_incl_allreduce': round(r['bwd_ms'], 3)},
                 'loss': round(r['loss'], 5), 'grad_bytes': r['grad_bytes'],
                 'per_rank_ms_per_step': ms_rank, 'dist': dist_info,
+                # the prediction for the 8-GPU node this step is meant for (32 MiB buckets, ctdet.dist.GradBucketer)
+                'allreduce_model_8gpu': allreduce_model(r['grad_bytes'], r.get('bucket_bytes', 32 << 20), 8),
             }
             if world > 1:
                 t_with, t_wo, t_ar = r['ms_per_step'], r['ms_per_step_no_allreduce'], r['allreduce_ms_alone']

@@ -97,3 +97,37 @@ def test_train_mode_two_ranks_reports_allreduce_and_overlap():
         assert d['backend'] == 'nccl' and d['rccl_ranks'] == 2 and len({x['device'] for x in d['ranks']}) == 2
     else:
         assert d['backend'] == 'gloo' and d['devices_shared']
+
+
+@pytest.mark.gpu
+def test_eight_rank_rehearsals_on_this_box():
+    """The 8-rank paths the driver's SCALE run takes, rehearsed on whatever this box has (one GPU: --share-devices, gloo;
+    eight: RCCL): `bench.py --gpus 8` weak scaling (bs 4 per rank), strong scaling (ONE bs-32 batch in eight shards of 4: the
+    reference's DataParallel scatter, train.py:296-297) and `bench.py --train --gpus 8` (eight gradient shards, the bucket schedule
+    at world 8, the global loss normaliser of multibox_loss_combined.py:119-122).  Asserts the contract of the lines, not speeds."""
+    import torch
+    ndev = torch.cuda.device_count()
+    share = [] if ndev >= 8 else ['--share-devices']
+    common = ['--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-other-configs']
+    r = _run(['--gpus', '8', '--batch', '4'] + common + share, {'CTDET_TUNE': '0'}, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _line(r.stdout)
+    assert line['n_gpus'] == 8 and line['scaling'] == 'weak' and line['config']['global_batch'] == 32
+    assert len(line['per_rank_ms_per_step']) == 8 and [x['rank'] for x in line['dist']['ranks']] == list(range(8))
+    assert abs(line['value'] - 32 / (line['ms_per_step'] * 1e-3)) < 0.02 * line['value']
+    assert line['dist']['devices_shared'] == (ndev < 8) and line['dist']['rccl_ranks'] == (8 if ndev >= 8 else 0)
+    r = _run(['--gpus', '8', '--batch', '32', '--scaling', 'strong'] + common + share, {'CTDET_TUNE': '0'}, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _line(r.stdout)
+    assert line['n_gpus'] == 8 and line['scaling'] == 'strong' and line['config']['global_batch'] == 32
+    assert abs(line['value'] - 32 / (line['ms_per_step'] * 1e-3)) < 0.02 * line['value']
+    r = _run(['--train', '--gpus', '8', '--steps', '1', '--warmup', '1', '--size', '300', '--batch', '2', '--classes', '20', '--phase', '1']
+             + share, {'CTDET_TUNE': '0'}, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _line(r.stdout)
+    assert line['n_gpus'] == 8 and line['config']['global_batch'] == 16 and len(line['per_rank_ms_per_step']) == 8
+    ar, model = line['allreduce'], line['allreduce_model_8gpu']
+    assert ar['buckets'] >= 4 and ar['ms_alone'] > 0 and 0.0 <= ar['overlap_frac'] <= 1.0
+    # the prediction a real 8-GPU run is read against: 2 (N - 1) / N of the gradient buffer through every GPU
+    assert model['ranks'] == 8 and abs(model['bytes_through_each_gpu'] - 1.75 * line['grad_bytes']) < 8
+    assert 0 < model['ms_per_step_seven_rings'] < model['ms_per_step_one_ring'] < 10.0
