@@ -186,9 +186,10 @@ def cpu_baseline(size, num_fg, images=4, reps=2):
 
 
 def load_pmc(workload):
-    """{kernel name prefix: HBM bytes per launch} from the newest committed rocprofv3 PMC passes recorded for THIS
+    """{kernel name prefix: HBM bytes per launch} from the NEWEST committed rocprofv3 PMC passes recorded for THIS
     workload (profiles/*_pmc_traffic*.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs, 2*FETCH+WRITE per
-    MI355X_MICROARCH.md)."""
+    MI355X_MICROARCH.md).  One file only: kernels change template signature between rounds and an older round's rows
+    must not answer for this round's kernels."""
     import glob
     best = {}
     for path in sorted(glob.glob(os.path.join(REPO, 'profiles', '*_pmc_traffic*.json'))):
@@ -198,27 +199,39 @@ def load_pmc(workload):
             continue
         if table.get('__workload__', {'size': 300, 'batch': 32, 'phase': 1, 'classes': 20}) != workload:
             continue
-        for k, v in table.items():
-            if k != '__workload__':
-                best[k] = (v['hbm_bytes'], os.path.basename(path))
+        rows = {k: (v['hbm_bytes'], os.path.basename(path)) for k, v in table.items() if k != '__workload__'}
+        if rows:
+            best = rows
     return best
 
 
 def pmc_lookup(pmc, name):
-    """HBM bytes per launch of kernel `name` (bench naming) in the PMC table (rocprof naming)."""
+    """HBM bytes per launch of kernel `name` (bench naming) in the PMC table (rocprof naming: template arguments spelled out; the
+    f16x2 instantiations are the ones whose LAST template argument is `true`)."""
     import re
     m = re.match(r'conv_igemm_f32<(\d+)x(\d+),(\d+)x(\d+)', name)
-    x = re.match(r'conv_x3_f32<\d+x\d+,(\d+)x(\d+)k(\d+)(d?)>', name)
+    x = re.match(r'conv_(x3|h2)_f32<\d+x\d+,(\d+)x(\d+)k(\d+)(d?)>', name)
+    alias = {'wino_f4x4_3x3_h2': ('wino_f4x4_3x3_x3<', True), 'wino_f4x4_3x3_x3': ('wino_f4x4_3x3_x3<', False)}
+
+    def targs(k):
+        return [t.strip() for t in k[k.find('<') + 1:k.rfind('>')].split(',')] if '<' in k else []
     for k, (v, _) in pmc.items():
-        if x:       # rocprof: conv_x3_f32<BM, BN, BK, dual>; one instantiation serves every filter geometry
-            f = [t.strip() for t in k[k.find('<') + 1:k.find('>')].split(',')] if '<' in k else []
-            if k.startswith('conv_x3_f32') and len(f) >= 4 and tuple(f[:3]) == x.groups()[:3] and \
-                    (f[3] in ('true', '1')) == bool(x.group(4)):
+        if x:       # rocprof: conv_x3_f32<BM, BN, BK, dual, h2>; one instantiation serves every filter geometry
+            f = targs(k)
+            if k.startswith('conv_x3_f32') and len(f) >= 4 and tuple(f[:3]) == x.groups()[1:4] and \
+                    (f[3] in ('true', '1')) == bool(x.group(5)) and ((f[4] in ('true', '1')) if len(f) > 4 else False) == (x.group(1) == 'h2'):
                 return v
         elif m:
-            f = [x.strip() for x in k[k.find('<') + 1:k.find('>')].split(',')] if '<' in k else []
+            f = targs(k)
             if k.startswith('conv_igemm_f32') and len(f) >= 5 and (f[0], f[1], f[3], f[4]) == m.groups():
                 return v
+        elif name in alias:
+            pre, h2 = alias[name]
+            f = targs(k)
+            if k.startswith(pre) and (len(f) >= 3 and f[2] in ('true', '1')) == h2:    # <SEG, PLAIN, H2>
+                return v
+        elif name == 'wino4s_gemm' and (k.startswith('wino4h_gemm') or k.startswith('wino4s_gemm')):
+            return v
         elif k.startswith(name):
             return v
     return None
@@ -272,6 +285,9 @@ def conv_roofline(rt, batch, pmc, pick=None):
     return {
         'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
         'frac': round(ach / peak, 4), 'traffic': pmc_lookup(pmc, name),
+        # the same multiply-adds priced as bf16x3 would execute them (six piece products): an f16x2 kernel issues half the
+        # products of its bf16x3 twin, so its `frac` halves while it gets faster -- this is the figure that compares across rounds
+        'frac_bf16x3_equivalent': round(ach / peak * (2.0 if (wino in WINOGRAD_H2 or name.startswith('conv_h2')) else 1.0), 4),
         'kernel': name, 'launches': n, 'avg_launch_us': round(t / n * 1e6, 2),
         'flops_per_launch': round(fx / n),
         'flops_definition': 'multiply-adds x2 executed on the matrix pipe per launch' +
@@ -435,6 +451,7 @@ def quick_config(size, num_fg, phase, setting, batch, dtype, dev, steps=5, warmu
            'conv_gflop_per_image': round(flops / batch / 1e9, 2),
            'conv_algorithmic_tflops': round(flops / dt / 1e12, 1),
            'live_tuned_layers': len(getattr(pipe.rt, 'live_tuned', [])),
+           'policy': pipe.rt.policy_record() if hasattr(pipe.rt, 'policy_record') else None,
            'operand_form': 'bf16' if dtype == 'bf16' else 'f16x2' if getattr(pipe.rt.backend, 'h2', False) else 'bf16x3'}
     if roofline:
         pipe.rt.event_log = []
@@ -817,6 +834,7 @@ def main():
     tuned = bool(pipe.rt.tuned)
     live_tuned = list(getattr(pipe.rt, 'live_tuned', []))
     operand_form = 'f16x2' if getattr(pipe.rt.backend, 'h2', False) else 'bf16x3'
+    policy = pipe.rt.policy_record()
     if live_tuned and not explicit_workload and a.dtype == 'f32' and os.environ.get('CTDET_BENCH_ALLOW_LIVE_TUNE') != '1':
         # the tests pin CTDET_TUNE=0 and therefore only ever see table tiles: a headline must not run tiles chosen by a live timing
         raise SystemExit('bench.py: %d conv shape(s) of the headline workload are not in the committed tile table (%s ...): add them '
@@ -885,7 +903,9 @@ def main():
                        'detections_per_batch': counts, 'conv_autotuned': tuned,
                        # shapes whose tile came from a live timing instead of the committed table (0 for a headline run: refused above)
                        'live_tuned_layers': {'count': len(live_tuned), 'keys': live_tuned[:16]},
-                       'operand_form': operand_form},
+                       'operand_form': operand_form,
+                       # every kernel-choice switch in force (engine.Runtime.policy_record)
+                       'policy': policy},
             'per_rank_ms_per_step': ms_rank, 'dist': dist_info,
             'roofline': roof, 'cpu_baseline': cpu, 'other_configs': other,
         }

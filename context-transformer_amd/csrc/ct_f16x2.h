@@ -17,8 +17,8 @@
 // (probe, question 1) a value 2^-14 below the scaled maximum still has an exact hi piece and an lo piece that is only
 // coarser in absolute terms (quantum 2^-24 of the scaled unit = 2^-39 of the maximum): the GEMM error is unchanged with a
 // scale 1024 x too small (probe, question 4).  The consumer multiplies the fp32 sums by 2^-(eA + eB) -- exact.
-// A NaN / Inf anywhere in a tensor makes its maximum NaN / Inf: the exponent is then 0 and the NaN / Inf propagates
-// through the pieces like through any fp32 kernel.
+// An Inf anywhere in an image makes its maximum Inf: the exponent is then 0; a NaN or Inf propagates through the pieces (binary16 has
+// both) like through any fp32 kernel, whatever the exponent.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -76,11 +76,12 @@ __device__ __forceinline__ int image_exponent(const unsigned* __restrict__ lines
     return exponent_for(lines[(size_t)n * kLineWords], growth_log2);
 }
 
-// running maximum of |v| in a thread (NaN sticks: the unsigned order puts it above everything)
+// running maximum of |v| in a thread: one v_max_f32 with the |.| source modifier per value.  A NaN is skipped (IEEE maxNum): it does
+// not need the maximum -- it turns every piece it is split into, and every sum it enters, into NaN whatever the exponent is; an Inf
+// becomes the maximum (exponent 0).
 __device__ __forceinline__ void track_absmax(float& run, float v)
 {
-    const unsigned a = __builtin_bit_cast(unsigned, v) & 0x7FFFFFFFu, r = __builtin_bit_cast(unsigned, run);
-    run = __builtin_bit_cast(float, a > r ? a : r);
+    run = __builtin_fmaxf(run, __builtin_fabsf(v));
 }
 
 // The producer side: every lane of a wave brings (image n, maximum of |v| over what it stored for that image; n < 0 = nothing);

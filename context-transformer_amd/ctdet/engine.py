@@ -1440,5 +1440,26 @@ class Runtime:
         self.load_input(x)
         return self.run_loaded()
 
+    def policy_record(self):
+        """Every switch that shaped this runtime's kernel choice, resolved to what is in force (bench.py prints it as
+        `config.policy`; a line measured under a non-default switch says so).  `env` lists the CTDET_* variables that are set --
+        the library reads a few of its own (launch geometry experiments), so they are named even where Python ignores them."""
+        b = self.backend
+        tiles = {}
+        for st in self.conv_steps():
+            w = st.rt.get('wino')
+            if w:
+                tiles[int(w)] = tiles.get(int(w), 0) + 1
+        return {
+            'operand_form': 'f16x2' if getattr(b, 'h2', False) else 'bf16x3',
+            'direct_twins_f16x2': bool(getattr(b, 'h2_direct', False)),
+            'ctx_tiles': ctx_policy(self.net),
+            'wino_tile_set': sorted(b.wino_tile_set) if getattr(b, 'wino_tile_set', None) is not None else None,
+            'winograd_layers_by_tile': {str(k): v for k, v in sorted(tiles.items())},
+            'tune_table': os.path.basename(TUNE_TABLE),
+            'live_tuned_layers': len(self.live_tuned),
+            'env': {k: v for k, v in sorted(os.environ.items()) if k.startswith('CTDET_')},
+        }
+
     def conv_steps(self):
         return [s for s in self.plan.steps if s.kind == 'conv']

@@ -6,9 +6,10 @@ Drop-in for the reference's ``models/RFB_Net_vgg.py``: same public names
 ``conf.``, ``obj.``, ``theta/phi/g/Wz/OBJ_Target/scale/fc_base``) so reference checkpoints load
 and ``utils/solver.py`` LR groups keep working -- but the modules below are only *parameter
 containers*.  ``RFBNet.forward`` hands the whole network to ``ctdet.engine`` which runs it as a
-flat sequence of hand-written HIP launches (fused implicit-GEMM convolutions on the fp32 MFMA
-path, pooling, the fused Context-Transformer attention kernel); no ATen convolution, matmul or
-softmax is executed.  There is no CPU path: a non-HIP ``device`` raises.
+flat sequence of hand-written HIP launches (fp32 convolutions carried on the 16-bit matrix pipe as
+split operands -- Winograd F(4x4,3x3) and direct implicit-GEMM kernels, f16x2 or bf16x3 pieces,
+csrc/ct_f16x2.h -- pooling, the fused Context-Transformer attention kernel); no ATen convolution,
+matmul or softmax is executed.  There is no CPU path: a non-HIP ``device`` raises.
 
 Reference behaviour reproduced (file:line in the reference):
   network topology / layer hyper-parameters      models/RFB_Net_vgg.py:26-112, :323-422

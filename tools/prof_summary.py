@@ -66,6 +66,7 @@ for r in rows:
         '%.1f' % hbm if hbm is not None else '-'))
 open(os.path.join(out_dir, '%s_kernel_stats.md' % a.tag), 'w').write('\n'.join(lines) + '\n')
 traffic['__workload__'] = dict(zip(('size', 'batch', 'phase', 'classes'), map(int, a.workload.split(','))))
-json.dump(traffic, open(os.path.join(out_dir, '%s_pmc_traffic.json' % a.tag), 'w'), indent=1, sort_keys=True)
+if len(traffic) > 1:      # no PMC passes (the training profile): no table
+    json.dump(traffic, open(os.path.join(out_dir, '%s_pmc_traffic.json' % a.tag), 'w'), indent=1, sort_keys=True)
 open(os.path.join(out_dir, '%s_kernel_stats.csv' % a.tag), 'w').write(open(a.stats).read())
 print('\n'.join(lines[:22]))
