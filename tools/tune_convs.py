@@ -32,7 +32,7 @@ ap.add_argument('--h2', type=float, default=0.0, metavar='MARGIN',
 ap.add_argument('--cases', nargs='*', default=['300:32:20:1', '300:32:60:2:transfer', '300:4:20:1', '300:1:20:1',
                                                  '300:2:20:1', '512:32:20:1', '512:1:20:1', '300:2:60:2:transfer',
                                                  '300:2:15:2:incre', '512:1:60:2:transfer', '300:8:20:1', '300:16:20:1',
-                                                 '512:16:20:1', '512:8:20:1', '512:4:20:1'])
+                                                 '512:16:20:1', '512:8:20:1', '512:4:20:1', '512:32:60:2:transfer', '512:8:60:2:transfer'])
 a = ap.parse_args()
 table = {}
 if os.path.exists(engine.TUNE_TABLE):
