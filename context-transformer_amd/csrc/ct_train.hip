@@ -3,6 +3,7 @@
 // backward, bias+ReLU backward, max-pool backward and the head-gradient gather.  The data gradient
 // of a convolution is the `transposed` mode of ct_conv2d_fwd (ct_conv.hip).
 #include "ct_common.h"
+#include "ct_f16x2.h"
 #include <algorithm>
 #include <mutex>
 #include <unordered_set>
@@ -465,7 +466,8 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
                                                            int y_ctot, int y_coff, int relu, int batch,
                                                            int C, int HW, float* __restrict__ dz,
                                                            int dz_ctot, int dz_coff,
-                                                           float* __restrict__ dbias, int per_slice)
+                                                           float* __restrict__ dbias, int per_slice,
+                                                           unsigned* __restrict__ amax)
 {
     __shared__ double red[4];
     const int c = blockIdx.x;
@@ -479,6 +481,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
         const float* g = dy + ((size_t)n * dy_ctot + dy_coff + c) * HW + i0;
         const float* yy = y ? y + ((size_t)n * y_ctot + y_coff + c) * HW + i0 : nullptr;
         float* o = dz + ((size_t)n * dz_ctot + dz_coff + c) * HW + i0;
+        float run = 0.f;                 // max |dz| of what this thread stores for image n (ct_f16x2.h: the f16x2 data gradients)
         if (vec) {
             for (int i = threadIdx.x * 4; i < len; i += 1024) {
                 float4 v = *reinterpret_cast<const float4*>(g + i);
@@ -491,6 +494,10 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
                 }
                 *reinterpret_cast<float4*>(o + i) = v;
                 sb += (double)((v.x + v.y) + (v.z + v.w));
+                ctdet::h2::track_absmax(run, v.x);
+                ctdet::h2::track_absmax(run, v.y);
+                ctdet::h2::track_absmax(run, v.z);
+                ctdet::h2::track_absmax(run, v.w);
             }
         } else {
             for (int i = threadIdx.x; i < len; i += 256) {
@@ -498,8 +505,10 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float* __restri
                 if (relu && yy[i] <= 0.f) v = 0.f;
                 o[i] = v;
                 sb += v;
+                ctdet::h2::track_absmax(run, v);
             }
         }
+        if (amax) ctdet::h2::flush_absmax(amax, n, run);         // uniform over the block: every lane is in the same image
         e += len;
         i0 = 0;
         ++n;
@@ -878,9 +887,9 @@ extern "C" int ct_bn_eval_backward(const float* dy, int dy_ctot, int dy_coff, co
                             z_coff, batch, channels, hw, scratch, stream);
 }
 
-extern "C" int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot,
-                                    int y_coff, int relu, int batch, int channels, int hw, float* dz,
-                                    int dz_ctot, int dz_coff, float* dbias, ct_stream_t stream)
+extern "C" int ct_bias_act_backward_amax(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot,
+                                         int y_coff, int relu, int batch, int channels, int hw, float* dz,
+                                         int dz_ctot, int dz_coff, float* dbias, unsigned* dz_absmax, ct_stream_t stream)
 {
     CT_REQUIRE(dy && dz && (!relu || y), "ct_bias_act_backward: null pointer");
     CT_REQUIRE(batch > 0 && channels > 0 && hw > 0, "ct_bias_act_backward: bad shape");
@@ -893,9 +902,17 @@ extern "C" int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, c
     slices = (int)((per_channel + per_slice - 1) / per_slice);
     if (dbias && !ctdet::scratch_prezeroed()) CT_HIP(hipMemsetAsync(dbias, 0, (size_t)channels * 4, st));
     hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(channels, slices), dim3(256), 0, st, dy, dy_ctot, dy_coff, y,
-                       y_ctot, y_coff, relu, batch, channels, hw, dz, dz_ctot, dz_coff, dbias, per_slice);
+                       y_ctot, y_coff, relu, batch, channels, hw, dz, dz_ctot, dz_coff, dbias, per_slice, dz_absmax);
     CT_LAUNCH_CHECK("bias_act_bwd_kernel");
     return CT_OK;
+}
+
+extern "C" int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot,
+                                    int y_coff, int relu, int batch, int channels, int hw, float* dz,
+                                    int dz_ctot, int dz_coff, float* dbias, ct_stream_t stream)
+{
+    return ct_bias_act_backward_amax(dy, dy_ctot, dy_coff, y, y_ctot, y_coff, relu, batch, channels, hw, dz, dz_ctot, dz_coff, dbias,
+                                     nullptr, stream);
 }
 
 extern "C" int ct_maxpool2d_bwd(const float* x, const float* dy, float* dx, long planes, int h, int w,

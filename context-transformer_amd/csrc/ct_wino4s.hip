@@ -30,6 +30,7 @@
 #include "ct_f16x2.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 namespace {
@@ -1033,13 +1034,13 @@ __global__ __launch_bounds__(256) void wino4s_wgrad_finish(const float* __restri
 // f16x2 weights: U = G g G^T in double (as the bf16x3 packing), times 2^eU, as two binary16 pieces in the GEMM operand order
 // [point 36][cout block of 128][k-group 16 ch][sub 4][piece 2][k half 2][row 32][8 f16]; eU from max |g| over the layer
 // (wino4h_wmax, one atomic per wave into the trailer behind the packed weights; the packing kernel records eU there).
-__global__ __launch_bounds__(256) void wino4h_wmax(const ctdet::WinoPackArgs p, unsigned* trailer)
+__device__ __forceinline__ void wino4h_wmax_body(const ctdet::WinoPackArgs& p, unsigned* trailer, int bx, int gx)
 {
     unsigned m = 0;
     for (int part = 0; part < p.nparts; ++part) {
         const long n = (long)(p.mbeg[part + 1] - p.mbeg[part]) * p.cin_fwd * 9;
         const float* w = p.w[part];
-        for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += gridDim.x * 256L) {
+        for (long i = bx * 256L + threadIdx.x; i < n; i += gx * 256L) {
             const unsigned a = __builtin_bit_cast(unsigned, w[i]) & 0x7FFFFFFFu;
             m = a > m ? a : m;
         }
@@ -1048,11 +1049,16 @@ __global__ __launch_bounds__(256) void wino4h_wmax(const ctdet::WinoPackArgs p, 
     if ((threadIdx.x & 63) == 0 && m != 0u) atomicMax(trailer, m);
 }
 
+__global__ __launch_bounds__(256) void wino4h_wmax(const ctdet::WinoPackArgs p, unsigned* trailer)
+{
+    wino4h_wmax_body(p, trailer, blockIdx.x, gridDim.x);
+}
+
 // one thread = one (cout, 8 consecutive input channels, transform row i): six 16-byte stores per piece
-__global__ __launch_bounds__(256) void wino4h_pack(const ctdet::WinoPackArgs p, unsigned* trailer)
+__device__ __forceinline__ void wino4h_pack_body(const ctdet::WinoPackArgs& p, unsigned* trailer, int bx, int gx)
 {
     const int eU = ctdet::h2::exponent_for(trailer[0], ctdet::h2::kGrowthGG);
-    if (blockIdx.x == 0 && threadIdx.x == 0) trailer[1] = (unsigned)eU;
+    if (bx == 0 && threadIdx.x == 0) trailer[1] = (unsigned)eU;
     const bool fused = p.tile == 48;                   // ct_wino4f.hip's unit order (64-cout blocks) instead of the GEMM operand's
     const int rows = p.kblocks * (fused ? ctdet::kWinoKB : BM);
     const int groups8 = p.cin / 8;
@@ -1060,7 +1066,7 @@ __global__ __launch_bounds__(256) void wino4h_pack(const ctdet::WinoPackArgs p, 
     unsigned char* const out = reinterpret_cast<unsigned char*>(p.U);
     const size_t plane = (size_t)p.kblocks * p.chunks * OPBH;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += gridDim.x * 256L) {
+    for (long idx = bx * 256L + threadIdx.x; idx < total; idx += gx * 256L) {
         const int co = (int)(idx % rows);
         const long rest = idx / rows;
         const int ci8 = (int)(rest % groups8);
@@ -1114,6 +1120,37 @@ __global__ __launch_bounds__(256) void wino4h_pack(const ctdet::WinoPackArgs p, 
             for (int pc = 0; pc < 2; ++pc) *reinterpret_cast<u32x4*>(q + pc * FRAG) = v[j][pc];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void wino4h_pack(const ctdet::WinoPackArgs p, unsigned* trailer)
+{
+    wino4h_pack_body(p, trailer, blockIdx.x, gridDim.x);
+}
+
+// The same three steps for a LIST of layers (the training engine re-packs every f16x2 layer once per optimizer step: one launch per
+// step instead of three per layer).  blockIdx.y = item; items read by reference from device memory (a by-value copy would put the
+// w[] / mbeg[] arrays, indexed by a run-time part number, into scratch).
+struct WinoH2Item {
+    ctdet::WinoPackArgs p;
+    unsigned* trailer;
+};
+
+__global__ __launch_bounds__(64) void wino4h_trailer_zero_list(const WinoH2Item* items, int n)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) { items[i].trailer[0] = 0u; items[i].trailer[1] = 0u; }
+}
+
+__global__ __launch_bounds__(256) void wino4h_wmax_list(const WinoH2Item* items)
+{
+    const WinoH2Item& it = items[blockIdx.y];
+    wino4h_wmax_body(it.p, it.trailer, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256) void wino4h_pack_list(const WinoH2Item* items)
+{
+    const WinoH2Item& it = items[blockIdx.y];
+    wino4h_pack_body(it.p, it.trailer, blockIdx.x, gridDim.x);
 }
 
 struct WgSizes { int TY, TX, NT, tblk32, kchunks, rb, cb, splits, cps; size_t e_plane, v_plane, m_plane, m_slab, e_bytes, v_bytes, m_bytes; };
@@ -1219,12 +1256,13 @@ size_t ctdet::wino_h2_trailer_offset(int cin, int cout, int tile)
                       : (size_t)NXI * ((cout + BM - 1) / BM) * (cin / CC) * OPBH;
 }
 
-int ctdet::pack_wino_h2(const float* const* w, const int* cout, int nparts, int cin, int dgrad, int tile, void* upacked,
-                        ct_stream_t stream, const char* who)
+namespace {
+int fill_h2_item(const float* const* w, const int* cout, int nparts, int cin, int dgrad, int tile, void* upacked, WinoH2Item& it, const char* who)
 {
     CT_REQUIRE(w && cout && upacked && nparts >= 1 && nparts <= 6, "%s: bad argument", who);
-    CT_REQUIRE(!ctdet::pack_recording(), "%s: the f16x2 packing takes the layer's maximum first and cannot be recorded (ct_pack_record_begin)", who);
-    ctdet::WinoPackArgs p{};
+    CT_REQUIRE(tile == 47 || tile == 48, "%s: tile %d (47 = three-kernel form, 48 = fused)", who, tile);
+    ctdet::WinoPackArgs& p = it.p;
+    p = ctdet::WinoPackArgs{};
     int tot = 0;
     for (int i = 0; i < nparts; ++i) {
         CT_REQUIRE(w[i] && cout[i] > 0, "%s: part %d", who, i);
@@ -1244,15 +1282,54 @@ int ctdet::pack_wino_h2(const float* const* w, const int* cout, int nparts, int 
     const int rowblock = tile == 48 ? ctdet::kWinoKB : BM;
     p.kblocks = (p.cout + rowblock - 1) / rowblock;
     p.U = static_cast<float*>(upacked);
+    it.trailer = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(upacked) + ctdet::wino_h2_trailer_offset(p.cin, p.cout, tile));
+    return CT_OK;
+}
+}  // namespace
+
+int ctdet::pack_wino_h2(const float* const* w, const int* cout, int nparts, int cin, int dgrad, int tile, void* upacked,
+                        ct_stream_t stream, const char* who)
+{
+    CT_REQUIRE(!ctdet::pack_recording(), "%s: the f16x2 packing takes the layer's maximum first and cannot be recorded (ct_pack_record_begin); "
+               "batch it with ct_conv_wino_h2_pack_item / _run", who);
+    WinoH2Item it;
+    if (int e = fill_h2_item(w, cout, nparts, cin, dgrad, tile, upacked, it, who)) return e;
+    const ctdet::WinoPackArgs& p = it.p;
     hipStream_t st = ctdet::as_stream(stream);
-    unsigned* trailer = reinterpret_cast<unsigned*>(static_cast<unsigned char*>(upacked) + ctdet::wino_h2_trailer_offset(p.cin, p.cout, tile));
-    CT_HIP(hipMemsetAsync(trailer, 0, ctdet::kWino4hTrailerBytes, st));
-    const long nw = (long)tot * cin * 9;
-    hipLaunchKernelGGL(wino4h_wmax, dim3((int)std::min<long>((nw + 255) / 256, 1024)), dim3(256), 0, st, p, trailer);
+    CT_HIP(hipMemsetAsync(it.trailer, 0, ctdet::kWino4hTrailerBytes, st));
+    const long nw = (long)p.mbeg[p.nparts] * cin * 9;
+    hipLaunchKernelGGL(wino4h_wmax, dim3((int)std::min<long>((nw + 255) / 256, 1024)), dim3(256), 0, st, p, it.trailer);
     CT_LAUNCH_CHECK("wino4h_wmax");
+    const int rowblock = tile == 48 ? ctdet::kWinoKB : BM;
     const long total = (long)p.kblocks * rowblock * (p.cin / 8) * 6;
-    hipLaunchKernelGGL(wino4h_pack, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, p, trailer);
+    hipLaunchKernelGGL(wino4h_pack, dim3((int)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, p, it.trailer);
     CT_LAUNCH_CHECK("wino4h_pack");
+    return CT_OK;
+}
+
+extern "C" size_t ct_conv_wino_h2_pack_item_bytes(void) { return sizeof(WinoH2Item); }
+
+extern "C" int ct_conv_wino_h2_pack_item(const float* const* w, const int* cout, int nparts, int cin, int dgrad, int tile, void* upacked,
+                                         void* item_out)
+{
+    CT_REQUIRE(item_out, "ct_conv_wino_h2_pack_item: null item");
+    WinoH2Item it;
+    if (int e = fill_h2_item(w, cout, nparts, cin, dgrad ? 1 : 0, tile, upacked, it, "ct_conv_wino_h2_pack_item")) return e;
+    std::memcpy(item_out, &it, sizeof(it));
+    return CT_OK;
+}
+
+extern "C" int ct_conv_wino_h2_pack_run(const void* items_dev, int n, ct_stream_t stream)
+{
+    CT_REQUIRE(items_dev && n > 0 && n <= 65535, "ct_conv_wino_h2_pack_run: bad argument");
+    const WinoH2Item* items = static_cast<const WinoH2Item*>(items_dev);
+    hipStream_t st = ctdet::as_stream(stream);
+    hipLaunchKernelGGL(wino4h_trailer_zero_list, dim3((n + 63) / 64), dim3(64), 0, st, items, n);
+    CT_LAUNCH_CHECK("wino4h_trailer_zero_list");
+    hipLaunchKernelGGL(wino4h_wmax_list, dim3(64, n), dim3(256), 0, st, items);
+    CT_LAUNCH_CHECK("wino4h_wmax_list");
+    hipLaunchKernelGGL(wino4h_pack_list, dim3(256, n), dim3(256), 0, st, items);
+    CT_LAUNCH_CHECK("wino4h_pack_list");
     return CT_OK;
 }
 

@@ -125,6 +125,7 @@ SIGNATURES = {
     'ct_bn_eval_backward': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _F, _I, _P, _F, _P, _I, _I, _I,
                                  _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'ct_bias_act_backward': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
+    'ct_bias_act_backward_amax': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
     'ct_maxpool2d_bwd': (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'ct_head_grad_gather': (_I, [C.POINTER(OutSegment), _I, _I, _I, _I, _P, _P]),
     'ct_conv_fold_epilogue': (_I, [_P, _P, _P, _P, _F, _P, _I, _I, _P, _P, _P]),
@@ -147,6 +148,9 @@ SIGNATURES = {
     'ct_conv_pack_weights_wino4s': (_I, [_P, _P, _I, _I, _P, _P]),
     'ct_conv_pack_weights_wino4s_dgrad': (_I, [_P, _P, _I, _I, _P, _P]),
     'ct_conv_wino4s_h2_packed_bytes': (_Z, [_I, _I]),
+    'ct_conv_wino_h2_pack_item_bytes': (_Z, []),
+    'ct_conv_wino_h2_pack_item': (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
+    'ct_conv_wino_h2_pack_run': (_I, [_P, _I, _P]),
     'ct_conv_pack_weights_wino4s_h2': (_I, [_P, _P, _I, _I, _P, _P]),
     'ct_conv_pack_weights_wino4s_h2_dgrad': (_I, [_P, _P, _I, _I, _P, _P]),
     'ct_conv2d_wino4s_fwd': (_I, [C.POINTER(ConvDesc), _P, _P, _Z, _I, _P]),

@@ -24,7 +24,8 @@ import os
 import torch
 
 from . import _lib, ops
-from .engine import F4_TILES, WINO4F_TILES, WINO4S_TILES, ConvPart, ConvStep, HipBackend, Plan, Runtime, apply_tuned, run_on_streams
+from .engine import (F4_TILES, H2_TILES, TRACK_TILES, WINO4F_TILES, WINO4S_TILES, ConvPart, ConvStep, HipBackend, Plan, Runtime,
+                     apply_tuned, operand_form_h2, run_on_streams)
 
 
 class _StepState:
@@ -62,6 +63,11 @@ class TrainRuntime:
         wg4s_ws = 0             # bytes: workspace of the three-kernel Winograd weight gradients
         # CTDET_TRAIN_WINO4=0 keeps forward and data-gradient convolutions on F(2x2,3x3) where the table says F(4x4,3x3)
         wino4 = os.environ.get('CTDET_TRAIN_WINO4', '1') != '0'
+        # The Winograd launches of the step (forward and data gradients) on the f16x2 operand form (csrc/ct_f16x2.h) wherever the
+        # table's bf16x3 tile has that twin, under the inference runtime's batch rule (engine.operand_form_h2); CTDET_TRAIN_H2=0
+        # keeps bf16x3.  Direct layers stay on bf16x3: their inputs come from the BatchNorm kernels, which do not track maxima.
+        self.h2 = os.environ.get('CTDET_TRAIN_H2', '1') != '0' and operand_form_h2(net, batch)[0]
+        backend.h2, backend.h2_direct = self.h2, False
         if self.plan.ctx:
             backend.w4f_max_cin = int(os.environ.get('CTDET_TRAIN_CTX_W4F_MAX_CIN', '128'))      # engine.apply_tuned
         for st in self.plan.steps:
@@ -147,8 +153,9 @@ class TrainRuntime:
                         # (CTDET_TRAIN_W4S=0 keeps the fused kernel); V / M workspace shared by all data gradients
                         if s.fwd.rt.get('wino') in WINO4S_TILES and os.environ.get('CTDET_TRAIN_W4S', '1') != '0' and \
                                 self.lib.ct_conv_wino4s_supported(C.byref(w2)):
-                            s.dgrad_tile = 44
-                            s.U_d = al((self.lib.ct_conv_wino4s_packed_bytes(zc, st.cin) // 4,))
+                            s.dgrad_tile = 47 if self.h2 else 44
+                            size = self.lib.ct_conv_wino4s_h2_packed_bytes if self.h2 else self.lib.ct_conv_wino4s_packed_bytes
+                            s.U_d = al(((size(zc, st.cin) + 3) // 4,))
                             w4s_ws = max(w4s_ws, self.lib.ct_conv_wino4s_workspace_bytes(C.byref(w2)))
                         elif s.fwd.rt.get('wino') in WINO4F_TILES and os.environ.get('CTDET_TRAIN_W4F', '1') != '0' and \
                                 zc <= (getattr(backend, 'w4f_max_cin', None) or 1 << 30) and \
@@ -156,8 +163,11 @@ class TrainRuntime:
                             # ... and the fused bf16x3 F(4x4,3x3) kernel (tile 46) where the forward launch runs it: the narrow
                             # layers on the big maps, whose data gradients were 7 launches x 1.13 ms of the 37.8 ms step on the
                             # fp32 kernel (profiles/r05_train_kernel_stats.md)
-                            s.dgrad_tile = 46
-                            s.U_d = al((self.lib.ct_conv_wino4f_packed_bytes(zc, st.cin) // 4,))
+                            # (f16x2, tile 48: where dZ comes from ct_bias_act_backward_amax, which leaves the maxima the fused
+                            # kernel needs -- the VGG trunk; a BatchNorm layer's dZ has none: bf16x3)
+                            s.dgrad_tile = 48 if self.h2 and not s.is_bn and not st.segs else 46
+                            size = self.lib.ct_conv_wino4f_h2_packed_bytes if s.dgrad_tile == 48 else self.lib.ct_conv_wino4f_packed_bytes
+                            s.U_d = al(((size(zc, st.cin) + 3) // 4,))
                         else:
                             sizeof = self.lib.ct_conv_wino4_packed_floats if s.dgrad_tile == 4 else self.lib.ct_conv_wino_packed_floats
                             s.U_d = al((sizeof(zc, st.cin),))
@@ -174,8 +184,9 @@ class TrainRuntime:
                     w2.ksplit, w2.ksplit_ws, w2.ksplit_ws_floats = 0, None, 0
                     if self.lib.ct_conv_wino4s_supported(C.byref(w2)):
                         s.dgrad_wino = w2
-                        s.dgrad_tile = 44
-                        s.U_d = al((self.lib.ct_conv_wino4s_packed_bytes(zc, st.cin) // 4,))
+                        s.dgrad_tile = 47 if self.h2 else 44
+                        size = self.lib.ct_conv_wino4s_h2_packed_bytes if self.h2 else self.lib.ct_conv_wino4s_packed_bytes
+                        s.U_d = al(((size(zc, st.cin) + 3) // 4,))
                         w4s_ws = max(w4s_ws, self.lib.ct_conv_wino4s_workspace_bytes(C.byref(w2)))
             # direct data gradients on the bf16 matrix pipe (bf16x3, ct_conv2d_x3_fwd transposed): every layer without
             # a Winograd data gradient whose channel counts fit the k-step; CTDET_X3=0 keeps ct_conv2d_fwd
@@ -268,6 +279,7 @@ class TrainRuntime:
             if st.kind == 'conv':
                 self.state[st.name].fwd.rt['ws_key'] = self.sid[i] if self.side is not None else 0
         backend.ws_rebuild([self.state[st.name].fwd for st in self.plan.steps if st.kind == 'conv'])
+        self._wire_absmax()
         # weight gradients beside the data-gradient chain (CTDET_TRAIN_STREAMS=1 keeps everything on the caller's stream).  The
         # stream is the forward pass's side stream: the two are never busy at the same time, and a training step with ONE side
         # stream can be captured as a hipGraph (a second one crashes hipStreamEndCapture on ROCm 7.2)
@@ -300,6 +312,72 @@ class TrainRuntime:
             assert all(self._prod_index[id(p.weight)] == i0 + k for k, p in enumerate(st.parts))
             a0 = self._arena_off[i0]
             s.dw = self.arena[a0:a0 + s.dw.numel()].view(s.dw.shape)
+
+    def _wire_absmax(self):
+        """Maxima of |activation| / |dZ| for the f16x2 launches of the step (engine.Runtime._wire_absmax is the inference version).
+        Forward: a buffer has a slot when every step that writes it is a convolution WITHOUT BatchNorm on a tracking kernel (the
+        BatchNorm layers' outputs are written by ct_bn_train_apply, which does not track); a pooled buffer shares its source's.
+        A fused f16x2 launch (tile 48) without a slot becomes its bf16x3 twin; the three-kernel form (47) takes the maxima
+        inside its launch.  Backward: the dZ of a layer without BatchNorm is written by ct_bias_act_backward_amax into a slot of
+        its own (s.dz_amax), read by that layer's data-gradient launch."""
+        be = self.be
+        if not self.h2:
+            return
+        steps = self.plan.steps
+        convs = [st for st in steps if st.kind == 'conv']
+
+        def fwd(st):
+            return self.state[st.name].fwd
+
+        def tracks(st):
+            if st.kind != 'conv' or st.segs or self.state[st.name].is_bn:
+                return False
+            w = fwd(st).rt.get('wino')
+            return w in TRACK_TILES if w else True
+        root = {ps.dst: ps.src for ps in steps if ps.kind == 'pool'}
+
+        def root_of(b):
+            while b in root:
+                b = root[b]
+            return b
+        writers = {}
+        for st in steps:
+            if st.kind == 'conv':
+                for b in ([sg.dst for sg in st.segs] if st.segs else [st.dst]):
+                    writers.setdefault(b, []).append(st)
+            elif st.kind != 'pool':
+                writers.setdefault(st.dst, []).append(st)
+        while True:
+            for st in convs:
+                fwd(st).rt['desc'].in_absmax = None
+                fwd(st).rt['desc'].out_absmax = None
+            slots, fallback = {}, []
+            be.slots_used = 0
+            for st in convs:
+                if fwd(st).rt.get('wino') not in H2_TILES:
+                    continue
+                b = root_of(st.src)
+                ws = writers.get(b, [])
+                if ws and all(tracks(w) for w in ws):
+                    if b not in slots:
+                        slots[b] = be.new_slot(self.batch)
+                        for w in ws:
+                            fwd(w).rt['desc'].out_absmax = slots[b]
+                    fwd(st).rt['desc'].in_absmax = slots[b]
+                elif fwd(st).rt.get('wino') == 48:
+                    fallback.append(st)
+            if not fallback:
+                break
+            for st in fallback:
+                be.enable_wino(fwd(st), tile=46)
+        for st in convs:
+            s = self.state[st.name]
+            s.dz_amax = None
+            if getattr(s, 'dgrad_wino', None) is not None and s.dgrad_tile in H2_TILES and not s.is_bn and not st.segs:
+                s.dz_amax = be.new_slot(self.batch)
+                s.dgrad_wino.in_absmax = s.dz_amax
+        self.amax_slots = slots
+        self._wired_epoch = be.kernel_epoch
 
     def _arena_view(self, prm, flat=None):
         i = self._prod_index[id(prm)]
@@ -345,7 +423,12 @@ class TrainRuntime:
         n = len(wts)
         ptrs = (C.c_void_p * n)(*[w for w, _ in wts])
         couts = (C.c_int * n)(*[c for _, c in wts])
-        if s.dgrad_wino is not None:
+        if s.dgrad_wino is not None and s.dgrad_tile in H2_TILES:
+            if getattr(self, '_recording', False):
+                return                  # takes the layer's maximum first: not recordable, batched by the f16x2 list of _repack_all
+            pack = self.lib.ct_conv_pack_weights_wino4s_h2_dgrad if s.dgrad_tile == 47 else self.lib.ct_conv_pack_weights_wino4f_h2_dgrad
+            _lib.check(pack(ptrs, couts, n, st.cin, s.U_d.data_ptr(), self._s()), st.name + ' pack dgrad (winograd, f16x2)')
+        elif s.dgrad_wino is not None:
             pack = {4: self.lib.ct_conv_pack_weights_wino4_dgrad, 44: self.lib.ct_conv_pack_weights_wino4s_dgrad,
                     46: self.lib.ct_conv_pack_weights_wino4f_dgrad}.get(s.dgrad_tile, self.lib.ct_conv_pack_weights_wino_dgrad)
             _lib.check(pack(ptrs, couts, n, st.cin, s.U_d.data_ptr(), self._s()), st.name + ' pack dgrad (winograd)')
@@ -375,7 +458,7 @@ class TrainRuntime:
                 x3 = rt.get('x3')
                 ptrs.append((st.name, rt.get('wino') or 0, -1 if x3 is None else x3,
                              tuple(sorted((k, v.data_ptr()) for k, v in rt.items()
-                                          if k in ('U', 'U4', 'UX', 'wpk') and v is not None)),
+                                          if k in ('U', 'U4', 'UX', 'U4H', 'U4FH', 'wpk') and v is not None)),
                              tuple(sorted((bk, t.data_ptr()) for bk, t in rt.get('wx3', {}).items()))))
         if self._pack_table is None or ptrs != self._pack_ptrs:
             lib = self.lib
@@ -388,7 +471,8 @@ class TrainRuntime:
                     s = self.state[st.name]
                     # bf16x3 forward layers are split by the batched x3 list below (ct_conv_pack_weights_x3 is not
                     # recordable and would launch right here): only their epilogue is folded
-                    self.be.pack_conv(s.fwd, weights=s.fwd.rt.get('x3') is None)
+                    # (... and the f16x2 Winograd layouts by the batched list further down: they take the layer's maximum first)
+                    self.be.pack_conv(s.fwd, weights=s.fwd.rt.get('x3') is None and s.fwd.rt.get('wino') not in H2_TILES)
                     if s.dgrad is not None:
                         self._pack_dgrad(st, s)
             finally:
@@ -431,6 +515,36 @@ class TrainRuntime:
         if self._x3_list[1]:
             _lib.check(self.lib.ct_conv_x3_pack_run(self._x3_list[0].data_ptr(), self._x3_list[1], self._s()),
                        'ct_conv_x3_pack_run')
+        # the f16x2 Winograd layouts (forward + data-gradient launches): maxima of the weights, then the split -- three launches
+        # for the whole list (ct_conv_wino_h2_pack_run)
+        if self.h2 and (getattr(self, '_h2_list', None) is None or self._h2_list[2] != ptrs):
+            items, nbytes = [], self.lib.ct_conv_wino_h2_pack_item_bytes()
+
+            def h2_item(parts, cin, dgrad, tile, dst, zero_w=None):
+                wts = [(p.weight.data_ptr(), p.cout) for p in parts]
+                if zero_w is not None:
+                    wts.append((zero_w.data_ptr(), zero_w.shape[0]))
+                n = len(wts)
+                wp = (C.c_void_p * n)(*[w for w, _ in wts])
+                co = (C.c_int * n)(*[c for _, c in wts])
+                buf = (C.c_ubyte * nbytes)()
+                _lib.check(self.lib.ct_conv_wino_h2_pack_item(wp, co, n, cin, dgrad, tile, dst.data_ptr(), buf),
+                           'ct_conv_wino_h2_pack_item')
+                items.append(bytes(buf))
+            for st in self.plan.steps:
+                if st.kind != 'conv':
+                    continue
+                s = self.state[st.name]
+                t = s.fwd.rt.get('wino')
+                if t in H2_TILES:
+                    h2_item(s.fwd.parts, s.fwd.cin, 0, t, s.fwd.rt['U4H' if t == 47 else 'U4FH'])
+                if getattr(s, 'dgrad_wino', None) is not None and s.dgrad_tile in H2_TILES:
+                    h2_item(st.parts, st.cin, 1, s.dgrad_tile, s.U_d, s.zero_w)
+            table = torch.frombuffer(bytearray(b''.join(items)), dtype=torch.uint8).to(self.be.device) if items else None
+            self._h2_list = (table, len(items), ptrs)
+        if self.h2 and self._h2_list[1]:
+            _lib.check(self.lib.ct_conv_wino_h2_pack_run(self._h2_list[0].data_ptr(), self._h2_list[1], self._s()),
+                       'ct_conv_wino_h2_pack_run')
 
     # ------------------------------------------------------------------ forward
     def _ctx_tensors(self):
@@ -447,6 +561,10 @@ class TrainRuntime:
                                   % (tuple(self.bufs['x'].shape), tuple(x.shape)))
         self.bufs['x'].copy_(x)
         self._repack_all()
+        if self.h2:
+            if self._wired_epoch != self.be.kernel_epoch:     # a step changed kernels since the slots were wired
+                self._wire_absmax()
+            self.be.zero_slots()                    # maxima of |activation| and |dZ| of this step (_wire_absmax)
         if self.prezero:
             self.bn_scratch.zero_()                 # one memset instead of one per BatchNorm statistics launch
         _lib.check(lib.ct_scratch_prezeroed(int(self.prezero)), 'ct_scratch_prezeroed')
@@ -625,10 +743,11 @@ class TrainRuntime:
                         put(p.bn.weight, s.dgamma[i])
                         put(p.bn.bias, s.dbeta[i])
                     else:
-                        _lib.check(lib.ct_bias_act_backward(
+                        _lib.check(lib.ct_bias_act_backward_amax(
                             gy.data_ptr(), gy.shape[1], st.dst_coff + off, y.data_ptr(), y.shape[1], st.dst_coff + off,
                             int(p.relu), B, p.cout, hw, s.dz.data_ptr(), ctot, off,
-                            s.dbias[i].data_ptr() if p.bias is not None else None, self._s()), st.name + ' bias bwd')
+                            s.dbias[i].data_ptr() if p.bias is not None else None, getattr(s, 'dz_amax', None), self._s()),
+                            st.name + ' bias bwd')
                         if p.bias is not None:
                             put(p.bias, s.dbias[i])
                     off += p.cout
@@ -661,21 +780,22 @@ class TrainRuntime:
                     if not self._batched_packs:
                         self._pack_dgrad(st, s)
                     s.dgrad_wino.res = self.grads[st.src].data_ptr() if acc else None
-                    if s.dgrad_tile == 44 and st.dil > 1 and acc:
+                    var4s = 3 if s.dgrad_tile == 47 else 1
+                    if s.dgrad_tile in (44, 47) and st.dil > 1 and acc:
                         g = self.grads[st.src]
                         tmp = torch.empty((g.shape[0], st.cin, st.h, st.w), device=g.device)
                         w3 = _lib.ConvDesc()
                         C.memmove(C.byref(w3), C.byref(s.dgrad_wino), C.sizeof(w3))
                         w3.res, w3.out, w3.out_ctot, w3.out_coff = None, tmp.data_ptr(), st.cin, 0
                         _lib.check(lib.ct_conv2d_wino4s_fwd(C.byref(w3), s.U_d.data_ptr(), self.dgrad_ws4s.data_ptr(),
-                                                            self.dgrad_ws4s.numel(), 1, self._s()), st.name + ' dgrad (winograd 4s, dilated)')
+                                                            self.dgrad_ws4s.numel(), var4s, self._s()), st.name + ' dgrad (winograd 4s, dilated)')
                         g[:, st.src_coff:st.src_coff + st.cin] += tmp
-                    elif s.dgrad_tile == 44:
+                    elif s.dgrad_tile in (44, 47):
                         _lib.check(lib.ct_conv2d_wino4s_fwd(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self.dgrad_ws4s.data_ptr(),
-                                                            self.dgrad_ws4s.numel(), 1, self._s()), st.name + ' dgrad (winograd 4s)')
-                    elif s.dgrad_tile == 46:
-                        _lib.check(lib.ct_conv2d_wino4f_fwd(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self._s()),
-                                   st.name + ' dgrad (winograd 4f)')
+                                                            self.dgrad_ws4s.numel(), var4s, self._s()), st.name + ' dgrad (winograd 4s)')
+                    elif s.dgrad_tile in (46, 48):
+                        _lib.check(lib.ct_conv2d_wino4f_pool_fwd_v(C.byref(s.dgrad_wino), s.U_d.data_ptr(), 2 if s.dgrad_tile == 48 else 1,
+                                                                   None, 0, 0, 0, 0, 1, self._s()), st.name + ' dgrad (winograd 4f)')
                     else:
                         run = lib.ct_conv2d_wino4_fwd if s.dgrad_tile == 4 else lib.ct_conv2d_wino_fwd
                         _lib.check(run(C.byref(s.dgrad_wino), s.U_d.data_ptr(), self._s()), st.name + ' dgrad (winograd)')

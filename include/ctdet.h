@@ -365,6 +365,15 @@ int ct_conv2d_wino_x3_pool_fwd(const ct_conv_desc* desc, const void* upacked, in
 int ct_conv_wino4s_supported(const ct_conv_desc* desc);
 size_t ct_conv_wino4s_packed_bytes(int cin, int cout);
 size_t ct_conv_wino4s_h2_packed_bytes(int cin, int cout);
+/* Batched f16x2 packing for callers that re-pack many layers per step (the training engine, once per optimizer step): fill one
+ * item per layer on the host (ct_conv_wino_h2_pack_item_bytes() bytes each; tile 47 = the layout of ct_conv_pack_weights_wino4s_h2,
+ * 48 = of ct_conv_pack_weights_wino4f_h2; dgrad != 0 = the data-gradient layouts), copy the items to the device as one array and
+ * replay it with ct_conv_wino_h2_pack_run: three launches for the whole list (trailers, maxima, packing) instead of three per
+ * layer.  Same bytes as the per-layer calls. */
+size_t ct_conv_wino_h2_pack_item_bytes(void);
+int ct_conv_wino_h2_pack_item(const float* const* w, const int* cout, int nparts, int cin, int dgrad, int tile, void* upacked,
+                              void* item_out);
+int ct_conv_wino_h2_pack_run(const void* items_dev, int n, ct_stream_t stream);
 size_t ct_conv_wino4s_workspace_bytes(const ct_conv_desc* desc);
 int ct_conv_pack_weights_wino4s(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
                                 ct_stream_t stream);
@@ -544,6 +553,11 @@ int ct_bn_eval_backward(const float* dy, int dy_ctot, int dy_coff, const float* 
 int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot, int y_coff,
                          int relu, int batch, int channels, int hw, float* dz, int dz_ctot, int dz_coff,
                          float* dbias, ct_stream_t stream);
+/* The same, and max |dz| per image folded into dz_absmax (lines as ct_conv_desc.out_absmax; NULL = off): dz is the INPUT of the
+ * layer's data-gradient convolution, whose f16x2 form takes its exponent from these maxima (train.py:222-229 backward). */
+int ct_bias_act_backward_amax(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot, int y_coff,
+                              int relu, int batch, int channels, int hw, float* dz, int dz_ctot, int dz_coff,
+                              float* dbias, unsigned* dz_absmax, ct_stream_t stream);
 /* max_pool2d backward: the gradient goes to the first maximum of each window (torch's rule). */
 int ct_maxpool2d_bwd(const float* x, const float* dy, float* dx, long planes, int h, int w, int oh, int ow,
                      int k, int stride, int pad, int accumulate, ct_stream_t stream);

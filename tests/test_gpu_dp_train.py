@@ -47,8 +47,11 @@ def _freeze_bn(net):
     return net
 
 
-def test_frozen_bn_network_gradients_match_fp64_autograd():
-    """Every parameter gradient of RFBNet-300 (bs 8, BatchNorm in eval mode) against float64 autograd at 1e-4
+@pytest.mark.parametrize('form', ['f16x2', 'bf16x3'])
+def test_frozen_bn_network_gradients_match_fp64_autograd(form, monkeypatch):
+    """(Both operand forms of the Winograd launches: f16x2 is what a bs-8 step runs by default -- forward AND data gradients,
+    maxima of |activation| / |dZ| from the producing kernels, train_engine._wire_absmax -- CTDET_TRAIN_H2=0 keeps bf16x3.)
+    Every parameter gradient of RFBNet-300 (bs 8, BatchNorm in eval mode) against float64 autograd at 1e-4
     normalised.  The loss is a fixed random linear functional of (loc, conf, obj), so nothing but the network's own
     backward kernels (dgrad / wgrad direct + Winograd, bias/ReLU, frozen-BN, pools, head gather) is between the output
     gradient and the parameters.
@@ -61,6 +64,8 @@ def test_frozen_bn_network_gradients_match_fp64_autograd():
     ReLU replaced by the device's activation pattern and every max-pool taken at the device's arg-max.  The free comparison against the oracle is kept as a loose
     bound."""
     from emu_backend import replay_plan_autograd
+    from ctdet.engine import H2_TILES
+    monkeypatch.setenv('CTDET_TRAIN_H2', '1' if form == 'f16x2' else '0')
     B = 8
     net = _freeze_bn(_net(300, 20).train())
     x = synth.images(B, 300, 'randn', 2024)
@@ -71,6 +76,13 @@ def test_frozen_bn_network_gradients_match_fp64_autograd():
     loss = sum((t * r.cuda()).sum() for t, r in zip(out, R))
     loss.backward()
     trt = net.train_runtime(B)
+    fwd_h2 = [n for n, s_ in trt.state.items() if s_.fwd.rt.get('wino') in H2_TILES]
+    dgrad_h2 = [n for n, s_ in trt.state.items() if getattr(s_, 'dgrad_wino', None) is not None and s_.dgrad_tile in H2_TILES]
+    if form == 'f16x2':
+        assert trt.h2 and len(fwd_h2) >= 15 and len(dgrad_h2) >= 15, (fwd_h2, dgrad_h2)
+        assert any(trt.state[n].dgrad_tile == 48 for n in dgrad_h2) and any(trt.state[n].dgrad_tile == 47 for n in dgrad_h2)
+    else:
+        assert not trt.h2 and not fwd_h2 and not dgrad_h2
     names = {id(p): n for n, p in net.named_parameters()}
     leaf = {i: sd[n].double().requires_grad_(True) for i, n in names.items()}
 
