@@ -68,17 +68,17 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (MI355X_MICROARCH.md), --dtype bf16 only
 PEAK_HBM_GBS = 8000.0               # HBM3E spec (6.3 TB/s achievable, MI355X_MICROARCH.md)
 # multiplications executed / direct-convolution multiplications: F(2x2,3x3) 16 per 4 outputs x 9, F(4x4,3x3) 36 per 16 x 9
-# st.rt['wino'] codes 23 / 24 are F(2x2,3x3) on the bf16 pipe (csrc/ct_wino_x3.hip): every
+# st.rt['wino'] code 23 is F(2x2,3x3) on the bf16 pipe (csrc/ct_wino_x3.hip): every
 # transform-domain multiplication is six bf16 MFMA products (bf16x3), priced against the bf16 MFMA peak
-WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0, 23: 16.0 / 36.0, 24: 16.0 / 36.0, 44: 36.0 / 144.0, 45: 36.0 / 144.0,
+WINOGRAD_MULT_RATIO = {2: 16.0 / 36.0, 4: 36.0 / 144.0, 23: 16.0 / 36.0, 44: 36.0 / 144.0,
                        46: 36.0 / 144.0, 47: 36.0 / 144.0, 48: 36.0 / 144.0}
-# 44 / 45: one conv launch = three kernels (csrc/ct_wino4s.hip: wino4s_in, wino4s_gemm<dual>, wino4s_out); 47: the same on the
+# 44: one conv launch = three kernels (csrc/ct_wino4s.hip: wino4s_in, wino4s_gemm, wino4s_out); 47: the same on the
 # f16x2 operand form (csrc/ct_f16x2.h: absmax pass, wino4s_in<h2>, wino4h_gemm, wino4s_out<h2>); 48: the fused kernel on f16x2
-WINOGRAD_KERNEL = {2: 'wino_f2x2_3x3_f32', 4: 'wino_f4x4_3x3_f32', 23: 'wino_f2x2_3x3_x3', 24: 'wino_f2x2_3x3_x3q',
-                   44: 'wino4s(in+gemm+out)', 45: 'wino4sq(in+gemm+out)', 46: 'wino_f4x4_3x3_x3',
+WINOGRAD_KERNEL = {2: 'wino_f2x2_3x3_f32', 4: 'wino_f4x4_3x3_f32', 23: 'wino_f2x2_3x3_x3',
+                   44: 'wino4s(in+gemm+out)', 46: 'wino_f4x4_3x3_x3',
                    47: 'wino4s_h2(absmax+in+gemm+out)', 48: 'wino_f4x4_3x3_h2'}
-WINOGRAD_X3 = (23, 24, 44, 45, 46, 47, 48)       # on the 16-bit matrix pipe; 46: F(4x4,3x3) fused on bf16x3 (csrc/ct_wino4f.hip)
-WINOGRAD_F4 = (4, 44, 45, 46, 47, 48)
+WINOGRAD_X3 = (23, 44, 46, 47, 48)       # on the 16-bit matrix pipe; 46: F(4x4,3x3) fused on bf16x3 (csrc/ct_wino4f.hip)
+WINOGRAD_F4 = (4, 44, 46, 47, 48)
 WINOGRAD_H2 = (47, 48)                   # f16x2: two binary16 pieces, THREE piece products per multiply-add (bf16x3: six)
 
 
@@ -357,7 +357,7 @@ def stage_rooflines(pipe, x, steps, pmc):
         # 20 B row in + 4 B kept index out per candidate (SURVEY 8d "20N in + 4N out"), both NMS passes share it
         'nms_segments_kernel': ('hbm', cand * 24),
     }
-    w4s = [st for st in pipe.rt.conv_steps() if int(st.rt.get('wino') or 0) in (44, 45, 47)]
+    w4s = [st for st in pipe.rt.conv_steps() if int(st.rt.get('wino') or 0) in (44, 47)]
     if w4s:
         # the three kernels of the F(4x4,3x3) / bf16x3 layers, summed over the layers of a step (csrc/ct_wino4s.hip):
         # tiles padded to 128, couts to 128; V = 36 points x 3 bf16 pieces, M = 36 points x fp32; dilated layers (pad = dilation)

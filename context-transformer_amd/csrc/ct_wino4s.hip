@@ -1367,7 +1367,8 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
         return ctdet::fail(CT_ERR_UNSUPPORTED, "ct_conv2d_wino4s_fwd: needs 3x3 stride 1 pad = dilation (dilated: plain NCHW output), cin %% 16 == 0 "
                            "(got %dx%d s%d d%d p%d cin=%d nseg=%d)", d->kh, d->kw, d->stride, d->dil,
                            d->pad_h, d->cin, d->nseg);
-    CT_REQUIRE(variant >= 1 && variant <= 3, "ct_conv2d_wino4s_fwd: variant %d (1 = bf16x3 two accumulators, 2 = bf16x3 one, 3 = f16x2 two accumulators)", variant);
+    CT_REQUIRE(variant == 1 || variant == 3, "ct_conv2d_wino4s_fwd: variant %d (1 = bf16x3, 3 = f16x2; both with two accumulators -- the one-accumulator "
+               "variant 2 of rounds 4-5 was removed)", variant);
     const bool h2 = variant == 3;
     CT_REQUIRE(d->batch > 0 && d->cout > 0, "ct_conv2d_wino4s_fwd: bad shape");
     CT_REQUIRE(write_full || pool_out, "ct_conv2d_wino4s_pool_fwd: nothing to write");
@@ -1406,7 +1407,7 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
             const std::pair<const void*, int> fs[] = {
                 {(const void*)wino4s_in<false>, IN_LDS_BYTES}, {(const void*)wino4s_in<true>, IN_LDS_BYTES},
                 {(const void*)wino4s_in_dil<false>, IN_LDS_BYTES}, {(const void*)wino4s_in_dil<true>, IN_LDS_BYTES},
-                {(const void*)wino4s_gemm<true>, GEMM_LDS_BYTES}, {(const void*)wino4s_gemm<false>, GEMM_LDS_BYTES},
+                {(const void*)wino4s_gemm<true>, GEMM_LDS_BYTES},
                 {(const void*)wino4h_gemm<true, 1, 4>, 4 * 2 * OPBH}, {(const void*)wino4h_gemm<true, 1, 5>, 5 * 2 * OPBH},
                 {(const void*)wino4h_gemm<true, 2, 2>, 2 * 2 * 2 * OPBH}};
             for (const auto& f : fs)
@@ -1499,8 +1500,7 @@ extern "C" int ct_conv2d_wino4s_pool_fwd(const ct_conv_desc* d, const void* upac
                 if (pipe == 22) hipLaunchKernelGGL((wino4h_gemm<true, 2, 2>), dim3(nwg), dim3(256), 2 * 2 * 2 * OPBH, st, g);
                 else if (pipe == 15) hipLaunchKernelGGL((wino4h_gemm<true, 1, 5>), dim3(nwg), dim3(256), 5 * 2 * OPBH, st, g);
                 else hipLaunchKernelGGL((wino4h_gemm<true, 1, 4>), dim3(nwg), dim3(256), 4 * 2 * OPBH, st, g);
-            } else if (variant == 1) hipLaunchKernelGGL(wino4s_gemm<true>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
-            else hipLaunchKernelGGL(wino4s_gemm<false>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
+            } else hipLaunchKernelGGL(wino4s_gemm<true>, dim3(nwg), dim3(256), GEMM_LDS_BYTES, st, g);
             CT_LAUNCH_CHECK("wino4s_gemm");
         }
         {

@@ -409,268 +409,6 @@ __global__ __launch_bounds__(512) void wino_f2x2_3x3_x3(const WinoX3Args a)
     }
 }
 
-// ---- the four-wave form: TWO workgroups per CU ----
-// Same tile (32 tiles x 64 couts), same U layout, 256 threads: wave w owns the FOUR points of transform row i = w
-// (accumulators 4 x 2 x 16 = 128 registers, one accumulator per output), a thread transforms two patches per chunk
-// (channels 4w + h and 4w + 2 + h).  With 80 KB of LDS and <= 256 registers two workgroups share a CU, one wave of each
-// per SIMD: while one workgroup is in its prologue, its output pass or in front of its barrier, the other one owns
-// the matrix pipe -- the eight-wave form above leaves the CU idle for ~7.6 us per 32-tile block.  V is double buffered
-// (2 x 32 KB); the fragments of a chunk's first point are split right after the barrier (the partner workgroup covers
-// that).  The output transform's row pass (over j) runs in registers on the wave's four points, so only 8 values per
-// (cout, tile) pass through LDS (80 KB with the 40-float rows).
-constexpr int Q_LDS_BYTES = 4 * 2 * MXI * 4;   // 80 KB: Z[i 4][jj 2][cout 64][tile 32 (+8)]; the main loop uses 64 KB
-
-template <bool PIN>
-__global__ __launch_bounds__(256, 2) void wino_f2x2_3x3_x3q(const WinoX3Args a)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int jx = blockIdx.x >> 3;
-    const int kb = jx % a.kblocks;
-    const int tblk = (jx / a.kblocks) * 8 + (blockIdx.x & 7);
-    if (tblk >= a.tile_blocks) return;
-    const int tb0 = tblk * TB;
-    const int HW = a.H * a.W;
-    int voffr[4];
-    bool lp, m2, m3;
-    {
-        const int T = tb0 + l31;
-        const bool live = T < a.NT;
-        const int n = T / (a.TY * a.TX);
-        const int rem = T - n * (a.TY * a.TX);
-        const int ty = rem / a.TX, tx = rem - ty * a.TX;
-        const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
-        lp = tx == 0;
-        m2 = x0 + 2 < a.W;
-        m3 = x0 + 3 < a.W;
-        const long base = (((long)n * a.in_ctot + a.in_coff + h) * a.H + y0) * (long)a.W + x0 + (lp ? 1 : 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool ok = live && (unsigned)(y0 + i) < (unsigned)a.H;
-            voffr[i] = ok ? (int)((base + (long)i * a.W) * 4) : kInvalidOff;
-        }
-    }
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.in, a.in_bytes);
-    const __amdgpu_buffer_rsrc_t rU = make_rsrc(a.U, a.u_bytes);
-    const int last = a.chunks - 1;
-    const int chunk_bytes = CC * HW * 4;
-    const int chan_base = 4 * wave * HW * 4;           // patch q of this thread: channel 4 wave + 2 q + h
-
-    auto load_patch = [&](int c, int q, i32x4 (&r)[4]) {
-        const int soff = c * chunk_bytes + chan_base + q * (2 * HW * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[i], soff, 0);
-    };
-    auto unpack_row = [&](const i32x4& r, float* d) {
-        const f32x4 q = __builtin_bit_cast(f32x4, r);
-        const float vx = q.x, vy = q.y, vz = q.z, vw = q.w;
-        d[0] = lp ? 0.f : vx;
-        d[1] = lp ? vx : vy;
-        d[2] = m2 ? (lp ? vy : vz) : 0.f;
-        d[3] = m3 ? (lp ? vz : vw) : 0.f;
-    };
-    auto col_pass = [&](const float* d, float* t, int j) {
-        t[0 * 4 + j] = d[0 * 4 + j] - d[2 * 4 + j];
-        t[1 * 4 + j] = d[1 * 4 + j] + d[2 * 4 + j];
-        t[2 * 4 + j] = d[2 * 4 + j] - d[1 * 4 + j];
-        t[3 * 4 + j] = d[1 * 4 + j] - d[3 * 4 + j];
-    };
-    // V[point][channel 16][tile 32]: (4 wave + 2 q + h) * 32 + l31 = wave * 128 + q * 64 + lane
-    float* const vw_base = lds + wave * 128 + lane;
-    auto row_pass_store = [&](const float* t, int i, int q, int buf) {
-        float* vp = vw_base + buf * V_FLOATS + q * 64 + (i * 4) * PT_STRIDE;
-        vp[0 * PT_STRIDE] = t[i * 4 + 0] - t[i * 4 + 2];
-        vp[1 * PT_STRIDE] = t[i * 4 + 1] + t[i * 4 + 2];
-        vp[2 * PT_STRIDE] = t[i * 4 + 2] - t[i * 4 + 1];
-        vp[3 * PT_STRIDE] = t[i * 4 + 1] - t[i * 4 + 3];
-    };
-    const float* const vr_base = lds + (8 * h) * TB + l31;
-    auto read_raw = [&](int buf, int x, float (&raw)[8]) {
-        const float* p = vr_base + buf * V_FLOATS + (4 * wave + x) * PT_STRIDE;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) raw[e] = p[e * TB];
-    };
-    auto split_pair = [&](const float (&raw)[8], int q, i32x4 (&fb)[3]) {
-        unsigned h0, m0, l0, h1, m1, l1;
-        split3(raw[2 * q], h0, m0, l0);
-        split3(raw[2 * q + 1], h1, m1, l1);
-        fb[0][q] = pack_hi(h0, h1);
-        fb[1][q] = pack_hi(m0, m1);
-        fb[2][q] = pack_hi(l0, l1);
-    };
-    const int u_voff = wave * (24 * 1024) + lane * 16;
-    const int u_kb = kb * a.chunks;
-    auto load_u = [&](int c, int x, int j, i32x4 (&ua)[6]) {           // j = cb * 3 + piece
-        const int soff = (u_kb + c) * U_CHUNK_BYTES + (x * 6 + j) * 1024;
-        ua[j] = __builtin_amdgcn_raw_buffer_load_b128(rU, u_voff, soff, 0);
-    };
-
-    f32x16 acc[4][2];                              // [point j of row i = wave][cout half]
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[x][i][r] = 0.f;
-
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
-#define WQ_MFMA(X, S, UA, FB)                                                                                      \
-    do {                                                                                                           \
-        constexpr int t_ = (S) >> 1, cb_ = (S) & 1;                                                                \
-        acc[X][cb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                                     \
-            __builtin_bit_cast(bf16x8, UA[cb_ * 3 + PA[t_]]), __builtin_bit_cast(bf16x8, FB[PB[t_]]), acc[X][cb_], 0, 0, 0); \
-    } while (0)
-#define WQ_PIN() do { if (PIN) __builtin_amdgcn_sched_barrier(0); } while (0)
-
-    // ---- prologue: V(0) in LDS, patch A of chunk 1 in registers, U of (chunk 0, point 0).  ONE register set for the
-    // patch rows: patch B of chunk c+1 is loaded behind point 0 and used behind point 2, patch A of chunk c+2 behind
-    // point 2 and used behind the next point 0 -- two points (24 MFMAs) of latency each.
-    i32x4 rw[4];
-    i32x4 ua0[6], ua1[6];
-    i32x4 fb0[3], fb1[3];
-    {
-        i32x4 r0[4], r1[4];
-        load_patch(0, 0, r0);
-        load_patch(0, 1, r1);
-        load_patch(min(1, last), 0, rw);
-#pragma unroll
-        for (int j = 0; j < 6; ++j) load_u(0, 0, j, ua0);
-        float d[16], t[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) unpack_row(r0[i], d + 4 * i);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) col_pass(d, t, j);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) row_pass_store(t, i, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) unpack_row(r1[i], d + 4 * i);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) col_pass(d, t, j);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) row_pass_store(t, i, 1, 0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    for (int c = 0; c < a.chunks; ++c) {
-        const int b0 = c & 1, b1 = b0 ^ 1;
-        const int cn = min(c + 1, last), cp2 = min(c + 2, last);
-        float d[16], t[16];
-        float raw[8];
-        // fragments of point 0: V(c) became complete at the barrier (the partner workgroup owns the pipe meanwhile)
-        read_raw(b0, 0, raw);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) split_pair(raw, q, fb0);
-        // ---- point 0.  Behind the MFMAs: fragments + U of point 1, B^T d of patch A of chunk c+1, the load of patch B
-        read_raw(b0, 1, raw);
-        WQ_PIN(); WQ_MFMA(0, 0, ua0, fb0);  load_u(c, 1, 0, ua1);
-        WQ_PIN(); WQ_MFMA(0, 1, ua0, fb0);  unpack_row(rw[0], d + 0); unpack_row(rw[1], d + 4); load_u(c, 1, 1, ua1);
-        WQ_PIN(); WQ_MFMA(0, 2, ua0, fb0);  unpack_row(rw[2], d + 8); unpack_row(rw[3], d + 12); load_u(c, 1, 2, ua1);
-        WQ_PIN(); WQ_MFMA(0, 3, ua0, fb0);  split_pair(raw, 0, fb1); load_u(c, 1, 3, ua1);
-        WQ_PIN(); WQ_MFMA(0, 4, ua0, fb0);  split_pair(raw, 1, fb1); load_u(c, 1, 4, ua1);
-        WQ_PIN(); WQ_MFMA(0, 5, ua0, fb0);  split_pair(raw, 2, fb1); load_u(c, 1, 5, ua1);
-        WQ_PIN(); WQ_MFMA(0, 6, ua0, fb0);  split_pair(raw, 3, fb1);
-        WQ_PIN(); WQ_MFMA(0, 7, ua0, fb0);  col_pass(d, t, 0); col_pass(d, t, 1);
-        WQ_PIN(); WQ_MFMA(0, 8, ua0, fb0);  col_pass(d, t, 2); col_pass(d, t, 3);
-        WQ_PIN(); WQ_MFMA(0, 9, ua0, fb0);
-        {
-            const int soff = cn * chunk_bytes + chan_base + 2 * HW * 4;           // patch B of chunk c+1
-            rw[0] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[0], soff, 0);
-            rw[1] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[1], soff, 0);
-            WQ_PIN(); WQ_MFMA(0, 10, ua0, fb0);
-            rw[2] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[2], soff, 0);
-            rw[3] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[3], soff, 0);
-        }
-        WQ_PIN(); WQ_MFMA(0, 11, ua0, fb0);
-        // ---- point 1.  fragments + U of point 2, row pass of patch A into V(c+1)
-        read_raw(b0, 2, raw);
-        WQ_PIN(); WQ_MFMA(1, 0, ua1, fb1);  load_u(c, 2, 0, ua0);
-        WQ_PIN(); WQ_MFMA(1, 1, ua1, fb1);  row_pass_store(t, 0, 0, b1); load_u(c, 2, 1, ua0);
-        WQ_PIN(); WQ_MFMA(1, 2, ua1, fb1);  row_pass_store(t, 1, 0, b1); load_u(c, 2, 2, ua0);
-        WQ_PIN(); WQ_MFMA(1, 3, ua1, fb1);  split_pair(raw, 0, fb0); load_u(c, 2, 3, ua0);
-        WQ_PIN(); WQ_MFMA(1, 4, ua1, fb1);  split_pair(raw, 1, fb0); load_u(c, 2, 4, ua0);
-        WQ_PIN(); WQ_MFMA(1, 5, ua1, fb1);  split_pair(raw, 2, fb0); load_u(c, 2, 5, ua0);
-        WQ_PIN(); WQ_MFMA(1, 6, ua1, fb1);  split_pair(raw, 3, fb0);
-        WQ_PIN(); WQ_MFMA(1, 7, ua1, fb1);  row_pass_store(t, 2, 0, b1);
-        WQ_PIN(); WQ_MFMA(1, 8, ua1, fb1);  row_pass_store(t, 3, 0, b1);
-        WQ_PIN(); WQ_MFMA(1, 9, ua1, fb1);
-        WQ_PIN(); WQ_MFMA(1, 10, ua1, fb1);
-        WQ_PIN(); WQ_MFMA(1, 11, ua1, fb1);
-        // ---- point 2.  fragments + U of point 3, B^T d of patch B of chunk c+1, its re-load
-        read_raw(b0, 3, raw);
-        WQ_PIN(); WQ_MFMA(2, 0, ua0, fb0);  load_u(c, 3, 0, ua1);
-        WQ_PIN(); WQ_MFMA(2, 1, ua0, fb0);  unpack_row(rw[0], d + 0); unpack_row(rw[1], d + 4); load_u(c, 3, 1, ua1);
-        WQ_PIN(); WQ_MFMA(2, 2, ua0, fb0);  unpack_row(rw[2], d + 8); unpack_row(rw[3], d + 12); load_u(c, 3, 2, ua1);
-        WQ_PIN(); WQ_MFMA(2, 3, ua0, fb0);  split_pair(raw, 0, fb1); load_u(c, 3, 3, ua1);
-        WQ_PIN(); WQ_MFMA(2, 4, ua0, fb0);  split_pair(raw, 1, fb1); load_u(c, 3, 4, ua1);
-        WQ_PIN(); WQ_MFMA(2, 5, ua0, fb0);  split_pair(raw, 2, fb1); load_u(c, 3, 5, ua1);
-        WQ_PIN(); WQ_MFMA(2, 6, ua0, fb0);  split_pair(raw, 3, fb1);
-        WQ_PIN(); WQ_MFMA(2, 7, ua0, fb0);  col_pass(d, t, 0); col_pass(d, t, 1);
-        WQ_PIN(); WQ_MFMA(2, 8, ua0, fb0);  col_pass(d, t, 2); col_pass(d, t, 3);
-        WQ_PIN(); WQ_MFMA(2, 9, ua0, fb0);
-        {
-            const int soff = cp2 * chunk_bytes + chan_base;                       // patch A of chunk c+2
-            rw[0] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[0], soff, 0);
-            rw[1] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[1], soff, 0);
-            WQ_PIN(); WQ_MFMA(2, 10, ua0, fb0);
-            rw[2] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[2], soff, 0);
-            rw[3] = __builtin_amdgcn_raw_buffer_load_b128(rin, voffr[3], soff, 0);
-        }
-        WQ_PIN(); WQ_MFMA(2, 11, ua0, fb0);
-        // ---- point 3.  U of (chunk c+1, point 0), row pass of patch B into V(c+1)
-        WQ_PIN(); WQ_MFMA(3, 0, ua1, fb1);  load_u(cn, 0, 0, ua0);
-        WQ_PIN(); WQ_MFMA(3, 1, ua1, fb1);  row_pass_store(t, 0, 1, b1); load_u(cn, 0, 1, ua0);
-        WQ_PIN(); WQ_MFMA(3, 2, ua1, fb1);  row_pass_store(t, 1, 1, b1); load_u(cn, 0, 2, ua0);
-        WQ_PIN(); WQ_MFMA(3, 3, ua1, fb1);  row_pass_store(t, 2, 1, b1); load_u(cn, 0, 3, ua0);
-        WQ_PIN(); WQ_MFMA(3, 4, ua1, fb1);  row_pass_store(t, 3, 1, b1); load_u(cn, 0, 4, ua0);
-        WQ_PIN(); WQ_MFMA(3, 5, ua1, fb1);  load_u(cn, 0, 5, ua0);
-        WQ_PIN(); WQ_MFMA(3, 6, ua1, fb1);
-        WQ_PIN(); WQ_MFMA(3, 7, ua1, fb1);
-        WQ_PIN(); WQ_MFMA(3, 8, ua1, fb1);
-        WQ_PIN(); WQ_MFMA(3, 9, ua1, fb1);
-        WQ_PIN(); WQ_MFMA(3, 10, ua1, fb1);
-        WQ_PIN(); WQ_MFMA(3, 11, ua1, fb1);
-        WQ_PIN();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-#undef WQ_MFMA
-#undef WQ_PIN
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-
-    // ---- output transform.  Row pass over j in registers (this wave holds the four points of row i), then
-    // Z[i][jj][cout 64][tile 32] through LDS (40-float rows) and the column pass over i per (cout, tile)
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.out, a.out_bytes);
-    const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            lds[(wave * 2 + 0) * MXI + k * MS + l31] = acc[0][i][r] + acc[1][i][r] + acc[2][i][r];
-            lds[(wave * 2 + 1) * MXI + k * MS + l31] = acc[1][i][r] - acc[2][i][r] - acc[3][i][r];
-        }
-    __syncthreads();
-    const int tl = tid & 31;
-    const int T = tb0 + tl;
-    const bool live = T < a.NT;
-    const int n = T / (a.TY * a.TX);
-    const int rem = T - n * (a.TY * a.TX);
-    const int ty = rem / a.TX, tx = rem - ty * a.TX;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int k = it * 8 + (tid >> 5);
-        const int co = kb * KB + k;
-        float z[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) z[e] = lds[e * MXI + k * MS + tl];      // e = i * 2 + jj
-        if (!live || co >= a.M) continue;
-        const float y[4] = {z[0] + z[2] + z[4], z[1] + z[3] + z[5], z[2] - z[4] - z[6], z[3] - z[5] - z[7]};
-        emit_tile(a, rout, rres, n, ty, tx, co, y);
-    }
-}
-
 bool winox3_ok(const ct_conv_desc* d)
 {
     return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->dil == 1 && d->pad_h == 1 && d->pad_w == 1 &&
@@ -701,7 +439,8 @@ extern "C" int ct_conv_pack_weights_wino_x3_dgrad(const float* const* w, const i
                                 "ct_conv_pack_weights_wino_x3_dgrad");
 }
 
-// variant 1: two accumulators, eight waves; 2: one accumulator, four-wave workgroups (two per CU)
+// variant 1: two accumulators, eight waves (the only one left: the four-wave / two-workgroups-per-CU form with one accumulator,
+// variant 2 of rounds 4-5, never won a layer in the pipeline and was removed in round 6)
 static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, float* pool_out, int pool_ctot,
                           int pool_coff, int pool_oh, int pool_ow, int write_full, ct_stream_t stream, const char* who)
 {
@@ -740,13 +479,9 @@ static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, 
         static hipError_t attr_err = hipSuccess;
         std::call_once(once, [] {
             const void* f8[] = {(const void*)wino_f2x2_3x3_x3<false>, (const void*)wino_f2x2_3x3_x3<true>};
-            const void* f4w[] = {(const void*)wino_f2x2_3x3_x3q<false>, (const void*)wino_f2x2_3x3_x3q<true>};
             for (const void* f : f8)
                 if (attr_err == hipSuccess)
                     attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, WX3_LDS_BYTES);
-            for (const void* f : f4w)
-                if (attr_err == hipSuccess)
-                    attr_err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, Q_LDS_BYTES);
         });
         CT_HIP(attr_err);
     }
@@ -782,16 +517,10 @@ static int launch_wino_x3(const ct_conv_desc* d, const void* upacked, int dual, 
         a.kblocks = (d->cout + KB - 1) / KB;
         // 8 XCD-local sequences of (tile block group, cout block); sequences past the last tile block exit at once
         const int groups = (a.tile_blocks + 7) / 8;
-        // every MFMA slot closed by a scheduling barrier (kernel template parameter PIN): measured +5 .. 8 % on both forms;
+        // every MFMA slot closed by a scheduling barrier (kernel template parameter PIN): measured +5 .. 8 %;
         // CTDET_WX3_PIN=0 selects the unpinned builds (A/B measurements)
         static const bool pin = [] { const char* e = getenv("CTDET_WX3_PIN"); return !e || e[0] != '0'; }();
         const dim3 grid(8 * groups * a.kblocks);
-        if (dual == 2) {            // the four-wave, two-workgroups-per-CU form (single accumulator)
-            if (pin) hipLaunchKernelGGL((wino_f2x2_3x3_x3q<true>), grid, dim3(256), Q_LDS_BYTES, st, a);
-            else hipLaunchKernelGGL((wino_f2x2_3x3_x3q<false>), grid, dim3(256), Q_LDS_BYTES, st, a);
-            CT_LAUNCH_CHECK("wino_f2x2_3x3_x3q");
-            continue;
-        }
         if (pin) hipLaunchKernelGGL((wino_f2x2_3x3_x3<true>), grid, dim3(512), WX3_LDS_BYTES, st, a);
         else hipLaunchKernelGGL((wino_f2x2_3x3_x3<false>), grid, dim3(512), WX3_LDS_BYTES, st, a);
         CT_LAUNCH_CHECK("wino_f2x2_3x3_x3");
@@ -803,7 +532,7 @@ extern "C" int ct_conv2d_wino_x3_pool_fwd(const ct_conv_desc* d, const void* upa
                                           int pool_ctot, int pool_coff, int pool_oh, int pool_ow, int write_full,
                                           ct_stream_t stream)
 {
-    if (dual != 1 && dual != 2) return ctdet::fail(CT_ERR_INVALID, "ct_conv2d_wino_x3_fwd: variant %d (1 or 2)", dual);
+    if (dual != 1) return ctdet::fail(CT_ERR_INVALID, "ct_conv2d_wino_x3_fwd: variant %d (only 1 = two accumulators exists)", dual);
     return launch_wino_x3(d, upacked, dual, pool_out, pool_ctot, pool_coff, pool_oh, pool_ow, write_full, stream,
                           "ct_conv2d_wino_x3_fwd");
 }

@@ -347,30 +347,28 @@ class Plan:
 WINO = -1          # ConvStep.rt['config'] value selecting the Winograd F(2x2,3x3) kernel
 WINO4 = -2         # ... the Winograd F(4x4,3x3) kernel
 WINOX = -3         # ... F(2x2,3x3) on the bf16 matrix pipe (bf16x3), two accumulators (csrc/ct_wino_x3.hip)
-WINOXQ = -5        # ... one accumulator, four-wave workgroups (two per CU)
 WINO4S = -6        # ... F(4x4,3x3) as transform / bf16x3 GEMM / transform kernels, two accumulators (csrc/ct_wino4s.hip)
-WINO4SQ = -7       # ... one accumulator
 WINO4F = -8        # ... F(4x4,3x3) fused on bf16x3, one 64-cout block per workgroup (csrc/ct_wino4f.hip): the narrow layers on big maps
 WINO4H = -9        # ... the three-kernel form on the f16x2 operand form (two binary16 pieces, three products; csrc/ct_f16x2.h)
 WINO4FH = -10      # ... the fused kernel on the f16x2 operand form
-# st.rt['wino'] values: 2, 4 = the fp32-MFMA kernels' tile sizes; F(2x2,3x3) on bf16x3: 23 = two accumulators (eight
-# waves), 24 = one accumulator in the four-wave / two-workgroups-per-CU form
-# 44 / 45 = F(4x4,3x3) in the three-kernel form with the GEMMs on bf16x3 (two / one accumulator); 46 = F(4x4,3x3) fused on bf16x3
+# st.rt['wino'] values: 2, 4 = the fp32-MFMA kernels' tile sizes; 23 = F(2x2,3x3) on bf16x3 (two accumulators, eight waves)
+# 44 = F(4x4,3x3) in the three-kernel form with the GEMMs on bf16x3 (two accumulators); 46 = F(4x4,3x3) fused on bf16x3
+# (codes 24 and 45, the one-accumulator variants of 23 and 44, existed in rounds 4-5: never selected, removed in round 6)
 # 47 = the three-kernel form with its GEMMs on f16x2 (two binary16 pieces, three products, two accumulators)
 # 48 = the fused F(4x4,3x3) kernel on f16x2
-WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINOXQ: 24, WINO4S: 44, WINO4SQ: 45, WINO4F: 46, WINO4H: 47, WINO4FH: 48}
-WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 24: 'winoxq', 44: 'wino4s', 45: 'wino4sq', 46: 'wino4f', 47: 'wino4h', 48: 'wino4fh'}
-WINOX_TILES = (23, 24)
-WINOX_VARIANT = {23: 1, 24: 2}               # the `variant` argument of ct_conv2d_wino_x3_fwd
-WINO4S_TILES = (44, 45, 47)
-WINO4S_VARIANT = {44: 1, 45: 2, 47: 3}       # the `variant` argument of ct_conv2d_wino4s_fwd
+WINO_TILE = {WINO: 2, WINO4: 4, WINOX: 23, WINO4S: 44, WINO4F: 46, WINO4H: 47, WINO4FH: 48}
+WINO_NAME = {2: 'wino', 4: 'wino4', 23: 'winox', 44: 'wino4s', 46: 'wino4f', 47: 'wino4h', 48: 'wino4fh'}
+WINOX_TILES = (23,)
+WINOX_VARIANT = {23: 1}               # the `variant` argument of ct_conv2d_wino_x3_fwd
+WINO4S_TILES = (44, 47)
+WINO4S_VARIANT = {44: 1, 47: 3}       # the `variant` argument of ct_conv2d_wino4s_fwd
 WINO4H_TILES = (47,)                         # ... whose weights come from ct_conv_pack_weights_wino4s_h2
 WINO4F_TILES = (46, 48)
 WINO4F_VARIANT = {46: 1, 48: 2}              # the `variant` argument of ct_conv2d_wino4f_pool_fwd_v
 WINO4FH_TILES = (48,)                        # ... whose weights come from ct_conv_pack_weights_wino4f_h2 and which needs desc.in_absmax
 H2_TILES = (47, 48)                          # the f16x2 operand form: consumers of a maximum of |input| (ct_conv_desc.in_absmax)
-TRACK_TILES = (44, 45, 47, 48)               # kernels that fold max |output| into ct_conv_desc.out_absmax (+ the 'valu' image layer)
-F4_TILES = (4, 44, 45, 46, 47, 48)           # every variant with F(4x4,3x3)'s rounding (accuracy policies treat them alike)
+TRACK_TILES = (44, 47, 48)               # kernels that fold max |output| into ct_conv_desc.out_absmax (+ the 'valu' image layer)
+F4_TILES = (4, 44, 46, 47, 48)           # every variant with F(4x4,3x3)'s rounding (accuracy policies treat them alike)
 
 
 class HipBackend:
@@ -519,8 +517,8 @@ class HipBackend:
 
     def enable_wino(self, st, on=True, tile=None):
         """Route this conv through a Winograd kernel (3x3 s1 d1 p1 layers only): tile 2 = F(2x2,3x3),
-        tile 4 = F(4x4,3x3), 23 / 24 = F(2x2,3x3) on the bf16 matrix pipe (cin % 16 == 0) with two accumulators / in the
-        four-wave form.  st.rt['wino'] holds the code in use."""
+        tile 4 = F(4x4,3x3), 23 = F(2x2,3x3) on the bf16 matrix pipe (cin % 16 == 0), 44 / 46 / 47 / 48 = the F(4x4,3x3) forms on the
+        16-bit pipe.  st.rt['wino'] holds the code in use."""
         rt = st.rt
         self.kernel_epoch += 1
         if not on:
@@ -536,7 +534,7 @@ class HipBackend:
             raise _lib.CtdetError('%s: geometry has no Winograd path' % st.name)
         rt['x3'] = None
         if tile not in (2, 4) + WINOX_TILES + WINO4S_TILES + WINO4F_TILES:
-            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23, 24, 44, 45, 46, 47 or 48)' % (st.name, tile))
+            raise _lib.CtdetError('%s: Winograd tile %r (2, 4, 23, 44, 46, 47 or 48)' % (st.name, tile))
         if tile not in WINO4S_TILES:
             rt.pop('ws4s_bytes', None)
         if tile in WINO4S_TILES:
@@ -868,10 +866,10 @@ def wino_tiles(backend=None, st=None):
     """Winograd variants the tuner / the table may use (st.rt['wino'] codes).  Default '2,4,44,46': the two fp32-MFMA kernels,
     the three-kernel F(4x4,3x3) / bf16x3 form with two accumulators (csrc/ct_wino4s.hip) and the fused F(4x4,3x3) / bf16x3
     kernel for the narrow layers on big maps (csrc/ct_wino4f.hip).  The fused F(2x2) bf16x3
-    forms (23: two accumulators; 24: four-wave workgroups) are faster than the fused fp32 kernels per layer ALONE
-    (512 -> 512 @38x38: 742 -> 630 us) but not in the two-stream pipeline (same-box A/B of two tables: 3 360-3 371 vs
-    3 228-3 398 images/s) and slower than tile 44 wherever that applies, so the committed table does
-    not hold them; CTDET_WINO_TILES=2,4,23,24,44,45 lets the tuner time all six.  A runtime with an accuracy policy
+    form (23) is faster than the fused fp32 kernels per layer ALONE (512 -> 512 @38x38: 742 -> 630 us) but not in the
+    two-stream pipeline (same-box A/B of two tables: 3 360-3 371 vs 3 228-3 398 images/s) and slower
+    than tile 44 wherever that applies, so the committed table does not hold it; CTDET_WINO_TILES=2,4,23,44 lets the tuner
+    time it.  A runtime with an accuracy policy
     (ctx_tile_set: networks with the Context-Transformer block) uses ITS set instead (narrowed by an explicit
     CTDET_WINO_TILES), plus F(4x4) / fp32 on layers with at most wino4_max_cin input channels (and tile 44 from
     ctx_w4s_min_cin input channels up, see apply_tuned)."""
@@ -1028,7 +1026,7 @@ def apply_tuned(backend, st, batch, wino4=True):
     if usable and st.dil > 1:
         # dilated layer on the three-kernel form: where tile 44 is allowed as such; a runtime with an accuracy policy
         # (Context-Transformer networks) takes it from ctx_w4s_min_cin input channels up (CTDET_CTX_DIL_W4S=0: never --
-        # the layer then runs the table's previous choice, '|alt').  Only tiles 44 / 45 exist for these layers: a caller
+        # the layer then runs the table's previous choice, '|alt').  Only tile 44 (and its f16x2 twin 47) exists for these layers: a caller
         # that rules out F(4x4) (wino4=False) gets the '|alt' entry as well.
         policy = getattr(backend, 'wino_tile_set', None) is not None
         if policy:

@@ -331,10 +331,10 @@ int ct_conv2d_wino4_pool_fwd(const ct_conv_desc* desc, const float* upacked, flo
  * the transform-domain products evaluated as six bf16 piece products ("bf16x3", see below) on v_mfma_f32_32x32x16_bf16
  * -- same layers (models/RFB_Net_vgg.py:7-22,219-227,238-248), descriptor, epilogue, pooling fusion and head scatter;
  * cin % 16 == 0.  The weights come pre-transformed AND pre-split from ct_conv_pack_weights_wino_x3
- * (ct_conv_wino_x3_packed_bytes bytes).  variant 1: eight-wave workgroups, the hi.hi products accumulate in their own
+ * (ct_conv_wino_x3_packed_bytes bytes).  `variant` must be 1: eight-wave workgroups, the hi.hi products accumulate in their own
  * register block (the large sum sees cin / 16 roundings; error vs fp64 about a third of ct_conv2d_wino_fwd's, a tenth of
- * ct_conv2d_wino4_fwd's); variant 2: four-wave workgroups, two per CU, one accumulator (6 cin / 16 roundings) -- the
- * faster one on most shapes. */
+ * ct_conv2d_wino4_fwd's).  (Variant 2 of rounds 4-5 -- four-wave workgroups, one accumulator -- was removed in round 6: it
+ * never won a layer inside the two-stream pipeline; CT_ERR_INVALID.) */
 int ct_conv_wino_x3_supported(const ct_conv_desc* desc);
 size_t ct_conv_wino_x3_packed_bytes(int cin, int cout);
 int ct_conv_pack_weights_wino_x3(const float* const* w, const int* cout, int nparts, int cin, void* upacked,
@@ -354,7 +354,8 @@ int ct_conv2d_wino_x3_pool_fwd(const ct_conv_desc* desc, const void* upacked, in
  * the loop); an output-transform kernel applies A^T M A and the epilogue.  V and M live in the caller's `workspace`
  * (ct_conv_wino4s_workspace_bytes(desc) bytes: 13.5 bytes per (output pixel, input channel) + 9 per (output pixel,
  * output channel); launches on different streams need different workspaces).  Weights: ct_conv_pack_weights_wino4s
- * (ct_conv_wino4s_packed_bytes bytes).  variant 1: the hi.hi products in their own accumulator; 2: one accumulator.
+ * (ct_conv_wino4s_packed_bytes bytes).  variant 1: bf16x3, the hi.hi products in their own accumulator (variant 2 of
+ * rounds 4-5, one accumulator, was removed in round 6: CT_ERR_BAD_ARG).
  * variant 3 (round 6): the "f16x2" operand form -- every transform-domain value as TWO binary16 pieces (hi = rne16(x 2^e),
  * lo = rne16(x 2^e - hi)) and a multiply-add as the THREE piece products hi.hi, hi.lo, lo.hi on the f16 matrix pipe, the hi.hi
  * products in their own accumulator: the same 22-24 bits as three bfloat16 pieces / six products (same error against fp64), half

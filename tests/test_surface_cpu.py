@@ -224,4 +224,4 @@ def test_committed_tune_table_is_consistent():
         if val in wino:
             assert (kh, kw, stride) == (3, 3, 1), (key, val)
             if dil > 1:
-                assert val in ('wino4s', 'wino4sq') and cin % 16 == 0 and key + '|alt' in table, (key, val)
+                assert val == 'wino4s' and cin % 16 == 0 and key + '|alt' in table, (key, val)

@@ -56,9 +56,8 @@ timeout 300 python bench.py --train --steps 5 --warmup 2 > "$O/bench_train.json.
 [ -n "${QUICK:-}" ] || { timeout 300 python tools/ctx_attn_time.py > "$O/ctx_attn_time.txt" 2>&1; }
 [ -n "${QUICK:-}" ] || { bash tools/wino_pmc.sh base.19 ${TAG}_w4 > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_w4/summary.txt" "$O/wino4_pmc.txt"; }
 # the three Winograd kernels on the same layer: SQ counters behind "SIMD time = MFMA cycles + 4 cycles per VALU instruction"
-[ -n "${QUICK:-}" ] || { bash tools/wino_pmc.sh base.19 ${TAG}_x3q 24 x3q > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_x3q/summary.txt" "$O/wino_x3q_pmc.txt"; }
 [ -n "${QUICK:-}" ] || { bash tools/wino_pmc.sh base.19 ${TAG}_x3d 23 "wino_f2x2_3x3_x3<" > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_x3d/summary.txt" "$O/wino_x3_pmc.txt"; }
-CTDET_WINO_TILES=2,4,23,24,44,46,47,48 TILES=2,4,23,24,44,46,47,48 timeout 600 python tools/wino_one.py base.2 base.5 base.7 base.10 base.12 base.17 base.19 base.24 head.0 > "$O/wino_variants.txt" 2>&1
+CTDET_WINO_TILES=2,4,23,44,46,47,48 TILES=2,4,23,44,46,47,48 timeout 600 python tools/wino_one.py base.2 base.5 base.7 base.10 base.12 base.17 base.19 base.24 head.0 > "$O/wino_variants.txt" 2>&1
 # the fused F(4x4,3x3) / bf16x3 kernel (tile 46) on conv1_2 and conv2_2: SQ counters, the LDS-DMA probe behind its patch staging
 # the fused F(4x4,3x3) kernel on the f16x2 operand form (tile 48; bf16x3 = 46 beside it) on conv1_2 and conv2_2: SQ counters
 [ -n "${QUICK:-}" ] || { bash tools/wino_pmc.sh base.2 ${TAG}_w4f 48 wino_f4x4_3x3_x3 > /dev/null 2>&1; cp "$R/gpurun_out/pmc_${TAG}_w4f/summary.txt" "$O/wino4f_pmc.txt"; }

@@ -7,7 +7,7 @@ cp $S/condensed/${R}_* $D/
 for f in bench_full.json.log rfb300_bench.json.log rfb512_bench.json.log rfb300ctx_bench.json.log bf16_512b16_bench.json.log \
          bench_train.json.log bench_2rank_rehearsal.json.log bench_train_2rank_rehearsal.json.log layer_report.txt layer_report_512.txt \
          ctx_policy.txt wino_variants.txt wino_accuracy.txt train_configs.txt nms_probe.txt attn_probe.txt ctx_attn_time.txt \
-         x3_probe.txt bf16_pmc.txt wino4_pmc.txt wino_x3_pmc.txt wino_x3q_pmc.txt wino4s_probe.txt wino4s_pmc.txt mfma_power.txt \
+         x3_probe.txt bf16_pmc.txt wino4_pmc.txt wino_x3_pmc.txt wino4s_probe.txt wino4s_pmc.txt mfma_power.txt \
          wino4f_pmc.txt wino4f_pmc_conv2_2.txt wino4f_x3_pmc.txt wino4s_x3_pmc.txt f16x2_probe.txt wino_accuracy_shipped.txt lds_dma12.txt wino4s_stage_split.txt res_probe.txt; do
   [ -s $S/$f ] && grep -v "amdgpu.ids" $S/$f > $D/${R}_$f
 done

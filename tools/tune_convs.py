@@ -11,8 +11,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, 'context-transformer_amd')); sys.path.insert(0, REPO)
 os.environ['CTDET_TUNE'] = '2'
 os.environ['CTDET_CTX_TILES'] = 'any'       # the table holds the unconstrained choice; policies map it at plan time
-# Winograd variants timed: the two fp32-MFMA kernels (default); CTDET_WINO_TILES=2,4,23,24 adds the F(2x2) bf16x3 forms, which
-# win per layer alone but not in the two-stream pipeline
+# Winograd variants timed: the two fp32-MFMA kernels (default); CTDET_WINO_TILES=2,4,23 adds the F(2x2) bf16x3 form, which
+# wins per layer alone but not in the two-stream pipeline
 from ctdet import engine, synth  # noqa: E402
 from models.RFB_Net_vgg import build_net  # noqa: E402
 

@@ -5,7 +5,7 @@ R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out; mkdir -p $O
 L=${@:-base.19 base.17b head.0 base.24 head.1 base.12}
 cd /tmp && export TMPDIR=/tmp
 {
-  TILES=${TILES:-4,24,44,45} ITERS=${ITERS:-20} python $R/tools/wino_one.py $L
+  TILES=${TILES:-4,23,44,47} ITERS=${ITERS:-20} python $R/tools/wino_one.py $L
   for l in $L; do
     rm -rf $O/w4s_stats
     CHECK=0 TILES=${PTILE:-44} ITERS=20 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/w4s_stats -o s -- python $R/tools/wino_one.py $l > /dev/null 2>&1

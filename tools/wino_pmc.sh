@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ counter passes for one Winograd layer:  bash tools/wino_pmc.sh base.19 tag [tile code] [kernel-name filter]
-#   -> gpurun_out/pmc_<tag>/summary.txt     (tile 4 / wino_f4x4_3x3_f32 by default; 24 / x3q; 23 / f2x2_3x3_x3; 43 / f4x4_3x3_x3)
+#   -> gpurun_out/pmc_<tag>/summary.txt     (tile 4 / wino_f4x4_3x3_f32 by default; 23 / f2x2_3x3_x3; 43 / f4x4_3x3_x3)
 L=${1:-base.19}; TAG=${2:-w4}; TILE=${3:-4}; FILT=${4:-wino_f4x4_3x3_f32}
 R=$(cd "$(dirname "$0")/.." && pwd); O=$R/gpurun_out/pmc_$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
