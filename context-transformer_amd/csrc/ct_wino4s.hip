@@ -1077,17 +1077,35 @@ __device__ __forceinline__ void wino4h_pack_body(const ctdet::WinoPackArgs& p, u
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) v[j][pc] = u32x4{0u, 0u, 0u, 0u};
         if (co < p.cout) {
+            // the 8 x 9 taps of this thread.  Forward layout: 72 consecutive floats of one filter row (288 bytes: eighteen 16-byte
+            // loads where the parameter is 16-byte aligned -- scalar loads of a wave whose lanes are cin * 36 bytes apart made this
+            // kernel 0.7 ms of a training step); data gradient: 8 forward couts, cin_fwd * 36 bytes apart, taps rotated by 180 degrees
+            float g[8][9];
+            if (!p.dgrad) {
+                const float* w = ctdet::wino_taps(p, co, ci8 * 8);
+                if ((reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 18; ++q4) {
+                        const float4 f = reinterpret_cast<const float4*>(w)[q4];
+                        (&g[0][0])[4 * q4 + 0] = f.x; (&g[0][0])[4 * q4 + 1] = f.y; (&g[0][0])[4 * q4 + 2] = f.z; (&g[0][0])[4 * q4 + 3] = f.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 72; ++k) (&g[0][0])[k] = w[k];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float* w = ctdet::wino_taps(p, co, ci8 * 8 + e);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) g[e][k] = w[8 - k];
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float* w = ctdet::wino_taps(p, co, ci8 * 8 + e);
                 double t[3];                                      // row i of G g
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    double o[6];
-                    if (p.dgrad) ctdet::w4::gmul6(w[(2 - 0) * 3 + (2 - c)], w[(2 - 1) * 3 + (2 - c)], w[(2 - 2) * 3 + (2 - c)], o);
-                    else ctdet::w4::gmul6(w[0 * 3 + c], w[1 * 3 + c], w[2 * 3 + c], o);
-                    t[c] = ctdet::wino_pick6(o, i);
-                }
+                for (int c = 0; c < 3; ++c) t[c] = ctdet::w4::gmul6_row(g[e][0 * 3 + c], g[e][1 * 3 + c], g[e][2 * 3 + c], i);
                 double o[6];                                      // (G g) G^T, row i
                 ctdet::w4::gmul6(t[0], t[1], t[2], o);
 #pragma unroll
