@@ -24,6 +24,8 @@
 //                        classifier OBJ_Target * scale, written to out[B,P,(d)+T].
 #include "ct_common.h"
 #include "ct_attn_common.h"
+#include "ct_f16x2.h"
+#include <cstdlib>
 
 namespace {
 
@@ -77,6 +79,111 @@ __global__ __launch_bounds__(256) void ctx_project_x3_kernel(const float* __rest
     }
 }
 
+// ---- the f16x2 operand form of the inference forward (round 6, csrc/ct_f16x2.h) ----
+// theta / phi / g as TWO binary16 pieces of y 2^e, three piece products per multiply-add on v_mfma_f32_32x32x16_f16: half the
+// matrix instructions of bf16x3 and 2 instead of 5.5 vector instructions per split probability, at the same error against
+// fp64.  Scales: a QUERY row carries its own exponent (the 64 features of a row sit in the 64 lanes of a wave: one wave_max;
+// the lane that owns the query in the attention kernel multiplies its logits by 2^-(eq + eK)), K and V one exponent per IMAGE
+// (a first pass of the same arithmetic takes max |y| per image; the projections of the M pooled rows are 1 % of the block), the
+// probabilities the fixed 2^14 (folded into the exponent of the exp2, cancelled by the normalisation).
+constexpr int NPH = 2;
+constexpr int XTH_BYTES = NPH * 8 * KT * 16;       // one 32-row tile as f16x2 fragments: 8 KB
+constexpr int XQH_BYTES = NPH * 8 * 16;            // one row in the register-operand layout: 256 B
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct ProjH2Set {                                 // one projection of a launch (blockIdx.z selects)
+    const float* x; const float* W; const float* bias;
+    unsigned short* out;                           // PASS 1: fragments (modes as x3_emit, two pieces)
+    int rows_valid, rows_pad, mode;
+    unsigned* amax;                                // [batch] bit patterns of max |y| per image (modes 1 / 2; PASS 0 writes, PASS 1 reads)
+    float* rowscale;                               // mode 0, PASS 1: [batch][rows_pad] 2^-e of every row
+};
+struct ProjH2Args { ProjH2Set s[2]; int d; };
+
+__device__ __forceinline__ void h2_emit(float y, int e, unsigned short* __restrict__ out, int mode, int b, int row, int rows_pad, int o)
+{
+    const float ys = __builtin_ldexpf(y, e);
+    const _Float16 hi = (_Float16)ys;
+    const _Float16 lo = (_Float16)(ys - (float)hi);
+    size_t base, pstride;        // in binary16 elements
+    if (mode == 0) {
+        base = ((size_t)b * rows_pad + row) * (XQH_BYTES / 2) + (o >> 3) * 8 + (o & 7);
+        pstride = 8 * 8;
+    } else {
+        const int tile = row / KT, kl = row % KT;
+        const size_t tb = ((size_t)b * (rows_pad / KT) + tile) * (XTH_BYTES / 2);
+        if (mode == 1) {
+            base = tb + ((size_t)(o >> 3) * KT + kl) * 8 + (o & 7);
+        } else {
+            const int h = (kl >> 2) & 1, rr = (kl & 3) + 4 * (kl >> 3);     // kl = acc_row(rr, h)
+            base = tb + ((size_t)((rr >> 3) * 2 + h) * DP + o) * 8 + (rr & 7);
+        }
+        pstride = 8 * KT * 8;
+    }
+    out[base] = __builtin_bit_cast(unsigned short, hi);
+    out[base + pstride] = __builtin_bit_cast(unsigned short, lo);
+}
+
+// PASS 0: max |y| per image (modes 1 / 2); PASS 1: the fragments.  Same arithmetic as ctx_project_x3_kernel (every output sums
+// its products in the order i = 0 .. 63), so both passes see the same y.
+template <int PASS>
+__global__ __launch_bounds__(256) void ctx_project_h2_kernel(const ProjH2Args a)
+{
+    __shared__ float Wt[DP * DP];
+    __shared__ __attribute__((aligned(16))) float Xt[DP * 64];
+    const ProjH2Set& ps = a.s[blockIdx.z];
+    const int b = blockIdx.y, d = a.d;
+    const int r0 = blockIdx.x * 64;
+    if (r0 >= ps.rows_pad) return;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < DP * DP; e += 256) {
+        const int i = e / DP, o = e % DP;
+        Wt[e] = (i < d && o < d) ? ps.W[o * d + i] : 0.f;
+    }
+    for (int e = tid; e < 64 * DP; e += 256) {
+        const int r = e / DP, i = e % DP;
+        const int row = r0 + r;
+        Xt[i * 64 + r] = (row < ps.rows_valid && i < d) ? ps.x[((size_t)b * ps.rows_valid + row) * d + i] : 0.f;
+    }
+    __syncthreads();
+    const int o = tid & 63, rg = tid >> 6;
+    const float bo = (o < d) ? ps.bias[o] : 0.f;
+    const int eimg = (PASS == 1 && ps.mode != 0) ? ctdet::h2::exponent_for(ps.amax[b], ctdet::h2::kGrowthNone) : 0;
+    float run = 0.f;
+    for (int rq = 0; rq < 4; ++rq) {
+        const int rl = 16 * rg + 4 * rq;
+        if (r0 + rl >= ps.rows_pad) break;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int i = 0; i < DP; ++i) {
+            const float w = Wt[i * DP + o];
+            const float4 xv = *reinterpret_cast<const float4*>(&Xt[i * 64 + rl]);
+            acc[0] += xv.x * w; acc[1] += xv.y * w; acc[2] += xv.z * w; acc[3] += xv.w * w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = r0 + rl + k;
+            if (row >= ps.rows_pad) break;                   // wave-uniform
+            const float y = (row < ps.rows_valid && o < d) ? acc[k] + bo + Xt[o * 64 + rl + k] : 0.f;
+            if (PASS == 0) {
+                ctdet::h2::track_absmax(run, y);
+            } else if (ps.mode == 0) {
+                // the 64 lanes of this wave hold the 64 features of the row
+                const unsigned m = ctdet::h2::wave_max(__builtin_bit_cast(unsigned, y) & 0x7FFFFFFFu);
+                const int e = ctdet::h2::exponent_for(m, ctdet::h2::kGrowthNone);
+                if (o == 0) ps.rowscale[(size_t)b * ps.rows_pad + row] = __builtin_ldexpf(1.f, -e);
+                h2_emit(y, e, ps.out, 0, b, row, ps.rows_pad, o);
+            } else {
+                h2_emit(y, eimg, ps.out, ps.mode, b, row, ps.rows_pad, o);
+            }
+        }
+    }
+    if (PASS == 0) {
+        const unsigned m = ctdet::h2::wave_max(__builtin_bit_cast(unsigned, run) & 0x7FFFFFFFu);
+        if ((tid & 63) == 0 && m != 0u) atomicMax(ps.amax + b, m);
+    }
+}
+
 struct AttnArgs {
     const unsigned char* Qx;
     const unsigned char* Kx;
@@ -89,11 +196,21 @@ struct AttnArgs {
     float* save_lse;    // training: log2-domain log-sum-exp of each affinity row, [B][P_pad]
     int P, P_pad, M, M_pad, d, T, ostride, ooff;
     float scale;
+    // f16x2 form: 2^-e of every query row, bit patterns of max |K| / max |V| per image
+    const float* qscale;
+    const unsigned* kmax;
+    const unsigned* vmax;
 };
 
+// H2: the f16x2 operand form (inference forward only: a.save_d == nullptr), see ctx_project_h2_kernel
+template <bool H2>
 __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char kv[2][2 * XT_BYTES];   // per buffer: K tile, V tile (fragments)
+    constexpr int NP = H2 ? NPH : 3;                       // pieces per value
+    constexpr int XT = H2 ? XTH_BYTES : XT_BYTES;          // one K or V tile
+    constexpr int XQ = H2 ? XQH_BYTES : XQ_BYTES;          // one query row
+    constexpr int NTR = XT / (256 * 16);                   // 16-byte units of a tile per thread
+    __shared__ __attribute__((aligned(16))) unsigned char kv[2][2 * XT];   // per buffer: K tile, V tile (fragments)
     __shared__ float objw[32 * DP];
     __shared__ float wzs[DP];
 
@@ -111,34 +228,40 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
     }
     if (tid < DP) wzs[tid] = tid < a.d ? a.wz[tid] : 0.f;
 
-    // Q fragments (B operand of S^T): group g = 16 features, lane half h = octet 2g + h, three pieces
-    i32x4 qf[4][3];
+    // Q fragments (B operand of S^T): group g = 16 features, lane half h = octet 2g + h, NP pieces
+    i32x4 qf[4][NP];
     {
-        const unsigned char* qp = a.Qx + ((size_t)b * a.P_pad + q) * XQ_BYTES;
+        const unsigned char* qp = a.Qx + ((size_t)b * a.P_pad + q) * XQ;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 qf[g][p] = *reinterpret_cast<const i32x4*>(qp + (p * 8 + 2 * g + h) * 16);
+    }
+    // f16x2: logits = (K 2^eK)(Q 2^eq)^T 2^-(eK + eq), O = (V 2^eV)(P 2^14)^T 2^-(eV + 14) (the 2^14 cancels in O / l)
+    float sf = 1.f, of = 1.f;
+    if (H2) {
+        sf = a.qscale[(size_t)b * a.P_pad + q] * __builtin_ldexpf(1.f, -ctdet::h2::exponent_for(a.kmax[b], ctdet::h2::kGrowthNone));
+        of = __builtin_ldexpf(1.f, -ctdet::h2::exponent_for(a.vmax[b], ctdet::h2::kGrowthNone));
     }
 
     const int nt = a.M_pad / KT;
-    const unsigned char* Kxb = a.Kx + (size_t)b * nt * XT_BYTES;
-    const unsigned char* Vxb = a.Vx + (size_t)b * nt * XT_BYTES;
+    const unsigned char* Kxb = a.Kx + (size_t)b * nt * XT;
+    const unsigned char* Vxb = a.Vx + (size_t)b * nt * XT;
 
-    i32x4 treg[6];                                         // 24 KB per tile / 256 threads
+    i32x4 treg[2 * NTR];                                   // 2 x 12 (8) KB per tile / 256 threads
     auto load_tile = [&](int t) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            treg[i] = *reinterpret_cast<const i32x4*>(Kxb + (size_t)t * XT_BYTES + (tid + 256 * i) * 16);
-            treg[3 + i] = *reinterpret_cast<const i32x4*>(Vxb + (size_t)t * XT_BYTES + (tid + 256 * i) * 16);
+        for (int i = 0; i < NTR; ++i) {
+            treg[i] = *reinterpret_cast<const i32x4*>(Kxb + (size_t)t * XT + (tid + 256 * i) * 16);
+            treg[NTR + i] = *reinterpret_cast<const i32x4*>(Vxb + (size_t)t * XT + (tid + 256 * i) * 16);
         }
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < NTR; ++i) {
             *reinterpret_cast<i32x4*>(&kv[buf][(tid + 256 * i) * 16]) = treg[i];
-            *reinterpret_cast<i32x4*>(&kv[buf][XT_BYTES + (tid + 256 * i) * 16]) = treg[3 + i];
+            *reinterpret_cast<i32x4*>(&kv[buf][XT + (tid + 256 * i) * 16]) = treg[NTR + i];
         }
     };
 
@@ -151,8 +274,13 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
     store_tile(0);
     __syncthreads();
 
-    // piece pairs (A piece, B piece) of the six products, smallest first; the last one is hi.hi
-    constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};
+    // piece pairs (A piece, B piece) of the six (f16x2: three) products, smallest first; the last one is hi.hi
+    constexpr int NPROD = H2 ? 3 : 6;
+    constexpr int PA[6] = {H2 ? 1 : 1, H2 ? 0 : 2, 0, 1, 0, 0}, PB[6] = {H2 ? 0 : 1, H2 ? 1 : 0, H2 ? 0 : 2, 0, 1, 0};
+    auto mma = [](const i32x4& A, const i32x4& B, const f32x16& C) -> f32x16 {
+        if constexpr (H2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, A), __builtin_bit_cast(bf16x8, B), C, 0, 0, 0);
+    };
     for (int t = 0; t < nt; ++t) {
         const int buf = t & 1;
         const bool more = t + 1 < nt;
@@ -166,18 +294,15 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
             const unsigned char* kb = &kv[buf][l31 * 16];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                i32x4 kf[3];
+                i32x4 kf[NP];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) kf[p] = *reinterpret_cast<const i32x4*>(kb + ((p * 8 + 2 * g + h) * KT) * 16);
+                for (int p = 0; p < NP; ++p) kf[p] = *reinterpret_cast<const i32x4*>(kb + ((p * 8 + 2 * g + h) * KT) * 16);
 #pragma unroll
-                for (int c = 0; c < 5; ++c)
-                    ss = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[PA[c]]),
-                                                                 __builtin_bit_cast(bf16x8, qf[g][PB[c]]), ss, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[0]),
-                                                            __builtin_bit_cast(bf16x8, qf[g][0]), s, 0, 0, 0);
+                for (int c = 0; c < NPROD - 1; ++c) ss = mma(kf[PA[c]], qf[g][PB[c]], ss);
+                s = mma(kf[0], qf[g][0], s);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] += ss[r];
+            for (int r = 0; r < 16; ++r) s[r] = H2 ? (s[r] + ss[r]) * sf : s[r] + ss[r];
         }
 
         // ---- online softmax over this tile's 32 keys (16 in-lane + partner lane^32) ----
@@ -204,9 +329,10 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
         const float alpha = __builtin_amdgcn_exp2f(mb_run - mb);
         mb_run = mb;
         float lsum = 0.f;
+        const float mbe = H2 ? mb - 14.f : mb;             // f16x2: probabilities as p 2^14 <= 2^14 (exact shift of the exponent; l and O carry it alike)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s[r] = __builtin_amdgcn_exp2f(s[r] * kLog2e - mb);
+            s[r] = __builtin_amdgcn_exp2f(s[r] * kLog2e - mbe);
             lsum += s[r];
         }
         lsum += __shfl_xor(lsum, 32);
@@ -217,34 +343,43 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
 
         // ---- O^T += V^T P^T ----  B operand: this lane's own probabilities (registers 8 kg .. 8 kg + 7), split in place
         {
-            i32x4 pf[2][3];
+            i32x4 pf[2][NP];
 #pragma unroll
             for (int kg = 0; kg < 2; ++kg) {
-                unsigned ph[8], pm[8], pl[8];
+                if constexpr (H2) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) split3(s[8 * kg + j], ph[j], pm[j], pl[j]);
+                    for (int w = 0; w < 4; ++w) {
+                        int hi, lo;
+                        ctdet::h2::split2(s[8 * kg + 2 * w], s[8 * kg + 2 * w + 1], hi, lo);
+                        pf[kg][0][w] = hi;
+                        pf[kg][1][w] = lo;
+                    }
+                } else {
+                    unsigned ph[8], pm[8], pl[8];
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    pf[kg][0][w] = pack_hi(ph[2 * w], ph[2 * w + 1]);
-                    pf[kg][1][w] = pack_hi(pm[2 * w], pm[2 * w + 1]);
-                    pf[kg][2][w] = pack_hi(pl[2 * w], pl[2 * w + 1]);
+                    for (int j = 0; j < 8; ++j) split3(s[8 * kg + j], ph[j], pm[j], pl[j]);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        pf[kg][0][w] = pack_hi(ph[2 * w], ph[2 * w + 1]);
+                        pf[kg][1][w] = pack_hi(pm[2 * w], pm[2 * w + 1]);
+                        pf[kg][NP - 1][w] = pack_hi(pl[2 * w], pl[2 * w + 1]);
+                    }
                 }
             }
-            const unsigned char* vb = &kv[buf][XT_BYTES + l31 * 16];
+            const unsigned char* vb = &kv[buf][XT + l31 * 16];
 #pragma unroll
             for (int kg = 0; kg < 2; ++kg) {
-                i32x4 vf[3][2];
+                i32x4 vf[NP][2];
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < NP; ++p)
 #pragma unroll
                     for (int db = 0; db < 2; ++db)
                         vf[p][db] = *reinterpret_cast<const i32x4*>(vb + ((((p * 2 + kg) * 2 + h) * DP) + 32 * db) * 16);
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[PA[c]][0]),
-                                                                 __builtin_bit_cast(bf16x8, pf[kg][PB[c]]), o0, 0, 0, 0);
-                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf[PA[c]][1]),
-                                                                 __builtin_bit_cast(bf16x8, pf[kg][PB[c]]), o1, 0, 0, 0);
+                for (int c = 0; c < NPROD; ++c) {
+                    const int cc = c == NPROD - 1 ? 5 : c;          // the last product is hi.hi (PA / PB entry 5)
+                    o0 = mma(vf[PA[cc]][0], pf[kg][PB[cc]], o0);
+                    o1 = mma(vf[PA[cc]][1], pf[kg][PB[cc]], o1);
                 }
             }
         }
@@ -265,7 +400,7 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
         }
         return;
     }
-    const float inv_l = 1.f / l_run;
+    const float inv_l = H2 ? of / l_run : 1.f / l_run;
     if (a.save_d) {
         float4* drow = reinterpret_cast<float4*>(a.save_d + ((size_t)b * a.P_pad + q) * DP);
 #pragma unroll
@@ -307,10 +442,22 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
 }
 
 struct Ws {
-    unsigned char *Qx, *Kx, *Vx;      // bf16x3 fragments (ctx_project_x3_kernel)
+    unsigned char *Qx, *Kx, *Vx;      // bf16x3 fragments (ctx_project_x3_kernel) or, two thirds the size, f16x2 ones (ctx_project_h2_kernel)
+    float* qscale;                    // f16x2: [batch][P_pad] 2^-e of every query row
+    unsigned* kvmax;                  // f16x2: [2][batch] bit patterns of max |K|, max |V| per image
     int P_pad, M_pad;
     size_t total;
 };
+
+// CTDET_ATTN_H2=1 runs the inference forward on the f16x2 form (read per call: tests and A/B runs switch it).  OFF by default:
+// +2 % images/s on RFBNet-300 + Context-Transformer bs 32, the same error against fp64 -- but a DIFFERENT rounding, and one of the
+// 18 (case, thread count) pairs of the parity sweep then lands at 1.03e-4 from the reference's fp32 CPU path (DESIGN.md section 2:
+// two correct fp32 evaluations of this block differ by that much); the default stays the form the sweep was passed with.
+bool attn_h2()
+{
+    const char* e = std::getenv("CTDET_ATTN_H2");
+    return e && e[0] == '1';
+}
 
 Ws carve(char* base, int batch, int P, int M)
 {
@@ -326,6 +473,8 @@ Ws carve(char* base, int batch, int P, int M)
     w.Qx = take((size_t)batch * w.P_pad * XQ_BYTES);
     w.Kx = take((size_t)batch * (w.M_pad / KT) * XT_BYTES);
     w.Vx = take((size_t)batch * (w.M_pad / KT) * XT_BYTES);
+    w.qscale = (float*)take((size_t)batch * w.P_pad * sizeof(float));
+    w.kvmax = (unsigned*)take((size_t)2 * batch * sizeof(unsigned));
     w.total = off;
     return w;
 }
@@ -352,6 +501,23 @@ int forward_impl(const float* conf, const float* pool, int batch, int num_priors
     const int ostride = (prm->fc_w ? d : 0) + prm->t;
     const dim3 blk(256);
     float* none = nullptr;
+    const bool h2 = !save_d && attn_h2();
+    if (h2) {
+        CT_HIP(hipMemsetAsync(w.kvmax, 0, (size_t)2 * batch * sizeof(unsigned), st));
+        ProjH2Args kv{};
+        kv.d = d;
+        kv.s[0] = ProjH2Set{pool, prm->phi_w, prm->phi_b, (unsigned short*)w.Kx, num_ctx, w.M_pad, 1, w.kvmax, nullptr};
+        kv.s[1] = ProjH2Set{pool, prm->g_w, prm->g_b, (unsigned short*)w.Vx, num_ctx, w.M_pad, 2, w.kvmax + batch, nullptr};
+        ProjH2Args qa{};
+        qa.d = d;
+        qa.s[0] = ProjH2Set{conf, prm->theta_w, prm->theta_b, (unsigned short*)w.Qx, num_priors, w.P_pad, 0, nullptr, w.qscale};
+        { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_h2_kernel<0>, dim3((w.M_pad + 63) / 64, batch, 2), blk, 0, st, kv); }
+        CT_LAUNCH_CHECK("ctx_project_h2_kernel<0>(phi, g)");
+        { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_h2_kernel<1>, dim3((w.M_pad + 63) / 64, batch, 2), blk, 0, st, kv); }
+        CT_LAUNCH_CHECK("ctx_project_h2_kernel<1>(phi, g)");
+        { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_h2_kernel<1>, dim3(w.P_pad / 64, batch, 1), blk, 0, st, qa); }
+        CT_LAUNCH_CHECK("ctx_project_h2_kernel<1>(theta)");
+    } else {
     { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_x3_kernel, dim3(w.P_pad / 64, batch), blk, 0, st, conf, num_priors,
                        w.P_pad, d, prm->theta_w, prm->theta_b, (unsigned short*)w.Qx, 0); }
     CT_LAUNCH_CHECK("ctx_project_x3_kernel(theta)");
@@ -361,6 +527,7 @@ int forward_impl(const float* conf, const float* pool, int batch, int num_priors
     { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_x3_kernel, dim3((w.M_pad + 63) / 64, batch), blk, 0, st, pool, num_ctx,
                        w.M_pad, d, prm->g_w, prm->g_b, (unsigned short*)w.Vx, 2); }
     CT_LAUNCH_CHECK("ctx_project_x3_kernel(g)");
+    }
     if (prm->fc_w) {
         { CT_PROF("ctx_project_kernel", st); hipLaunchKernelGGL(ctx_project_kernel, dim3((num_priors + 63) / 64, batch), blk, 0, st, conf,
                            num_priors, num_priors, d, prm->fc_w, prm->fc_b, none, none, none, out, ostride); }
@@ -373,7 +540,9 @@ int forward_impl(const float* conf, const float* pool, int batch, int num_priors
     a.P = num_priors; a.P_pad = w.P_pad; a.M = num_ctx; a.M_pad = w.M_pad;
     a.d = d; a.T = prm->t; a.ostride = ostride; a.ooff = prm->fc_w ? d : 0;
     a.scale = prm->scale;
-    { CT_PROF("ctx_attn_kernel", st); hipLaunchKernelGGL(ctx_attn_kernel, dim3(w.P_pad / QB, batch), blk, 0, st, a); }
+    a.qscale = w.qscale; a.kmax = w.kvmax; a.vmax = w.kvmax + batch;
+    if (h2) { CT_PROF("ctx_attn_kernel", st); hipLaunchKernelGGL(ctx_attn_kernel<true>, dim3(w.P_pad / QB, batch), blk, 0, st, a); }
+    else { CT_PROF("ctx_attn_kernel", st); hipLaunchKernelGGL(ctx_attn_kernel<false>, dim3(w.P_pad / QB, batch), blk, 0, st, a); }
     CT_LAUNCH_CHECK("ctx_attn_kernel");
     return CT_OK;
 }
@@ -384,6 +553,8 @@ extern "C" size_t ct_ctx_attention_workspace_bytes(int batch, int num_priors, in
 {
     return carve(nullptr, batch, num_priors, num_ctx).total;
 }
+
+extern "C" int ct_ctx_attention_piece_products(void) { return attn_h2() ? 3 : 6; }
 
 extern "C" int ct_ctx_attention_fwd(const float* conf, const float* pool, int batch, int num_priors,
                                     int num_ctx, const ct_ctx_params* prm, float* out, void* workspace,

@@ -104,17 +104,6 @@ __device__ __forceinline__ void gmul6(double a0, double a1, double a2, double (&
     o[5] = a2;
 }
 
-// element i of gmul6's result alone (the same expressions, hence the same bits): the weight packing needs one row of G g per thread
-__device__ __forceinline__ double gmul6_row(double a0, double a1, double a2, int i)
-{
-    if (i == 0) return a0 * (1.0 / N0);
-    if (i == 5) return a2;
-    const bool q = i >= 3;
-    const double e = (a0 + (double)(q ? Q2 : P2) * a2) * (q ? 1.0 / NQ : 1.0 / NP);
-    const double o = ((double)(q ? Q : P) * a1) * (q ? 1.0 / NQ : 1.0 / NP);
-    return (i & 1) ? e + o : e - o;
-}
-
 // u -> G^T u for a 6-vector u (weight gradient: dw = G^T dU G), fp32 like the accumulators it reads
 __device__ __forceinline__ void gt3(const float (&u)[6], float (&o)[3])
 {

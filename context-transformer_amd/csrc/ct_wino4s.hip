@@ -1105,7 +1105,13 @@ __device__ __forceinline__ void wino4h_pack_body(const ctdet::WinoPackArgs& p, u
             for (int e = 0; e < 8; ++e) {
                 double t[3];                                      // row i of G g
 #pragma unroll
-                for (int c = 0; c < 3; ++c) t[c] = ctdet::w4::gmul6_row(g[e][0 * 3 + c], g[e][1 * 3 + c], g[e][2 * 3 + c], i);
+                for (int c = 0; c < 3; ++c) {
+                    // (all six rows and a select, not the one row needed: the packed bits of rounds 1-6 -- and with them the last
+                    // digits of every committed parity measurement -- come from THIS expression tree as the compiler contracts it)
+                    double o[6];
+                    ctdet::w4::gmul6(g[e][0 * 3 + c], g[e][1 * 3 + c], g[e][2 * 3 + c], o);
+                    t[c] = ctdet::wino_pick6(o, i);
+                }
                 double o[6];                                      // (G g) G^T, row i
                 ctdet::w4::gmul6(t[0], t[1], t[2], o);
 #pragma unroll

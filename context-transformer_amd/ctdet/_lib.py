@@ -192,6 +192,7 @@ SIGNATURES = {
     'ct_mixup_blend': (_I, [_P, _P, _P, _I, _L, _P, _P]),
     'ct_ctx_pool_fwd': (_I, [_P, _LL, _P, _LL, _I, _I, _I, _I, _I, _P]),
     'ct_ctx_attention_workspace_bytes': (_Z, [_I, _I, _I, _I]),
+    'ct_ctx_attention_piece_products': (_I, []),
     'ct_ctx_attention_fwd': (_I, [_P, _P, _I, _I, _I, C.POINTER(CtxParams), _P, _P, _Z, _P]),
     'ct_ctx_attention_saved_bytes': (_Z, [_I, _I]),
     'ct_ctx_attention_fwd_train': (_I, [_P, _P, _I, _I, _I, C.POINTER(CtxParams), _P, _P, _Z, _P, _Z, _P]),

@@ -606,7 +606,11 @@ int ct_ctx_pool_fwd(const float* in, long long in_img_stride, float* out, long l
  *   delta = softmax(theta phi^T, dim=2) g * Wz;  nov = normalize(conf+delta) OBJ^T * scale
  *   setting 'incre' (fc_w != NULL): out = cat(Lin_fc(conf)+conf, nov)
  * conf dev [B,P,d], pool dev [B,M,d], out dev [B,P,(fc_w?d:0)+T]; d <= 64, T <= 32.
- * Linear weights are [d,d] row-major (out,in) as torch.nn.Linear stores them. */
+ * Linear weights are [d,d] row-major (out,in) as torch.nn.Linear stores them.
+ * Both contractions carry their fp32 operands on the 16-bit matrix pipe: since round 6 the inference forward as two binary16
+ * pieces / three products (csrc/ct_f16x2.h; a query row scaled by its own power of two, phi and g by one per image, the
+ * probabilities by 2^14), the training forward as three bfloat16 pieces / six products.  ct_ctx_attention_piece_products()
+ * returns the number of piece products per multiply-add of ct_ctx_attention_fwd (3, or 6 under CTDET_ATTN_H2=0). */
 typedef struct ct_ctx_params {
     const float *theta_w, *theta_b, *phi_w, *phi_b, *g_w, *g_b;
     const float *wz;          /* [d] */
@@ -616,6 +620,7 @@ typedef struct ct_ctx_params {
     int d, t;
 } ct_ctx_params;
 size_t ct_ctx_attention_workspace_bytes(int batch, int num_priors, int num_ctx, int d);
+int ct_ctx_attention_piece_products(void);
 int ct_ctx_attention_fwd(const float* conf, const float* pool, int batch, int num_priors,
                          int num_ctx, const ct_ctx_params* prm, float* out,
                          void* workspace, size_t workspace_bytes, ct_stream_t stream);

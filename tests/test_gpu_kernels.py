@@ -456,8 +456,13 @@ def test_postprocess_partial_sort_paths_vs_oracle(regime):
 
 
 # ------------------------------------------------------------------ context attention
+@pytest.mark.parametrize('form', ['bf16x3', 'f16x2'])
 @pytest.mark.parametrize('setting,d,T', [('transfer', 60, 20), ('incre', 15, 5)])
-def test_ctx_attention_vs_oracle(setting, d, T):
+def test_ctx_attention_vs_oracle(setting, d, T, form, monkeypatch):
+    """Both operand forms of the inference forward: bf16x3 (default) and the opt-in f16x2 one (CTDET_ATTN_H2=1: a query row
+    scaled by its own power of two, phi / g per image, probabilities by 2^14)."""
+    monkeypatch.setenv('CTDET_ATTN_H2', '1' if form == 'f16x2' else '0')
+    assert ops.lib().ct_ctx_attention_piece_products() == (3 if form == 'f16x2' else 6)
     B, P, M = 2, 11620, 1858
     shapes = {k: v for k, v in rfbnet_ref.param_shapes(300, d, 2, 'ours', setting).items()
               if k.split('.')[0] in ('theta', 'phi', 'g', 'Wz', 'OBJ_Target', 'scale', 'fc_base')}

@@ -17,7 +17,7 @@ for k in ('theta', 'phi', 'g'):
     prm[k + '_w'] = torch.randn(d, d, generator=g) * 0.05
     prm[k + '_b'] = torch.randn(d, generator=g) * 0.1
 prm = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in prm.items()}
-for (B, P, M) in ((32, 11620, 1858), (32, 32756, 4964))     # engine.Plan.M of the two networks:
+for (B, P, M) in ((32, 11620, 1858), (32, 32756, 4964)):     # engine.Plan.M of the two networks
     conf = torch.randn(B, P, d, device=dev) * 2.7
     pool = torch.randn(B, M, d, device=dev) * 7.5
     out, ws = ops.ctx_attention_buffers(B, P, M, d, T, False, dev)
