@@ -402,6 +402,10 @@ def stage_rooflines(pipe, x, steps, pmc):
             # the MFMAs the 128 x 128 blocks issue, padding included (tiles and couts rounded up to 128)
             out[key]['executed_incl_padding_per_launch'] = int(gemm_padded / (cnt / steps))
             out[key]['executed_incl_padding_frac'] = round(gemm_padded / (cnt / steps) / avg / 1e12 / peak, 4)
+    if 'ctx_attn_kernel' in out:
+        from ctdet import _lib as _l
+        # piece products per multiply-add of the attention's two contractions: 6 = bf16x3 (default), 3 = f16x2 (CTDET_ATTN_H2=1)
+        out['ctx_attn_kernel']['piece_products'] = int(_l.lib().ct_ctx_attention_piece_products())
     out['other_kernels_us_per_step'] = {k: round(v[0] / steps * 1e6, 2) for k, v in sorted(agg.items())
                                         if k not in [w.split('.')[0] for w in work]}
     out['candidates_per_step'] = cand
