@@ -215,6 +215,7 @@ def pmc_lookup(pmc, name):
 
     def targs(k):
         return [t.strip() for t in k[k.find('<') + 1:k.rfind('>')].split(',')] if '<' in k else []
+    cands = []
     for k, (v, _) in pmc.items():
         if x:       # rocprof: conv_x3_f32<BM, BN, BK, dual, h2>; one instantiation serves every filter geometry
             f = targs(k)
@@ -233,8 +234,10 @@ def pmc_lookup(pmc, name):
         elif name == 'wino4s_gemm' and (k.startswith('wino4h_gemm') or k.startswith('wino4s_gemm')):
             return v
         elif k.startswith(name):
-            return v
-    return None
+            cands.append(v)
+    # several instantiations share a bench name (select_sort_kernel<4096, true> and the near-empty re-sort launch <4096, false>):
+    # the one that moves the bytes
+    return max(cands, key=lambda t: t[0] if isinstance(t, tuple) else t) if cands else None
 
 
 def conv_roofline(rt, batch, pmc, pick=None):

@@ -5,6 +5,7 @@
 // reference's rounding sequence (no FMA contraction), so integer results derived from these
 // values (arg-max indices, match labels) are reproducible against the CPU path.
 #include "ct_common.h"
+#include <cstdint>
 #include <mutex>
 #include <algorithm>
 
@@ -129,6 +130,101 @@ __global__ __launch_bounds__(256) void detect_kernel(const float4* __restrict__ 
     for (int e = threadIdx.x; e < rows * (C + 1); e += 256) {
         const int rr = e / (C + 1), k = e - rr * (C + 1);
         sout[e] = tile[rr * LDC + k];
+    }
+}
+
+// The same for C <= CMAX classes with the row in registers (round 6).  detect_kernel above spends most of its time on the
+// integer divisions of its strided LDS copies (e / C per element, twice): here the 256 rows of a workgroup are ONE contiguous,
+// 16-byte aligned block of 256 C floats in and 256 (C + 1) floats out, copied linearly with 16-byte accesses; a thread reads its
+// row from the linear tile (16-byte reads where C % 4 == 0: conflict-free for the C = 20 / 60 of the reference's settings),
+// keeps it in registers across the barrier that lets the output tile take the same LDS, and does the row's arithmetic in the
+// reference's order -- the same expressions as detect_kernel, hence the same bits.
+template <bool SOFTMAX, int CMAX>
+__global__ __launch_bounds__(256) void detect_rows_kernel(const float4* __restrict__ loc, const float* __restrict__ conf,
+                                                          const float2* __restrict__ obj, const float4* __restrict__ priors,
+                                                          int batch, int P, int C, float v0, float v1,
+                                                          const float* __restrict__ scale4, int per_image,
+                                                          float4* __restrict__ boxes, float* __restrict__ scores)
+{
+    extern __shared__ __attribute__((aligned(16))) float tile[];           // 256 (C + 1) floats: input rows, then output rows
+    const long total = (long)batch * P;
+    const long row0 = (long)blockIdx.x * 256;
+    const int rows = (int)min((long)256, total - row0);
+    {
+        const float* cin = conf + row0 * C;                // 16-byte aligned: row0 is a multiple of 256
+        const int n = rows * C, n4 = n >> 2;
+        for (int e = threadIdx.x; e < n4; e += 256)
+            reinterpret_cast<float4*>(tile)[e] = reinterpret_cast<const float4*>(cin)[e];
+        for (int e = 4 * n4 + threadIdx.x; e < n; e += 256) tile[e] = cin[e];
+    }
+    __syncthreads();
+    const int r = threadIdx.x;
+    float c[CMAX];
+    if (r < rows) {
+        const float* src = tile + r * C;
+        if ((C & 3) == 0) {
+#pragma unroll
+            for (int k4 = 0; k4 < CMAX / 4; ++k4)
+                if (4 * k4 < C) {
+                    const float4 f = reinterpret_cast<const float4*>(src)[k4];
+                    c[4 * k4] = f.x; c[4 * k4 + 1] = f.y; c[4 * k4 + 2] = f.z; c[4 * k4 + 3] = f.w;
+                }
+        } else {
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k)
+                if (k < C) c[k] = src[k];
+        }
+    }
+    __syncthreads();                                       // every input row is in registers: the tile becomes the output tile
+    if (r < rows) {
+        const long idx = row0 + r;
+        const int p = (int)(idx % P);
+        float4 bx = decode_one(loc[idx], priors[p], v0, v1);
+        if (scale4) {
+            const float* sc = scale4 + (per_image ? 4 * (idx / P) : 0);
+            bx.x *= sc[0]; bx.y *= sc[1]; bx.z *= sc[2]; bx.w *= sc[3];
+        }
+        boxes[idx] = bx;
+        float2 o = obj[idx];
+        if (SOFTMAX) {
+            const float om = fmaxf(o.x, o.y);
+            const float e0 = expf(o.x - om), e1 = expf(o.y - om);
+            const float os = e0 + e1;
+            o.x = e0 / os;
+            o.y = e1 / os;
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k)
+                if (k < C) m = fmaxf(m, c[k]);
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k)
+                if (k < C) {
+                    const float ex = expf(c[k] - m);
+                    c[k] = ex;
+                    sum += ex;
+                }
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k)
+                if (k < C) c[k] = o.y * (c[k] / sum);
+        } else {
+#pragma unroll
+            for (int k = 0; k < CMAX; ++k)
+                if (k < C) c[k] = o.y * c[k];
+        }
+        float* dst = tile + r * (C + 1);
+        dst[0] = o.x;
+#pragma unroll
+        for (int k = 0; k < CMAX; ++k)
+            if (k < C) dst[1 + k] = c[k];
+    }
+    __syncthreads();
+    {
+        float* sout = scores + row0 * (C + 1);             // 16-byte aligned
+        const int n = rows * (C + 1), n4 = n >> 2;
+        for (int e = threadIdx.x; e < n4; e += 256)
+            reinterpret_cast<float4*>(sout)[e] = reinterpret_cast<const float4*>(tile)[e];
+        for (int e = 4 * n4 + threadIdx.x; e < n; e += 256) sout[e] = tile[e];
     }
 }
 
@@ -308,8 +404,32 @@ extern "C" int ct_detect_fused(const float* loc, const float* conf, const float*
     const long nblk = ((long)batch * num_priors + 255) / 256;
     CT_REQUIRE(nblk < 0x7FFFFFFFL, "ct_detect_fused: too many rows");
     const dim3 grid((unsigned)nblk), block(256);
-    const size_t smem = (size_t)256 * (num_fg + 2) * sizeof(float);
     hipStream_t st = ctdet::as_stream(stream);
+    // up to 64 classes (every setting of the reference: 15 / 20 / 60): the row-in-registers kernel; conf and scores must be 16-byte
+    // aligned for its linear copies (torch allocations are), else -- or with more classes -- the strided-copy kernel below
+    const bool aligned = (reinterpret_cast<uintptr_t>(conf) & 15) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0;
+    if (num_fg <= 64 && aligned) {
+        const size_t lds = (size_t)256 * (num_fg + 1) * sizeof(float);
+        static std::once_flag once_rows;
+        static hipError_t er = hipSuccess;
+        std::call_once(once_rows, [] {
+            const void* fs[] = {(const void*)detect_rows_kernel<true, 32>, (const void*)detect_rows_kernel<false, 32>,
+                                (const void*)detect_rows_kernel<true, 64>, (const void*)detect_rows_kernel<false, 64>};
+            for (const void* f : fs)
+                if (er == hipSuccess) er = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 256 * 65 * 4);
+        });
+        CT_HIP(er);
+        CT_PROF("detect_kernel", st);
+#define CT_DETECT_ROWS(SM, CM)                                                                                              \
+        hipLaunchKernelGGL((detect_rows_kernel<SM, CM>), grid, block, lds, st, (const float4*)loc, conf, (const float2*)obj,     \
+                           (const float4*)priors, batch, num_priors, num_fg, var0, var1, scale4, scale_per_image, (float4*)boxes, scores)
+        if (num_fg <= 32) { if (apply_softmax) CT_DETECT_ROWS(true, 32); else CT_DETECT_ROWS(false, 32); }
+        else { if (apply_softmax) CT_DETECT_ROWS(true, 64); else CT_DETECT_ROWS(false, 64); }
+#undef CT_DETECT_ROWS
+        CT_LAUNCH_CHECK("detect_rows_kernel");
+        return CT_OK;
+    }
+    const size_t smem = (size_t)256 * (num_fg + 2) * sizeof(float);
     if (smem > 64 * 1024) {
         static std::once_flag once;
         static hipError_t e1 = hipSuccess, e2 = hipSuccess;

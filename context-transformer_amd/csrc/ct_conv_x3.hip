@@ -527,6 +527,8 @@ __device__ __forceinline__ void x3_pack_body(const X3PackArgs& p, long first, lo
         unsigned short* base = p.out + (((step * np) * oct + o) * (long)p.m_pad + m) * 8;
         const long piece_stride = (long)oct * p.m_pad * 8;
         const int eW = p.trailer ? ctdet::h2::exponent_for(p.trailer[0], ctdet::h2::kGrowthNone) : 0;
+        // the eight channels of a row: pieces collected in registers, ONE 16-byte store per piece (24 two-byte stores before)
+        unsigned q0[4] = {0u, 0u, 0u, 0u}, q1[4] = {0u, 0u, 0u, 0u}, q2[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int ci = cg * p.bk + o * 8 + e;
@@ -539,20 +541,25 @@ __device__ __forceinline__ void x3_pack_body(const X3PackArgs& p, long first, lo
                     if (i < p.nparts && ci >= p.mbeg[i] && ci < p.mbeg[i + 1])
                         v = p.w[i][((size_t)(ci - p.mbeg[i]) * p.cin + m) * p.khw + tap];
             }
+            const int sh = 16 * (e & 1);
             if (p.trailer) {
                 const float vs = __builtin_ldexpf(v, eW);
                 const _Float16 hi = (_Float16)vs;
                 const _Float16 lo = (_Float16)(vs - (float)hi);
-                base[e] = __builtin_bit_cast(unsigned short, hi);
-                base[piece_stride + e] = __builtin_bit_cast(unsigned short, lo);
+                q0[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, hi) << sh;
+                q1[e >> 1] |= (unsigned)__builtin_bit_cast(unsigned short, lo) << sh;
                 continue;
             }
             unsigned h, mid, l;
             split3(v, h, mid, l);
-            base[e] = (unsigned short)(h >> 16);
-            base[piece_stride + e] = (unsigned short)(mid >> 16);
-            base[2 * piece_stride + e] = (unsigned short)(l >> 16);
+            q0[e >> 1] |= (h >> 16) << sh;
+            q1[e >> 1] |= (mid >> 16) << sh;
+            q2[e >> 1] |= (l >> 16) << sh;
         }
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u32x4*>(base) = u32x4{q0[0], q0[1], q0[2], q0[3]};
+        *reinterpret_cast<u32x4*>(base + piece_stride) = u32x4{q1[0], q1[1], q1[2], q1[3]};
+        if (!p.trailer) *reinterpret_cast<u32x4*>(base + 2 * piece_stride) = u32x4{q2[0], q2[1], q2[2], q2[3]};
     }
     if (p.trailer && first == 0) p.trailer[1] = (unsigned)ctdet::h2::exponent_for(p.trailer[0], ctdet::h2::kGrowthNone);
 }

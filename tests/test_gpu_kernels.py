@@ -248,6 +248,34 @@ def test_decode_encode_detect_softmax():
     np.testing.assert_allclose(gs.cpu().numpy(), ws.numpy(), rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize('C', [15, 20, 60, 64, 65])
+@pytest.mark.parametrize('softmax', [False, True])
+def test_detect_kernels_agree_bit_for_bit(C, softmax):
+    """ct_detect_fused has two kernels (csrc/ct_box.hip): the row-in-registers one (up to 64 classes, 16-byte aligned conf and
+    scores: linear 16-byte copies, no integer divisions) and the strided-copy one (any class count, any alignment).  Same
+    expressions in the same order: identical bits -- checked by handing the same values over once aligned and once through a view
+    that starts 4 bytes into its buffer (ragged last workgroup: 2 x 11 620 rows)."""
+    priors = box_ref.prior_box(box_ref.ANCHOR_CFGS['VOC_300'])
+    P = priors.shape[0]
+    g = torch.Generator().manual_seed(100 + C)
+    loc = _cuda(torch.randn(2, P, 4, generator=g))
+    conf = torch.randn(2, P, C, generator=g) * 3
+    obj = torch.randn(2, P, 2, generator=g)
+    if not softmax:
+        conf, obj = torch.softmax(conf, -1), torch.softmax(obj, -1)
+    conf, obj = _cuda(conf), _cuda(obj)
+    gb, gs = ops.detect_fused(loc, conf, obj, _cuda(priors), [0.1, 0.2], softmax)
+    raw = torch.empty(conf.numel() + 1, device=conf.device)
+    shifted = raw[1:].view(2, P, C)
+    shifted.copy_(conf)
+    assert shifted.data_ptr() % 16 == 4 and conf.data_ptr() % 16 == 0
+    hb, hs = ops.detect_fused(loc, shifted, obj, _cuda(priors), [0.1, 0.2], softmax)
+    assert torch.equal(gb, hb) and torch.equal(gs, hs)
+    wb, ws = box_ref.detect(loc.cpu(), conf.cpu() if not softmax else torch.softmax(conf.cpu(), -1),
+                            obj.cpu() if not softmax else torch.softmax(obj.cpu(), -1), priors)
+    np.testing.assert_allclose(gs.cpu().numpy(), ws.numpy(), rtol=1e-5, atol=1e-7)
+
+
 def test_jaccard_and_match_exact(golden):
     g = golden('box_ops.npz')
     priors = box_ref.prior_box(box_ref.ANCHOR_CFGS['VOC_300'])
