@@ -202,7 +202,7 @@ struct AttnArgs {
     const unsigned* vmax;
 };
 
-// H2: the f16x2 operand form (inference forward only: a.save_d == nullptr), see ctx_project_h2_kernel
+// H2: the f16x2 operand form, see ctx_project_h2_kernel
 template <bool H2>
 __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
 {
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void ctx_attn_kernel(const AttnArgs a)
             drow[8 + 2 * g + h] = make_float4(o1[4 * g] * inv_l, o1[4 * g + 1] * inv_l, o1[4 * g + 2] * inv_l,
                                               o1[4 * g + 3] * inv_l);
         }
-        if (h == 0) a.save_lse[(size_t)b * a.P_pad + q] = mb_run + log2f(l_run);
+        if (h == 0) a.save_lse[(size_t)b * a.P_pad + q] = mb_run + log2f(l_run) - (H2 ? 14.f : 0.f);      // f16x2: l carries the probabilities' 2^14
     }
     const float* crow = a.conf + ((size_t)b * a.P + q) * a.d;
     float x[32];
@@ -501,7 +501,7 @@ int forward_impl(const float* conf, const float* pool, int batch, int num_priors
     const int ostride = (prm->fc_w ? d : 0) + prm->t;
     const dim3 blk(256);
     float* none = nullptr;
-    const bool h2 = !save_d && attn_h2();
+    const bool h2 = attn_h2();                 // (the training forward too: its saved rows and log-sum-exp do not depend on the form)
     if (h2) {
         CT_HIP(hipMemsetAsync(w.kvmax, 0, (size_t)2 * batch * sizeof(unsigned), st));
         ProjH2Args kv{};

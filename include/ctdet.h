@@ -607,10 +607,11 @@ int ct_ctx_pool_fwd(const float* in, long long in_img_stride, float* out, long l
  *   setting 'incre' (fc_w != NULL): out = cat(Lin_fc(conf)+conf, nov)
  * conf dev [B,P,d], pool dev [B,M,d], out dev [B,P,(fc_w?d:0)+T]; d <= 64, T <= 32.
  * Linear weights are [d,d] row-major (out,in) as torch.nn.Linear stores them.
- * Both contractions carry their fp32 operands on the 16-bit matrix pipe: since round 6 the inference forward as two binary16
- * pieces / three products (csrc/ct_f16x2.h; a query row scaled by its own power of two, phi and g by one per image, the
- * probabilities by 2^14), the training forward as three bfloat16 pieces / six products.  ct_ctx_attention_piece_products()
- * returns the number of piece products per multiply-add of ct_ctx_attention_fwd (3, or 6 under CTDET_ATTN_H2=0). */
+ * Both contractions carry their fp32 operands on the 16-bit matrix pipe: as three bfloat16 pieces / six products (default), or,
+ * with CTDET_ATTN_H2=1 in the environment (read per call; round 6), as two binary16 pieces / three products (csrc/ct_f16x2.h: a
+ * query row scaled by its own power of two, phi and g by one per image, the probabilities by 2^14) -- 1.2-1.34x faster, same error
+ * against fp64, another rounding.  ct_ctx_attention_piece_products() returns the products per multiply-add in force (6 or 3);
+ * ct_ctx_attention_fwd_train follows the same switch. */
 typedef struct ct_ctx_params {
     const float *theta_w, *theta_b, *phi_w, *phi_b, *g_w, *g_b;
     const float *wz;          /* [d] */
