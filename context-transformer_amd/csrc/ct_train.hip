@@ -637,6 +637,53 @@ __global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const float* __rest
     }
 }
 
+// MaxPool2d(2, 2) backward FUSED with the bias + ReLU backward of the convolution that feeds the pool (conv1_2 / conv2_2 /
+// conv3_3 of the VGG trunk: the pool is the only reader of their output): dz = (y > 0) * [this element is the first maximum of its
+// window] * dy_pool, dbias[c] = sum dz, max |dz| per image -- the pool's input gradient (as large as the activation) is never
+// written and read back, and y is read once instead of twice: 2.2 GB less per step on 64 x 300 x 300 x 32.  One block per (n, c) plane.
+__global__ __launch_bounds__(256) void maxpool2x2_bias_relu_bwd_kernel(const float* __restrict__ y, int y_ctot, int y_coff,
+                                                                       const float* __restrict__ dy, int C, int H, int W,
+                                                                       int OH, int OW, float* __restrict__ dz, int dz_ctot,
+                                                                       int dz_coff, float* __restrict__ dbias,
+                                                                       unsigned* __restrict__ amax)
+{
+    __shared__ double red[4];
+    const int n = blockIdx.x / C, c = blockIdx.x - n * C;
+    const int WH = (H + 1) >> 1, WW = (W + 1) >> 1;
+    const float* xp = y + ((size_t)n * y_ctot + y_coff + c) * H * W;
+    float* dp = dz + ((size_t)n * dz_ctot + dz_coff + c) * H * W;
+    const float* gp = dy + (size_t)blockIdx.x * OH * OW;
+    double sb = 0.0;
+    float run = 0.f;
+    for (unsigned idx = threadIdx.x; idx < (unsigned)(WH * WW); idx += 256) {
+        const int wh = idx / (unsigned)WW, ww = idx - wh * WW;
+        const int h0 = 2 * wh, w0 = 2 * ww;
+        const bool h1 = h0 + 1 < H, w1 = w0 + 1 < W;
+        const float g = (wh < OH && ww < OW) ? gp[wh * OW + ww] : 0.f;
+        const int o = h0 * W + w0;
+        const float v00 = xp[o];
+        const float v01 = w1 ? xp[o + 1] : -INFINITY;
+        const float v10 = h1 ? xp[o + W] : -INFINITY;
+        const float v11 = (h1 && w1) ? xp[o + W + 1] : -INFINITY;
+        int sel = -1;
+        float m = -INFINITY;
+        if (v00 > m) { m = v00; sel = 0; }
+        if (v01 > m) { m = v01; sel = 1; }
+        if (v10 > m) { m = v10; sel = 2; }
+        if (v11 > m) { m = v11; sel = 3; }
+        const float gm = m <= 0.f ? 0.f : g;               // ReLU: the selected element passes its gradient only where y > 0
+        dp[o] = sel == 0 ? gm : 0.f;
+        if (w1) dp[o + 1] = sel == 1 ? gm : 0.f;
+        if (h1) dp[o + W] = sel == 2 ? gm : 0.f;
+        if (h1 && w1) dp[o + W + 1] = sel == 3 ? gm : 0.f;
+        sb += (double)gm;
+        ctdet::h2::track_absmax(run, gm);
+    }
+    if (amax) ctdet::h2::flush_absmax(amax, n, run);
+    sb = block_sum(sb, red);
+    if (threadIdx.x == 0 && dbias) unsafeAtomicAdd(&dbias[c], (float)sb);
+}
+
 // gradient of the channels-last head scatter: dz[n][co][pix] = dflat[n*img_stride + base + pix*ps + (co-co0)]
 struct HeadGatherArgs {
     ct_out_segment seg[3];
@@ -936,6 +983,23 @@ extern "C" int ct_maxpool2d_bwd(const float* x, const float* dy, float* dx, long
     hipLaunchKernelGGL(maxpool2d_bwd_kernel, dim3(grid_for(planes * h * w)), dim3(256), 0,
                        ctdet::as_stream(stream), x, dy, dx, planes, h, w, oh, ow, k, stride, pad, accumulate);
     CT_LAUNCH_CHECK("maxpool2d_bwd_kernel");
+    return CT_OK;
+}
+
+extern "C" int ct_maxpool2x2_bias_relu_bwd(const float* y, int y_ctot, int y_coff, const float* dy, int batch, int channels, int h,
+                                           int w, int oh, int ow, float* dz, int dz_ctot, int dz_coff, float* dbias,
+                                           unsigned* dz_absmax, ct_stream_t stream)
+{
+    CT_REQUIRE(y && dy && dz && batch > 0 && channels > 0 && h > 0 && w > 0, "ct_maxpool2x2_bias_relu_bwd: bad arguments");
+    CT_REQUIRE(oh <= (h + 1) / 2 && ow <= (w + 1) / 2 && oh >= h / 2 && ow >= w / 2, "ct_maxpool2x2_bias_relu_bwd: %dx%d is not a 2x2 / stride 2 "
+               "pooling of %dx%d", oh, ow, h, w);
+    CT_REQUIRE(y_coff >= 0 && y_coff + channels <= y_ctot && dz_coff >= 0 && dz_coff + channels <= dz_ctot, "ct_maxpool2x2_bias_relu_bwd: channel slice");
+    CT_REQUIRE((long)batch * channels <= 0x7FFFFFFFL, "ct_maxpool2x2_bias_relu_bwd: too many planes");
+    hipStream_t st = ctdet::as_stream(stream);
+    if (dbias && !ctdet::scratch_prezeroed()) CT_HIP(hipMemsetAsync(dbias, 0, (size_t)channels * 4, st));
+    hipLaunchKernelGGL(maxpool2x2_bias_relu_bwd_kernel, dim3((unsigned)(batch * channels)), dim3(256), 0, st, y, y_ctot, y_coff, dy,
+                       channels, h, w, oh, ow, dz, dz_ctot, dz_coff, dbias, dz_absmax);
+    CT_LAUNCH_CHECK("maxpool2x2_bias_relu_bwd_kernel");
     return CT_OK;
 }
 

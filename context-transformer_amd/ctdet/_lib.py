@@ -125,6 +125,7 @@ SIGNATURES = {
     'ct_bn_eval_backward': (_I, [_P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _F, _I, _P, _F, _P, _I, _I, _I,
                                  _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'ct_bias_act_backward': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P]),
+    'ct_maxpool2x2_bias_relu_bwd': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
     'ct_bias_act_backward_amax': (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _P, _P, _P]),
     'ct_maxpool2d_bwd': (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'ct_head_grad_gather': (_I, [C.POINTER(OutSegment), _I, _I, _I, _I, _P, _P]),

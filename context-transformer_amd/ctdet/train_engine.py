@@ -280,6 +280,24 @@ class TrainRuntime:
                 self.state[st.name].fwd.rt['ws_key'] = self.sid[i] if self.side is not None else 0
         backend.ws_rebuild([self.state[st.name].fwd for st in self.plan.steps if st.kind == 'conv'])
         self._wire_absmax()
+        # MaxPool2d(2, 2) whose input only the pool reads, under a convolution with bias + ReLU and no BatchNorm (conv1_2, conv2_2,
+        # conv3_3): the pool's backward and the convolution's bias / ReLU backward are ONE pass (ct_maxpool2x2_bias_relu_bwd) -- the
+        # gradient of the pool's input is never materialised.  CTDET_TRAIN_FUSE_POOL_BWD=0 keeps the two kernels.
+        self._pool_bwd = {}
+        if os.environ.get('CTDET_TRAIN_FUSE_POOL_BWD', '1') != '0':
+            steps = self.plan.steps
+            for ps in steps:
+                if ps.kind != 'pool' or (ps.k, ps.stride, ps.pad) != (2, 2, 0):
+                    continue
+                prods = [st for st in steps if st.kind == 'conv' and st.dst == ps.src and not st.segs]
+                others = [st for st in steps if st is not ps and (getattr(st, 'src', None) == ps.src or getattr(st, 'res', None) == ps.src)]
+                if len(prods) != 1 or others:
+                    continue
+                pr = prods[0]
+                s_ = self.state[pr.name]
+                if not s_.is_bn and len(pr.parts) == 1 and pr.parts[0].relu and pr.parts[0].bias is not None and pr.dst_coff == 0 and \
+                        pr.cout == ps.ch and s_.zc == pr.cout and pr.res is None and self.grads[ps.dst].shape[1] == ps.ch:
+                    self._pool_bwd[ps.name] = pr
         # weight gradients beside the data-gradient chain (CTDET_TRAIN_STREAMS=1 keeps everything on the caller's stream).  The
         # stream is the forward pass's side stream: the two are never busy at the same time, and a training step with ONE side
         # stream can be captured as a hipGraph (a second one crashes hipStreamEndCapture on ROCm 7.2)
@@ -695,6 +713,15 @@ class TrainRuntime:
         for st in reversed(self.plan.steps):
             if st.kind == 'ctxpool':
                 continue
+            if st.kind == 'pool' and st.name in self._pool_bwd and not overlaps(st.src, 0, st.ch):
+                pr = self._pool_bwd[st.name]
+                sp = self.state[pr.name]
+                y = self.bufs[pr.dst]
+                _lib.check(lib.ct_maxpool2x2_bias_relu_bwd(y.data_ptr(), y.shape[1], pr.dst_coff, self.grads[st.dst].data_ptr(), B, st.ch,
+                                                           st.h, st.w, st.oh, st.ow, sp.dz.data_ptr(), sp.zc, 0, sp.dbias[0].data_ptr(),
+                                                           getattr(sp, 'dz_amax', None), self._s()), st.name + ' + ' + pr.name + ' bias bwd')
+                sp.dz_from_pool = True
+                continue
             if st.kind == 'pool':
                 acc = overlaps(st.src, 0, st.ch)
                 _lib.check(lib.ct_maxpool2d_bwd(self.bufs[st.src].data_ptr(), self.grads[st.dst].data_ptr(),
@@ -742,6 +769,10 @@ class TrainRuntime:
                             B, p.cout, hw, s.scratch[i].data_ptr(), self._s()), st.name + ' bn bwd')
                         put(p.bn.weight, s.dgamma[i])
                         put(p.bn.bias, s.dbeta[i])
+                    elif getattr(s, 'dz_from_pool', False):
+                        s.dz_from_pool = False          # dZ and dbias came from the pool's fused backward (above)
+                        if p.bias is not None:
+                            put(p.bias, s.dbias[i])
                     else:
                         _lib.check(lib.ct_bias_act_backward_amax(
                             gy.data_ptr(), gy.shape[1], st.dst_coff + off, y.data_ptr(), y.shape[1], st.dst_coff + off,

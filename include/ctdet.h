@@ -559,6 +559,13 @@ int ct_bias_act_backward(const float* dy, int dy_ctot, int dy_coff, const float*
 int ct_bias_act_backward_amax(const float* dy, int dy_ctot, int dy_coff, const float* y, int y_ctot, int y_coff,
                               int relu, int batch, int channels, int hw, float* dz, int dz_ctot, int dz_coff,
                               float* dbias, unsigned* dz_absmax, ct_stream_t stream);
+/* MaxPool2d(2, 2) backward and the bias + ReLU backward of the convolution under the pool in one pass (train.py:222-229 backward of
+ * models/RFB_Net_vgg.py:323-336 conv + ReLU + 'M'): y = the convolution's (post-ReLU) output = the pool's input, dy = the gradient
+ * of the POOLED map [batch][channels][oh*ow]; writes dz = (y > 0) * (first maximum of its window) * dy into a channel slice,
+ * dbias[c] += sum dz (NULL = skip), max |dz| per image into dz_absmax (NULL = off).  For a convolution whose output only the pool reads. */
+int ct_maxpool2x2_bias_relu_bwd(const float* y, int y_ctot, int y_coff, const float* dy, int batch, int channels, int h, int w,
+                                int oh, int ow, float* dz, int dz_ctot, int dz_coff, float* dbias, unsigned* dz_absmax,
+                                ct_stream_t stream);
 /* max_pool2d backward: the gradient goes to the first maximum of each window (torch's rule). */
 int ct_maxpool2d_bwd(const float* x, const float* dy, float* dx, long planes, int h, int w, int oh, int ow,
                      int k, int stride, int pad, int accumulate, ct_stream_t stream);

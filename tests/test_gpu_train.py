@@ -152,6 +152,40 @@ def test_pool_and_bias_backward():
     assert torch.equal(dz.cpu(), want) and rel_err(dbias.cpu(), want.sum((0, 2, 3))) < 1e-5
 
 
+@pytest.mark.parametrize('H,W,ceil', [(30, 30, False), (15, 13, False), (75, 75, True), (150, 150, False)])
+def test_fused_pool_and_bias_relu_backward(H, W, ceil):
+    """ct_maxpool2x2_bias_relu_bwd = ct_maxpool2d_bwd followed by ct_bias_act_backward (what the backward of conv + ReLU + 'M' of
+    models/RFB_Net_vgg.py:323-336 was before the two passes were fused): dZ bit for bit, dbias to summation order, max |dZ| per image;
+    channel slices on both sides, ties inside windows, windows of zeros (ReLU: no gradient)."""
+    lib = _lib.lib()
+    gen = torch.Generator().manual_seed(11)
+    B, C, ytot, ycoff, ztot, zcoff = 3, 5, 8, 2, 7, 1
+    y = torch.relu(torch.randn(B, ytot, H, W, generator=gen))
+    y[0, ycoff, :4, :4] = 1.5                       # ties
+    y[1, ycoff + 1, :6, :6] = 0.0                   # dead windows
+    OH = (H + 1) // 2 if ceil else H // 2
+    OW = (W + 1) // 2 if ceil else W // 2
+    dyp = torch.randn(B, C, OH, OW, generator=gen) * 3
+    yd, dyd = _cuda(y), _cuda(dyp)
+    ysl = yd[:, ycoff:ycoff + C].contiguous()
+    dx = torch.empty(B, C, H, W, device=DEV)
+    _lib.check(lib.ct_maxpool2d_bwd(ysl.data_ptr(), dyd.data_ptr(), dx.data_ptr(), B * C, H, W, OH, OW, 2, 2, 0, 0, _s()), 'pool bwd')
+    dz_ref = torch.zeros(B, ztot, H, W, device=DEV)
+    db_ref = torch.zeros(C, device=DEV)
+    _lib.check(lib.ct_bias_act_backward(dx.data_ptr(), C, 0, yd.data_ptr(), ytot, ycoff, 1, B, C, H * W, dz_ref.data_ptr(), ztot, zcoff,
+                                        db_ref.data_ptr(), _s()), 'bias bwd')
+    dz = torch.zeros(B, ztot, H, W, device=DEV)
+    db = torch.zeros(C, device=DEV)
+    amax = torch.zeros(B * _lib.ABSMAX_LINE_BYTES // 4, dtype=torch.int32, device=DEV)
+    _lib.check(lib.ct_maxpool2x2_bias_relu_bwd(yd.data_ptr(), ytot, ycoff, dyd.data_ptr(), B, C, H, W, OH, OW, dz.data_ptr(), ztot, zcoff,
+                                               db.data_ptr(), amax.data_ptr(), _s()), 'fused')
+    torch.cuda.synchronize()
+    assert torch.equal(dz, dz_ref)
+    assert rel_err(db.cpu(), db_ref.cpu()) < 1e-5
+    got = amax.view(B, -1)[:, 0].cpu().view(torch.float32)
+    assert torch.equal(got, dz_ref[:, zcoff:zcoff + C].abs().amax(dim=(1, 2, 3)).cpu())
+
+
 def _net(size, C, phase=1, setting='transfer'):
     from models.RFB_Net_vgg import build_net
     net = build_net(types.SimpleNamespace(method='ours', phase=phase, setting=setting), size, C)
