@@ -525,7 +525,7 @@ class TrainRuntime:
                 s = self.state[st.name]
                 if s.fwd.rt.get('x3') is not None:
                     bk = self.be.x3_bk(s.fwd.rt['x3'])
-                    item(s.fwd.parts, s.fwd.cin, s.fwd.kh, s.fwd.kw, bk, s.fwd.rt['wx3'][(bk, False)], 0)      # (k-step, f16x2 form): training runs bf16x3
+                    item(s.fwd.parts, s.fwd.cin, s.fwd.kh, s.fwd.kw, bk, s.fwd.rt['wx3'][(bk, False)], 0)      # (k-step, f16x2 form): the direct layers of a training step run bf16x3
                 if s.dgrad is not None and s.dgrad_x3 is not None:
                     item(st.parts, st.cin, st.kh, st.kw, self.lib.ct_conv_x3_config_bk(s.dgrad_x3), s.wx3_d, 1, s.zero_w)
             table = torch.frombuffer(bytearray(b''.join(items)), dtype=torch.uint8).to(self.be.device) if items else None

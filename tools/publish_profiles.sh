@@ -13,11 +13,11 @@ for f in bench_full.json.log rfb300_bench.json.log rfb512_bench.json.log rfb300c
 done
 [ -s $S/ctx_parity.txt ] && grep -v "amdgpu.ids" $S/ctx_parity.txt > $D/${R}_ctx_parity.txt
 # the training step's kernel table (rocprofv3 --stats of tools/train_bench.py --batch 32 --steps 10)
-python tools/prof_summary.py --stats "$(ls $S/train_stats/*kernel_stats.csv | head -1)" --tag "${R}_train" --workload 300,32,1,20 \
+python tools/prof_summary.py --stats "$(ls -t $S/train_stats/*kernel_stats.csv | head -1)" --tag "${R}_train" --workload 300,32,1,20 \
     --cmd "python tools/train_bench.py --batch 32 --steps 10" --out $D > /dev/null
 # ... and of configs[3]'s per-GPU shape, when the collection made it; the suite's tail
 if ls $S/train512ctx_stats/*kernel_stats.csv > /dev/null 2>&1; then
-  python tools/prof_summary.py --stats "$(ls $S/train512ctx_stats/*kernel_stats.csv | head -1)" --tag "${R}_train512ctx" --workload 512,8,2,60 \
+  python tools/prof_summary.py --stats "$(ls -t $S/train512ctx_stats/*kernel_stats.csv | head -1)" --tag "${R}_train512ctx" --workload 512,8,2,60 \
       --cmd "python tools/train_bench.py --size 512 --batch 8 --phase 2 --classes 60 --steps 10" --out $D > /dev/null
 fi
 [ -s $S/pytest_gpu.txt ] && grep -v "amdgpu.ids" $S/pytest_gpu.txt > $D/${R}_pytest_gpu.txt
