@@ -47,3 +47,63 @@ def test_f16x2_packed_weight_bits_are_pinned():
             torch.cuda.synchronize()
             got[(name, cout, cin)] = hashlib.sha256(u.cpu().numpy().tobytes()).hexdigest()[:16]
     assert got == PINNED, got
+
+
+def test_batched_f16x2_packing_equals_the_per_layer_calls():
+    """ct_conv_wino_h2_pack_item / _run (what a training step uses: three launches for all layers) writes the bytes of
+    ct_conv_pack_weights_wino4s_h2 / wino4f_h2 [_dgrad], trailer (maximum, exponent) included -- multi-part layers and the zero
+    rows a data-gradient layout is padded with as well."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    layers = []        # (parts, cin, dgrad, tile)
+    for (couts, cin, dgrad, tile) in (((64,), 64, 0, 48), ((96, 32), 128, 0, 47), ((128,), 64, 1, 48), ((100, 28), 48, 1, 47), ((156,), 512, 0, 47)):
+        ws = [(torch.randn(c, cin, 3, 3, generator=g) * (2.0 / (cin * 9)) ** 0.5 * (1 + 3 * i)).cuda() for i, c in enumerate(couts)]
+        layers.append((ws, cin, dgrad, tile))
+    nbytes = L.ct_conv_wino_h2_pack_item_bytes()
+    items, outs_b, outs_s = [], [], []
+    for ws, cin, dgrad, tile in layers:
+        tot = sum(w.shape[0] for w in ws)
+        size = L.ct_conv_wino4s_h2_packed_bytes if tile == 47 else L.ct_conv_wino4f_h2_packed_bytes
+        nb = size(tot, cin) if dgrad else size(cin, tot)
+        n = len(ws)
+        ptrs = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+        co = (C.c_int * n)(*[w.shape[0] for w in ws])
+        ub = torch.full((nb,), 0xAB, dtype=torch.uint8, device='cuda')
+        us = torch.full((nb,), 0xAB, dtype=torch.uint8, device='cuda')
+        buf = (C.c_ubyte * nbytes)()
+        _lib.check(L.ct_conv_wino_h2_pack_item(ptrs, co, n, cin, dgrad, tile, ub.data_ptr(), buf), 'item')
+        items.append(bytes(buf))
+        name = {(47, 0): 'ct_conv_pack_weights_wino4s_h2', (47, 1): 'ct_conv_pack_weights_wino4s_h2_dgrad',
+                (48, 0): 'ct_conv_pack_weights_wino4f_h2', (48, 1): 'ct_conv_pack_weights_wino4f_h2_dgrad'}[(tile, dgrad)]
+        _lib.check(getattr(L, name)(ptrs, co, n, cin, us.data_ptr(), None), name)
+        outs_b.append(ub)
+        outs_s.append(us)
+    table = torch.frombuffer(bytearray(b''.join(items)), dtype=torch.uint8).cuda()
+    _lib.check(L.ct_conv_wino_h2_pack_run(table.data_ptr(), len(items), None), 'run')
+    torch.cuda.synchronize()
+    for i, (b, s) in enumerate(zip(outs_b, outs_s)):
+        # the trailer is 256 bytes of which two words are written: compare everything either call wrote
+        assert torch.equal(b[:-256], s[:-256]), i
+        assert torch.equal(b[-256:-248], s[-256:-248]), i
+
+
+def test_bias_act_backward_amax_lines():
+    """ct_bias_act_backward_amax: dZ as ct_bias_act_backward, and max |dZ| per image in the first word of each line (what the f16x2
+    data-gradient launch reads, csrc/ct_f16x2.h) -- ragged sizes, a channel slice, an image whose dZ is all zero."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(9)
+    for (B, Cc, H, W, ztot, zoff) in ((3, 5, 7, 9, 8, 2), (2, 64, 38, 38, 64, 0), (4, 3, 1, 1, 3, 0)):
+        y = torch.randn(B, Cc, H, W, generator=g)
+        dy = torch.randn(B, Cc, H, W, generator=g) * 5
+        y[B - 1] = -1.0                                   # ReLU dead everywhere: the image's maximum stays 0
+        yd, dyd = y.cuda(), dy.cuda()
+        dz = torch.zeros(B, ztot, H, W, device='cuda')
+        db = torch.zeros(Cc, device='cuda')
+        amax = torch.zeros(B * _lib.ABSMAX_LINE_BYTES // 4, dtype=torch.int32, device='cuda')
+        _lib.check(L.ct_bias_act_backward_amax(dyd.data_ptr(), Cc, 0, yd.data_ptr(), Cc, 0, 1, B, Cc, H * W, dz.data_ptr(), ztot, zoff,
+                                               db.data_ptr(), amax.data_ptr(), None), 'bias bwd amax')
+        torch.cuda.synchronize()
+        want = dy * (y > 0)
+        assert torch.equal(dz[:, zoff:zoff + Cc].cpu(), want)
+        got = amax.view(B, -1)[:, 0].cpu().view(torch.float32)
+        assert torch.equal(got, want.abs().amax(dim=(1, 2, 3))), (got, want.abs().amax(dim=(1, 2, 3)))
