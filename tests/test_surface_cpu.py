@@ -225,3 +225,34 @@ def test_committed_tune_table_is_consistent():
             assert (kh, kw, stride) == (3, 3, 1), (key, val)
             if dil > 1:
                 assert val == 'wino4s' and cin % 16 == 0 and key + '|alt' in table, (key, val)
+
+
+def test_operand_form_policy_host_logic(monkeypatch):
+    """engine.operand_form_h2 / ctx_policy (which operand form a runtime's Winograd and direct layers run; host logic, no device):
+    plain networks switch to f16x2 from batch x size^2 >= 8 x 300^2 up, networks with the Context-Transformer block follow their
+    policy ('h2': Winograd forms on f16x2 at every batch size, direct layers never; a tile list: neither), CTDET_H2 overrides."""
+    for k in ('CTDET_H2', 'CTDET_H2_X3', 'CTDET_CTX_TILES'):
+        monkeypatch.delenv(k, raising=False)
+    plain300 = types.SimpleNamespace(method='ours', phase=1, size=300)
+    plain512 = types.SimpleNamespace(method='ours', phase=1, size=512)
+    ctx300 = types.SimpleNamespace(method='ours', phase=2, size=300)
+    f = engine.operand_form_h2
+    assert engine.ctx_policy(plain300) is None and engine.ctx_policy(ctx300) == 'h2'
+    assert f(plain300, 4) == (False, False) and f(plain300, 8) == (True, True) and f(plain300, 32) == (True, True)
+    assert f(plain512, 2) == (False, False) and f(plain512, 4) == (True, True)          # 4 x 512^2 > 8 x 300^2
+    assert f(ctx300, 2) == (True, False) and f(ctx300, 32) == (True, False)
+    monkeypatch.setenv('CTDET_H2_X3', '0')
+    assert f(plain300, 32) == (True, False)
+    monkeypatch.delenv('CTDET_H2_X3')
+    monkeypatch.setenv('CTDET_H2', '0')
+    assert f(plain300, 32) == (False, False) and f(ctx300, 32) == (False, False)
+    monkeypatch.setenv('CTDET_H2', '2')
+    assert f(plain300, 1) == (True, True)
+    monkeypatch.delenv('CTDET_H2')
+    monkeypatch.setenv('CTDET_CTX_TILES', '2,23')
+    assert f(ctx300, 32) == (False, False) and engine.ctx_tile_set(ctx300) is not None
+    monkeypatch.setenv('CTDET_CTX_TILES', 'any')
+    assert f(ctx300, 32) == (True, True) and f(ctx300, 2) == (False, False) and engine.ctx_tile_set(ctx300) is None
+    # the table maps its bf16x3 names onto the f16x2 twins, never the other way round
+    assert engine.H2_OF_TILE == {44: 47, 46: 48} and set(engine.H2_TILES) == {47, 48}
+    assert set(engine.WINO_NAME) == {2, 4, 23, 44, 46, 47, 48}                         # codes 24 / 45 are gone
