@@ -40,6 +40,11 @@ def test_bench_line_contract():
         assert abs(r['flops_per_launch'] / r['algorithmic_flops_per_launch'] - (3.0 if on_h2 else 6.0)) < 1e-6
     assert 'arith' in d and 'bf16x3' in d['arith'] and 'f16x2' in d['arith']
     assert d['config']['operand_form'] in ('f16x2', 'bf16x3') and d['config']['live_tuned_layers']['count'] == 0
+    # every kernel-choice switch in force is on the line (engine.Runtime.policy_record), and the fraction that compares across operand forms
+    pol = d['config']['policy']
+    assert pol['operand_form'] == d['config']['operand_form'] and pol['live_tuned_layers'] == 0 and pol['tune_table'] == 'conv_tune_gfx950.json'
+    assert isinstance(pol['env'], dict) and all(k.startswith('CTDET_') for k in pol['env'])
+    assert abs(r['frac_bf16x3_equivalent'] - r['frac'] * (2.0 if on_h2 else 1.0)) < 1e-3
     assert len(d['per_rank_ms_per_step']) == 1 and d['dist']['rccl_ranks'] == 1
     if r['kernel'] == 'wino4s_gemm':
         # a three-kernel launch dominates: kernel-level fields = its matrix kernel, launch-level ones kept beside them
@@ -62,3 +67,4 @@ def test_bench_phase2_reports_the_attention_stage():
     st = d['roofline']['stages']
     assert st['ctx_attn_kernel']['bound'] == 'mfma' and 0 < st['ctx_attn_kernel']['frac'] < 1
     assert st['ctx_attn_kernel.hbm']['bound'] == 'hbm'
+    assert st['ctx_attn_kernel']['piece_products'] == 6          # bf16x3 unless CTDET_ATTN_H2=1 (opt-in: DESIGN.md section 8 item 9)
